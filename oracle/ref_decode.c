@@ -1,0 +1,201 @@
+/* CPU restatement of the index/integer part of the hot path.  TEST INFRASTRUCTURE ONLY
+ * (see oracle/__init__.py): never linked into or called from the product library.
+ *
+ * Follows (ref: = /root/reference/, d2z: = inside /root/reference/detectron2.7z):
+ *   CenterNet.inference / predict_instances / predict_single_level
+ *        ref:fewx/modeling/fsod/fsod_rpn.py:1066-1097, 1101-1113, 1117-1181
+ *   CenterNet.compute_grids            ref:fewx/modeling/fsod/fsod_rpn.py:782-800
+ *   CenterNet.nms_and_topK             ref:fewx/modeling/fsod/fsod_rpn.py:1185-1210
+ *   ml_nms -> batched_nms              ref:CenterNet2/centernet/modeling/layers/ml_nms.py:4-31,
+ *                                      d2z:layers/nms.py:10-30
+ *   torchvision.ops.nms (UN-VENDORED third-party dependency, torchvision 0.8.2+cu101 per
+ *   ref:log/fsod_finetune_stone_vovnet_25_test_log.txt:19): restated from its published algorithm
+ *   (sort scores descending; greedy; suppress j when inter/(area_i+area_j-inter) > thr; areas
+ *   (x2-x1)*(y2-y1), no +1).  The reference holds no test/golden vector for NMS => for NMS itself
+ *   parity is UNPINNED by the reference; this file is the definition of "bit-exact keep mask".
+ *
+ * Canonicalisation where the reference is implementation-defined:
+ *   (i)  topk(sorted=False): the selected SET is exact (value desc, ties -> lower flat index);
+ *        emitted in ascending flat-index order per level, levels concatenated p3,p4,p5;
+ *   (ii) NMS sort is stable descending (ties -> lower concatenated index first);
+ *   (iii) post-NMS filter keeps every score >= k-th largest kept score (ties may keep > k).
+ *
+ * Bit-reproducibility GPU<->CPU: every float op below is a single IEEE-754 binary32 operation
+ * (mul, add, fma, div, sqrt, rint, max); the HIP twin (csrc/ore_detect.hip) performs the same
+ * sequence and is compiled with -ffp-contract=off.  The sigmoid uses ore_expf below (a fixed
+ * Cephes-style polynomial) instead of libm so both sides agree to the bit; it is within 4 ulp of
+ * torch.sigmoid (checked in tests/test_oracle_golden.py against the reference-run fixtures).
+ *
+ * Build: gcc -O2 -fPIC -shared -ffp-contract=off -fno-fast-math (oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float ore_expf(float x) {
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float e = fmaf(p, r * r, r) + 1.0f;
+    int32_t ni = (int32_t)n;
+    union { uint32_t u; float f; } s;
+    s.u = (uint32_t)(ni + 127) << 23;
+    return e * s.f;
+}
+
+float oracle_sigmoid(float x) { return 1.0f / (1.0f + ore_expf(-x)); }
+
+void oracle_sigmoid_array(const float* x, float* y, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) y[i] = oracle_sigmoid(x[i]);
+}
+
+typedef struct { float v; int64_t i; } cand_t;
+
+static int cmp_val_desc_idx_asc(const void* a, const void* b) {
+    const cand_t* x = (const cand_t*)a; const cand_t* y = (const cand_t*)b;
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+static int cmp_idx_asc(const void* a, const void* b) {
+    const cand_t* x = (const cand_t*)a; const cand_t* y = (const cand_t*)b;
+    return (x->i > y->i) - (x->i < y->i);
+}
+
+/* One image.  hm[l]: H*W logits (row-major y,x).  reg[l]: [H*W][4] (l,t,r,b) AFTER Scale+ReLU, in
+ * stride units (predict_instances multiplies by the stride, fsod_rpn.py:1107).
+ * Outputs (capacity n_levels*pre_topk each):
+ *   pre_boxes [n_pre][4], pre_scores [n_pre] (sqrt(sigmoid)), pre_loc [n_pre] = global location id
+ *   (sum of H*W of earlier levels + flat index), pre_level [n_pre];
+ *   keep_idx [n_keep] int64 indices into the pre list, descending score order, after the post-NMS filter.
+ * Returns 0, or -1 on allocation failure. */
+int oracle_decode_nms(int n_levels, const int32_t* H, const int32_t* W, const int32_t* stride,
+                      const float* const* hm, const float* const* reg,
+                      float score_thresh, int32_t pre_topk, float nms_thresh, int32_t post_topk,
+                      float* pre_boxes, float* pre_scores, int64_t* pre_loc, int32_t* pre_level,
+                      int32_t* n_pre_out, int64_t* keep_idx, int32_t* n_keep_out) {
+    int64_t n_pre = 0, loc_base = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int64_t hw = (int64_t)H[l] * W[l];
+        cand_t* c = (cand_t*)malloc(sizeof(cand_t) * (size_t)(hw > 0 ? hw : 1));
+        if (!c) return -1;
+        int64_t nc = 0;
+        for (int64_t i = 0; i < hw; ++i) {
+            float s = oracle_sigmoid(hm[l][i]);
+            if (s > score_thresh) { c[nc].v = s; c[nc].i = i; ++nc; }   /* fsod_rpn.py:1134 */
+        }
+        int64_t k = nc < pre_topk ? nc : pre_topk;                    /* :1135-1137 */
+        if (nc > k) {                                                  /* :1157-1162 topk */
+            qsort(c, (size_t)nc, sizeof(cand_t), cmp_val_desc_idx_asc);
+            qsort(c, (size_t)k, sizeof(cand_t), cmp_idx_asc);
+        }
+        const float st = (float)stride[l];
+        const float half = (float)(stride[l] / 2);                     /* :798 strides[level] // 2 */
+        for (int64_t j = 0; j < k; ++j) {
+            const int64_t i = c[j].i;
+            const float gx = (float)((i % W[l]) * stride[l]) + half;   /* compute_grids :782-800 */
+            const float gy = (float)((i / W[l]) * stride[l]) + half;
+            const float* r = reg[l] + 4 * i;
+            float x1 = gx - r[0] * st, y1 = gy - r[1] * st;            /* :1164-1169 */
+            float x2 = gx + r[2] * st, y2 = gy + r[3] * st;
+            x2 = fmaxf(x2, x1 + 0.01f);                                /* :1172-1173 */
+            y2 = fmaxf(y2, y1 + 0.01f);
+            float* b = pre_boxes + 4 * n_pre;
+            b[0] = x1; b[1] = y1; b[2] = x2; b[3] = y2;
+            pre_scores[n_pre] = sqrtf(c[j].v);                         /* :1175 with_agn_hm */
+            pre_loc[n_pre] = loc_base + i;
+            pre_level[n_pre] = l;
+            ++n_pre;
+        }
+        free(c);
+        loc_base += hw;
+    }
+    *n_pre_out = (int32_t)n_pre;
+
+    /* ---- NMS (torchvision.ops.nms semantics; all class ids are 0 so batched_nms offsets are 0) */
+    int64_t n_keep = 0;
+    if (nms_thresh <= 0.0f) {                                          /* ml_nms.py:17-18 */
+        for (int64_t i = 0; i < n_pre; ++i) keep_idx[i] = i;
+        n_keep = n_pre;
+    } else if (n_pre > 0) {
+        cand_t* o = (cand_t*)malloc(sizeof(cand_t) * (size_t)n_pre);
+        unsigned char* dead = (unsigned char*)calloc((size_t)n_pre, 1);
+        float* area = (float*)malloc(sizeof(float) * (size_t)n_pre);
+        if (!o || !dead || !area) { free(o); free(dead); free(area); return -1; }
+        for (int64_t i = 0; i < n_pre; ++i) {
+            o[i].v = pre_scores[i]; o[i].i = i;
+            const float* b = pre_boxes + 4 * i;
+            area[i] = (b[2] - b[0]) * (b[3] - b[1]);
+        }
+        qsort(o, (size_t)n_pre, sizeof(cand_t), cmp_val_desc_idx_asc);
+        for (int64_t a = 0; a < n_pre; ++a) {
+            if (dead[a]) continue;
+            const int64_t i = o[a].i;
+            keep_idx[n_keep++] = i;
+            const float* bi = pre_boxes + 4 * i;
+            for (int64_t c2 = a + 1; c2 < n_pre; ++c2) {
+                if (dead[c2]) continue;
+                const int64_t j = o[c2].i;
+                const float* bj = pre_boxes + 4 * j;
+                const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+                const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+                const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+                const float inter = w * h;
+                const float ovr = inter / (area[i] + area[j] - inter);
+                if (ovr > nms_thresh) dead[c2] = 1;
+            }
+        }
+        free(o); free(dead); free(area);
+    }
+    /* ---- post-NMS top-k (fsod_rpn.py:1196-1206): kthvalue(scores, n-k+1) = k-th largest */
+    if (n_keep > post_topk && post_topk > 0) {
+        const float thr = pre_scores[keep_idx[post_topk - 1]];
+        int64_t m = 0;
+        for (int64_t a = 0; a < n_keep; ++a)
+            if (pre_scores[keep_idx[a]] >= thr) keep_idx[m++] = keep_idx[a];
+        n_keep = m;
+    }
+    *n_keep_out = (int32_t)n_keep;
+    return 0;
+}
+
+/* Plain greedy NMS on an arbitrary box list (used by the golden-vector generator as the
+ * `batched_nms` the reference's ml_nms calls, and by nms edge-case tests).
+ * keep: indices in descending-score (stable) order.  Returns the number kept. */
+int64_t oracle_nms(const float* boxes, const float* scores, int64_t n, float thr, int64_t* keep) {
+    if (n <= 0) return 0;
+    cand_t* o = (cand_t*)malloc(sizeof(cand_t) * (size_t)n);
+    unsigned char* dead = (unsigned char*)calloc((size_t)n, 1);
+    if (!o || !dead) { free(o); free(dead); return -1; }
+    for (int64_t i = 0; i < n; ++i) { o[i].v = scores[i]; o[i].i = i; }
+    qsort(o, (size_t)n, sizeof(cand_t), cmp_val_desc_idx_asc);
+    int64_t nk = 0;
+    for (int64_t a = 0; a < n; ++a) {
+        if (dead[a]) continue;
+        const int64_t i = o[a].i;
+        keep[nk++] = i;
+        const float* bi = boxes + 4 * i;
+        const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+        for (int64_t c2 = a + 1; c2 < n; ++c2) {
+            if (dead[c2]) continue;
+            const float* bj = boxes + 4 * o[c2].i;
+            const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+            const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+            const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+            const float inter = w * h;
+            if (inter / (ai + aj - inter) > thr) dead[c2] = 1;
+        }
+    }
+    free(o); free(dead);
+    return nk;
+}

@@ -1,0 +1,331 @@
+"""Plain-PyTorch fp32 CPU restatement of the floating-point part of the hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Every function takes a flat ``state_dict``-style mapping with the reference's own
+parameter names and NCHW fp32 tensors, exactly like the
+reference modules, and cites the reference lines it restates:
+
+  d2z: = path inside /root/reference/detectron2.7z (the vendored, modified Detectron2)
+  ref: = path under /root/reference/
+
+Parity pinning: the reference ships no tests or golden vectors, so
+this restatement is pinned by executing the reference's own files in this container
+(``oracle/refrun/gen_golden.py``) on seeded inputs and committing the outputs under
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against them.
+torchvision (nms / roi_align) is an un-vendored dependency: see ref_decode.c.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Mapping, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Mapping[str, Tensor]
+
+# d2z:modeling/backbone/vovnet.py:28-96 -- the stage tables (only non-depthwise bodies).
+VOVNET_SPECS = {
+    "V-19-slim-eSE": dict(stem=(64, 64, 128), conv=(64, 80, 96, 112), out=(112, 256, 384, 512),
+                          layers=3, blocks=(1, 1, 1, 1)),
+    "V-19-eSE": dict(stem=(64, 64, 128), conv=(128, 160, 192, 224), out=(256, 512, 768, 1024),
+                     layers=3, blocks=(1, 1, 1, 1)),
+    "V-39-eSE": dict(stem=(64, 64, 128), conv=(128, 160, 192, 224), out=(256, 512, 768, 1024),
+                     layers=5, blocks=(1, 1, 2, 2)),
+    "V-57-eSE": dict(stem=(64, 64, 128), conv=(128, 160, 192, 224), out=(256, 512, 768, 1024),
+                     layers=5, blocks=(1, 1, 4, 3)),
+    "V-99-eSE": dict(stem=(64, 64, 128), conv=(128, 160, 192, 224), out=(256, 512, 768, 1024),
+                     layers=5, blocks=(1, 3, 9, 3)),
+}
+
+PIXEL_MEAN = (103.530, 116.280, 123.675)  # d2z:config/defaults.py PIXEL_MEAN (BGR)
+PIXEL_STD = (1.0, 1.0, 1.0)
+
+
+# --------------------------------------------------------------------------------------
+# a4  preprocess (ref:fewx/modeling/fsod/fsod_cen.py:540-555, d2z:structures/image_list.py:69-121)
+# --------------------------------------------------------------------------------------
+def preprocess(image_chw: Tensor, size_divisibility: int = 32,
+               mean: Sequence[float] = PIXEL_MEAN, std: Sequence[float] = PIXEL_STD) -> Tensor:
+    """(x - mean) / std per BGR channel, then zero-pad bottom/right to a multiple of 32."""
+    x = image_chw.to(torch.float32)
+    m = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+    x = (x - m) / s
+    h, w = x.shape[-2:]
+    hp = (h + size_divisibility - 1) // size_divisibility * size_divisibility
+    wp = (w + size_divisibility - 1) // size_divisibility * size_divisibility
+    x = F.pad(x, (0, wp - w, 0, hp - h), value=0.0)
+    return x.unsqueeze(0)
+
+
+# --------------------------------------------------------------------------------------
+# a2  FrozenBatchNorm2d (d2z:layers/batch_norm.py:44-66)
+# --------------------------------------------------------------------------------------
+def frozen_bn(x: Tensor, sd: SD, prefix: str, eps: float = 1e-5) -> Tensor:
+    return F.batch_norm(x, sd[prefix + "running_mean"], sd[prefix + "running_var"],
+                        sd[prefix + "weight"], sd[prefix + "bias"], training=False, eps=eps)
+
+
+def conv_bn_relu(x: Tensor, sd: SD, name: str, stride: int, pad: int) -> Tensor:
+    """conv (no bias) -> FrozenBN -> ReLU; d2z:modeling/backbone/vovnet.py:205-235."""
+    x = F.conv2d(x, sd[name + "/conv.weight"], None, stride, pad)
+    return F.relu(frozen_bn(x, sd, name + "/norm."))
+
+
+# --------------------------------------------------------------------------------------
+# a1  VoVNet (d2z:modeling/backbone/vovnet.py)
+# --------------------------------------------------------------------------------------
+def ese(x: Tensor, sd: SD, prefix: str) -> Tensor:
+    """eSE: x * relu6(fc(avgpool(x)) + 3) / 6   (vovnet.py:238-260)."""
+    s = F.adaptive_avg_pool2d(x, 1)
+    s = F.conv2d(s, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
+    s = F.relu6(s + 3.0) / 6.0
+    return x * s
+
+
+def osa_module(x: Tensor, sd: SD, prefix: str, mod: str, n_layers: int, identity: bool) -> Tensor:
+    """_OSA_module.forward (vovnet.py:310-332), non-depthwise, no DCN."""
+    feats = [x]
+    y = x
+    for i in range(n_layers):
+        y = conv_bn_relu(y, sd, f"{prefix}layers.{i}.{mod}_{i}", 1, 1)
+        feats.append(y)
+    y = torch.cat(feats, dim=1)
+    y = conv_bn_relu(y, sd, f"{prefix}concat.{mod}_concat", 1, 0)
+    y = ese(y, sd, prefix + "ese.")
+    if identity:
+        y = y + x
+    return y
+
+
+def vovnet(x: Tensor, sd: SD, prefix: str = "backbone.bottom_up.",
+           body: str = "V-19-slim-eSE") -> Dict[str, Tensor]:
+    """VoVNet.forward (vovnet.py:471-481): stem + stage2..stage5."""
+    spec = VOVNET_SPECS[body]
+    x = conv_bn_relu(x, sd, prefix + "stem.stem_1", 2, 1)
+    x = conv_bn_relu(x, sd, prefix + "stem.stem_2", 1, 1)
+    x = conv_bn_relu(x, sd, prefix + "stem.stem_3", 2, 1)
+    out = {"stem": x}
+    for si in range(4):
+        k = si + 2
+        if k != 2:  # _OSA_stage (vovnet.py:349-350)
+            x = F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True)
+        for b in range(spec["blocks"][si]):
+            mod = f"OSA{k}_{b + 1}"
+            x = osa_module(x, sd, f"{prefix}stage{k}.{mod}.", mod, spec["layers"], identity=b > 0)
+        out[f"stage{k}"] = x
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a3  FPN (d2z:modeling/backbone/fpn.py:113-154), TOP_LEVELS=0, fuse "sum", bias, no norm
+# --------------------------------------------------------------------------------------
+def fpn(feats: Mapping[str, Tensor], sd: SD, prefix: str = "backbone.",
+        in_features: Sequence[str] = ("stage3", "stage4", "stage5"),
+        stages: Sequence[int] = (3, 4, 5)) -> Dict[str, Tensor]:
+    res: Dict[str, Tensor] = {}
+    prev = None
+    for name, st in reversed(list(zip(in_features, stages))):
+        lat = F.conv2d(feats[name], sd[f"{prefix}fpn_lateral{st}.weight"], sd[f"{prefix}fpn_lateral{st}.bias"])
+        if prev is not None:
+            lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+        prev = lat
+        res[f"p{st}"] = F.conv2d(lat, sd[f"{prefix}fpn_output{st}.weight"],
+                                 sd[f"{prefix}fpn_output{st}.bias"], padding=1)
+    return {k: res[k] for k in sorted(res)}
+
+
+def backbone_fpn(x: Tensor, sd: SD, body: str = "V-19-slim-eSE") -> Dict[str, Tensor]:
+    """build_fcos_vovnet_fpn_backbone(...).forward (vovnet.py:527-555)."""
+    return fpn(vovnet(x, sd, body=body), sd)
+
+
+# --------------------------------------------------------------------------------------
+# a5  SM_Block / MLP (ref:fewx/modeling/fsod/fsod_cen.py:573-630), eval mode (dropout = id)
+# --------------------------------------------------------------------------------------
+def sm_block(x: Tensor, sd: SD, prefix: str, seg_dim: int) -> Tensor:
+    """x: [B,H,W,C] -> [B,H,W,C]."""
+    B, H, W, C = x.shape
+    S = C // seg_dim
+    h = x.reshape(B, H, W, seg_dim, S).permute(0, 3, 2, 1, 4).reshape(B, seg_dim, W, H * S)
+    h = F.linear(h, sd[prefix + "mlp_h.weight"])
+    h = h.reshape(B, seg_dim, W, H, S).permute(0, 3, 2, 1, 4).reshape(B, H, W, C)
+    w = x.reshape(B, H, W, seg_dim, S).permute(0, 3, 1, 2, 4).reshape(B, seg_dim, H, W * S)
+    w = F.linear(w, sd[prefix + "mlp_w.weight"])
+    w = w.reshape(B, seg_dim, H, W, S).permute(0, 2, 3, 1, 4).reshape(B, H, W, C)
+    a = (h + w).permute(0, 3, 1, 2).flatten(2).mean(2)
+    a = F.linear(a, sd[prefix + "reweighting.fc1.weight"], sd[prefix + "reweighting.fc1.bias"])
+    a = F.gelu(a)
+    a = F.linear(a, sd[prefix + "reweighting.fc2.weight"], sd[prefix + "reweighting.fc2.bias"])
+    a = a.reshape(B, C, 2).permute(2, 0, 1).softmax(0).unsqueeze(2).unsqueeze(2)
+    y = w * a[0] + h * a[1]
+    return F.linear(y, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
+
+
+def support_prototype(p_feat: Tensor, sd: SD, level: int) -> Tensor:
+    """Support branch for one FPN level (fsod_cen.py:216-227 train / :367-377 init_model).
+
+    p_feat [N,128,h,w] -> AdaptiveAvgPool to (32|16|8)^2 -> NHWC -> SM_Block ->
+    permute(0,3,2,1) (this swaps H and W: SURVEY Appendix C.3, preserved) -> mean over shots.
+    Returns [1,128,s,s].
+    """
+    size = {3: 32, 4: 16, 5: 8}[level]
+    x = F.adaptive_avg_pool2d(p_feat, (size, size)).permute(0, 2, 3, 1)
+    x = sm_block(x, sd, f"vip_p{level}.", size).permute(0, 3, 2, 1)
+    return x.mean(0, True)
+
+
+# --------------------------------------------------------------------------------------
+# a6  support kernels + depthwise correlation (fsod_cen.py:454-509 eval, :229-275 train)
+# --------------------------------------------------------------------------------------
+def support_kernels(s_pool: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """[1,C,s,s] -> k11 [C], k13 [C,3], k31 [C,3] (adaptive avg pools 1x1, 1x3, 3x1)."""
+    k11 = F.adaptive_avg_pool2d(s_pool, (1, 1))[0, :, 0, 0]
+    k13 = F.adaptive_avg_pool2d(s_pool, (1, 3))[0, :, 0, :]
+    k31 = F.adaptive_avg_pool2d(s_pool, (3, 1))[0, :, :, 0]
+    return k11.contiguous(), k13.contiguous(), k31.contiguous()
+
+
+def correlation(q: Tensor, s_pool: Tensor, conv3_w: Tensor, conv3_b: Tensor) -> Tensor:
+    """q [1,C,H,W], s_pool [1,C,s,s] -> relu(conv3(cat(attn, q))) [1,128,H,W]."""
+    C = q.shape[1]
+    k11 = F.adaptive_avg_pool2d(s_pool, (1, 1)).permute(1, 0, 2, 3)
+    k13 = F.adaptive_avg_pool2d(s_pool, (1, 3)).permute(1, 0, 2, 3)
+    k31 = F.adaptive_avg_pool2d(s_pool, (3, 1)).permute(1, 0, 2, 3)
+    a = F.relu(F.conv2d(q, k11, padding=(0, 0), groups=C))
+    a = F.relu(F.conv2d(a, k11, padding=(0, 0), groups=C))
+    b = F.relu(F.conv2d(q, k13, padding=(0, 1), groups=C))
+    b = F.relu(F.conv2d(b, k31, padding=(1, 0), groups=C))
+    attn = a + b + q
+    return F.relu(F.conv2d(torch.cat((attn, q), 1), conv3_w, conv3_b))
+
+
+# --------------------------------------------------------------------------------------
+# a7  CenterNetHead (ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:141-161)
+#     only_proposal=True, with_agn_hm=True, NUM_BOX_CONVS=1, NORM=GN  (log:697-715)
+# --------------------------------------------------------------------------------------
+def centernet_head(feats: Sequence[Tensor], sd: SD,
+                   prefix: str = "proposal_generator.centernet_head.") -> Tuple[List[Tensor], List[Tensor]]:
+    regs, hms = [], []
+    for l, x in enumerate(feats):
+        t = F.conv2d(x, sd[prefix + "bbox_tower.0.weight"], sd[prefix + "bbox_tower.0.bias"], padding=1)
+        t = F.group_norm(t, 32, sd[prefix + "bbox_tower.1.weight"], sd[prefix + "bbox_tower.1.bias"], eps=1e-5)
+        t = F.relu(t)
+        hms.append(F.conv2d(t, sd[prefix + "agn_hm.weight"], sd[prefix + "agn_hm.bias"], padding=1))
+        r = F.conv2d(t, sd[prefix + "bbox_pred.weight"], sd[prefix + "bbox_pred.bias"], padding=1)
+        r = r * sd[prefix + f"scales.{l}.scale"]
+        regs.append(F.relu(r))
+    return regs, hms
+
+
+# --------------------------------------------------------------------------------------
+# hot path a1..a7 in one call (eval): image -> (reg, hm) per level
+# --------------------------------------------------------------------------------------
+def eval_dense(image_chw: Tensor, sd: SD, support: Mapping[str, Tensor],
+               body: str = "V-19-slim-eSE") -> Dict[str, object]:
+    """support: {'p3': [1,128,32,32], 'p4': [1,128,16,16], 'p5': [1,128,8,8]} (cached prototypes)."""
+    x = preprocess(image_chw)
+    feats = backbone_fpn(x, sd, body)
+    pos = [correlation(feats[k], support[k], sd["conv3.weight"], sd["conv3.bias"]) for k in ("p3", "p4", "p5")]
+    regs, hms = centernet_head(pos, sd)
+    return {"features": feats, "pos_features": pos, "reg": regs, "hm": hms}
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic weights: reference initialisers + non-trivial FrozenBN statistics.
+# --------------------------------------------------------------------------------------
+def synth_state_dict(seed: int = 0, body: str = "V-19-slim-eSE", fpn_ch: int = 128) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    spec = VOVNET_SPECS[body]
+    sd: Dict[str, Tensor] = {}
+
+    def randn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    def rand(*shape, lo=0.0, hi=1.0):
+        return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+    def conv_bn(name, cin, cout, k):
+        fan_in = cin * k * k
+        sd[name + "/conv.weight"] = randn(cout, cin, k, k, std=math.sqrt(2.0 / fan_in))
+        sd[name + "/norm.weight"] = rand(cout, lo=0.5, hi=1.5)
+        sd[name + "/norm.bias"] = randn(cout, std=0.1)
+        sd[name + "/norm.running_mean"] = randn(cout, std=0.1)
+        sd[name + "/norm.running_var"] = rand(cout, lo=0.5, hi=1.5)
+
+    p = "backbone.bottom_up."
+    stem = spec["stem"]
+    conv_bn(p + "stem.stem_1", 3, stem[0], 3)
+    conv_bn(p + "stem.stem_2", stem[0], stem[1], 3)
+    conv_bn(p + "stem.stem_3", stem[1], stem[2], 3)
+    cin = stem[2]
+    for si in range(4):
+        k = si + 2
+        sc, oc = spec["conv"][si], spec["out"][si]
+        for b in range(spec["blocks"][si]):
+            mod = f"OSA{k}_{b + 1}"
+            pre = f"{p}stage{k}.{mod}."
+            c = cin
+            for i in range(spec["layers"]):
+                conv_bn(f"{pre}layers.{i}.{mod}_{i}", c, sc, 3)
+                c = sc
+            conv_bn(f"{pre}concat.{mod}_concat", cin + spec["layers"] * sc, oc, 1)
+            sd[pre + "ese.fc.weight"] = randn(oc, oc, 1, 1, std=math.sqrt(1.0 / oc))
+            sd[pre + "ese.fc.bias"] = randn(oc, std=0.5)
+            cin = oc
+    for st, c in zip((3, 4, 5), spec["out"][1:]):
+        # c2_xavier_fill = kaiming_uniform_(a=1): U(-sqrt(3/fan_in), +)
+        for nm, ci, kk in ((f"backbone.fpn_lateral{st}", c, 1), (f"backbone.fpn_output{st}", fpn_ch, 3)):
+            bound = math.sqrt(3.0 / (ci * kk * kk))
+            sd[nm + ".weight"] = rand(fpn_ch, ci, kk, kk, lo=-bound, hi=bound)
+            sd[nm + ".bias"] = randn(fpn_ch, std=0.02)
+    C = fpn_ch
+    for lvl in (3, 4, 5):
+        pre = f"vip_p{lvl}."
+        b = 1.0 / math.sqrt(C)
+        sd[pre + "mlp_h.weight"] = rand(C, C, lo=-b, hi=b)
+        sd[pre + "mlp_w.weight"] = rand(C, C, lo=-b, hi=b)
+        sd[pre + "reweighting.fc1.weight"] = rand(C // 2, C, lo=-b, hi=b)
+        sd[pre + "reweighting.fc1.bias"] = rand(C // 2, lo=-b, hi=b)
+        b2 = 1.0 / math.sqrt(C // 2)
+        sd[pre + "reweighting.fc2.weight"] = rand(2 * C, C // 2, lo=-b2, hi=b2)
+        sd[pre + "reweighting.fc2.bias"] = rand(2 * C, lo=-b2, hi=b2)
+        sd[pre + "proj.weight"] = rand(C, C, lo=-b, hi=b)
+        sd[pre + "proj.bias"] = rand(C, lo=-b, hi=b)
+    for nm, co, ci in (("conv1", C // 2, C), ("conv2", C // 2, C), ("conv3", C, 2 * C)):
+        b = 1.0 / math.sqrt(ci)
+        sd[nm + ".weight"] = rand(co, ci, 1, 1, lo=-b, hi=b)
+        sd[nm + ".bias"] = rand(co, lo=-b, hi=b)
+    h = "proposal_generator.centernet_head."
+    sd[h + "bbox_tower.0.weight"] = randn(C, C, 3, 3, std=0.01)
+    sd[h + "bbox_tower.0.bias"] = torch.zeros(C)
+    sd[h + "bbox_tower.1.weight"] = rand(C, lo=0.5, hi=1.5)
+    sd[h + "bbox_tower.1.bias"] = randn(C, std=0.1)
+    sd[h + "bbox_pred.weight"] = randn(4, C, 3, 3, std=0.01)
+    sd[h + "bbox_pred.bias"] = torch.full((4,), 8.0)
+    sd[h + "agn_hm.weight"] = randn(1, C, 3, 3, std=0.01)
+    sd[h + "agn_hm.bias"] = torch.full((1,), -math.log(99.0))
+    for l in range(3):
+        sd[h + f"scales.{l}.scale"] = torch.tensor([1.0 + 0.1 * l])
+    sd["pixel_mean"] = torch.tensor(PIXEL_MEAN).view(3, 1, 1)
+    sd["pixel_std"] = torch.tensor(PIXEL_STD).view(3, 1, 1)
+    return sd
+
+
+def synth_support(seed: int = 0, C: int = 128) -> Dict[str, Tensor]:
+    """Cached eval support prototypes: N(0,1)*0.1."""
+    g = torch.Generator().manual_seed(seed + 1000)
+    return {f"p{l}": torch.randn(1, C, s, s, generator=g) * 0.1 for l, s in ((3, 32), (4, 16), (5, 8))}
+
+
+def synth_image(seed: int = 0, h: int = 640, w: int = 640) -> Tensor:
+    """uint8 BGR CHW 'ore-like' texture: low-passed uniform noise in [40,200]."""
+    g = torch.Generator().manual_seed(seed + 2000)
+    x = torch.rand(1, 3, h // 4 + 2, w // 4 + 2, generator=g)
+    x = F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False)
+    x = x + 0.15 * (torch.rand(1, 3, h, w, generator=g) - 0.5)
+    x = (x.clamp(0, 1) * 160 + 40).round().to(torch.uint8)
+    return x[0]
