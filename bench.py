@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Faster-OreFSDet on MI355X -- headline benchmark (BASELINE.json: images/s at 640x640, 25-shot).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload at N=1 = BASELINE.json configs[1]: finetune_vovnet.yaml, 25-shot eval-only, bs=1, 640x640 synthetic image,
+cached support prototypes, random-init weights (no dataset / checkpoint exists offline).  One "step" = one pass of the
+hot path (fused preprocess + VoVNet-19-slim-eSE + FPN -> query<->support correlation ->
+CenterNet head -> sigmoid/top-k/decode/NMS) over one image that is already resident in HBM, replayed as a hipGraph.
+N>1: pure data parallel, every rank runs the same per-GPU work on its own images, no data-path collective (weak scaling);
+RCCL (backend "nccl") is used only for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     dominant kernel = the fp32 MFMA implicit-GEMM conv (k_conv_igemm): algorithmic FLOPs of all its launches in
+               one image / their summed duration, measured live with HIP events on the launch stream (eager passes after
+               the timed region), against the 157.3 TFLOP/s fp32 matrix peak of gfx950.
+  cpu_baseline the CPU oracle (oracle/: plain-PyTorch fp32 + C decode/NMS restatement of the reference) timed on this
+               box's host cores on a bounded sample of the same workload (kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "faster-orefsdet_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+def synth_image(seed, h=640, w=640):
+    """uint8 BGR CHW ore-like texture (low-passed noise in [40,200]); content does not change the work."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    x = torch.rand(1, 3, h // 4 + 2, w // 4 + 2, generator=g)
+    x = torch.nn.functional.interpolate(x, size=(h, w), mode="bilinear", align_corners=False)
+    x = x + 0.15 * (torch.rand(1, 3, h, w, generator=g) - 0.5)
+    return (x.clamp(0, 1) * 160 + 40).round().to(torch.uint8)[0]
+
+
+def build_model(device):
+    """finetune_vovnet.yaml through the fewx registry surface, reference initialisers + non-trivial FrozenBN statistics."""
+    from fewx.config import get_cfg
+    from detectron2.modeling import build_model as _build
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "faster-orefsdet_amd", "configs", "fsod", "finetune_vovnet.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(device), "INPUT.MAX_SIZE_TEST", 640])
+    cfg.freeze()
+    torch.manual_seed(0)
+    model = _build(cfg)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for name, mod in model.named_modules():
+            if type(mod).__name__ == "FrozenBatchNorm2d":
+                n = mod.num_features
+                mod.weight.copy_(torch.rand(n, generator=g) + 0.5)
+                mod.bias.copy_(torch.randn(n, generator=g) * 0.1)
+                mod.running_mean.copy_(torch.randn(n, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(n, generator=g) + 0.5)
+            elif isinstance(mod, torch.nn.Conv2d) and "bottom_up" in name and mod.bias is None:
+                torch.nn.init.kaiming_normal_(mod.weight, generator=g)
+    model.eval()
+    C = cfg.MODEL.FPN.OUT_CHANNELS
+    support = {f"p{l}": {0: torch.randn(1, C, s, s, generator=g) * 0.1} for l, s in ((3, 32), (4, 16), (5, 8))}
+    support["rcnn_8"] = {0: torch.randn(24, C, 8, 8, generator=g) * 0.1}
+    support["rcnn_4"] = {0: torch.randn(24, C, 4, 4, generator=g) * 0.1}
+    model.set_support_dict(support)
+    return model, cfg
+
+
+def cpu_baseline(model, img, budget_s=12.0):
+    """Oracle (CPU restatement of the reference) on the host cores; bounded sample of the same workload."""
+    from oracle import decode as odec
+    from oracle import ref_model as R
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    support = {k: model.support_dict[k][0].cpu() for k in ("p3", "p4", "p5")}
+
+    def one():
+        with torch.no_grad():
+            o = R.eval_dense(img, sd, support)
+        hms = [h[0, 0].numpy() for h in o["hm"]]
+        regs = [r[0].permute(1, 2, 0).contiguous().numpy() for r in o["reg"]]
+        return odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+
+    for _ in range(2):
+        one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 200:
+            break
+    return {"value": round(n / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} images of the same 640x640 bs=1 eval workload (oracle/ref_model.py + oracle/ref_decode.c, "
+                      f"torch {torch.__version__} CPU, {el:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-passes", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    device = torch.device("cuda", local_rank)
+    model, cfg = build_model(device)
+    # each rank owns its shard of images (pure data parallel); a handful of distinct images is cycled
+    imgs = [synth_image(rank * 1000 + i).to(device) for i in range(4)]
+    eng = model.engine()
+    use_graph = not args.no_graph
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_prop = int(eng.buffer("counts")[1, 0].item())
+
+    # per-image latency with a host sync after every image (the reference's inference_on_dataset protocol)
+    lat = []
+    for i in range(min(args.steps, 50)):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - a)
+    lat.sort()
+
+    roof = None
+    if rank == 0:
+        # roofline leg: eager passes with HIP events around every conv launch, on the launch stream
+        eng.set_profiling(True)
+        for i in range(3):
+            eng.eval_forward(imgs[0], use_graph=False)
+        eng.read_profile()
+        for i in range(args.profile_passes):
+            eng.eval_forward(imgs[i % len(imgs)], use_graph=False)
+        ms, fl, nl = eng.read_profile()
+        eng.set_profiling(False)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv, incl. split-K reduce)",
+                "launches_per_image": nl // max(args.profile_passes, 1),
+                "gflop_per_image": round(fl / max(args.profile_passes, 1) / 1e9, 3),
+                "kernel_ms_per_image": round(ms / max(args.profile_passes, 1), 4)}
+
+    if rank == 0:
+        total_images = args.steps * world
+        out = {
+            "metric": "images/sec at 640x640 25-shot (eval FPS, bs=1 per GPU)",
+            "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]): "
+                                   "preprocess+VoVNet-19-slim-eSE+FPN -> correlation -> CenterNet head -> top-k/NMS proposals",
+                       "parallelism": f"dp{world} (images sharded, no data-path collective)", "hipgraph": use_graph,
+                       "proposals_last_image": n_prop},
+            "latency_ms_host_sync": {"p50": round(lat[len(lat) // 2] * 1e3, 4), "min": round(lat[0] * 1e3, 4)},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, imgs[0].cpu())
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

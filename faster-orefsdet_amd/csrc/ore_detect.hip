@@ -1,0 +1,505 @@
+// Detection tail on device, no host sync: sigmoid -> threshold -> per-level top-k -> box decode ->
+// stable descending sort -> bitmask NMS -> post-NMS top-k.  Bit-exact twin of oracle/ref_decode.c:
+// every float operation is the same single IEEE binary32 op in the same order, and this
+// translation unit is compiled with -ffp-contract=off (see csrc/Makefile) so nothing is fused.
+//
+// Replaces CenterNet.inference/predict_instances/predict_single_level/nms_and_topK
+// (ref:fewx/modeling/fsod/fsod_rpn.py:1066-1210), ml_nms (ref:CenterNet2/.../layers/ml_nms.py:4-31),
+// batched_nms (d2z:layers/nms.py:10-30) and torchvision.ops.nms (un-vendored, restated).
+//
+// Kernels
+//   k_level_select  one 1024-thread block per FPN level: candidate count, exact k-th value by a
+//                   4x8-bit radix select on the sigmoid bits (wavefront ballots + LDS histogram),
+//                   ties resolved by ascending flat index through an ordered block scan, decode.
+//   k_rank_scatter  rank of every candidate by counting (score desc, concatenated index asc) with
+//                   16 lanes per candidate; scatters boxes/scores into sorted order.
+//   k_nms_mask      64x64 IoU tiles -> one 64-bit suppression word per (row, column block).
+//   k_nms_scan      one block walks the 64-row blocks in order: in-block greedy resolution on the
+//                   diagonal word (wave-uniform), then all waves OR the kept rows into the removed
+//                   set; stops early once post_topk survivors (plus score ties) are known.
+#include "ore_common.h"
+
+namespace {
+
+__device__ __forceinline__ float ore_expf(float x) {
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float e = fmaf(p, r * r, r) + 1.0f;
+    const int ni = (int)n;
+    return e * __uint_as_float((unsigned)(ni + 127) << 23);
+}
+__device__ __forceinline__ float ore_sigmoid(float x) { return 1.0f / (1.0f + ore_expf(-x)); }
+
+struct DetP {
+    int n_levels;
+    const float* head[8]; int head_ld;
+    int H[8], W[8], stride[8];
+    float score_thresh; int pre_topk; float nms_thresh; int post_topk;
+    // per-level staging (capacity pre_topk each)
+    int* lvl_cnt; float* lvl_boxes; float* lvl_scores; long long* lvl_loc;
+    // concatenated outputs
+    float* pre_boxes; float* pre_scores; long long* pre_loc; int* pre_level;
+    // sorted staging
+    float* s_boxes; float* s_scores; int* s_order;
+    unsigned long long* mask; int mask_words;
+    long long* keep_idx; int* counts; float* out_boxes; float* out_scores;
+    int cap;
+};
+
+constexpr int SEL_T = 1024;
+constexpr int NMS_MAX_WORDS = 256;  // up to 16384 candidates
+
+// block-wide exclusive scan of one int per thread (SEL_T threads); returns exclusive prefix, total via *total
+__device__ __forceinline__ int block_excl_scan(int v, int* lds_w, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds_w[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < SEL_T / 64; ++w) {
+        const int s = lds_w[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
+    __shared__ int hist[256];
+    __shared__ int wsum[SEL_T / 64];
+    __shared__ int sh_i[4];
+    const int l = blockIdx.x;
+    const int HW = p.H[l] * p.W[l];
+    const float* hd = p.head[l];
+    const int tid = threadIdx.x;
+    auto sig = [&](int i) { return ore_sigmoid(hd[(size_t)i * p.head_ld + 4]); };
+
+    // ---- candidate count
+    int cnt = 0;
+    for (int i = tid; i < HW; i += SEL_T) cnt += sig(i) > p.score_thresh ? 1 : 0;
+    int nc;
+    block_excl_scan(cnt, wsum, &nc);
+    const int k = nc < p.pre_topk ? nc : p.pre_topk;
+
+    // ---- exact k-th largest sigmoid (bits are order-preserving for positive floats)
+    unsigned T = 0;      // threshold key; select key > T, plus `quota` lowest-index elements with key == T
+    int quota = 0;
+    bool take_all = true;
+    if (nc > k) {
+        take_all = false;
+        unsigned prefix = 0, pmask = 0;
+        int remaining = k;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += SEL_T) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < HW; i += SEL_T) {
+                const float s = sig(i);
+                const unsigned key = __float_as_uint(s);
+                if (s > p.score_thresh && (key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d > 0; --d) {
+                    if (acc + hist[d] >= remaining) break;
+                    acc += hist[d];
+                }
+                sh_i[0] = d; sh_i[1] = remaining - acc;
+            }
+            __syncthreads();
+            prefix |= (unsigned)sh_i[0] << shift;
+            pmask |= 255u << shift;
+            remaining = sh_i[1];
+            __syncthreads();
+        }
+        T = prefix; quota = remaining;  // `remaining` of the elements equal to T are taken
+    }
+
+    // ---- ordered selection + decode (ascending flat index)
+    const float st = (float)p.stride[l];
+    const float half = (float)(p.stride[l] / 2);
+    int tie_base = 0, out_base = 0;
+    long long loc_base = 0;
+    for (int j = 0; j < l; ++j) loc_base += (long long)p.H[j] * p.W[j];
+    for (int i0 = 0; i0 < HW; i0 += SEL_T) {
+        const int i = i0 + tid;
+        float s = 0.f;
+        bool cand = false, gt = false, tie = false;
+        if (i < HW) {
+            s = sig(i);
+            cand = s > p.score_thresh;
+            const unsigned key = __float_as_uint(s);
+            gt = cand && (take_all || key > T);
+            tie = cand && !take_all && key == T;
+        }
+        int tie_tot, sel_tot;
+        const int tie_pre = block_excl_scan(tie ? 1 : 0, wsum, &tie_tot);
+        const bool sel = gt || (tie && tie_base + tie_pre < quota);
+        const int pos = out_base + block_excl_scan(sel ? 1 : 0, wsum, &sel_tot);
+        if (sel) {
+            const float gx = (float)((i % p.W[l]) * p.stride[l]) + half;
+            const float gy = (float)((i / p.W[l]) * p.stride[l]) + half;
+            const f32x4 r = *reinterpret_cast<const f32x4*>(hd + (size_t)i * p.head_ld);
+            const float x1 = gx - r.x * st, y1 = gy - r.y * st;
+            float x2 = gx + r.z * st, y2 = gy + r.w * st;
+            x2 = fmaxf(x2, x1 + 0.01f);
+            y2 = fmaxf(y2, y1 + 0.01f);
+            const size_t o = (size_t)l * p.pre_topk + pos;
+            *reinterpret_cast<f32x4*>(p.lvl_boxes + o * 4) = f32x4{x1, y1, x2, y2};
+            p.lvl_scores[o] = sqrtf(s);
+            p.lvl_loc[o] = loc_base + i;
+        }
+        tie_base += tie_tot;
+        out_base += sel_tot;
+    }
+    if (tid == 0) p.lvl_cnt[l] = out_base;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rank_scatter(DetP p) {
+    extern __shared__ float sc[];  // concatenated scores [n]
+    __shared__ int off[9];
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int l = 0; l < p.n_levels; ++l) { off[l] = a; a += p.lvl_cnt[l]; }
+        off[p.n_levels] = a;
+    }
+    __syncthreads();
+    const int n = off[p.n_levels];
+    if (n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.counts[0] = 0;
+        return;
+    }
+    if ((int)blockIdx.x * 16 >= n) return;
+    for (int l = 0; l < p.n_levels; ++l)
+        for (int i = threadIdx.x; i < off[l + 1] - off[l]; i += 256) sc[off[l] + i] = p.lvl_scores[(size_t)l * p.pre_topk + i];
+    __syncthreads();
+    const int e = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const bool valid = e < n;
+    const float se = valid ? sc[e] : 0.f;
+    int cntb = 0;
+    if (valid)
+        for (int f = sub; f < n; f += 16) {
+            const float sf = sc[f];
+            cntb += (sf > se || (sf == se && f < e)) ? 1 : 0;
+        }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) cntb += __shfl_xor(cntb, d);
+    if (valid && sub == 0) {
+        int l = 0;
+        while (e >= off[l + 1]) ++l;
+        const size_t src = (size_t)l * p.pre_topk + (e - off[l]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.lvl_boxes + src * 4);
+        *reinterpret_cast<f32x4*>(p.pre_boxes + (size_t)e * 4) = b;
+        p.pre_scores[e] = se;
+        p.pre_loc[e] = p.lvl_loc[src];
+        p.pre_level[e] = l;
+        *reinterpret_cast<f32x4*>(p.s_boxes + (size_t)cntb * 4) = b;
+        p.s_scores[cntb] = se;
+        p.s_order[cntb] = e;
+        if (e == 0) p.counts[0] = n;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ n_ptr,
+                                                  float thr, unsigned long long* __restrict__ mask, int words) {
+    const int n = *n_ptr;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
+    __shared__ float cb[64 * 4];
+    __shared__ float ca[64];
+    const int t = threadIdx.x;
+    const int j = bj * 64 + t;
+    if (j < n) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(boxes + (size_t)j * 4);
+        cb[t * 4 + 0] = b.x; cb[t * 4 + 1] = b.y; cb[t * 4 + 2] = b.z; cb[t * 4 + 3] = b.w;
+        ca[t] = (b.z - b.x) * (b.w - b.y);
+    }
+    __syncthreads();
+    const int i = bi * 64 + t;
+    if (i >= n) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(boxes + (size_t)i * 4);
+    const float ai = (a.z - a.x) * (a.w - a.y);
+    unsigned long long bits = 0;
+    const int jmax = min(64, n - bj * 64);
+    for (int c = 0; c < jmax; ++c) {
+        if (bj * 64 + c <= i) continue;
+        const float xx1 = fmaxf(a.x, cb[c * 4 + 0]), yy1 = fmaxf(a.y, cb[c * 4 + 1]);
+        const float xx2 = fminf(a.z, cb[c * 4 + 2]), yy2 = fminf(a.w, cb[c * 4 + 3]);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / (ai + ca[c] - inter);
+        if (ovr > thr) bits |= 1ull << c;
+    }
+    mask[(size_t)i * words + bj] = bits;
+}
+
+// One block (256 threads).  removed[] lives in LDS as 64-bit words.
+__global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
+                                                  const int* __restrict__ s_order, const int* __restrict__ n_ptr,
+                                                  const unsigned long long* __restrict__ mask, int words, float nms_thresh,
+                                                  int post_topk, long long* __restrict__ keep_idx,
+                                                  float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                  int* __restrict__ n_keep_out) {
+    __shared__ unsigned long long removed[NMS_MAX_WORDS];
+    __shared__ unsigned long long sh_kept;
+    __shared__ int cnt_sh;
+    const int n = *n_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = (n + 63) >> 6;
+    for (int w = tid; w < words; w += 256) removed[w] = 0ull;
+    if (tid == 0) cnt_sh = 0;
+    __syncthreads();
+    int n_keep = 0;       // uniform
+    float thr_score = 0.f;
+    bool have_thr = false;
+    const bool do_nms = nms_thresh > 0.0f;
+    for (int bi = 0; bi < nb; ++bi) {
+        if (wave == 0) {
+            const int row = bi * 64 + lane;
+            unsigned long long diag = (do_nms && row < n) ? mask[(size_t)row * words + bi] : 0ull;
+            unsigned long long rem = removed[bi];
+            const int nvalid = min(64, n - bi * 64);
+            if (nvalid < 64) rem |= ~0ull << nvalid;
+            if (__ballot(diag != 0ull) != 0ull) {
+                for (int t = 0; t < 64; ++t) {
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)diag, t);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), t);
+                    if (!((rem >> t) & 1ull)) rem |= ((unsigned long long)hi << 32) | lo;
+                }
+            }
+            const unsigned long long kept = ~rem;
+            if (lane == 0) sh_kept = kept;
+            // emit survivors of this block in order
+            if ((kept >> lane) & 1ull) {
+                const int pos = n_keep + __popcll(kept & ((1ull << lane) - 1ull));
+                keep_idx[pos] = (long long)s_order[row];
+                *reinterpret_cast<f32x4*>(out_boxes + (size_t)pos * 4) = *reinterpret_cast<const f32x4*>(s_boxes + (size_t)row * 4);
+                out_scores[pos] = s_scores[row];
+            }
+        }
+        __syncthreads();
+        const unsigned long long kept = sh_kept;
+        const int kc = __popcll(kept);
+        // post-NMS top-k bookkeeping (uniform across the block)
+        if (post_topk > 0 && !have_thr && n_keep + kc >= post_topk) {
+            // the post_topk-th survivor sits in this block
+            int need = post_topk - n_keep, t = 0;
+            unsigned long long m = kept;
+            while (need > 1) { m &= m - 1; --need; }
+            t = __ffsll((long long)m) - 1;
+            thr_score = s_scores[bi * 64 + t];
+            have_thr = true;
+        }
+        n_keep += kc;
+        bool stop = false;
+        if (have_thr) {
+            const int last = min(n, (bi + 1) * 64) - 1;
+            if (s_scores[last] < thr_score) stop = true;  // later rows are all below the threshold score
+        }
+        if (stop || bi + 1 >= nb) break;
+        // OR the kept rows of this block into removed[bi+1 ..]
+        if (do_nms && kept) {
+            int idx = 0;
+            unsigned long long m = kept;
+            while (m) {
+                const int t = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if ((idx & 3) == wave) {
+                    const size_t rowoff = (size_t)(bi * 64 + t) * words;
+                    for (int w = bi + 1 + lane; w < nb; w += 64) {
+                        const unsigned long long v = mask[rowoff + w];
+                        if (v) atomicOr(&removed[w], v);
+                    }
+                }
+                ++idx;
+            }
+        }
+        __syncthreads();
+    }
+    // final count: survivors with score >= thr (a prefix, the list is in descending score order)
+    __syncthreads();
+    if (have_thr) {
+        int c = 0;
+        for (int i = tid; i < n_keep; i += 256) c += out_scores[i] >= thr_score ? 1 : 0;
+        atomicAdd(&cnt_sh, c);
+        __syncthreads();
+        n_keep = cnt_sh;
+    }
+    if (tid == 0) *n_keep_out = n_keep;
+}
+
+__global__ void k_fill_upper_zero(unsigned long long* mask, size_t nwords) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nwords) mask[i] = 0ull;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct DetLayout {
+    size_t lvl_cnt, lvl_boxes, lvl_scores, lvl_loc, s_boxes, s_scores, s_order, mask, total;
+    int words;
+};
+DetLayout det_layout(int L, int P) {
+    DetLayout o{};
+    const size_t cap = (size_t)L * P;
+    size_t a = 0;
+    o.lvl_cnt = a; a = align256(a + sizeof(int) * 16);
+    o.lvl_boxes = a; a = align256(a + cap * 16);
+    o.lvl_scores = a; a = align256(a + cap * 4);
+    o.lvl_loc = a; a = align256(a + cap * 8);
+    o.s_boxes = a; a = align256(a + cap * 16);
+    o.s_scores = a; a = align256(a + cap * 4);
+    o.s_order = a; a = align256(a + cap * 4);
+    o.words = (int)((cap + 63) / 64);
+    o.mask = a; a = align256(a + cap * (size_t)o.words * 8);
+    o.total = a;
+    return o;
+}
+
+}  // namespace
+
+extern "C" size_t ore_detect_workspace_bytes(int32_t n_levels, int32_t pre_topk) {
+    if (n_levels <= 0 || pre_topk <= 0) return 0;
+    return det_layout(n_levels, pre_topk).total;
+}
+
+extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
+    ORE_CHECK_ARG(d && d->n_levels > 0 && d->n_levels <= 8 && d->pre_topk > 0, "ore_detect_fwd: bad args");
+    ORE_CHECK_ARG(d->head_ld >= 8 && d->head_ld % 4 == 0, "ore_detect_fwd: head_ld=%d (need >= 8, %%4)", d->head_ld);
+    ORE_CHECK_ARG(d->pre_boxes && d->pre_scores && d->pre_loc && d->pre_level && d->keep_idx && d->counts && d->out_boxes &&
+                      d->out_scores && d->workspace, "ore_detect_fwd: null pointer");
+    const DetLayout lay = det_layout(d->n_levels, d->pre_topk);
+    if (d->workspace_bytes < lay.total) {
+        ore_set_error("ore_detect_fwd: workspace %zu < %zu", d->workspace_bytes, lay.total);
+        return ORE_ENOMEM;
+    }
+    const int cap = d->n_levels * d->pre_topk;
+    ORE_CHECK_ARG((size_t)cap * 4 <= 150 * 1024 && lay.words <= NMS_MAX_WORDS, "ore_detect_fwd: cap %d too large", cap);
+    ORE_CHECK_ARG(d->nms_thresh > 0.0f, "ore_detect_fwd: nms_thresh <= 0 (NMS disabled) is not supported");
+    char* ws = (char*)d->workspace;
+    DetP p{};
+    p.n_levels = d->n_levels; p.head_ld = d->head_ld;
+    for (int l = 0; l < d->n_levels; ++l) {
+        ORE_CHECK_ARG(d->head[l] && d->H[l] > 0 && d->W[l] > 0 && d->stride[l] > 0, "ore_detect_fwd: level %d", l);
+        p.head[l] = d->head[l]; p.H[l] = d->H[l]; p.W[l] = d->W[l]; p.stride[l] = d->stride[l];
+    }
+    p.score_thresh = d->score_thresh; p.pre_topk = d->pre_topk; p.nms_thresh = d->nms_thresh; p.post_topk = d->post_topk;
+    p.lvl_cnt = (int*)(ws + lay.lvl_cnt); p.lvl_boxes = (float*)(ws + lay.lvl_boxes);
+    p.lvl_scores = (float*)(ws + lay.lvl_scores); p.lvl_loc = (long long*)(ws + lay.lvl_loc);
+    p.pre_boxes = d->pre_boxes; p.pre_scores = d->pre_scores; p.pre_loc = (long long*)d->pre_loc; p.pre_level = d->pre_level;
+    p.s_boxes = (float*)(ws + lay.s_boxes); p.s_scores = (float*)(ws + lay.s_scores); p.s_order = (int*)(ws + lay.s_order);
+    p.mask = (unsigned long long*)(ws + lay.mask); p.mask_words = lay.words;
+    p.keep_idx = (long long*)d->keep_idx; p.counts = d->counts; p.out_boxes = d->out_boxes; p.out_scores = d->out_scores;
+    p.cap = cap;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    hipLaunchKernelGGL(k_level_select, dim3(d->n_levels), dim3(SEL_T), 0, st, p);
+    if ((rc = ore_launch_status("k_level_select"))) return rc;
+    const size_t sc_bytes = (size_t)cap * 4;
+    if (sc_bytes > 64 * 1024)
+        ORE_HIP(hipFuncSetAttribute((const void*)k_rank_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_bytes));
+    hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(cap, 16)), dim3(256), sc_bytes, st, p);
+    if ((rc = ore_launch_status("k_rank_scatter"))) return rc;
+    if (d->nms_thresh > 0.0f) {
+        hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(64), 0, st, p.s_boxes, p.counts, d->nms_thresh, p.mask,
+                           lay.words);
+        if ((rc = ore_launch_status("k_nms_mask"))) return rc;
+    }
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), 0, st, p.s_boxes, p.s_scores, p.s_order, p.counts,
+                       p.mask, lay.words, d->nms_thresh, d->post_topk, p.keep_idx, p.out_boxes, p.out_scores, p.counts + 1);
+    return ore_launch_status("k_nms_scan");
+}
+
+// ---- stand-alone NMS (same kernels; scores sorted by the rank kernel through a 1-level DetP) -------
+namespace {
+__global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ boxes, const float* __restrict__ scores, int n,
+                                                  float* s_boxes, float* s_scores, int* s_order, int* n_out) {
+    extern __shared__ float sc[];
+    for (int i = threadIdx.x; i < n; i += 256) sc[i] = scores[i];
+    __syncthreads();
+    const int e = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const bool valid = e < n;
+    const float se = valid ? sc[e] : 0.f;
+    int c = 0;
+    if (valid)
+        for (int f = sub; f < n; f += 16) {
+            const float sf = sc[f];
+            c += (sf > se || (sf == se && f < e)) ? 1 : 0;
+        }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if (valid && sub == 0) {
+        *reinterpret_cast<f32x4*>(s_boxes + (size_t)c * 4) = *reinterpret_cast<const f32x4*>(boxes + (size_t)e * 4);
+        s_scores[c] = se;
+        s_order[c] = e;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n;
+}
+struct NmsLayout { size_t s_boxes, s_scores, s_order, n, mask, out_b, out_s, total; int words; };
+NmsLayout nms_layout(int n) {
+    NmsLayout o{};
+    const size_t cap = n > 0 ? n : 1;
+    size_t a = 0;
+    o.s_boxes = a; a = align256(a + cap * 16);
+    o.s_scores = a; a = align256(a + cap * 4);
+    o.s_order = a; a = align256(a + cap * 4);
+    o.n = a; a = align256(a + 16);
+    o.words = (int)((cap + 63) / 64);
+    o.mask = a; a = align256(a + cap * (size_t)o.words * 8);
+    o.out_b = a; a = align256(a + cap * 16);
+    o.out_s = a; a = align256(a + cap * 4);
+    o.total = a;
+    return o;
+}
+}  // namespace
+
+extern "C" size_t ore_nms_workspace_bytes(int32_t n) { return nms_layout(n).total; }
+
+extern "C" int ore_nms_fwd(const float* boxes, const float* scores, int32_t n, float thr, int64_t* keep_idx, int32_t* count,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    ORE_CHECK_ARG(keep_idx && count && workspace && n >= 0, "ore_nms_fwd: bad args");
+    const NmsLayout lay = nms_layout(n);
+    if (workspace_bytes < lay.total) {
+        ore_set_error("ore_nms_fwd: workspace %zu < %zu", workspace_bytes, lay.total);
+        return ORE_ENOMEM;
+    }
+    ORE_CHECK_ARG((size_t)n * 4 <= 150 * 1024 && lay.words <= NMS_MAX_WORDS, "ore_nms_fwd: n=%d too large", n);
+    ORE_CHECK_ARG(thr > 0.0f, "ore_nms_fwd: thr must be > 0");
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    float* s_boxes = (float*)(ws + lay.s_boxes); float* s_scores = (float*)(ws + lay.s_scores);
+    int* s_order = (int*)(ws + lay.s_order); int* n_dev = (int*)(ws + lay.n);
+    unsigned long long* mask = (unsigned long long*)(ws + lay.mask);
+    int rc;
+    const size_t sc_bytes = (size_t)(n > 0 ? n : 1) * 4;
+    if (sc_bytes > 64 * 1024)
+        ORE_HIP(hipFuncSetAttribute((const void*)k_nms_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_bytes));
+    hipLaunchKernelGGL(k_nms_prep, dim3(ceil_div(n > 0 ? n : 1, 16)), dim3(256), sc_bytes, st, boxes, scores, n, s_boxes,
+                       s_scores, s_order, n_dev);
+    if ((rc = ore_launch_status("k_nms_prep"))) return rc;
+    if (thr > 0.0f && n > 0) {
+        hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(64), 0, st, s_boxes, n_dev, thr, mask, lay.words);
+        if ((rc = ore_launch_status("k_nms_mask"))) return rc;
+    }
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), 0, st, s_boxes, s_scores, s_order, n_dev, mask,
+                       lay.words, thr, 0, (long long*)keep_idx, (float*)(ws + lay.out_b), (float*)(ws + lay.out_s), count);
+    return ore_launch_status("k_nms_scan");
+}

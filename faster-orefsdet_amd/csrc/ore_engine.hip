@@ -1,0 +1,582 @@
+// ore_engine: owns packed weights + every intermediate NHWC buffer of the eval hot path and enqueues
+// the whole layer sequence (optionally as one replayed hipGraph):
+//
+//   image -> stem_1 (fused preprocess) -> stem_2 -> stem_3 -> 4 x OSA stage [maxpool(gated) ->
+//   3 x conv3x3 writing channel slices of ONE concat buffer -> 1x1 concat conv -> eSE gate] ->
+//   FPN (gate folded into the lateral 1x1, top-down add in its epilogue) -> depthwise correlation ->
+//   shared 1x1 conv3 over [attn|q] -> CenterNet tower conv -> GroupNorm stats -> fused (reg|hm) conv
+//   with GN+ReLU on its input -> sigmoid/top-k/decode/NMS.
+//
+// The OSA concat, the eSE product, the FPN upsample+add, torch.cat((attn,q)) and the GroupNorm output
+// are never materialised.  Reference call sites: include/ore_hip.h.
+#include <map>
+#include <string>
+#include <vector>
+#include <math.h>
+#include <string.h>
+#include "ore_common.h"
+
+extern "C" int ore_conv_plan(int M, int Cout, int nchunks, int req_splitk, int* BM, int* BN, int* S, int* cps);
+
+namespace {
+
+struct HostTensor { std::vector<float> v; std::vector<int64_t> shape; };
+
+struct Conv {
+    float* w = nullptr; float* scale = nullptr; float* shift = nullptr;
+    int Cin = 0, Cout = 0, k = 1, stride = 1, pad = 0, relu_cout = 0;
+};
+
+struct Buf { float* p = nullptr; int ld = 0; size_t rows = 0; };
+
+struct Geo { int B, H, W, Hp, Wp; int h[6], w[6]; };  // h[1]=Hp/2 (stem), h[2]=Hp/4 ... h[5]=Hp/32
+
+}  // namespace
+
+struct ore_engine {
+    ore_model_cfg cfg{};
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> allocs;
+    // weights
+    float* stem1_w = nullptr; float* stem1_scale = nullptr; float* stem1_shift = nullptr;
+    Conv stem2, stem3;
+    struct Stage { Conv layer[8]; Conv concat; float* fc_w = nullptr; float* fc_b = nullptr; int in_ch, conv_ch, out_ch, cat_ch; } stage[4];
+    Conv lateral[3], output[3], conv3, tower, pred[3];
+    float* gn_gamma = nullptr; float* gn_beta = nullptr;
+    float* k11[3] = {}, *k13[3] = {}, *k31[3] = {};
+    HostTensor support[3];
+    bool support_set[3] = {false, false, false};
+    // buffers
+    void* img_in = nullptr; size_t img_bytes = 0;
+    Buf s1, s2, cat[4], sout[4], lat[3], pcat[3], pos[3], tow[3], head[3];
+    float* gate[4] = {};
+    float* gn_mul[3] = {}, *gn_add[3] = {};
+    float* ws = nullptr; size_t ws_floats = 0;
+    float* ese_ws = nullptr;
+    // detect
+    float* pre_boxes = nullptr; float* pre_scores = nullptr; int64_t* pre_loc = nullptr; int32_t* pre_level = nullptr;
+    int64_t* keep_idx = nullptr; int32_t* counts = nullptr; float* out_boxes = nullptr; float* out_scores = nullptr;
+    void* det_ws = nullptr; size_t det_ws_bytes = 0;
+    // graph cache
+    hipStream_t cap_stream = nullptr;
+    struct GraphKey { int u8, H, W; hipGraphExec_t exec; };
+    std::vector<GraphKey> graphs;
+    Geo last{};
+    double last_flops = 0.0;
+    // optional per-launch HIP-event timing of the conv kernels (eager mode only; bench.py roofline leg)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct EvSpan { size_t a, b; double flops; };
+    std::vector<EvSpan> spans;
+    hipEvent_t next_event() {
+        if (ev_used == ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev_pool.push_back(e); }
+        return ev_pool[ev_used++];
+    }
+
+    template <typename T> int dalloc(T** p, size_t n) {
+        void* q = nullptr;
+        ORE_HIP(hipMalloc(&q, (n ? n : 1) * sizeof(T)));
+        allocs.push_back(q);
+        *p = (T*)q;
+        return ORE_OK;
+    }
+    int upload(float** dst, const std::vector<float>& v) {
+        int rc = dalloc(dst, v.size());
+        if (rc) return rc;
+        ORE_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return ORE_OK;
+    }
+    const HostTensor* get(const std::string& n) const {
+        auto it = host.find(n);
+        return it == host.end() ? nullptr : &it->second;
+    }
+};
+
+namespace {
+
+int need(const ore_engine* e, const std::string& name, const HostTensor** out, std::vector<int64_t> shape) {
+    const HostTensor* t = e->get(name);
+    if (!t) { ore_set_error("missing tensor '%s'", name.c_str()); return ORE_ENOENT; }
+    if (!shape.empty() && t->shape != shape) {
+        std::string a, b;
+        for (auto d : t->shape) a += std::to_string(d) + ",";
+        for (auto d : shape) b += std::to_string(d) + ",";
+        ore_set_error("tensor '%s' has shape [%s], expected [%s]", name.c_str(), a.c_str(), b.c_str());
+        return ORE_EINVAL;
+    }
+    *out = t;
+    return ORE_OK;
+}
+
+// conv (no bias) + FrozenBN folded to (scale, shift) applied in the epilogue; weights stay unscaled.
+int make_conv_bn(ore_engine* e, const std::string& name, int Cin, int Cout, int k, int stride, Conv* c) {
+    const HostTensor *w, *g, *b, *m, *v;
+    int rc;
+    if ((rc = need(e, name + "/conv.weight", &w, {Cout, Cin, k, k}))) return rc;
+    if ((rc = need(e, name + "/norm.weight", &g, {Cout}))) return rc;
+    if ((rc = need(e, name + "/norm.bias", &b, {Cout}))) return rc;
+    if ((rc = need(e, name + "/norm.running_mean", &m, {Cout}))) return rc;
+    if ((rc = need(e, name + "/norm.running_var", &v, {Cout}))) return rc;
+    std::vector<float> packed(ore_packed_weight_floats(Cout, Cin, k, k));
+    ore_pack_conv_weight_host(w->v.data(), Cout, Cin, k, k, packed.data());
+    std::vector<float> sc(Cout), sh(Cout);
+    for (int n = 0; n < Cout; ++n) {  // d2z:layers/batch_norm.py:48-49
+        sc[n] = g->v[n] * (1.0f / sqrtf(v->v[n] + 1e-5f));
+        sh[n] = b->v[n] - m->v[n] * sc[n];
+    }
+    if ((rc = e->upload(&c->w, packed))) return rc;
+    if ((rc = e->upload(&c->scale, sc))) return rc;
+    if ((rc = e->upload(&c->shift, sh))) return rc;
+    c->Cin = Cin; c->Cout = Cout; c->k = k; c->stride = stride; c->pad = k / 2; c->relu_cout = Cout;
+    return ORE_OK;
+}
+
+int make_conv_bias(ore_engine* e, const std::string& name, int Cin, int Cout, int k, int relu, Conv* c) {
+    const HostTensor *w, *b;
+    int rc;
+    if ((rc = need(e, name + ".weight", &w, {Cout, Cin, k, k}))) return rc;
+    if ((rc = need(e, name + ".bias", &b, {Cout}))) return rc;
+    std::vector<float> packed(ore_packed_weight_floats(Cout, Cin, k, k));
+    ore_pack_conv_weight_host(w->v.data(), Cout, Cin, k, k, packed.data());
+    if ((rc = e->upload(&c->w, packed))) return rc;
+    if ((rc = e->upload(&c->shift, b->v))) return rc;
+    c->scale = nullptr;
+    c->Cin = Cin; c->Cout = Cout; c->k = k; c->stride = 1; c->pad = k / 2; c->relu_cout = relu ? Cout : 0;
+    return ORE_OK;
+}
+
+int alloc_buf(ore_engine* e, Buf* b, size_t rows, int ld) {
+    b->ld = ld; b->rows = rows;
+    return e->dalloc(&b->p, rows * ld);
+}
+
+int pool_out(int n) { int o = (n - 3 + 1) / 2 + 1; if (n < 3) o = 1; if ((o - 1) * 2 >= n) --o; return o < 1 ? 1 : o; }
+
+Geo make_geo(int B, int H, int W) {
+    Geo g{};
+    g.B = B; g.H = H; g.W = W;
+    g.Hp = round_up(H, 32); g.Wp = round_up(W, 32);
+    g.h[1] = g.Hp / 2; g.w[1] = g.Wp / 2;
+    g.h[2] = (g.h[1] - 1) / 2 + 1; g.w[2] = (g.w[1] - 1) / 2 + 1;  // stem_3: 3x3 s2 p1
+    for (int k = 3; k <= 5; ++k) { g.h[k] = pool_out(g.h[k - 1]); g.w[k] = pool_out(g.w[k - 1]); }
+    return g;
+}
+
+struct Run {
+    ore_engine* e; hipStream_t st; double flops = 0.0; int rc = ORE_OK; bool prof = false;
+    void conv(const Conv& c, const float* in, int in_ld, int in_coff, int B, int H, int W, float* out, int out_ld,
+              int out_coff, const float* in_mul = nullptr, const float* in_add = nullptr, int in_relu = 0,
+              const float* add = nullptr, int add_ld = 0, int add_coff = 0) {
+        if (rc) return;
+        ore_conv_desc d{};
+        d.in = in; d.in_ld = in_ld; d.in_coff = in_coff; d.B = B; d.H = H; d.W = W; d.Cin = c.Cin;
+        d.w = c.w; d.Cout = c.Cout; d.kh = d.kw = c.k; d.stride = c.stride; d.pad = c.pad;
+        d.scale = c.scale; d.shift = c.shift; d.relu_cout = c.relu_cout;
+        d.in_mul = in_mul; d.in_add = in_add; d.in_relu = in_relu;
+        d.add = add; d.add_ld = add_ld; d.add_coff = add_coff;
+        d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
+        d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
+        const int Ho = (H + 2 * c.pad - c.k) / c.stride + 1, Wo = (W + 2 * c.pad - c.k) / c.stride + 1;
+        const double fl = 2.0 * B * Ho * Wo * (double)c.Cout * c.Cin * c.k * c.k;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        size_t ia = 0;
+        if (prof) { ia = e->ev_used; ea = e->next_event(); eb = e->next_event(); if (ea) (void)hipEventRecord(ea, st); }
+        rc = ore_conv2d_fwd(&d, st);
+        if (prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl}); }
+        flops += fl;
+    }
+};
+
+int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStream_t st, double* flops) {
+    const ore_model_cfg& c = e->cfg;
+    Run r{e, st};
+    r.prof = e->profiling;
+    int rc = ore_stem1_fwd(img, is_u8, g.B, g.H, g.W, g.Hp, g.Wp, c.pixel_mean, c.pixel_std, e->stem1_w, e->stem1_scale,
+                           e->stem1_shift, c.stem_ch[0], e->s1.p, e->s1.ld, 0, st);
+    if (rc) return rc;
+    r.flops += 2.0 * g.B * g.h[1] * g.w[1] * 27.0 * c.stem_ch[0];
+    r.conv(e->stem2, e->s1.p, e->s1.ld, 0, g.B, g.h[1], g.w[1], e->s2.p, e->s2.ld, 0);
+    r.conv(e->stem3, e->s2.p, e->s2.ld, 0, g.B, g.h[1], g.w[1], e->cat[0].p, e->cat[0].ld, 0);
+    for (int s = 0; s < 4 && !r.rc; ++s) {
+        auto& S = e->stage[s];
+        const int k = s + 2;
+        Buf& cat = e->cat[s];
+        if (s > 0) {
+            r.rc = ore_maxpool3x3s2_fwd(e->sout[s - 1].p, e->sout[s - 1].ld, 0, g.B, g.h[k - 1], g.w[k - 1], S.in_ch,
+                                        e->gate[s - 1], cat.p, cat.ld, 0, st);
+            if (r.rc) break;
+        }
+        int src = 0, dst = S.in_ch;
+        for (int i = 0; i < c.layers_per_block; ++i) {
+            r.conv(S.layer[i], cat.p, cat.ld, src, g.B, g.h[k], g.w[k], cat.p, cat.ld, dst);
+            src = dst; dst += S.conv_ch;
+        }
+        r.conv(S.concat, cat.p, cat.ld, 0, g.B, g.h[k], g.w[k], e->sout[s].p, e->sout[s].ld, 0);
+        if (r.rc) break;
+        r.rc = ore_ese_gate_fwd(e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s],
+                                e->ese_ws, st);
+    }
+    // FPN top-down: level index 2 = p5, 1 = p4, 0 = p3; outputs land in the q half of pcat
+    const int F = c.fpn_ch;
+    for (int l = 2; l >= 0 && !r.rc; --l) {
+        const int k = l + 3, s = l + 1;
+        const float* add = l < 2 ? e->lat[l + 1].p : nullptr;
+        r.conv(e->lateral[l], e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, e->gate[s], nullptr, 0,
+               add, F, 0);
+        r.conv(e->output[l], e->lat[l].p, F, 0, g.B, g.h[k], g.w[k], e->pcat[l].p, 2 * F, F);
+    }
+    *flops = r.flops;
+    return r.rc;
+}
+
+int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
+    const ore_model_cfg& c = e->cfg;
+    const int F = c.fpn_ch;
+    Run r{e, st};
+    r.prof = e->profiling;
+    for (int l = 0; l < 3 && !r.rc; ++l) {
+        const int k = l + 3, H = g.h[k], W = g.w[k];
+        if (!e->support_set[l]) { ore_set_error("support prototype for level %d not set", k); return ORE_EINVAL; }
+        r.rc = ore_correlation_fwd(e->pcat[l].p, 2 * F, F, g.B, H, W, F, e->k11[l], e->k13[l], e->k31[l], e->pcat[l].p, 2 * F, 0, st);
+        if (r.rc) break;
+        r.flops += 2.0 * 8.0 * g.B * H * W * F;
+        r.conv(e->conv3, e->pcat[l].p, 2 * F, 0, g.B, H, W, e->pos[l].p, F, 0);
+        r.conv(e->tower, e->pos[l].p, F, 0, g.B, H, W, e->tow[l].p, F, 0);
+        if (r.rc) break;
+        r.rc = ore_groupnorm_affine_fwd(e->tow[l].p, F, 0, g.B, H * W, F, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->gn_mul[l],
+                                        e->gn_add[l], st);
+        if (r.rc) break;
+        r.conv(e->pred[l], e->tow[l].p, F, 0, g.B, H, W, e->head[l].p, 8, 0, e->gn_mul[l], e->gn_add[l], 1);
+    }
+    *flops = r.flops;
+    return r.rc;
+}
+
+int run_detect(ore_engine* e, const Geo& g, hipStream_t st) {
+    const ore_model_cfg& c = e->cfg;
+    ore_detect_desc d{};
+    d.n_levels = 3; d.head_ld = 8;
+    for (int l = 0; l < 3; ++l) { d.head[l] = e->head[l].p; d.H[l] = g.h[l + 3]; d.W[l] = g.w[l + 3]; d.stride[l] = c.strides[l]; }
+    d.score_thresh = c.score_thresh; d.pre_topk = c.pre_topk; d.nms_thresh = c.nms_thresh; d.post_topk = c.post_topk;
+    d.pre_boxes = e->pre_boxes; d.pre_scores = e->pre_scores; d.pre_loc = e->pre_loc; d.pre_level = e->pre_level;
+    d.keep_idx = e->keep_idx; d.counts = e->counts; d.out_boxes = e->out_boxes; d.out_scores = e->out_scores;
+    d.workspace = e->det_ws; d.workspace_bytes = e->det_ws_bytes;
+    return ore_detect_fwd(&d, st);
+}
+
+}  // namespace
+
+extern "C" int ore_engine_create(const ore_model_cfg* cfg, int32_t device, ore_engine** out) {
+    ORE_CHECK_ARG(cfg && out, "ore_engine_create: null");
+    ORE_CHECK_ARG(cfg->layers_per_block >= 1 && cfg->layers_per_block <= 8, "layers_per_block");
+    ORE_CHECK_ARG(cfg->fpn_ch % 16 == 0 && cfg->max_batch >= 1 && cfg->max_h >= 32 && cfg->max_w >= 32, "bad cfg");
+    for (int i = 0; i < 3; ++i) ORE_CHECK_ARG(cfg->stem_ch[i] % 16 == 0, "stem channels must be multiples of 16");
+    for (int i = 0; i < 4; ++i)
+        ORE_CHECK_ARG(cfg->stage_conv_ch[i] % 16 == 0 && cfg->stage_out_ch[i] % 16 == 0, "stage channels must be multiples of 16");
+    ORE_HIP(hipSetDevice(device));
+    ore_engine* e = new ore_engine();
+    e->cfg = *cfg; e->device = device;
+    *out = e;
+    return ORE_OK;
+}
+
+extern "C" void ore_engine_destroy(ore_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    for (auto& g : e->graphs) hipGraphExecDestroy(g.exec);
+    if (e->cap_stream) hipStreamDestroy(e->cap_stream);
+    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    for (void* p : e->allocs) hipFree(p);
+    delete e;
+}
+
+extern "C" int ore_engine_set_tensor(ore_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    ORE_CHECK_ARG(e && name && data && ndim >= 0 && ndim <= 8, "ore_engine_set_tensor: bad args");
+    ORE_CHECK_ARG(!e->finalized, "ore_engine_set_tensor: engine already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.v.assign(data, data + n);
+    e->host[name] = std::move(t);
+    return ORE_OK;
+}
+
+extern "C" int ore_engine_set_support(ore_engine* e, int32_t level, const float* proto, int32_t C, int32_t s) {
+    ORE_CHECK_ARG(e && proto && level >= 3 && level <= 5 && C == e->cfg.fpn_ch && s >= 1, "ore_engine_set_support: bad args");
+    const int l = level - 3;
+    e->support[l].v.assign(proto, proto + (size_t)C * s * s);
+    e->support[l].shape = {C, s, s};
+    if (e->finalized) {
+        ORE_HIP(hipSetDevice(e->device));
+        float* tmp = nullptr;
+        ORE_HIP(hipMalloc((void**)&tmp, (size_t)C * s * s * sizeof(float)));
+        hipError_t err = hipMemcpy(tmp, proto, (size_t)C * s * s * sizeof(float), hipMemcpyHostToDevice);
+        int rc = err == hipSuccess ? ore_support_kernels_fwd(tmp, C, s, e->k11[l], e->k13[l], e->k31[l], nullptr) : ORE_EHIP;
+        hipDeviceSynchronize();
+        hipFree(tmp);
+        if (rc) return rc;
+    }
+    e->support_set[l] = true;
+    return ORE_OK;
+}
+
+extern "C" int ore_engine_finalize(ore_engine* e) {
+    ORE_CHECK_ARG(e && !e->finalized, "ore_engine_finalize: bad state");
+    ORE_HIP(hipSetDevice(e->device));
+    const ore_model_cfg& c = e->cfg;
+    int rc;
+    const std::string bu = "backbone.bottom_up.";
+    {   // stem_1 stays OIHW-flat [Cout][27]
+        const HostTensor *w, *g, *b, *m, *v;
+        const int C0 = c.stem_ch[0];
+        if ((rc = need(e, bu + "stem.stem_1/conv.weight", &w, {C0, 3, 3, 3}))) return rc;
+        if ((rc = need(e, bu + "stem.stem_1/norm.weight", &g, {C0}))) return rc;
+        if ((rc = need(e, bu + "stem.stem_1/norm.bias", &b, {C0}))) return rc;
+        if ((rc = need(e, bu + "stem.stem_1/norm.running_mean", &m, {C0}))) return rc;
+        if ((rc = need(e, bu + "stem.stem_1/norm.running_var", &v, {C0}))) return rc;
+        std::vector<float> sc(C0), sh(C0);
+        for (int n = 0; n < C0; ++n) { sc[n] = g->v[n] * (1.0f / sqrtf(v->v[n] + 1e-5f)); sh[n] = b->v[n] - m->v[n] * sc[n]; }
+        if ((rc = e->upload(&e->stem1_w, w->v)) || (rc = e->upload(&e->stem1_scale, sc)) || (rc = e->upload(&e->stem1_shift, sh))) return rc;
+    }
+    if ((rc = make_conv_bn(e, bu + "stem.stem_2", c.stem_ch[0], c.stem_ch[1], 3, 1, &e->stem2))) return rc;
+    if ((rc = make_conv_bn(e, bu + "stem.stem_3", c.stem_ch[1], c.stem_ch[2], 3, 2, &e->stem3))) return rc;
+    int cin = c.stem_ch[2];
+    for (int s = 0; s < 4; ++s) {
+        auto& S = e->stage[s];
+        const int k = s + 2;
+        const std::string mod = "OSA" + std::to_string(k) + "_1";
+        const std::string pre = bu + "stage" + std::to_string(k) + "." + mod + ".";
+        S.in_ch = cin; S.conv_ch = c.stage_conv_ch[s]; S.out_ch = c.stage_out_ch[s];
+        S.cat_ch = cin + c.layers_per_block * S.conv_ch;
+        int ci = cin;
+        for (int i = 0; i < c.layers_per_block; ++i) {
+            if ((rc = make_conv_bn(e, pre + "layers." + std::to_string(i) + "." + mod + "_" + std::to_string(i), ci, S.conv_ch, 3, 1, &S.layer[i]))) return rc;
+            ci = S.conv_ch;
+        }
+        if ((rc = make_conv_bn(e, pre + "concat." + mod + "_concat", S.cat_ch, S.out_ch, 1, 1, &S.concat))) return rc;
+        const HostTensor *fw, *fb;
+        if ((rc = need(e, pre + "ese.fc.weight", &fw, {S.out_ch, S.out_ch, 1, 1}))) return rc;
+        if ((rc = need(e, pre + "ese.fc.bias", &fb, {S.out_ch}))) return rc;
+        if ((rc = e->upload(&S.fc_w, fw->v)) || (rc = e->upload(&S.fc_b, fb->v))) return rc;
+        cin = S.out_ch;
+    }
+    const int F = c.fpn_ch;
+    for (int l = 0; l < 3; ++l) {
+        const std::string st = std::to_string(l + 3);
+        if ((rc = make_conv_bias(e, "backbone.fpn_lateral" + st, c.stage_out_ch[l + 1], F, 1, 0, &e->lateral[l]))) return rc;
+        if ((rc = make_conv_bias(e, "backbone.fpn_output" + st, F, F, 3, 0, &e->output[l]))) return rc;
+    }
+    if ((rc = make_conv_bias(e, "conv3", 2 * F, F, 1, 1, &e->conv3))) return rc;
+    const std::string hp = "proposal_generator.centernet_head.";
+    if ((rc = make_conv_bias(e, hp + "bbox_tower.0", F, F, 3, 0, &e->tower))) return rc;
+    {
+        const HostTensor *g, *b, *wr, *br, *wh, *bh;
+        if ((rc = need(e, hp + "bbox_tower.1.weight", &g, {F})) || (rc = need(e, hp + "bbox_tower.1.bias", &b, {F}))) return rc;
+        if ((rc = e->upload(&e->gn_gamma, g->v)) || (rc = e->upload(&e->gn_beta, b->v))) return rc;
+        if ((rc = need(e, hp + "bbox_pred.weight", &wr, {4, F, 3, 3})) || (rc = need(e, hp + "bbox_pred.bias", &br, {4}))) return rc;
+        if ((rc = need(e, hp + "agn_hm.weight", &wh, {1, F, 3, 3})) || (rc = need(e, hp + "agn_hm.bias", &bh, {1}))) return rc;
+        std::vector<float> w5(wr->v);
+        w5.insert(w5.end(), wh->v.begin(), wh->v.end());
+        std::vector<float> packed(ore_packed_weight_floats(5, F, 3, 3));
+        ore_pack_conv_weight_host(w5.data(), 5, F, 3, 3, packed.data());
+        float* wdev = nullptr;
+        if ((rc = e->upload(&wdev, packed))) return rc;
+        for (int l = 0; l < 3; ++l) {
+            const HostTensor* sc;
+            if ((rc = need(e, hp + "scales." + std::to_string(l) + ".scale", &sc, {1}))) return rc;
+            const float s = sc->v[0];
+            // reg = relu(scale_l * (conv + bias)); hm = conv + bias   (centernet_head.py:150-159)
+            std::vector<float> scale = {s, s, s, s, 1.0f}, shift = {br->v[0] * s, br->v[1] * s, br->v[2] * s, br->v[3] * s, bh->v[0]};
+            Conv& p = e->pred[l];
+            p.w = wdev; p.Cin = F; p.Cout = 5; p.k = 3; p.stride = 1; p.pad = 1; p.relu_cout = 4;
+            if ((rc = e->upload(&p.scale, scale)) || (rc = e->upload(&p.shift, shift))) return rc;
+        }
+    }
+    // ---- buffers for the largest padded geometry
+    const Geo g = make_geo(c.max_batch, c.max_h, c.max_w);
+    const size_t B = g.B;
+    e->img_bytes = B * 3 * (size_t)c.max_h * c.max_w * sizeof(float);
+    ORE_HIP(hipMalloc(&e->img_in, e->img_bytes));
+    e->allocs.push_back(e->img_in);
+    if ((rc = alloc_buf(e, &e->s1, B * g.h[1] * g.w[1], c.stem_ch[0]))) return rc;
+    if ((rc = alloc_buf(e, &e->s2, B * g.h[1] * g.w[1], c.stem_ch[1]))) return rc;
+    size_t ws_need = 0, cmax = 0;
+    auto plan = [&](size_t M, const Conv& cv) {
+        int BM, BN, S, cps;
+        ore_conv_plan((int)M, cv.Cout, cv.k * cv.k * cv.Cin / 16, 0, &BM, &BN, &S, &cps);
+        if (S > 1) { const size_t n = (size_t)S * M * round_up(cv.Cout, 16); if (n > ws_need) ws_need = n; }
+    };
+    plan(B * g.h[1] * g.w[1], e->stem2);
+    plan(B * g.h[2] * g.w[2], e->stem3);
+    for (int s = 0; s < 4; ++s) {
+        const int k = s + 2;
+        const size_t M = B * g.h[k] * g.w[k];
+        if ((rc = alloc_buf(e, &e->cat[s], M, e->stage[s].cat_ch))) return rc;
+        if ((rc = alloc_buf(e, &e->sout[s], M, e->stage[s].out_ch))) return rc;
+        if ((rc = e->dalloc(&e->gate[s], B * e->stage[s].out_ch))) return rc;
+        for (int i = 0; i < c.layers_per_block; ++i) plan(M, e->stage[s].layer[i]);
+        plan(M, e->stage[s].concat);
+        if ((size_t)e->stage[s].out_ch > cmax) cmax = e->stage[s].out_ch;
+    }
+    for (int l = 0; l < 3; ++l) {
+        const int k = l + 3;
+        const size_t M = B * g.h[k] * g.w[k];
+        if ((rc = alloc_buf(e, &e->lat[l], M, F)) || (rc = alloc_buf(e, &e->pcat[l], M, 2 * F)) || (rc = alloc_buf(e, &e->pos[l], M, F)) ||
+            (rc = alloc_buf(e, &e->tow[l], M, F)) || (rc = alloc_buf(e, &e->head[l], M, 8))) return rc;
+        if ((rc = e->dalloc(&e->gn_mul[l], B * F)) || (rc = e->dalloc(&e->gn_add[l], B * F))) return rc;
+        if ((rc = e->dalloc(&e->k11[l], (size_t)F)) || (rc = e->dalloc(&e->k13[l], (size_t)F * 3)) || (rc = e->dalloc(&e->k31[l], (size_t)F * 3))) return rc;
+        plan(M, e->lateral[l]); plan(M, e->output[l]); plan(M, e->conv3); plan(M, e->tower); plan(M, e->pred[l]);
+        ORE_HIP(hipMemset(e->head[l].p, 0, M * 8 * sizeof(float)));
+    }
+    if (ws_need < ((size_t)8 << 20)) ws_need = (size_t)8 << 20;  // smaller inputs may split deeper
+    e->ws_floats = ws_need;
+    if ((rc = e->dalloc(&e->ws, ws_need))) return rc;
+    if ((rc = e->dalloc(&e->ese_ws, B * ORE_ESE_PARTS * cmax))) return rc;
+    const size_t cap = (size_t)3 * c.pre_topk;
+    if ((rc = e->dalloc(&e->pre_boxes, cap * 4)) || (rc = e->dalloc(&e->pre_scores, cap)) || (rc = e->dalloc(&e->pre_loc, cap)) ||
+        (rc = e->dalloc(&e->pre_level, cap)) || (rc = e->dalloc(&e->keep_idx, cap)) || (rc = e->dalloc(&e->counts, (size_t)4)) ||
+        (rc = e->dalloc(&e->out_boxes, cap * 4)) || (rc = e->dalloc(&e->out_scores, cap))) return rc;
+    ORE_HIP(hipMemset(e->counts, 0, 4 * sizeof(int32_t)));
+    e->det_ws_bytes = ore_detect_workspace_bytes(3, c.pre_topk);
+    char* dws = nullptr;
+    if ((rc = e->dalloc(&dws, e->det_ws_bytes))) return rc;
+    e->det_ws = dws;
+    ORE_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    e->finalized = true;
+    for (int l = 0; l < 3; ++l)
+        if (!e->support[l].v.empty()) {
+            e->support_set[l] = false;
+            if ((rc = ore_engine_set_support(e, l + 3, e->support[l].v.data(), (int)e->support[l].shape[0], (int)e->support[l].shape[1]))) return rc;
+        }
+    e->host.clear();
+    ORE_HIP(hipDeviceSynchronize());
+    return ORE_OK;
+}
+
+static int check_geo(ore_engine* e, int B, int H, int W) {
+    ORE_CHECK_ARG(e && e->finalized, "engine not finalized");
+    ORE_CHECK_ARG(B >= 1 && B <= e->cfg.max_batch && H >= 1 && W >= 1 && round_up(H, 32) <= round_up(e->cfg.max_h, 32) &&
+                      round_up(W, 32) <= round_up(e->cfg.max_w, 32) &&
+                      (size_t)B * round_up(H, 32) * round_up(W, 32) <= (size_t)e->cfg.max_batch * round_up(e->cfg.max_h, 32) * round_up(e->cfg.max_w, 32),
+                  "input %dx%dx%d exceeds the engine's max %dx%dx%d", B, H, W, e->cfg.max_batch, e->cfg.max_h, e->cfg.max_w);
+    return ORE_OK;
+}
+
+extern "C" int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t B, int32_t H, int32_t W, void* stream) {
+    int rc = check_geo(e, B, H, W);
+    if (rc) return rc;
+    ORE_CHECK_ARG(img, "null image");
+    const Geo g = make_geo(B, H, W);
+    e->last = g;
+    return run_backbone(e, img, is_u8, g, (hipStream_t)stream, &e->last_flops);
+}
+
+extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t H, int32_t W, int32_t use_graph,
+                                   void* stream) {
+    int rc = check_geo(e, 1, H, W);
+    if (rc) return rc;
+    ORE_CHECK_ARG(img, "null image");
+    hipStream_t st = (hipStream_t)stream;
+    const Geo g = make_geo(1, H, W);
+    e->last = g;
+    const size_t bytes = (size_t)3 * H * W * (is_u8 ? 1 : 4);
+    ORE_HIP(hipMemcpyAsync(e->img_in, img, bytes, hipMemcpyDeviceToDevice, st));
+    auto body = [&](hipStream_t s, double* fl) -> int {
+        double f1 = 0, f2 = 0;
+        int r = run_backbone(e, e->img_in, is_u8, g, s, &f1);
+        if (!r) r = run_heads(e, g, s, &f2);
+        if (!r) r = run_detect(e, g, s);
+        *fl = f1 + f2;
+        return r;
+    };
+    if (!use_graph) return body(st, &e->last_flops);
+    for (auto& k : e->graphs)
+        if (k.u8 == is_u8 && k.H == H && k.W == W) {
+            ORE_HIP(hipGraphLaunch(k.exec, st));
+            return ORE_OK;
+        }
+    // capture once on the engine's own stream, replay on the caller's
+    hipGraph_t graph = nullptr;
+    const bool was_prof = e->profiling;
+    e->profiling = false;
+    ORE_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    rc = body(e->cap_stream, &e->last_flops);
+    e->profiling = was_prof;
+    hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) { ore_set_error("hipStreamEndCapture -> %s", hipGetErrorString(ce)); return ORE_EHIP; }
+    hipGraphExec_t exec = nullptr;
+    ORE_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    e->graphs.push_back({is_u8, H, W, exec});
+    ORE_HIP(hipGraphLaunch(exec, st));
+    return ORE_OK;
+}
+
+extern "C" double ore_engine_last_flops(ore_engine* e) { return e ? e->last_flops : 0.0; }
+
+extern "C" int ore_engine_set_profiling(ore_engine* e, int32_t enable) {
+    ORE_CHECK_ARG(e, "ore_engine_set_profiling: null");
+    e->profiling = enable != 0;
+    e->ev_used = 0;
+    e->spans.clear();
+    return ORE_OK;
+}
+
+extern "C" int ore_engine_read_profile(ore_engine* e, double* conv_ms, double* conv_flops, int32_t* n_launches) {
+    ORE_CHECK_ARG(e && conv_ms && conv_flops && n_launches, "ore_engine_read_profile: null");
+    ORE_HIP(hipDeviceSynchronize());
+    double ms = 0.0, fl = 0.0;
+    for (auto& s : e->spans) {
+        float t = 0.f;
+        ORE_HIP(hipEventElapsedTime(&t, e->ev_pool[s.a], e->ev_pool[s.b]));
+        ms += t; fl += s.flops;
+    }
+    *conv_ms = ms; *conv_flops = fl; *n_launches = (int32_t)e->spans.size();
+    e->ev_used = 0;
+    e->spans.clear();
+    return ORE_OK;
+}
+
+extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, int64_t dims[4]) {
+    ORE_CHECK_ARG(e && e->finalized && name && ptr && dims, "ore_engine_buffer: bad args");
+    const Geo& g = e->last;
+    const std::string n(name);
+    const int F = e->cfg.fpn_ch;
+    auto set = [&](void* p, int64_t rows, int64_t ch, int64_t ld, int64_t coff) {
+        *ptr = p; dims[0] = rows; dims[1] = ch; dims[2] = ld; dims[3] = coff; return ORE_OK;
+    };
+    const int64_t cap = (int64_t)3 * e->cfg.pre_topk;
+    if (n == "stem1") return set(e->s1.p, (int64_t)g.B * g.h[1] * g.w[1], e->cfg.stem_ch[0], e->s1.ld, 0);
+    if (n == "stem2") return set(e->s2.p, (int64_t)g.B * g.h[1] * g.w[1], e->cfg.stem_ch[1], e->s2.ld, 0);
+    if (n == "stem3") return set(e->cat[0].p, (int64_t)g.B * g.h[2] * g.w[2], e->cfg.stem_ch[2], e->cat[0].ld, 0);
+    for (int s = 0; s < 4; ++s) {
+        const int64_t rows = (int64_t)g.B * g.h[s + 2] * g.w[s + 2];
+        if (n == "stage" + std::to_string(s + 2)) return set(e->sout[s].p, rows, e->stage[s].out_ch, e->sout[s].ld, 0);  // pre-gate
+        if (n == "gate" + std::to_string(s + 2)) return set(e->gate[s], g.B, e->stage[s].out_ch, e->stage[s].out_ch, 0);
+        if (n == "cat" + std::to_string(s + 2)) return set(e->cat[s].p, rows, e->stage[s].cat_ch, e->cat[s].ld, 0);
+    }
+    for (int l = 0; l < 3; ++l) {
+        const std::string k = std::to_string(l + 3);
+        const int64_t rows = (int64_t)g.B * g.h[l + 3] * g.w[l + 3];
+        if (n == "p" + k) return set(e->pcat[l].p, rows, F, 2 * F, F);
+        if (n == "attn" + k) return set(e->pcat[l].p, rows, F, 2 * F, 0);
+        if (n == "lat" + k) return set(e->lat[l].p, rows, F, F, 0);
+        if (n == "pos" + k) return set(e->pos[l].p, rows, F, F, 0);
+        if (n == "tower" + k) return set(e->tow[l].p, rows, F, F, 0);
+        if (n == "head" + k) return set(e->head[l].p, rows, 5, 8, 0);
+    }
+    if (n == "pre_boxes") return set(e->pre_boxes, cap, 4, 4, 0);
+    if (n == "pre_scores") return set(e->pre_scores, cap, 1, 1, 0);
+    if (n == "pre_loc") return set(e->pre_loc, cap, 1, 1, 0);
+    if (n == "pre_level") return set(e->pre_level, cap, 1, 1, 0);
+    if (n == "keep_idx") return set(e->keep_idx, cap, 1, 1, 0);
+    if (n == "counts") return set(e->counts, 4, 1, 1, 0);
+    if (n == "out_boxes") return set(e->out_boxes, cap, 4, 4, 0);
+    if (n == "out_scores") return set(e->out_scores, cap, 1, 1, 0);
+    ore_set_error("ore_engine_buffer: unknown buffer '%s'", name);
+    return ORE_ENOENT;
+}

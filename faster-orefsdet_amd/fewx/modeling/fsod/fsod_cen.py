@@ -1,0 +1,211 @@
+"""CenterNet2Detector meta-architecture (ref:fewx/modeling/fsod/fsod_cen.py:38-555) on the MI355X HIP path.
+
+Eval hot path = ONE call into libore_hip.so's engine, replayed as a hipGraph:
+stem_1 with fused BGR normalisation -> VoVNet OSA stages -> FPN -> query<->support depthwise correlation ->
+conv3 -> CenterNet head -> sigmoid/top-k/decode/NMS.  The support prototypes are loaded ONCE (the reference re-reads
+support_feature.pkl on every forward) and the engine is rebuilt only when parameters change."""
+import logging
+import os
+import pickle
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from detectron2.layers import _require_gpu
+from detectron2.modeling import META_ARCH_REGISTRY, build_backbone, build_proposal_generator
+from detectron2.modeling.postprocessing import detector_postprocess
+from detectron2.structures import ImageList
+
+from .fsod_roi_heads import build_roi_heads
+from .fsod_rpn import make_proposals
+
+
+class MLP(nn.Module):
+    """ref fsod_cen.py:573-582."""
+
+    def __init__(self, in_features, hidden_features, out_features, act_layer=nn.GELU, drop=0.1):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+def _hip_linear(x2d, weight, bias=None):
+    """[R,K] @ W[N,K]^T (+bias) as a 1x1 'conv' on the MFMA implicit-GEMM kernel."""
+    import orehip
+    R, K = x2d.shape
+    w = orehip.pack_conv_weight(weight.detach().reshape(weight.shape[0], K, 1, 1))
+    y = orehip.conv2d(x2d.contiguous().view(1, 1, R, K), w, weight.shape[0], 1, shift=None if bias is None else bias.detach().contiguous())
+    return y.view(R, weight.shape[0])
+
+
+class SM_Block(nn.Module):
+    """Support 'sparse-MLP' block (ref fsod_cen.py:584-630): H-mixing and W-mixing Linear(dim,dim) over (seg, S) groups,
+    softmax re-weighting, projection.  The three big Linears run on the MFMA GEMM kernel; eval only this round."""
+
+    def __init__(self, dim, seg_dim=8, qkv_bias=False, proj_drop=0.0):
+        super().__init__()
+        self.seg_dim = seg_dim
+        self.mlp_h = nn.Linear(dim, dim, bias=qkv_bias)
+        self.mlp_w = nn.Linear(dim, dim, bias=qkv_bias)
+        self.reweighting = MLP(dim, dim // 2, dim * 2)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        _require_gpu(x, "SM_Block")
+        if self.training:
+            raise NotImplementedError("SM_Block training (dropout + backward) is not built yet (round 1 covers the eval path)")
+        B, H, W, C = x.shape
+        S = C // self.seg_dim
+        h = x.reshape(B, H, W, self.seg_dim, S).permute(0, 3, 2, 1, 4).reshape(-1, H * S)
+        h = _hip_linear(h, self.mlp_h.weight).reshape(B, self.seg_dim, W, H, S).permute(0, 3, 2, 1, 4).reshape(B, H, W, C)
+        w = x.reshape(B, H, W, self.seg_dim, S).permute(0, 3, 1, 2, 4).reshape(-1, W * S)
+        w = _hip_linear(w, self.mlp_w.weight).reshape(B, self.seg_dim, H, W, S).permute(0, 2, 3, 1, 4).reshape(B, H, W, C)
+        a = (h + w).permute(0, 3, 1, 2).flatten(2).mean(2)
+        a = self.reweighting(a).reshape(B, C, 2).permute(2, 0, 1).softmax(0).unsqueeze(2).unsqueeze(2)
+        y = w * a[0] + h * a[1]
+        return _hip_linear(y.reshape(-1, C), self.proj.weight, self.proj.bias).reshape(B, H, W, C)
+
+
+@META_ARCH_REGISTRY.register()
+class CenterNet2Detector(nn.Module):
+    def __init__(self, cfg, pos_encoding=True):
+        super().__init__()
+        self.backbone = build_backbone(cfg)
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.roi_heads = build_roi_heads(cfg, self.backbone.output_shape())
+        self.vis_period = cfg.VIS_PERIOD
+        self.input_format = cfg.INPUT.FORMAT
+        assert len(cfg.MODEL.PIXEL_MEAN) == len(cfg.MODEL.PIXEL_STD)
+        self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1))
+        self.in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        self.support_way = cfg.INPUT.FS.SUPPORT_WAY
+        self.support_shot = cfg.INPUT.FS.SUPPORT_SHOT
+        self.logger = logging.getLogger(__name__)
+        C = cfg.MODEL.FPN.OUT_CHANNELS
+        assert C == 128, "CenterNet2Detector is hard-wired to 128 FPN channels in the reference (fsod_cen.py:69-78)"
+        self.vip_p3, self.vip_p4, self.vip_p5 = SM_Block(C, 32), SM_Block(C, 16), SM_Block(C, 8)
+        self.conv1 = nn.Conv2d(C, C // 2, 1)   # unused by the reference forward; kept for checkpoints
+        self.conv2 = nn.Conv2d(C, C // 2, 1)
+        self.conv3 = nn.Conv2d(2 * C, C, 1)
+        self._cfg_engine = dict(
+            body=cfg.MODEL.VOVNET.CONV_BODY, fpn_ch=C, strides=tuple(cfg.MODEL.CENTERNET.FPN_STRIDES),
+            pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), pixel_std=tuple(cfg.MODEL.PIXEL_STD),
+            score_thresh=cfg.MODEL.CENTERNET.INFERENCE_TH, pre_topk=cfg.MODEL.CENTERNET.PRE_NMS_TOPK_TEST,
+            nms_thresh=cfg.MODEL.CENTERNET.NMS_TH_TEST, post_topk=cfg.MODEL.CENTERNET.POST_NMS_TOPK_TEST)
+        self.support_dict = None
+        self._engine = None
+        self._engine_key = None
+        self.max_hw = (int(cfg.INPUT.MAX_SIZE_TEST), int(cfg.INPUT.MAX_SIZE_TEST))
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ---- support prototypes ------------------------------------------------------------------------------------
+    def set_support_dict(self, support_dict):
+        """{'p3': {cls: [1,C,32,32]}, 'p4': ..., 'p5': ..., 'rcnn_8': ..., 'rcnn_4': ...} (the support_feature.pkl layout)."""
+        self.support_dict = {k: {c: f.to(self.device) for c, f in v.items()} for k, v in support_dict.items()}
+        self._engine_key = None
+
+    def init_model(self, support_file="./support_dir/support_feature.pkl"):
+        """ref fsod_cen.py:313-415, minus its two defects: the pickle is read once (not per forward) and tensors go to
+        self.device (not a hard-coded .cuda()).  Generating the pickle from a support dataframe needs the ore dataset
+         and is not built."""
+        if self.support_dict is not None:
+            return
+        if not os.path.exists(support_file):
+            raise FileNotFoundError(f"{support_file} not found: generating support features needs the few-shot support set "
+                                    "(datasets/coco/*_shot_support_df.pkl, SURVEY 8f row 3); call set_support_dict() instead")
+        with open(support_file, "rb") as f:
+            self.set_support_dict(pickle.load(f, encoding="latin1"))
+
+    # ---- engine -------------------------------------------------------------------------------------------------
+    def _state_key(self):
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+
+    def engine(self):
+        import orehip
+        from detectron2.modeling.backbone.vovnet import _STAGE_SPECS
+        key = (self._state_key(), str(self.device))
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            c = self._cfg_engine
+            spec = _STAGE_SPECS[c["body"]]
+            assert all(b == 1 for b in spec["block_per_stage"]), "the fused engine covers one OSA block per stage (V-19 bodies)"
+            dev = self.device
+            assert dev.type == "cuda", "CenterNet2Detector inference runs on the MI355X only"
+            e = orehip.Engine(stem=spec["stem"], conv=spec["stage_conv_ch"], out=spec["stage_out_ch"], layers=spec["layer_per_block"],
+                              fpn_ch=c["fpn_ch"], strides=c["strides"], pixel_mean=c["pixel_mean"], pixel_std=c["pixel_std"],
+                              score_thresh=c["score_thresh"], pre_topk=c["pre_topk"], nms_thresh=c["nms_thresh"],
+                              post_topk=c["post_topk"], max_batch=1, max_h=self.max_hw[0], max_w=self.max_hw[1],
+                              device=dev.index or 0)
+            e.load_state_dict(self.state_dict())
+            assert self.support_dict is not None, "support prototypes not set (init_model / set_support_dict)"
+            cls_id = list(self.support_dict["p3"].keys())[-1]   # the reference keeps only the last class
+            e.set_support({k: self.support_dict[k][cls_id] for k in ("p3", "p4", "p5")})
+            e.finalize()
+            self._engine, self._engine_key = e, key
+        return self._engine
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def forward(self, batched_inputs):
+        if not self.training:
+            self.init_model()
+            return self.inference(batched_inputs)
+        raise NotImplementedError("CenterNet2Detector training step (SURVEY 8a rows a12/a13) is not built yet; "
+                                  "round 1 covers the eval hot path")
+
+    @torch.no_grad()
+    def inference_proposals(self, batched_inputs, use_graph=True):
+        """The built hot path: image -> proposals (Instances with proposal_boxes / objectness_logits / scores / pred_classes)."""
+        assert not self.training
+        assert len(batched_inputs) == 1, "only 1 query image in test (ref fsod_cen.py:438-439)"
+        img = batched_inputs[0]["image"].to(self.device)
+        if img.dtype != torch.uint8:
+            img = img.float()
+        img = img.contiguous()
+        e = self.engine()
+        e.eval_forward(img, use_graph=use_graph)
+        boxes, scores, _ = e.proposals()
+        return [make_proposals((img.shape[-2], img.shape[-1]), boxes.clone(), scores.clone())]
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
+        assert not self.training
+        self.init_model()
+        proposals = self.inference_proposals(batched_inputs)
+        e = self._engine
+        img = batched_inputs[0]["image"]
+        H, W = img.shape[-2:]
+        Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+        features = {f"p{l}": e.buffer(f"p{l}", (1, Hp >> l, Wp >> l)) for l in (3, 4, 5)}
+        cls_id = list(self.support_dict["p3"].keys())[-1]
+        support = [self.support_dict["rcnn_8"][cls_id], self.support_dict["rcnn_4"][cls_id]]
+        images = ImageList(torch.empty(0), [(H, W)])
+        results, _ = self.roi_heads(images, features, support, proposals, None)
+        if do_postprocess:
+            return CenterNet2Detector._postprocess(results, batched_inputs, images.image_sizes)
+        return results
+
+    def preprocess_image(self, batched_inputs):
+        """ref fsod_cen.py:540-555 (kept for API parity; the engine fuses this into stem_1)."""
+        images = [x["image"].to(self.device) for x in batched_inputs]
+        images = [(x - self.pixel_mean) / self.pixel_std for x in images]
+        return ImageList.from_tensors(images, self.backbone.size_divisibility)
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        out = []
+        for res, inp, size in zip(instances, batched_inputs, image_sizes):
+            r = detector_postprocess(res, inp.get("height", size[0]), inp.get("width", size[1]))
+            out.append({"instances": r})
+        return out

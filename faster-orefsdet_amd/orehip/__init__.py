@@ -1,0 +1,424 @@
+"""ctypes binding of libore_hip.so (include/ore_hip.h) -- the only way the Python host side reaches
+the HIP kernels.  PyTorch is used for device memory (tensor.data_ptr()) and streams only.
+
+There is NO CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libore_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+ESE_PARTS = 64
+
+
+class OreError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libore_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise OreError("building libore_hip.so failed:\n" + out.stdout[-4000:] + out.stderr[-4000:])
+    if verbose:
+        print(out.stdout[-2000:])
+    return LIB_PATH
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_ld", C.c_int32), ("in_coff", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("w", C.c_void_p),
+                ("Cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("relu_cout", C.c_int32),
+                ("in_mul", C.c_void_p), ("in_add", C.c_void_p), ("in_relu", C.c_int32),
+                ("add", C.c_void_p), ("add_ld", C.c_int32), ("add_coff", C.c_int32),
+                ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_coff", C.c_int32),
+                ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+
+
+class DetectDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("head", C.c_void_p * 8), ("head_ld", C.c_int32),
+                ("H", C.c_int32 * 8), ("W", C.c_int32 * 8), ("stride", C.c_int32 * 8),
+                ("score_thresh", C.c_float), ("pre_topk", C.c_int32), ("nms_thresh", C.c_float), ("post_topk", C.c_int32),
+                ("pre_boxes", C.c_void_p), ("pre_scores", C.c_void_p), ("pre_loc", C.c_void_p), ("pre_level", C.c_void_p),
+                ("keep_idx", C.c_void_p), ("counts", C.c_void_p), ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("stem_ch", C.c_int32 * 3), ("stage_conv_ch", C.c_int32 * 4), ("stage_out_ch", C.c_int32 * 4),
+                ("layers_per_block", C.c_int32), ("fpn_ch", C.c_int32), ("strides", C.c_int32 * 3),
+                ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3),
+                ("score_thresh", C.c_float), ("pre_topk", C.c_int32), ("nms_thresh", C.c_float), ("post_topk", C.c_int32),
+                ("max_batch", C.c_int32), ("max_h", C.c_int32), ("max_w", C.c_int32)]
+
+
+# every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
+SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+           "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
+           "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
+           "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
+           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
+           "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OreError(f"{LIB_PATH} not found: build it with `make -C {CSRC}` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.ore_last_error.restype = C.c_char_p
+        L.ore_packed_weight_floats.restype = C.c_size_t
+        L.ore_detect_workspace_bytes.restype = C.c_size_t
+        L.ore_nms_workspace_bytes.restype = C.c_size_t
+        L.ore_engine_last_flops.restype = C.c_double
+        L.ore_engine_last_flops.argtypes = [C.c_void_p]
+        L.ore_engine_destroy.argtypes = [C.c_void_p]
+        L.ore_engine_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise OreError(f"{what} failed ({rc}): {lib().ore_last_error().decode()}")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "libore_hip.so works on device memory only"
+    return t.data_ptr()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------
+# layout helpers: the library is NHWC; torch.channels_last IS that layout for a logical NCHW tensor
+# ---------------------------------------------------------------------------------------------------
+def to_nhwc(x_nchw: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] any layout -> contiguous [B,H,W,C] fp32."""
+    return x_nchw.permute(0, 2, 3, 1).contiguous().float()
+
+
+def as_nchw(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """[B,H,W,C] -> logical [B,C,H,W] view (channels_last strides, zero copy)."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """OIHW (any device) -> packed [Cout16][kh*kw*Cin] on the weight's device."""
+    w = w_oihw.detach().float().cpu().contiguous()
+    co, ci, kh, kw = w.shape
+    n = lib().ore_packed_weight_floats(co, ci, kh, kw)
+    dst = np.empty(n, dtype=np.float32)
+    _chk(lib().ore_pack_conv_weight_host(C.c_void_p(w.data_ptr()), co, ci, kh, kw, dst.ctypes.data_as(C.c_void_p)),
+         "ore_pack_conv_weight_host")
+    return torch.from_numpy(dst).to(w_oihw.device)
+
+
+def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: int = 1, pad: Optional[int] = None, *,
+           in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, relu_cout: int = 0, in_mul=None,
+           in_add=None, in_relu: bool = False, add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           out_coff: int = 0, splitk: int = 0, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: [B,H,W,ld] NHWC fp32.  Returns `out` ([B,Ho,Wo,out_ld]); only channels [out_coff, out_coff+Cout) are written."""
+    _f32(x)
+    B, H, W, ld = x.shape
+    Cin = Cin if Cin is not None else ld - in_coff
+    pad = k // 2 if pad is None else pad
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    _f32(out)
+    assert out.shape[:3] == (B, Ho, Wo)
+    M = B * Ho * Wo
+    if workspace is None and splitk != 1:
+        workspace = _default_ws(x.device)
+    d = ConvDesc()
+    d.in_, d.in_ld, d.in_coff = _ptr(x), ld, in_coff
+    d.B, d.H, d.W, d.Cin = B, H, W, Cin
+    d.w = _ptr(_f32(w_packed))
+    d.Cout, d.kh, d.kw, d.stride, d.pad = Cout, k, k, stride, pad
+    d.scale, d.shift, d.relu_cout = _ptr(scale), _ptr(shift), relu_cout
+    d.in_mul, d.in_add, d.in_relu = _ptr(in_mul), _ptr(in_add), int(in_relu)
+    if add is not None:
+        _f32(add)
+        d.add, d.add_ld, d.add_coff = _ptr(add), add.shape[-1], 0
+    d.out, d.out_ld, d.out_coff = _ptr(out), out.shape[-1], out_coff
+    d.splitk = splitk
+    if workspace is not None:
+        d.workspace, d.workspace_floats = _ptr(workspace), workspace.numel()
+    _chk(lib().ore_conv2d_fwd(C.byref(d), _stream()), "ore_conv2d_fwd")
+    return out
+
+
+_WS: Dict[str, torch.Tensor] = {}
+
+
+def _default_ws(device) -> torch.Tensor:
+    k = str(device)
+    if k not in _WS:
+        _WS[k] = torch.empty(1 << 23, device=device, dtype=torch.float32)  # 32 MiB split-K slab space
+    return _WS[k]
+
+
+def stem1(img: torch.Tensor, Hp: int, Wp: int, mean: Sequence[float], std: Sequence[float], w_oihw: torch.Tensor,
+          scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """img [B,3,H,W] uint8 or fp32 (planar) -> [B,Hp/2,Wp/2,Cout]."""
+    assert img.is_contiguous() and img.dtype in (torch.uint8, torch.float32)
+    B, _, H, W = img.shape
+    Cout = w_oihw.shape[0]
+    out = torch.empty(B, Hp // 2, Wp // 2, Cout, device=img.device, dtype=torch.float32)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    _chk(lib().ore_stem1_fwd(C.c_void_p(_ptr(img)), int(img.dtype == torch.uint8), B, H, W, Hp, Wp, m, s,
+                             C.c_void_p(_ptr(_f32(w_oihw))), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)), Cout,
+                             C.c_void_p(_ptr(out)), Cout, 0, _stream()), "ore_stem1_fwd")
+    return out
+
+
+def maxpool3x3s2(x: torch.Tensor, in_mul: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _f32(x)
+    B, H, W, Cc = x.shape
+
+    def osz(n):
+        o = (n - 3 + 1) // 2 + 1 if n >= 3 else 1
+        if (o - 1) * 2 >= n:
+            o -= 1
+        return max(o, 1)
+    out = torch.empty(B, osz(H), osz(W), Cc, device=x.device, dtype=torch.float32)
+    _chk(lib().ore_maxpool3x3s2_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(in_mul)),
+                                    C.c_void_p(_ptr(out)), Cc, 0, _stream()), "ore_maxpool3x3s2_fwd")
+    return out
+
+
+def ese_gate(x: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
+    _f32(x)
+    B, H, W, Cc = x.shape
+    gate = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * ESE_PARTS * Cc, device=x.device, dtype=torch.float32)
+    _chk(lib().ore_ese_gate_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H * W, Cc, C.c_void_p(_ptr(_f32(fc_w.reshape(Cc, Cc)))),
+                                C.c_void_p(_ptr(_f32(fc_b))), C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(ws)), _stream()),
+         "ore_ese_gate_fwd")
+    return gate
+
+
+def scale_channels(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    _f32(x)
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    _chk(lib().ore_scale_channels_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H * W, Cc, C.c_void_p(_ptr(_f32(gate))),
+                                      C.c_void_p(_ptr(y)), Cc, 0, _stream()), "ore_scale_channels_fwd")
+    return y
+
+
+def support_kernels(proto_chw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    _f32(proto_chw)
+    Cc, s, s2 = proto_chw.shape
+    assert s == s2
+    k11 = torch.empty(Cc, device=proto_chw.device)
+    k13 = torch.empty(Cc, 3, device=proto_chw.device)
+    k31 = torch.empty(Cc, 3, device=proto_chw.device)
+    _chk(lib().ore_support_kernels_fwd(C.c_void_p(_ptr(proto_chw)), Cc, s, C.c_void_p(_ptr(k11)), C.c_void_p(_ptr(k13)),
+                                       C.c_void_p(_ptr(k31)), _stream()), "ore_support_kernels_fwd")
+    return k11, k13, k31
+
+
+def correlation(q: torch.Tensor, k11, k13, k31, out: Optional[torch.Tensor] = None, q_coff: int = 0, out_coff: int = 0,
+                Cc: Optional[int] = None) -> torch.Tensor:
+    _f32(q)
+    B, H, W, ld = q.shape
+    Cc = Cc if Cc is not None else ld
+    if out is None:
+        out = torch.empty(B, H, W, Cc, device=q.device, dtype=torch.float32)
+    _chk(lib().ore_correlation_fwd(C.c_void_p(_ptr(q)), ld, q_coff, B, H, W, Cc, C.c_void_p(_ptr(_f32(k11))),
+                                   C.c_void_p(_ptr(_f32(k13))), C.c_void_p(_ptr(_f32(k31))), C.c_void_p(_ptr(out)),
+                                   out.shape[-1], out_coff, _stream()), "ore_correlation_fwd")
+    return out
+
+
+def groupnorm_affine(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    _f32(x)
+    B, H, W, Cc = x.shape
+    mul = torch.empty(B, Cc, device=x.device)
+    add = torch.empty(B, Cc, device=x.device)
+    _chk(lib().ore_groupnorm_affine_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H * W, Cc, groups, C.c_float(eps),
+                                        C.c_void_p(_ptr(_f32(gamma))), C.c_void_p(_ptr(_f32(beta))), C.c_void_p(_ptr(mul)),
+                                        C.c_void_p(_ptr(add)), _stream()), "ore_groupnorm_affine_fwd")
+    return mul, add
+
+
+def detect(heads: Sequence[torch.Tensor], strides: Sequence[int], score_thresh: float, pre_topk: int, nms_thresh: float,
+           post_topk: int) -> Dict[str, torch.Tensor]:
+    """heads[l]: [H,W,ld>=8] fp32: channels 0..3 reg (after Scale+ReLU), 4 = heatmap logit.  No host sync inside."""
+    L = len(heads)
+    dev = heads[0].device
+    cap = L * pre_topk
+    o = {"pre_boxes": torch.zeros(cap, 4, device=dev), "pre_scores": torch.zeros(cap, device=dev),
+         "pre_loc": torch.zeros(cap, dtype=torch.int64, device=dev), "pre_level": torch.zeros(cap, dtype=torch.int32, device=dev),
+         "keep_idx": torch.zeros(cap, dtype=torch.int64, device=dev), "counts": torch.zeros(4, dtype=torch.int32, device=dev),
+         "out_boxes": torch.zeros(cap, 4, device=dev), "out_scores": torch.zeros(cap, device=dev)}
+    wsb = lib().ore_detect_workspace_bytes(L, pre_topk)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    d = DetectDesc()
+    d.n_levels, d.head_ld = L, heads[0].shape[-1]
+    for l, h in enumerate(heads):
+        _f32(h)
+        assert h.dim() == 3 and h.shape[-1] == d.head_ld
+        d.head[l], d.H[l], d.W[l], d.stride[l] = _ptr(h), h.shape[0], h.shape[1], strides[l]
+    d.score_thresh, d.pre_topk, d.nms_thresh, d.post_topk = score_thresh, pre_topk, nms_thresh, post_topk
+    for k in ("pre_boxes", "pre_scores", "pre_loc", "pre_level", "keep_idx", "counts", "out_boxes", "out_scores"):
+        setattr(d, k, _ptr(o[k]))
+    d.workspace, d.workspace_bytes = _ptr(ws), wsb
+    _chk(lib().ore_detect_fwd(C.byref(d), _stream()), "ore_detect_fwd")
+    o["_ws"] = ws
+    return o
+
+
+def nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
+    """torchvision.ops.nms semantics (stable order); returns int64 keep indices (this call syncs to read the count)."""
+    n = scores.numel()
+    dev = boxes.device
+    keep = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib().ore_nms_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    b = boxes.float().contiguous() if n else torch.zeros(1, 4, device=dev)
+    s = scores.float().contiguous() if n else torch.zeros(1, device=dev)
+    _chk(lib().ore_nms_fwd(C.c_void_p(_ptr(b)), C.c_void_p(_ptr(s)), n, C.c_float(thr), C.c_void_p(_ptr(keep)),
+                           C.c_void_p(_ptr(cnt)), C.c_void_p(_ptr(ws)), C.c_size_t(wsb), _stream()), "ore_nms_fwd")
+    return keep[: int(cnt.item())]
+
+
+# ---------------------------------------------------------------------------------------------------
+class Engine:
+    """ore_engine: whole eval hot path (backbone+FPN -> correlation -> head -> top-k/NMS) behind one call."""
+
+    def __init__(self, *, stem=(64, 64, 128), conv=(64, 80, 96, 112), out=(112, 256, 384, 512), layers=3, fpn_ch=128,
+                 strides=(8, 16, 32), pixel_mean=(103.530, 116.280, 123.675), pixel_std=(1.0, 1.0, 1.0),
+                 score_thresh=1e-5, pre_topk=1000, nms_thresh=0.6, post_topk=256, max_batch=1, max_h=640, max_w=640,
+                 device: int = 0):
+        cfg = ModelCfg()
+        cfg.stem_ch[:] = stem
+        cfg.stage_conv_ch[:] = conv
+        cfg.stage_out_ch[:] = out
+        cfg.layers_per_block, cfg.fpn_ch = layers, fpn_ch
+        cfg.strides[:] = strides
+        cfg.pixel_mean[:] = pixel_mean
+        cfg.pixel_std[:] = pixel_std
+        cfg.score_thresh, cfg.pre_topk, cfg.nms_thresh, cfg.post_topk = score_thresh, pre_topk, nms_thresh, post_topk
+        cfg.max_batch, cfg.max_h, cfg.max_w = max_batch, max_h, max_w
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self.pre_topk = pre_topk
+        self.fpn_ch = fpn_ch
+        self._h = C.c_void_p()
+        _chk(lib().ore_engine_create(C.byref(cfg), device, C.byref(self._h)), "ore_engine_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().ore_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd) -> None:
+        """All tensors by their reference state_dict names; unknown keys are ignored by the engine."""
+        for k, v in sd.items():
+            t = v.detach().float().cpu().contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            _chk(lib().ore_engine_set_tensor(self._h, k.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()),
+                 f"ore_engine_set_tensor({k})")
+
+    def set_support(self, protos: Dict[str, torch.Tensor]) -> None:
+        """{'p3': [1,C,32,32], 'p4': [1,C,16,16], 'p5': [1,C,8,8]} -- support_feature.pkl prototypes."""
+        for lvl in (3, 4, 5):
+            t = protos[f"p{lvl}"].detach().float().cpu().contiguous()
+            t = t.reshape(t.shape[-3], t.shape[-2], t.shape[-1])
+            _chk(lib().ore_engine_set_support(self._h, lvl, C.c_void_p(t.data_ptr()), t.shape[0], t.shape[1]),
+                 "ore_engine_set_support")
+
+    def finalize(self) -> None:
+        _chk(lib().ore_engine_finalize(self._h), "ore_engine_finalize")
+
+    def backbone(self, img: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """img [B,3,H,W] u8/f32 on device -> {'p3','p4','p5'} as logical NCHW views of engine-owned NHWC buffers."""
+        assert img.is_cuda and img.is_contiguous()
+        B, _, H, W = img.shape
+        _chk(lib().ore_engine_backbone_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), B, H, W, _stream()),
+             "ore_engine_backbone_fwd")
+        Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+        return {f"p{l}": self.buffer(f"p{l}", (B, Hp >> l, Wp >> l)) for l in (3, 4, 5)}
+
+    def eval_forward(self, img: torch.Tensor, use_graph: bool = True) -> None:
+        """img [3,H,W] u8/f32 on device.  Enqueues the whole path; results via .buffer()/.proposals()."""
+        assert img.is_cuda and img.is_contiguous() and img.dim() == 3
+        _, H, W = img.shape
+        _chk(lib().ore_engine_eval_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W,
+                                       int(use_graph), _stream()), "ore_engine_eval_fwd")
+
+    def last_flops(self) -> float:
+        return float(lib().ore_engine_last_flops(self._h))
+
+    def set_profiling(self, enable: bool) -> None:
+        _chk(lib().ore_engine_set_profiling(self._h, int(enable)), "ore_engine_set_profiling")
+
+    def read_profile(self) -> Tuple[float, float, int]:
+        """(conv kernel ms, conv algorithmic FLOPs, conv launches) accumulated over eager forwards since the last read."""
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
+        _chk(lib().ore_engine_read_profile(self._h, C.byref(ms), C.byref(fl), C.byref(n)), "ore_engine_read_profile")
+        return ms.value, fl.value, n.value
+
+    def buffer(self, name: str, bhw: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+        """Zero-copy torch view of a named engine buffer.  With bhw=(B,H,W): logical NCHW view of the channel slice."""
+        p = C.c_void_p()
+        dims = (C.c_int64 * 4)()
+        _chk(lib().ore_engine_buffer(self._h, name.encode(), C.byref(p), dims), f"ore_engine_buffer({name})")
+        rows, ch, ld, coff = (int(x) for x in dims)
+        dt = {"pre_loc": torch.int64, "keep_idx": torch.int64, "pre_level": torch.int32, "counts": torch.int32}.get(name, torch.float32)
+        flat = _from_ptr(p.value, rows * ld, dt, self.device)
+        t = flat.view(rows, ld)[:, coff:coff + ch]
+        if bhw is not None:
+            B, H, W = bhw
+            assert B * H * W == rows, (bhw, rows)
+            t = t.reshape(B, H, W, ch) if coff == 0 and ch == ld else flat.view(B, H, W, ld)[..., coff:coff + ch]
+            return t.permute(0, 3, 1, 2)
+        return t
+
+    def proposals(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(boxes [n,4], scores [n], keep_idx [n]) -- reads the device-side count (one sync)."""
+        n = int(self.buffer("counts")[1, 0].item())
+        return self.buffer("out_boxes")[:n], self.buffer("out_scores")[:n, 0], self.buffer("keep_idx")[:n, 0]
+
+
+class _Arr:
+    def __init__(self, ptr, n, dt):
+        tstr = {torch.float32: "<f4", torch.int64: "<i8", torch.int32: "<i4"}[dt]
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": tstr, "data": (ptr, False), "version": 2}
+
+
+def _from_ptr(ptr: int, n: int, dt, device) -> torch.Tensor:
+    return torch.as_tensor(_Arr(ptr, n, dt), device=device)

@@ -1,0 +1,191 @@
+/* ore_hip.h -- C-ABI of libore_hip.so, the MI355X (gfx950) hot path of Faster-OreFSDet.
+ *
+ * The reference (MVME-HBUT/Faster-OreFSDet) is pure Python on PyTorch and has no FFI boundary of
+ * its own; its plug-in surface is Detectron2's registry + nn.Module call protocol.  This header is
+ * what the Python host side (faster-orefsdet_amd/orehip/, ctypes) binds; every entry point names
+ * the reference interface it replaces (ref: = reference repo path, d2z: = path inside the
+ * reference's vendored detectron2.7z).
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers unless the name ends in _host;
+ *   - activations are fp32 NHWC with an explicit channel stride (ld) and channel offset (coff), so a
+ *     layer can read/write a channel slice of a wider buffer (OSA concat is never materialised by a copy);
+ *   - the caller owns every buffer; kernels are enqueued on the hipStream_t passed as void* and
+ *     return without synchronising; nothing is allocated inside an op call;
+ *   - return value: 0 = ok, negative = error (ORE_E*), message via ore_last_error();
+ *   - thread-compatible: one ore_engine per process/GPU, no hidden global state besides the
+ *     last-error string.
+ */
+#ifndef ORE_HIP_H_
+#define ORE_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORE_OK 0
+#define ORE_EINVAL (-22)  /* bad shape / unsupported configuration */
+#define ORE_ENOMEM (-12)  /* workspace too small */
+#define ORE_EHIP (-5)     /* HIP runtime error */
+#define ORE_ENOENT (-2)   /* unknown tensor name */
+
+const char* ore_last_error(void);
+int ore_version(void);
+
+/* ------------------------------------------------------------------ low-level ops ------------ */
+
+/* Fused conv descriptor: implicit-GEMM NHWC conv on fp32 MFMA (v_mfma_f32_16x16x4_f32) with
+ *   optional per-(batch,channel) affine(+ReLU) on the INPUT  (eSE scale folded into the consumer,
+ *                                                            GroupNorm+ReLU folded into the head convs)
+ *   y = acc * scale[n] + shift[n]                            (FrozenBN / bias / Scale)
+ *   y += nearest2x(add)[b, oy/2, ox/2, n]                    (FPN top-down sum)
+ *   ReLU on output channels n < relu_cout.
+ * Replaces: F.conv2d + FrozenBatchNorm2d + ReLU  d2z:layers/wrappers.py:48-91, d2z:layers/batch_norm.py:44-66,
+ *           d2z:modeling/backbone/vovnet.py:205-235 (conv3x3/conv1x1), d2z:modeling/backbone/fpn.py:126-145,
+ *           ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:141-161.
+ * Requirements: Cin % 16 == 0; weights packed by ore_pack_conv_weight_host ([Cout16][kh*kw*Cin], tap-major).
+ * Split-K (splitk > 1) needs workspace >= splitk * M * Cout16 floats, M = B*Ho*Wo. */
+typedef struct ore_conv_desc {
+    const float* in;   int32_t in_ld, in_coff;
+    int32_t B, H, W, Cin;
+    const float* w;    /* packed weights */
+    int32_t Cout, kh, kw, stride, pad;
+    const float* scale;   /* [Cout] or NULL (= 1) */
+    const float* shift;   /* [Cout] or NULL (= 0) */
+    int32_t relu_cout;    /* ReLU applied to output channels < relu_cout */
+    const float* in_mul;  /* [B][Cin] or NULL */
+    const float* in_add;  /* [B][Cin] or NULL */
+    int32_t in_relu;      /* ReLU after the input affine */
+    const float* add;  int32_t add_ld, add_coff;  /* [B][ceil(Ho/2)][ceil(Wo/2)] x add_ld, or NULL */
+    float* out;        int32_t out_ld, out_coff;
+    int32_t splitk;       /* 0 = choose automatically, 1 = none */
+    float* workspace;  size_t workspace_floats;
+} ore_conv_desc;
+
+int ore_conv2d_fwd(const ore_conv_desc* d, void* stream);
+
+/* Host helper: OIHW fp32 -> packed [Cout16][kh][kw][Cin] (rows >= Cout zero). dst has ore_packed_weight_floats(). */
+size_t ore_packed_weight_floats(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw);
+int ore_pack_conv_weight_host(const float* w_oihw_host, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw,
+                              float* dst_host);
+
+/* stem_1: (x - mean)/std, zero-pad to (Hp,Wp), conv3x3 stride 2 pad 1 (3 -> Cout), FrozenBN, ReLU, in one pass.
+ * img: [B][3][H][W] planar, uint8 (img_is_u8=1) or fp32 (device).  w_oihw: device [Cout][27] (= OIHW flat).
+ * mean3_host/std3_host: 3 HOST floats each (passed by value to the kernel).
+ * Replaces CenterNet2Detector.preprocess_image ref:fewx/modeling/fsod/fsod_cen.py:540-555 +
+ * ImageList.from_tensors d2z:structures/image_list.py:69-121 + stem_1 d2z:modeling/backbone/vovnet.py:409. */
+int ore_stem1_fwd(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp, int32_t Wp,
+                  const float* mean3_host, const float* std3_host, const float* w_oihw, const float* scale,
+                  const float* shift, int32_t Cout, float* out, int32_t out_ld, int32_t out_coff, void* stream);
+
+/* MaxPool2d(3, stride 2, ceil_mode=True) with optional per-(b,c) multiplier on the input
+ * (eSE scale >= 0 commutes with max).  d2z:modeling/backbone/vovnet.py:349-350. */
+int ore_maxpool3x3s2_fwd(const float* in, int32_t in_ld, int32_t in_coff, int32_t B, int32_t H, int32_t W,
+                         int32_t C, const float* in_mul, float* out, int32_t out_ld, int32_t out_coff,
+                         void* stream);
+
+/* eSE gate: s[b][c] = relu6(fc(mean_hw(x))[c] + 3) / 6.   d2z:modeling/backbone/vovnet.py:238-260.
+ * fc_w [C][C] (out,in), fc_b [C].  workspace >= B * ORE_ESE_PARTS * C floats. */
+#define ORE_ESE_PARTS 64
+int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
+                     const float* fc_w, const float* fc_b, float* gate, float* workspace, void* stream);
+
+/* y = x * gate[b][c]  (materialises the eSE output; the fused engine folds the gate into consumers). */
+int ore_scale_channels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
+                           const float* gate, float* y, int32_t y_ld, int32_t y_coff, void* stream);
+
+/* Query<->support depthwise correlation (ref:fewx/modeling/fsod/fsod_cen.py:454-509 eval, :229-275 train):
+ *   a = relu(k11*relu(k11*q));  b = relu(dw3x1_k31(relu(dw1x3_k13(q))));  attn = a + b + q
+ * q: [B][H][W] x q_ld (+q_coff), k11 [C], k13 [C][3], k31 [C][3]; attn written to out (may alias a
+ * different channel slice of the same buffer as q). */
+int ore_correlation_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                        const float* k11, const float* k13, const float* k31,
+                        float* out, int32_t out_ld, int32_t out_coff, void* stream);
+
+/* Support kernels from a prototype [C][s][s] (NCHW, as cached in support_feature.pkl):
+ * adaptive avg pools (1,1), (1,3), (3,1).  ref:fewx/modeling/fsod/fsod_cen.py:457-459. */
+int ore_support_kernels_fwd(const float* proto_chw, int32_t C, int32_t s, float* k11, float* k13, float* k31,
+                            void* stream);
+
+/* GroupNorm statistics folded to a per-(b,c) affine: mul = rstd*gamma, add = beta - mean*mul.
+ * ref:...centernet_head.py:72-76 (nn.GroupNorm(32, C), eps 1e-5). */
+int ore_groupnorm_affine_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
+                             int32_t groups, float eps, const float* gamma, const float* beta,
+                             float* mul, float* add, void* stream);
+
+/* ------------------------------------------------------------------ detection tail ---------- */
+/* CenterNet.inference: sigmoid -> threshold -> per-level top-k -> decode -> NMS -> post-NMS top-k, all on
+ * device, no host sync.  ref:fewx/modeling/fsod/fsod_rpn.py:1066-1210, ml_nms.py:4-31, d2z:layers/nms.py:10-30,
+ * torchvision.ops.nms (un-vendored).  Bit-exact twin of oracle/ref_decode.c.
+ * head[l]: [H*W] x head_ld floats, channels 0..3 = (l,t,r,b) after Scale+ReLU (stride units), channel 4 = hm logit.
+ * Outputs: pre_* (capacity n_levels*pre_topk), keep_idx int64 (capacity same), counts[0]=n_pre, counts[1]=n_keep,
+ * out_boxes/out_scores = pre_*[keep] (capacity same).  workspace: ore_detect_workspace_bytes(). */
+typedef struct ore_detect_desc {
+    int32_t n_levels;
+    const float* head[8]; int32_t head_ld;
+    int32_t H[8], W[8], stride[8];
+    float score_thresh; int32_t pre_topk; float nms_thresh; int32_t post_topk;
+    float* pre_boxes; float* pre_scores; int64_t* pre_loc; int32_t* pre_level;
+    int64_t* keep_idx; int32_t* counts;
+    float* out_boxes; float* out_scores;
+    void* workspace; size_t workspace_bytes;
+} ore_detect_desc;
+size_t ore_detect_workspace_bytes(int32_t n_levels, int32_t pre_topk);
+int ore_detect_fwd(const ore_detect_desc* d, void* stream);
+
+/* Stand-alone NMS on n boxes (torchvision.ops.nms semantics, stable order): keep_idx int64 [n], count[0]. */
+size_t ore_nms_workspace_bytes(int32_t n);
+int ore_nms_fwd(const float* boxes, const float* scores, int32_t n, float thr, int64_t* keep_idx,
+                int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ engine ------------------- */
+/* Whole eval hot path for one model instance: owns packed weights and all
+ * intermediate buffers, replays a captured hipGraph per image.
+ * Replaces CenterNet2Detector.inference up to the proposals handed to the ROI heads
+ * (ref:fewx/modeling/fsod/fsod_cen.py:418-527) and build_fcos_vovnet_fpn_backbone(...).forward. */
+typedef struct ore_engine ore_engine;
+
+typedef struct ore_model_cfg {
+    int32_t stem_ch[3];
+    int32_t stage_conv_ch[4], stage_out_ch[4];
+    int32_t layers_per_block;
+    int32_t fpn_ch;               /* 128 */
+    int32_t strides[3];           /* 8,16,32 */
+    float pixel_mean[3], pixel_std[3];
+    float score_thresh; int32_t pre_topk; float nms_thresh; int32_t post_topk;
+    int32_t max_batch, max_h, max_w;  /* padded input size the buffers are allocated for */
+} ore_model_cfg;
+
+int ore_engine_create(const ore_model_cfg* cfg, int32_t device, ore_engine** out);
+void ore_engine_destroy(ore_engine* e);
+/* Host fp32 tensor by its reference state_dict name, e.g.
+ * "backbone.bottom_up.stem.stem_1/conv.weight".  All tensors must be set before the first forward. */
+int ore_engine_set_tensor(ore_engine* e, const char* name, const float* data_host, const int64_t* shape, int32_t ndim);
+/* Cached support prototypes [128][s][s] for level 3/4/5 (support_feature.pkl 'p3','p4','p5'), host. */
+int ore_engine_set_support(ore_engine* e, int32_t level, const float* proto_chw_host, int32_t C, int32_t s);
+int ore_engine_finalize(ore_engine* e);   /* fold BN, pack weights, upload */
+
+/* Backbone+FPN only: img [B][3][H][W] (u8 or f32, device) -> p3,p4,p5 NHWC device pointers owned by the engine. */
+int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W,
+                            void* stream);
+/* Whole eval path for B=1: ... -> proposals.  use_graph=1 replays a captured hipGraph (captured on first use
+ * for this (H,W)).  Results stay on device; query with ore_engine_buffer(). */
+int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t use_graph,
+                        void* stream);
+/* Named device buffers: "p3","p4","p5" (NHWC, ld=2*fpn_ch, coff=fpn_ch), "pos3".."pos5", "head3".."head5",
+ * "pre_boxes","pre_scores","pre_loc","keep_idx","counts","out_boxes","out_scores", "stage2".."stage5", ...
+ * Returns device pointer and fills dims[0..3] = {rows(H*W*B), channels, ld, coff}. */
+int ore_engine_buffer(ore_engine* e, const char* name, void** dev_ptr, int64_t dims[4]);
+/* Algorithmic FLOPs of the dense part of the last forward (2*MAC of every conv), for roofline accounting. */
+double ore_engine_last_flops(ore_engine* e);
+/* Measurement aid (bench.py roofline leg): when enabled, every implicit-GEMM conv launch of an EAGER forward is
+ * bracketed by hipEvents on the launch stream; read_profile synchronises, returns the summed conv-kernel time,
+ * the algorithmic FLOPs of those launches and the launch count since the last read, and resets the counters. */
+int ore_engine_set_profiling(ore_engine* e, int32_t enable);
+int ore_engine_read_profile(ore_engine* e, double* conv_ms, double* conv_flops, int32_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORE_HIP_H_ */
