@@ -48,7 +48,7 @@ def build_model(device):
     from detectron2.modeling import build_model as _build
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(ROOT, "faster-orefsdet_amd", "configs", "fsod", "finetune_vovnet.yaml"))
-    cfg.merge_from_list(["MODEL.DEVICE", str(device), "INPUT.MAX_SIZE_TEST", 640])
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "INPUT.MAX_SIZE_TEST", 640])  # init on the host, then move
     cfg.freeze()
     torch.manual_seed(0)
     model = _build(cfg)
@@ -63,7 +63,7 @@ def build_model(device):
                 mod.running_var.copy_(torch.rand(n, generator=g) + 0.5)
             elif isinstance(mod, torch.nn.Conv2d) and "bottom_up" in name and mod.bias is None:
                 torch.nn.init.kaiming_normal_(mod.weight, generator=g)
-    model.eval()
+    model.to(device).eval()
     C = cfg.MODEL.FPN.OUT_CHANNELS
     support = {f"p{l}": {0: torch.randn(1, C, s, s, generator=g) * 0.1} for l, s in ((3, 32), (4, 16), (5, 8))}
     support["rcnn_8"] = {0: torch.randn(24, C, 8, 8, generator=g) * 0.1}
@@ -81,6 +81,7 @@ def cpu_baseline(model, img, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)  # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     support = {k: model.support_dict[k][0].cpu() for k in ("p3", "p4", "p5")}
