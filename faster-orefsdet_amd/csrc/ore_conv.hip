@@ -1,100 +1,146 @@
 // Implicit-GEMM NHWC convolution on the gfx950 fp32 matrix cores (v_mfma_f32_16x16x4_f32).
 //
-//   M = B*Ho*Wo output pixels (GEMM rows, on the MFMA "A" side), N = Cout (MFMA "B" side -> the lane
-//   index of the accumulator is the output channel, so NHWC stores are contiguous per 16 lanes),
-//   K = kh*kw*Cin walked tap-major in chunks of 16 input channels (every Cin on the path is a
-//   multiple of 16, so a chunk never straddles a tap and is one 64-byte run of the NHWC input).
+//   M = output pixels (GEMM rows, MFMA "A" side), N = Cout (MFMA "B" side: the accumulator's lane index is the
+//   output channel, so NHWC stores are contiguous per 16 lanes), K = kh*kw*Cin walked tap-major in chunks of 16
+//   input channels (every Cin on the path is a multiple of 16: a chunk never straddles a tap and is one 64-byte
+//   run of the NHWC input).
 //
-// Per chunk a 256-thread block stages an im2col tile A[BM][16] (zero-filled at the image border,
-// optional per-(batch,channel) affine+ReLU applied on the fly) and a weight tile B[BN][16] through
-// registers into LDS (row stride 20 floats: ds_read_b128 of 16 rows that differ mod 16 is
-// conflict-free), double-buffered with one barrier per chunk; each wave owns a (TM*16)x(TN*16)
-// sub-tile and issues TM*TN*4 MFMAs per chunk, each lane feeding k = 4*(lane>>4)+s in step s.
+// One 256-thread block owns a BM x BN output tile.  Its 4 waves are arranged WGM x WGN x WGK: WGM*WGN waves tile
+// the output, WGK wave groups split every K step (BK = 16*WGK channels are staged per step, group kg consumes
+// slice kg) -- the small late-stage layers (M = 400..1600 rows at batch 1) get their parallelism from K, not M.
+// Per step the block stages an im2col tile A[BM][BK] (zero-filled at the border, optional per-(image,channel)
+// affine+ReLU on the fly) and a weight tile B[BN][BK] through registers into LDS (row stride BK+4 floats:
+// ds_read_b128 of 16 rows is bank-conflict-free), double-buffered, one barrier per step.
+// Split-K across blocks (grid.z) is reduced INSIDE the launch: every slice stores its fp32 tile to a slab, an
+// agent-scope release + ticket counter elects the last arriver, which acquires and sums the slabs in slice order
+// (bitwise deterministic) and runs the fused epilogue.  The counters reset themselves.
+//
+// Fused epilogue: y = acc*scale[n] + shift[n] (+ nearest-2x top-down add) (+ ReLU on n < relu_cout), optional
+// per-tile column sums of y (the eSE average pool) so no extra pass over the activation is needed.
+// Rows may span several pyramid levels (level-major), so p3/p4/p5 run as ONE launch with per-level epilogue params.
 //
 // Replaces F.conv2d + FrozenBatchNorm2d + ReLU / bias / Scale of the reference (see include/ore_hip.h).
 #include "ore_common.h"
 
 namespace {
 
+struct Lvl { int orow0, irow0, H, W, Ho, Wo; };
+
 struct ConvP {
     const float* in; int in_ld, in_coff;
-    int B, H, W, Cin;
+    int B, Cin;
+    int nlev; Lvl lv[4];
     const float* w;
-    int Cout, Cout16, kh, kw, stride, pad, Ho, Wo, M, K;
-    const float* scale; const float* shift; int relu_cout;
+    int Cout, Cout16, kh, kw, stride, pad, M, K;
+    const float* scale; const float* shift; int ep_stride; int relu_cout;
     const float* in_mul; const float* in_add; int in_relu;
     const float* add; int add_ld, add_coff, add_H, add_W;
     float* out; int out_ld, out_coff;
-    int splitk, chunks_per_split, nchunks;
-    float* ws;
+    float* colsum;                       // [gridDim.x][Cout16] or null
+    int splitk, steps_per_split, nchunks;
+    float* ws; int* tile_cnt;
 };
 
-constexpr int LDS_LD = 20;  // floats per LDS row (16 + 4 pad)
+struct RowInfo { int sid, iy, ix, ibase; };   // sid = level*B + b ; ibase = first input row of that image
+
+__device__ __forceinline__ void decode_row(const ConvP& p, int m, int& lvl, int& b, int& oy, int& ox) {
+    lvl = 0;
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+        if (l < p.nlev && m >= p.lv[l].orow0) lvl = l;
+    const Lvl& L = p.lv[lvl];
+    const int r = m - L.orow0, hw = L.Ho * L.Wo;
+    b = r / hw;
+    const int q = r - b * hw;
+    oy = q / L.Wo;
+    ox = q - oy * L.Wo;
+}
 
 __device__ __forceinline__ float epilogue_one(const ConvP& p, float acc, int m, int n) {
     float v = acc;
-    if (p.scale) v = v * p.scale[n];
-    if (p.shift) v = v + p.shift[n];
-    if (p.add) {
-        const int hw = p.Ho * p.Wo;
-        const int b = m / hw, r = m - b * hw;
-        const int oy = r / p.Wo, ox = r - oy * p.Wo;
-        v += p.add[(size_t)((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + n];
-    }
+    int lvl = 0, b = 0, oy = 0, ox = 0;
+    if (p.ep_stride || p.add) decode_row(p, m, lvl, b, oy, ox);
+    if (p.scale) v = v * p.scale[lvl * p.ep_stride + n];
+    if (p.shift) v = v + p.shift[lvl * p.ep_stride + n];
+    if (p.add) v += p.add[(size_t)((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + n];
     if (n < p.relu_cout) v = fmaxf(v, 0.0f);
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int WGK>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
-    static_assert(WGM * WGN == 4 && WM % 16 == 0 && WN % 16 == 0, "tile");
-    constexpr int A_IT = (BM * 4 + 255) / 256, B_IT = (BN * 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+    constexpr int BK = 16 * WGK, LD = BK + 4;
+    static_assert(WGM * WGN * WGK == 4 && WM % 16 == 0 && WN % 16 == 0, "tile");
+    constexpr int QPR = BK / 4;                                  // float4 per tile row
+    constexpr int A_IT = (BM * QPR + 255) / 256, B_IT = (BN * QPR + 255) / 256;
+    constexpr int STAGE = 2 * (BM + BN) * LD;                    // staging floats (double buffered)
+    constexpr int RED = (WGK - 1) * BM * BN;                     // in-block K reduction scratch
+    constexpr int LDSF = STAGE > RED ? STAGE : RED;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF + 8];
     float* As = lds;
-    float* Bs = lds + 2 * BM * LDS_LD;
+    float* Bs = lds + 2 * BM * LD;
+    int* sh_flag = reinterpret_cast<int*>(lds + LDSF);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int kg = wave % WGK, wmn = wave / WGK;
+    const int wm = wmn / WGN, wn = wmn % WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int c_begin = blockIdx.z * p.chunks_per_split;
-    const int c_end = min(c_begin + p.chunks_per_split, p.nchunks);
-    const int cpt = p.Cin >> 4;  // chunks per tap
+    const int nsteps = (p.nchunks + WGK - 1) / WGK;
+    const int s_begin = blockIdx.z * p.steps_per_split;
+    const int s_end = min(s_begin + p.steps_per_split, nsteps);
+    const int cpt = p.Cin >> 4;                                  // chunks per tap
 
-    // per-thread A rows: pixel coordinates are fixed across the K loop
-    int a_b[A_IT], a_iy[A_IT], a_ix[A_IT];
+    // ---- per-thread A rows: pixel coordinates are fixed across the K loop
+    int a_sid[A_IT], a_iy[A_IT], a_ix[A_IT], a_base[A_IT], a_H[A_IT], a_W[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int f = tid + i * 256, row = f >> 2;
+        const int f = tid + i * 256, row = f / QPR;
         const int m = m0 + row;
-        if (f < BM * 4 && m < p.M) {
-            const int hw = p.Ho * p.Wo;
-            const int b = m / hw, r = m - b * hw;
-            const int oy = r / p.Wo, ox = r - oy * p.Wo;
-            a_b[i] = b; a_iy[i] = oy * p.stride - p.pad; a_ix[i] = ox * p.stride - p.pad;
-        } else {
-            a_b[i] = -1; a_iy[i] = 0; a_ix[i] = 0;
+        a_sid[i] = -1; a_iy[i] = a_ix[i] = a_base[i] = 0; a_H[i] = a_W[i] = 0;
+        if (f < BM * QPR && m < p.M) {
+            int lvl, b, oy, ox;
+            decode_row(p, m, lvl, b, oy, ox);
+            const Lvl& L = p.lv[lvl];
+            a_sid[i] = lvl * p.B + b;
+            a_iy[i] = oy * p.stride - p.pad; a_ix[i] = ox * p.stride - p.pad;
+            a_base[i] = L.irow0 + b * L.H * L.W; a_H[i] = L.H; a_W[i] = L.W;
         }
     }
-    f32x4 ra[A_IT], rb[B_IT];
+    constexpr int PF = 3;                                        // register ring depth: a load has PF K-steps to land
+    f32x4 ra[PF][A_IT], rb[PF][B_IT];
 
-    auto gload = [&](int c) {
-        const int tap = c / cpt, c0 = (c - tap * cpt) << 4;
-        const int dy = tap / p.kw, dx = tap - dy * p.kw;
+    // (dy, dx, c0) per float4 column group of the NEXT step, advanced incrementally (no divisions in the K loop).
+    // A thread's float4 sits in K-slice ks = q / 4 of the step, i.e. chunk (step*WGK + ks).
+    // QPR divides 256, so a thread's K-slice (tid % QPR) >> 2 is the same for all its float4s: one (dy, dx, c0) per thread.
+    const int my_q = tid % QPR, my_ks = my_q >> 2;
+    int n_dy, n_dx, n_c0;
+    {
+        const int c = s_begin * WGK + my_ks;
+        const int tap = c / cpt;
+        n_c0 = (c - tap * cpt) << 4;
+        n_dy = tap / p.kw; n_dx = tap - n_dy * p.kw;
+    }
+    auto gload = [&](int step, f32x4 (&ra)[A_IT], f32x4 (&rb)[B_IT]) {
+        const int c = step * WGK + my_ks;
+        const int dy = n_dy, dx = n_dx, c0 = n_c0;
+        n_c0 += BK;
+        while (n_c0 >= p.Cin) { n_c0 -= p.Cin; if (++n_dx == p.kw) { n_dx = 0; ++n_dy; } }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int q = (tid + i * 256) & 3;
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            const int f = tid + i * 256, q = my_q;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_b[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                const int ch = c0 + q * 4;
-                v = *reinterpret_cast<const f32x4*>(
-                    p.in + (size_t)((a_b[i] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch);
-                if (p.in_mul) {
-                    v = v * *reinterpret_cast<const f32x4*>(p.in_mul + a_b[i] * p.Cin + ch);
-                    if (p.in_add) v = v + *reinterpret_cast<const f32x4*>(p.in_add + a_b[i] * p.Cin + ch);
-                    if (p.in_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            if (f < BM * QPR && a_sid[i] >= 0 && c < p.nchunks) {
+                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                if ((unsigned)iy < (unsigned)a_H[i] && (unsigned)ix < (unsigned)a_W[i]) {
+                    const int ch = c0 + (q & 3) * 4;
+                    v = *reinterpret_cast<const f32x4*>(p.in + (size_t)(a_base[i] + iy * a_W[i] + ix) * p.in_ld + p.in_coff + ch);
+                    if (p.in_mul) {
+                        v = v * *reinterpret_cast<const f32x4*>(p.in_mul + a_sid[i] * p.Cin + ch);
+                        if (p.in_add) v = v + *reinterpret_cast<const f32x4*>(p.in_add + a_sid[i] * p.Cin + ch);
+                        if (p.in_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
                     }
                 }
             }
@@ -102,23 +148,23 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int f = tid + i * 256, n = n0 + (f >> 2), q = f & 3;
+            const int f = tid + i * 256, n = n0 + f / QPR, q = my_q;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f < BN * 4 && n < p.Cout16)
-                v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + (c << 4) + q * 4);
+            if (f < BN * QPR && n < p.Cout16 && c < p.nchunks)
+                v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + (c << 4) + (q & 3) * 4);
             rb[i] = v;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const f32x4 (&ra)[A_IT], const f32x4 (&rb)[B_IT]) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int f = tid + i * 256;
-            if (f < BM * 4) *reinterpret_cast<f32x4*>(As + buf * BM * LDS_LD + (f >> 2) * LDS_LD + (f & 3) * 4) = ra[i];
+            if (f < BM * QPR) *reinterpret_cast<f32x4*>(As + buf * BM * LD + (f / QPR) * LD + (f % QPR) * 4) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int f = tid + i * 256;
-            if (f < BN * 4) *reinterpret_cast<f32x4*>(Bs + buf * BN * LDS_LD + (f >> 2) * LDS_LD + (f & 3) * 4) = rb[i];
+            if (f < BN * QPR) *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (f / QPR) * LD + (f % QPR) * 4) = rb[i];
         }
     };
 
@@ -128,34 +174,112 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fk = (lane >> 4) * 4;
-    if (c_begin < c_end) {
-        gload(c_begin);
-        lstore(0);
+    const int frow = lane & 15, fk = kg * 16 + (lane >> 4) * 4;
+    if (s_begin < s_end) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) gload(s_begin + u, ra[u], rb[u]);       // steps past s_end load zeros (c >= nchunks guard)
+        lstore(0, ra[0], rb[0]);
         __syncthreads();
-        for (int c = c_begin; c < c_end; ++c) {
-            const int cur = (c - c_begin) & 1;
-            if (c + 1 < c_end) gload(c + 1);
-            f32x4 af[TM], bf[TN];
+        for (int s0 = s_begin; s0 < s_end; s0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {                                    // static ring slots (no runtime-indexed registers)
+                const int s = s0 + u;
+                if (s < s_end) {
+                    const int cur = (s - s_begin) & 1;
+                    if (s + PF < s_end) gload(s + PF, ra[u], rb[u]);          // slot u was stored to LDS one step ago: free
+                    f32x4 af[TM], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[i] = *reinterpret_cast<const f32x4*>(As + cur * BM * LD + (wm * WM + i * 16 + frow) * LD + fk);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[j] = *reinterpret_cast<const f32x4*>(Bs + cur * BN * LD + (wn * WN + j * 16 + frow) * LD + fk);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+                    if (s + 1 < s_end) lstore(cur ^ 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
+    // ---- in-block K reduction: groups kg>0 park their tiles in LDS, group 0 adds them in group order
+    if (WGK > 1) {
+        __syncthreads();
+        if (kg > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(As + cur * BM * LDS_LD + (wm * WM + i * 16 + frow) * LDS_LD + fk);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(Bs + cur * BN * LDS_LD + (wn * WN + j * 16 + frow) * LDS_LD + fk);
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<f32x4*>(lds + (((kg - 1) * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4) = acc[i][j];
+        }
+        __syncthreads();
+        if (kg == 0) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int g = 1; g < WGK; ++g)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-            if (c + 1 < c_end) lstore(cur ^ 1);
-            __syncthreads();
+                        acc[i][j] += *reinterpret_cast<const f32x4*>(lds + (((g - 1) * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4);
         }
     }
 
-    // epilogue: accumulator (col = lane&15 -> n, row = (lane>>4)*4 + r -> m)
+    // accumulator element (i, j, r) of this lane is row m0 + wm*WM + i*16 + (lane>>4)*4 + r, column n0 + wn*WN + j*16 + (lane&15)
+    const int ntile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.splitk > 1) {
+        // ---- publish this slice's tile, elect the last arriver (cdna guide: split-K slab reducer recipe)
+        float* slab = p.ws + ((size_t)ntile * p.splitk + blockIdx.z) * (BM * BN);
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<f32x4*>(slab + ((wmn * TM + i) * TN + j) * 256 + lane * 4) = acc[i][j];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(p.tile_cnt + ntile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.splitk - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.tile_cnt + ntile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-reset
+            }
+            *sh_flag = last;
+        }
+        __syncthreads();
+        if (!*sh_flag) return;
+        if (kg == 0) {
+            const float* base = p.ws + (size_t)ntile * p.splitk * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                    for (int z = 0; z < p.splitk; ++z)
+                        s += *reinterpret_cast<const f32x4*>(base + (size_t)z * (BM * BN) + ((wmn * TM + i) * TN + j) * 256 + lane * 4);
+                    acc[i][j] = s;
+                }
+        }
+    }
+    if (kg != 0) {
+        if (p.colsum && WGM > 1) { __syncthreads(); __syncthreads(); }   // keep barrier counts uniform (see below)
+        return;
+    }
+
+    // ---- fused epilogue
+    float csum[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) csum[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -164,48 +288,120 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-                if (m < p.M && n < p.Cout16) {
-                    if (p.splitk > 1) {
-                        p.ws[((size_t)blockIdx.z * p.M + m) * p.Cout16 + n] = acc[i][j][r];
-                    } else if (n < p.Cout) {
-                        p.out[(size_t)m * p.out_ld + p.out_coff + n] = epilogue_one(p, acc[i][j][r], m, n);
-                    }
+                if (m < p.M && n < p.Cout) {
+                    const float v = epilogue_one(p, acc[i][j][r], m, n);
+                    p.out[(size_t)m * p.out_ld + p.out_coff + n] = v;
+                    csum[j] += v;
                 }
             }
         }
-}
-
-// split-K second pass: deterministic in-order sum of the partial slabs + the fused epilogue
-__global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvP p) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int total = p.M * p.Cout16;
-    if (idx >= total) return;
-    const int m = idx / p.Cout16, n = idx - m * p.Cout16;
-    if (n >= p.Cout) return;
-    float s = 0.f;
-    for (int z = 0; z < p.splitk; ++z) s += p.ws[(size_t)z * total + idx];
-    p.out[(size_t)m * p.out_ld + p.out_coff + n] = epilogue_one(p, s, m, n);
-}
-
-template <int BM, int BN, int WGM, int WGN>
-void launch_conv(const ConvP& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN>), grid, dim3(256), 0, st, p);
-}
-
-template <int BM>
-int dispatch_bn(const ConvP& p, int BN, dim3 grid, hipStream_t st) {
-    switch (BN) {
-        case 16: launch_conv<BM, 16, 4, 1>(p, grid, st); break;
-        case 32: launch_conv<BM, 32, 4, 1>(p, grid, st); break;
-        case 48: launch_conv<BM, 48, 4, 1>(p, grid, st); break;
-        case 64: launch_conv<BM, 64, 4, 1>(p, grid, st); break;
-        case 80: launch_conv<BM, 80, 4, 1>(p, grid, st); break;
-        case 96: launch_conv<BM, 96, 4, 1>(p, grid, st); break;
-        case 112: launch_conv<BM, 112, 4, 1>(p, grid, st); break;
-        case 128: launch_conv<BM, 128, 2, 2>(p, grid, st); break;
-        default: return ORE_EINVAL;
+    if (p.colsum) {
+        // column sums of this tile: 4 lane groups hold different rows of the same column -> xor 16 / 32, then across WGM waves
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            csum[j] += __shfl_xor(csum[j], 16);
+            csum[j] += __shfl_xor(csum[j], 32);
+        }
+        if (WGM > 1) {
+            __syncthreads();
+            if (lane < 16)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) lds[(wm * WGN + wn) * (TN * 16) + j * 16 + lane] = csum[j];
+            __syncthreads();
+            if (wm == 0 && lane < 16)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float s = csum[j];
+                    for (int w2 = 1; w2 < WGM; ++w2) s += lds[(w2 * WGN + wn) * (TN * 16) + j * 16 + lane];
+                    csum[j] = s;
+                }
+        }
+        if (wm == 0 && lane < 16)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + lane;
+                if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = csum[j];
+            }
     }
-    return ORE_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN, int WGK>
+void launch_conv(const ConvP& p, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK>), grid, dim3(256), 0, st, p);
+}
+
+struct TileCfg { int BM, BN, WGM, WGN, WGK; };
+
+int dispatch(const ConvP& p, const TileCfg& t, dim3 grid, hipStream_t st) {
+#define ORE_CASE(bm, bn, wgm, wgn, wgk)                                                              \
+    if (t.BM == bm && t.BN == bn && t.WGM == wgm && t.WGN == wgn && t.WGK == wgk) {                  \
+        launch_conv<bm, bn, wgm, wgn, wgk>(p, grid, st);                                             \
+        return ORE_OK;                                                                               \
+    }
+    // large-M tiles: 4 waves along M, whole N in the block
+    ORE_CASE(128, 16, 4, 1, 1) ORE_CASE(128, 32, 4, 1, 1) ORE_CASE(128, 48, 4, 1, 1) ORE_CASE(128, 64, 4, 1, 1)
+    ORE_CASE(128, 80, 4, 1, 1) ORE_CASE(128, 96, 4, 1, 1) ORE_CASE(128, 112, 4, 1, 1) ORE_CASE(128, 128, 2, 2, 1)
+    ORE_CASE(64, 16, 4, 1, 1) ORE_CASE(64, 32, 4, 1, 1) ORE_CASE(64, 48, 4, 1, 1) ORE_CASE(64, 64, 4, 1, 1)
+    ORE_CASE(64, 80, 4, 1, 1) ORE_CASE(64, 96, 4, 1, 1) ORE_CASE(64, 112, 4, 1, 1) ORE_CASE(64, 128, 2, 2, 1)
+    // mid/small-M tiles: waves split K inside the block
+    ORE_CASE(64, 64, 2, 1, 2) ORE_CASE(64, 32, 2, 1, 2) ORE_CASE(64, 16, 2, 1, 2) ORE_CASE(64, 48, 2, 1, 2)
+    ORE_CASE(32, 64, 1, 1, 4) ORE_CASE(32, 48, 1, 1, 4) ORE_CASE(32, 32, 1, 1, 4) ORE_CASE(32, 16, 1, 1, 4)
+    ORE_CASE(16, 64, 1, 1, 4) ORE_CASE(16, 48, 1, 1, 4) ORE_CASE(16, 32, 1, 1, 4) ORE_CASE(16, 16, 1, 1, 4)
+    ORE_CASE(64, 128, 2, 1, 2) ORE_CASE(64, 96, 2, 1, 2) ORE_CASE(64, 80, 2, 1, 2) ORE_CASE(64, 112, 2, 1, 2)
+    ORE_CASE(32, 128, 1, 1, 4) ORE_CASE(32, 96, 1, 1, 4) ORE_CASE(32, 80, 1, 1, 4) ORE_CASE(32, 112, 1, 1, 4)
+    ORE_CASE(32, 128, 2, 1, 2) ORE_CASE(32, 64, 2, 1, 2) ORE_CASE(32, 32, 2, 1, 2)
+    ORE_CASE(128, 64, 2, 1, 2) ORE_CASE(128, 128, 2, 1, 2)
+#undef ORE_CASE
+    return ORE_EINVAL;
+}
+
+// Tile / split plan.  Goal: >= ~768 waves' worth of blocks (256 CUs x 3) when the layer allows it, slabs small enough
+// for the in-kernel last-arriver reduction (splitk * BM*BN*4 bytes per tile stays in the tens of KB).
+TileCfg g_override = {0, 0, 0, 0, 0};   // tuning aid (ore_conv_set_plan_override); BM == 0 -> automatic
+
+void plan_conv(int M, int Cout, int nchunks, int req_splitk, TileCfg* t, int* S_out, int* sps_out) {
+    const int C16 = round_up(Cout, 16);
+    if (g_override.BM > 0) {
+        *t = g_override;
+        if (t->BN > C16) t->BN = C16;
+        const int nst = ceil_div(nchunks, t->WGK);
+        int S = req_splitk > 0 ? req_splitk : 1;
+        if (S > nst) S = nst;
+        const int sps = ceil_div(nst, S);
+        *S_out = ceil_div(nst, sps); *sps_out = sps;
+        return;
+    }
+    // Plan table distilled from tools/conv_tune.py sweeps on MI355X (profiles/r01_conv_tune.txt): small tiles with the K
+    // dimension split across the block's waves win almost everywhere -- they keep several blocks resident per CU, which
+    // hides the per-step barrier/LDS latency that dominates this kernel -- and cross-block split-K only pays for the
+    // deepest K (stage-5 layer 0).
+    int bn;
+    if (M >= 16384) {
+        if (C16 % 64 == 0) *t = {32, 64, 2, 1, 2};
+        else *t = {64, C16 <= 128 ? C16 : 64, 4, 1, 1};
+    } else if (M >= 2048) {
+        if (C16 % 64 == 0) *t = {32, 64, 2, 1, 2};
+        else if (C16 >= 32) *t = {32, 32, 1, 1, 4};
+        else *t = {16, 16, 1, 1, 4};
+    } else {
+        bn = C16 >= 32 ? 32 : 16;
+        *t = {16, bn, 1, 1, 4};
+    }
+    const int nsteps = ceil_div(nchunks, t->WGK);
+    const int blocks = ceil_div(M, t->BM) * ceil_div(C16, t->BN);
+    int S = req_splitk;
+    if (S <= 0) {
+        S = 1;
+        if (nsteps >= 48 && blocks < 256) {
+            S = ceil_div(300, blocks);
+            if (S > 4) S = 4;
+        }
+    }
+    if (S > nsteps) S = nsteps;
+    if (S < 1) S = 1;
+    const int sps = ceil_div(nsteps, S);
+    S = ceil_div(nsteps, sps);
+    *S_out = S; *sps_out = sps;
 }
 
 }  // namespace
@@ -226,81 +422,111 @@ extern "C" int ore_pack_conv_weight_host(const float* w, int32_t Cout, int32_t C
     return ORE_OK;
 }
 
-// Tile / split-K plan shared with the engine (so it can size workspaces).
-extern "C" int ore_conv_plan(int M, int Cout, int nchunks, int req_splitk, int* BM_out, int* BN_out, int* splitk_out,
-                             int* cps_out) {
-    const int C16 = round_up(Cout, 16);
-    const int BN = C16 <= 128 ? C16 : 128;
-    int BM = M >= 16384 ? 128 : 64;
-    const int blocks = ceil_div(M, BM) * ceil_div(C16, BN);
-    int S = req_splitk;
-    if (S <= 0) {
-        S = 1;
-        if (blocks < 192) {
-            S = ceil_div(512, blocks);
-            const int maxS = nchunks / 4 > 0 ? nchunks / 4 : 1;
-            if (S > maxS) S = maxS;
-        }
-    }
-    if (S > nchunks) S = nchunks;
-    if (S < 1) S = 1;
-    const int cps = ceil_div(nchunks, S);
-    S = ceil_div(nchunks, cps);
-    *BM_out = BM; *BN_out = BN; *splitk_out = S; *cps_out = cps;
+extern "C" size_t ore_conv_workspace_floats(void) { return ORE_CONV_WS_FLOATS; }
+
+// Tuning aid (tools/conv_tune.py): force the tile configuration of subsequent ore_conv2d*_fwd calls; BM = 0 restores the
+// automatic plan.  Not used by the product path.
+extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK) {
+    g_override = {BM, BN, WGM, WGN, WGK};
     return ORE_OK;
 }
 
-extern "C" int ore_conv2d_fwd(const ore_conv_desc* d, void* stream) {
+extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
+    if (!d) return 0;
+    const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    TileCfg t; int S, sps;
+    plan_conv(d->B * Ho * Wo, d->Cout, d->kh * d->kw * (d->Cin / 16), d->splitk, &t, &S, &sps);
+    return ceil_div(d->B * Ho * Wo, t.BM);
+}
+
+static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t workspace_floats, hipStream_t st) {
+    TileCfg t; int S, sps;
+    plan_conv(p.M, p.Cout, p.nchunks, req_splitk, &t, &S, &sps);
+    const int gx = ceil_div(p.M, t.BM), gy = ceil_div(p.Cout16, t.BN);
+    if (S > 1) {
+        const size_t need = ORE_CONV_CNT_INTS + (size_t)gx * gy * S * t.BM * t.BN;
+        if (!workspace || workspace_floats < need || gx * gy > ORE_CONV_CNT_INTS) {
+            if (req_splitk > 1) {
+                ore_set_error("ore_conv2d_fwd: split-K %d needs %zu workspace floats (have %zu) and <= %d tiles (have %d)", S, need,
+                              workspace_floats, ORE_CONV_CNT_INTS, gx * gy);
+                return ORE_ENOMEM;
+            }
+            S = 1; sps = ceil_div(p.nchunks, t.WGK);       // automatic plan falls back to no split
+        }
+    }
+    p.splitk = S; p.steps_per_split = sps;
+    p.tile_cnt = reinterpret_cast<int*>(workspace);
+    p.ws = workspace ? workspace + ORE_CONV_CNT_INTS : nullptr;
+    const int rc = dispatch(p, t, dim3(gx, gy, S), st);
+    if (rc != ORE_OK) {
+        ore_set_error("ore_conv2d_fwd: no kernel for tile %dx%d (%d,%d,%d)", t.BM, t.BN, t.WGM, t.WGN, t.WGK);
+        return rc;
+    }
+    return ore_launch_status("k_conv_igemm");
+}
+
+static int conv_common_checks(const ore_conv_desc* d) {
     ORE_CHECK_ARG(d && d->in && d->w && d->out, "ore_conv2d_fwd: null pointer");
     ORE_CHECK_ARG(d->Cin > 0 && d->Cin % 16 == 0, "ore_conv2d_fwd: Cin=%d must be a multiple of 16", d->Cin);
     ORE_CHECK_ARG(d->in_ld % 4 == 0 && d->in_coff % 4 == 0 && d->in_coff + d->Cin <= d->in_ld,
                   "ore_conv2d_fwd: input slice ld=%d coff=%d Cin=%d", d->in_ld, d->in_coff, d->Cin);
     ORE_CHECK_ARG(d->out_coff + d->Cout <= d->out_ld && d->Cout > 0, "ore_conv2d_fwd: output slice");
-    ORE_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0,
-                  "ore_conv2d_fwd: bad geometry");
+    ORE_CHECK_ARG(d->B > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "ore_conv2d_fwd: bad geometry");
     ORE_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "ore_conv2d_fwd: 16-byte alignment");
-    ConvP p{};
+    ORE_CHECK_ARG(d->in_mul || !d->in_add, "ore_conv2d_fwd: in_add needs in_mul");
+    return ORE_OK;
+}
+
+static void fill_common(ConvP& p, const ore_conv_desc* d) {
     p.in = d->in; p.in_ld = d->in_ld; p.in_coff = d->in_coff;
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.w = d->w;
+    p.B = d->B; p.Cin = d->Cin; p.w = d->w;
     p.Cout = d->Cout; p.Cout16 = round_up(d->Cout, 16);
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
-    p.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
-    p.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
-    ORE_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "ore_conv2d_fwd: empty output");
-    p.M = d->B * p.Ho * p.Wo;
     p.K = d->kh * d->kw * d->Cin;
     p.scale = d->scale; p.shift = d->shift; p.relu_cout = d->relu_cout;
     p.in_mul = d->in_mul; p.in_add = d->in_mul ? d->in_add : nullptr; p.in_relu = d->in_relu;
-    ORE_CHECK_ARG(d->in_mul || !d->in_add, "ore_conv2d_fwd: in_add needs in_mul");
-    p.add = d->add; p.add_ld = d->add_ld; p.add_coff = d->add_coff;
-    p.add_H = (p.Ho + 1) / 2; p.add_W = (p.Wo + 1) / 2;
     p.out = d->out; p.out_ld = d->out_ld; p.out_coff = d->out_coff;
     p.nchunks = d->kh * d->kw * (d->Cin / 16);
-    int BM, BN, S, cps;
-    ore_conv_plan(p.M, p.Cout, p.nchunks, d->splitk, &BM, &BN, &S, &cps);
-    if (S > 1) {
-        const size_t need = (size_t)S * p.M * p.Cout16;
-        if (!d->workspace || d->workspace_floats < need) {
-            if (d->splitk > 1) {
-                ore_set_error("ore_conv2d_fwd: split-K %d needs %zu workspace floats, have %zu", S, need,
-                              d->workspace_floats);
-                return ORE_ENOMEM;
-            }
-            S = 1; cps = p.nchunks;  // automatic plan falls back to no split
-        }
+    p.colsum = d->colsum;
+}
+
+extern "C" int ore_conv2d_fwd(const ore_conv_desc* d, void* stream) {
+    int rc = conv_common_checks(d);
+    if (rc) return rc;
+    ORE_CHECK_ARG(d->H > 0 && d->W > 0, "ore_conv2d_fwd: bad geometry");
+    ConvP p{};
+    fill_common(p, d);
+    p.nlev = 1;
+    Lvl& L = p.lv[0];
+    L.orow0 = 0; L.irow0 = 0; L.H = d->H; L.W = d->W;
+    L.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    L.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    ORE_CHECK_ARG(L.Ho > 0 && L.Wo > 0, "ore_conv2d_fwd: empty output");
+    p.M = d->B * L.Ho * L.Wo;
+    p.ep_stride = 0;
+    p.add = d->add; p.add_ld = d->add_ld; p.add_coff = d->add_coff;
+    p.add_H = (L.Ho + 1) / 2; p.add_W = (L.Wo + 1) / 2;
+    return conv_launch(p, d->splitk, d->workspace, d->workspace_floats, (hipStream_t)stream);
+}
+
+// Same conv over several pyramid levels in ONE launch: rows are level-major ([level][b][y][x]) in both the input
+// and the output matrix; scale/shift may differ per level (ep_stride floats apart); in_mul/in_add are [level*B+b][Cin].
+extern "C" int ore_conv2d_levels_fwd(const ore_conv_desc* d, int32_t n_levels, const int32_t* H, const int32_t* W,
+                                     int32_t ep_stride, void* stream) {
+    int rc = conv_common_checks(d);
+    if (rc) return rc;
+    ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && H && W, "ore_conv2d_levels_fwd: 1..4 levels");
+    ORE_CHECK_ARG(d->stride == 1 && d->pad == d->kh / 2 && d->kh == d->kw && !d->add, "ore_conv2d_levels_fwd: 'same' convs only, no add");
+    ConvP p{};
+    fill_common(p, d);
+    p.nlev = n_levels;
+    int rows = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        ORE_CHECK_ARG(H[l] > 0 && W[l] > 0, "ore_conv2d_levels_fwd: level %d geometry", l);
+        p.lv[l] = {rows, rows, H[l], W[l], H[l], W[l]};
+        rows += d->B * H[l] * W[l];
     }
-    p.splitk = S; p.chunks_per_split = cps; p.ws = d->workspace;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid(ceil_div(p.M, BM), ceil_div(p.Cout16, BN), S);
-    int rc = BM == 128 ? dispatch_bn<128>(p, BN, grid, st) : dispatch_bn<64>(p, BN, grid, st);
-    if (rc != ORE_OK) {
-        ore_set_error("ore_conv2d_fwd: no kernel for BN=%d", BN);
-        return rc;
-    }
-    if ((rc = ore_launch_status("k_conv_igemm")) != ORE_OK) return rc;
-    if (S > 1) {
-        hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(ceil_div(p.M * p.Cout16, 256)), dim3(256), 0, st, p);
-        if ((rc = ore_launch_status("k_conv_splitk_reduce")) != ORE_OK) return rc;
-    }
-    return ORE_OK;
+    p.M = rows;
+    p.ep_stride = ep_stride;
+    return conv_launch(p, d->splitk, d->workspace, d->workspace_floats, (hipStream_t)stream);
 }

@@ -81,6 +81,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds_w, int* total) {
 }
 
 __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
+    extern __shared__ __attribute__((aligned(16))) float sv[];   // sigmoid of every location of this level (computed once)
     __shared__ int hist[256];
     __shared__ int wsum[SEL_T / 64];
     __shared__ int sh_i[4];
@@ -88,16 +89,19 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     const int HW = p.H[l] * p.W[l];
     const float* hd = p.head[l];
     const int tid = threadIdx.x;
-    auto sig = [&](int i) { return ore_sigmoid(hd[(size_t)i * p.head_ld + 4]); };
 
-    // ---- candidate count
+    // ---- sigmoid once + candidate count
     int cnt = 0;
-    for (int i = tid; i < HW; i += SEL_T) cnt += sig(i) > p.score_thresh ? 1 : 0;
+    for (int i = tid; i < HW; i += SEL_T) {
+        const float s = ore_sigmoid(hd[(size_t)i * p.head_ld + 4]);
+        sv[i] = s;
+        cnt += s > p.score_thresh ? 1 : 0;
+    }
     int nc;
-    block_excl_scan(cnt, wsum, &nc);
+    block_excl_scan(cnt, wsum, &nc);   // (its barriers also publish sv[])
     const int k = nc < p.pre_topk ? nc : p.pre_topk;
 
-    // ---- exact k-th largest sigmoid (bits are order-preserving for positive floats)
+    // ---- exact k-th largest sigmoid (bits are order-preserving for positive floats): 4 x 8-bit radix select
     unsigned T = 0;      // threshold key; select key > T, plus `quota` lowest-index elements with key == T
     int quota = 0;
     bool take_all = true;
@@ -110,18 +114,32 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
             for (int i = tid; i < 256; i += SEL_T) hist[i] = 0;
             __syncthreads();
             for (int i = tid; i < HW; i += SEL_T) {
-                const float s = sig(i);
+                const float s = sv[i];
                 const unsigned key = __float_as_uint(s);
                 if (s > p.score_thresh && (key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, d = 255;
-                for (; d > 0; --d) {
-                    if (acc + hist[d] >= remaining) break;
-                    acc += hist[d];
+            if (tid < 64) {
+                // lane L owns bins 4L..4L+3; suffix sums over lanes locate the bin where the count from the top reaches `remaining`
+                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int t = h0 + h1 + h2 + h3;
+                int suf = t;                                   // inclusive suffix sum over lanes >= tid
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_down(suf, d);
+                    if (tid + d < 64) suf += o;
                 }
-                sh_i[0] = d; sh_i[1] = remaining - acc;
+                const int above = suf - t;
+                if (suf >= remaining && above < remaining) {   // exactly one lane
+                    int acc = above, dsel, rem;
+                    if (acc + h3 >= remaining) { dsel = 3; rem = remaining - acc; }
+                    else { acc += h3;
+                        if (acc + h2 >= remaining) { dsel = 2; rem = remaining - acc; }
+                        else { acc += h2;
+                            if (acc + h1 >= remaining) { dsel = 1; rem = remaining - acc; }
+                            else { acc += h1; dsel = 0; rem = remaining - acc; } } }
+                    sh_i[0] = 4 * tid + dsel; sh_i[1] = rem;
+                }
             }
             __syncthreads();
             prefix |= (unsigned)sh_i[0] << shift;
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
         T = prefix; quota = remaining;  // `remaining` of the elements equal to T are taken
     }
 
-    // ---- ordered selection + decode (ascending flat index)
+    // ---- ordered selection + decode (ascending flat index); one packed scan per tile: low 16 bits = ties, high = greater
     const float st = (float)p.stride[l];
     const float half = (float)(p.stride[l] / 2);
     int tie_base = 0, out_base = 0;
@@ -141,19 +159,22 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     for (int i0 = 0; i0 < HW; i0 += SEL_T) {
         const int i = i0 + tid;
         float s = 0.f;
-        bool cand = false, gt = false, tie = false;
+        bool gt = false, tie = false;
         if (i < HW) {
-            s = sig(i);
-            cand = s > p.score_thresh;
+            s = sv[i];
+            const bool cand = s > p.score_thresh;
             const unsigned key = __float_as_uint(s);
             gt = cand && (take_all || key > T);
             tie = cand && !take_all && key == T;
         }
-        int tie_tot, sel_tot;
-        const int tie_pre = block_excl_scan(tie ? 1 : 0, wsum, &tie_tot);
+        int tot;
+        const int pre = block_excl_scan((gt ? 65536 : 0) | (tie ? 1 : 0), wsum, &tot);
+        const int tie_pre = pre & 0xffff, gt_pre = pre >> 16;
+        const int ties_taken_before_tile = min(tie_base, quota);
+        const int ties_taken_before_me = min(tie_base + tie_pre, quota) - ties_taken_before_tile;
         const bool sel = gt || (tie && tie_base + tie_pre < quota);
-        const int pos = out_base + block_excl_scan(sel ? 1 : 0, wsum, &sel_tot);
         if (sel) {
+            const int pos = out_base + gt_pre + ties_taken_before_me;
             const float gx = (float)((i % p.W[l]) * p.stride[l]) + half;
             const float gy = (float)((i / p.W[l]) * p.stride[l]) + half;
             const f32x4 r = *reinterpret_cast<const f32x4*>(hd + (size_t)i * p.head_ld);
@@ -166,8 +187,9 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
             p.lvl_scores[o] = sqrtf(s);
             p.lvl_loc[o] = loc_base + i;
         }
-        tie_base += tie_tot;
-        out_base += sel_tot;
+        const int tile_ties = tot & 0xffff, tile_gt = tot >> 16;
+        out_base += tile_gt + (min(tie_base + tile_ties, quota) - ties_taken_before_tile);
+        tie_base += tile_ties;
     }
     if (tid == 0) p.lvl_cnt[l] = out_base;
 }
@@ -251,44 +273,73 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
     mask[(size_t)i * words + bj] = bits;
 }
 
-// One block (256 threads).  removed[] lives in LDS as 64-bit words.
+// One block (256 threads).  removed[] lives in LDS as 64-bit words.  All global latency is taken one 64-row block
+// ahead: while block bi is being resolved, the diagonal word and the suppression rows of block bi+1 are already in
+// flight into registers (speculatively -- only the rows that survive are OR-ed into removed[] afterwards).
+template <int KW>   // 64-bit words per lane per row beyond the diagonal: KW*64 >= mask words
 __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
                                                   const int* __restrict__ s_order, const int* __restrict__ n_ptr,
                                                   const unsigned long long* __restrict__ mask, int words, float nms_thresh,
                                                   int post_topk, long long* __restrict__ keep_idx,
                                                   float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                   int* __restrict__ n_keep_out) {
+    extern __shared__ unsigned long long diag_lds[];   // [nb*64] diagonal suppression word of every row, loaded once
     __shared__ unsigned long long removed[NMS_MAX_WORDS];
-    __shared__ unsigned long long sh_kept;
-    __shared__ int cnt_sh;
+    __shared__ unsigned long long sh_misc[2];          // [0] = kept mask of the current block, [1] = final count (keeps LDS 8-byte sized)
+    unsigned long long& sh_kept = sh_misc[0];
+    int& cnt_sh = *reinterpret_cast<int*>(&sh_misc[1]);
     const int n = *n_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = (n + 63) >> 6;
     for (int w = tid; w < words; w += 256) removed[w] = 0ull;
+    for (int r = tid; r < nb * 64; r += 256) diag_lds[r] = r < n ? mask[(size_t)r * words + (r >> 6)] : 0ull;
     if (tid == 0) cnt_sh = 0;
-    __syncthreads();
     int n_keep = 0;       // uniform
     float thr_score = 0.f;
     bool have_thr = false;
-    const bool do_nms = nms_thresh > 0.0f;
+    unsigned long long rows[16][KW];
+    auto prefetch = [&](int b) {                       // rows of block b handled by this wave: b*64 + wave*16 + r
+        if (b >= nb) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = b * 64 + wave * 16 + r;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int w = b + 1 + lane + 64 * k;
+                rows[r][k] = (row < n && w < nb) ? mask[(size_t)row * words + w] : 0ull;
+            }
+        }
+    };
+    prefetch(0);
+    __syncthreads();
     for (int bi = 0; bi < nb; ++bi) {
         if (wave == 0) {
             const int row = bi * 64 + lane;
-            unsigned long long diag = (do_nms && row < n) ? mask[(size_t)row * words + bi] : 0ull;
+            const unsigned long long diag = diag_lds[row];
             unsigned long long rem = removed[bi];
             const int nvalid = min(64, n - bi * 64);
             if (nvalid < 64) rem |= ~0ull << nvalid;
+            // Greedy resolution inside the block as a fixpoint: K <- cand & ~OR_{s in K} diag[s].  diag[s] only has bits > s,
+            // so iteration i is exact on the first i rows and the unique fixpoint IS the sequential greedy answer; it is
+            // reached after (longest suppression chain) iterations, typically a handful instead of 64 serial steps.
+            const unsigned long long cand = ~rem;
+            unsigned long long kept = cand;
             if (__ballot(diag != 0ull) != 0ull) {
-                for (int t = 0; t < 64; ++t) {
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)diag, t);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), t);
-                    if (!((rem >> t) & 1ull)) rem |= ((unsigned long long)hi << 32) | lo;
+                for (int it = 0; it < 64; ++it) {
+                    unsigned long long sup = ((kept >> lane) & 1ull) ? diag : 0ull;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) {
+                        const unsigned lo = __shfl_xor((unsigned)sup, d);
+                        const unsigned hi = __shfl_xor((unsigned)(sup >> 32), d);
+                        sup |= ((unsigned long long)hi << 32) | lo;
+                    }
+                    const unsigned long long kn = cand & ~sup;
+                    if (kn == kept) break;
+                    kept = kn;
                 }
             }
-            const unsigned long long kept = ~rem;
             if (lane == 0) sh_kept = kept;
-            // emit survivors of this block in order
-            if ((kept >> lane) & 1ull) {
+            if ((kept >> lane) & 1ull) {               // emit survivors of this block in order
                 const int pos = n_keep + __popcll(kept & ((1ull << lane) - 1ull));
                 keep_idx[pos] = (long long)s_order[row];
                 *reinterpret_cast<f32x4*>(out_boxes + (size_t)pos * 4) = *reinterpret_cast<const f32x4*>(s_boxes + (size_t)row * 4);
@@ -298,14 +349,11 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_bo
         __syncthreads();
         const unsigned long long kept = sh_kept;
         const int kc = __popcll(kept);
-        // post-NMS top-k bookkeeping (uniform across the block)
-        if (post_topk > 0 && !have_thr && n_keep + kc >= post_topk) {
-            // the post_topk-th survivor sits in this block
-            int need = post_topk - n_keep, t = 0;
+        if (post_topk > 0 && !have_thr && n_keep + kc >= post_topk) {   // the post_topk-th survivor sits in this block
+            int need = post_topk - n_keep;
             unsigned long long m = kept;
             while (need > 1) { m &= m - 1; --need; }
-            t = __ffsll((long long)m) - 1;
-            thr_score = s_scores[bi * 64 + t];
+            thr_score = s_scores[bi * 64 + (__ffsll((long long)m) - 1)];
             have_thr = true;
         }
         n_keep += kc;
@@ -315,23 +363,18 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_bo
             if (s_scores[last] < thr_score) stop = true;  // later rows are all below the threshold score
         }
         if (stop || bi + 1 >= nb) break;
-        // OR the kept rows of this block into removed[bi+1 ..]
-        if (do_nms && kept) {
-            int idx = 0;
-            unsigned long long m = kept;
-            while (m) {
-                const int t = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if ((idx & 3) == wave) {
-                    const size_t rowoff = (size_t)(bi * 64 + t) * words;
-                    for (int w = bi + 1 + lane; w < nb; w += 64) {
-                        const unsigned long long v = mask[rowoff + w];
-                        if (v) atomicOr(&removed[w], v);
-                    }
+        // OR the surviving rows of this block (already in registers) into removed[bi+1 ..]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((kept >> (wave * 16 + r)) & 1ull) {
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int w = bi + 1 + lane + 64 * k;
+                    if (rows[r][k]) atomicOr(&removed[w], rows[r][k]);
                 }
-                ++idx;
             }
         }
+        prefetch(bi + 1);
         __syncthreads();
     }
     // final count: survivors with score >= thr (a prefix, the list is in descending score order)
@@ -344,6 +387,26 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_bo
         n_keep = cnt_sh;
     }
     if (tid == 0) *n_keep_out = n_keep;
+}
+
+static int launch_nms_scan(int words, hipStream_t st, const float* s_boxes, const float* s_scores, const int* s_order, const int* n_ptr,
+                           const unsigned long long* mask, float thr, int post_topk, long long* keep_idx, float* out_boxes,
+                           float* out_scores, int* n_keep_out) {
+    const size_t dl = (size_t)words * 64 * 8;   // diagonal words (<= 128 KB at 16384 boxes)
+    if (dl > 48 * 1024) {
+        const void* f = words <= 64 ? (const void*)k_nms_scan<1> : (words <= 128 ? (const void*)k_nms_scan<2> : (const void*)k_nms_scan<4>);
+        ORE_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
+    }
+    if (words <= 64)
+        hipLaunchKernelGGL(k_nms_scan<1>, dim3(1), dim3(256), dl, st, s_boxes, s_scores, s_order, n_ptr, mask, words, thr, post_topk,
+                           keep_idx, out_boxes, out_scores, n_keep_out);
+    else if (words <= 128)
+        hipLaunchKernelGGL(k_nms_scan<2>, dim3(1), dim3(256), dl, st, s_boxes, s_scores, s_order, n_ptr, mask, words, thr, post_topk,
+                           keep_idx, out_boxes, out_scores, n_keep_out);
+    else
+        hipLaunchKernelGGL(k_nms_scan<4>, dim3(1), dim3(256), dl, st, s_boxes, s_scores, s_order, n_ptr, mask, words, thr, post_topk,
+                           keep_idx, out_boxes, out_scores, n_keep_out);
+    return ore_launch_status("k_nms_scan");
 }
 
 __global__ void k_fill_upper_zero(unsigned long long* mask, size_t nwords) {
@@ -411,7 +474,13 @@ extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
     p.cap = cap;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    hipLaunchKernelGGL(k_level_select, dim3(d->n_levels), dim3(SEL_T), 0, st, p);
+    int hw_max = 0;
+    for (int l = 0; l < d->n_levels; ++l) hw_max = max(hw_max, d->H[l] * d->W[l]);
+    const size_t sv_bytes = (size_t)hw_max * 4;
+    ORE_CHECK_ARG(sv_bytes <= 120 * 1024, "ore_detect_fwd: a level with %d locations exceeds the 30720-location LDS cache", hw_max);
+    if (sv_bytes > 48 * 1024)
+        ORE_HIP(hipFuncSetAttribute((const void*)k_level_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv_bytes));
+    hipLaunchKernelGGL(k_level_select, dim3(d->n_levels), dim3(SEL_T), sv_bytes, st, p);
     if ((rc = ore_launch_status("k_level_select"))) return rc;
     const size_t sc_bytes = (size_t)cap * 4;
     if (sc_bytes > 64 * 1024)
@@ -423,9 +492,8 @@ extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
                            lay.words);
         if ((rc = ore_launch_status("k_nms_mask"))) return rc;
     }
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), 0, st, p.s_boxes, p.s_scores, p.s_order, p.counts,
-                       p.mask, lay.words, d->nms_thresh, d->post_topk, p.keep_idx, p.out_boxes, p.out_scores, p.counts + 1);
-    return ore_launch_status("k_nms_scan");
+    return launch_nms_scan(lay.words, st, p.s_boxes, p.s_scores, p.s_order, p.counts, p.mask, d->nms_thresh, d->post_topk, p.keep_idx,
+                           p.out_boxes, p.out_scores, p.counts + 1);
 }
 
 // ---- stand-alone NMS (same kernels; scores sorted by the rank kernel through a 1-level DetP) -------
@@ -499,7 +567,6 @@ extern "C" int ore_nms_fwd(const float* boxes, const float* scores, int32_t n, f
         hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(64), 0, st, s_boxes, n_dev, thr, mask, lay.words);
         if ((rc = ore_launch_status("k_nms_mask"))) return rc;
     }
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), 0, st, s_boxes, s_scores, s_order, n_dev, mask,
-                       lay.words, thr, 0, (long long*)keep_idx, (float*)(ws + lay.out_b), (float*)(ws + lay.out_s), count);
-    return ore_launch_status("k_nms_scan");
+    return launch_nms_scan(lay.words, st, s_boxes, s_scores, s_order, n_dev, mask, thr, 0, (long long*)keep_idx,
+                           (float*)(ws + lay.out_b), (float*)(ws + lay.out_s), count);
 }

@@ -16,7 +16,6 @@
 #include <string.h>
 #include "ore_common.h"
 
-extern "C" int ore_conv_plan(int M, int Cout, int nchunks, int req_splitk, int* BM, int* BN, int* S, int* cps);
 
 namespace {
 
@@ -43,18 +42,21 @@ struct ore_engine {
     float* stem1_w = nullptr; float* stem1_scale = nullptr; float* stem1_shift = nullptr;
     Conv stem2, stem3;
     struct Stage { Conv layer[8]; Conv concat; float* fc_w = nullptr; float* fc_b = nullptr; int in_ch, conv_ch, out_ch, cat_ch; } stage[4];
-    Conv lateral[3], output[3], conv3, tower, pred[3];
+    Conv lateral[3], output[3], conv3, tower, pred;      // pred.scale/shift are [3 levels][16]
     float* gn_gamma = nullptr; float* gn_beta = nullptr;
-    float* k11[3] = {}, *k13[3] = {}, *k31[3] = {};
+    float* k11 = nullptr, *k13 = nullptr, *k31 = nullptr; // level-major [3][C], [3][C][3], [3][C][3]
     HostTensor support[3];
     bool support_set[3] = {false, false, false};
     // buffers
     void* img_in = nullptr; size_t img_bytes = 0;
-    Buf s1, s2, cat[4], sout[4], lat[3], pcat[3], pos[3], tow[3], head[3];
+    Buf s1, s2, cat[4], sout[4], lat[3];
+    Buf pcat, pos, tow, head;                    // all pyramid levels in ONE level-major matrix each ([level][b][y][x])
     float* gate[4] = {};
-    float* gn_mul[3] = {}, *gn_add[3] = {};
-    float* ws = nullptr; size_t ws_floats = 0;
+    float* gn_mul = nullptr, *gn_add = nullptr;  // [3*B][C]
+    float* ws = nullptr; size_t ws_floats = 0;   // conv split-K counters + slabs (include/ore_hip.h workspace contract)
     float* ese_ws = nullptr;
+    float* gn_ws = nullptr;
+    float* colsum = nullptr; size_t colsum_floats = 0;
     // detect
     float* pre_boxes = nullptr; float* pre_scores = nullptr; int64_t* pre_loc = nullptr; int32_t* pre_level = nullptr;
     int64_t* keep_idx = nullptr; int32_t* counts = nullptr; float* out_boxes = nullptr; float* out_scores = nullptr;
@@ -167,9 +169,31 @@ Geo make_geo(int B, int H, int W) {
 
 struct Run {
     ore_engine* e; hipStream_t st; double flops = 0.0; int rc = ORE_OK; bool prof = false;
+    // one launch over all pyramid levels (level-major rows)
+    void conv_levels(const Conv& c, const float* in, int in_ld, int in_coff, int B, const int* H, const int* W, float* out,
+                     int out_ld, int out_coff, int ep_stride = 0, const float* in_mul = nullptr, const float* in_add = nullptr,
+                     int in_relu = 0) {
+        if (rc) return;
+        ore_conv_desc d{};
+        d.in = in; d.in_ld = in_ld; d.in_coff = in_coff; d.B = B; d.Cin = c.Cin;
+        d.w = c.w; d.Cout = c.Cout; d.kh = d.kw = c.k; d.stride = 1; d.pad = c.pad;
+        d.scale = c.scale; d.shift = c.shift; d.relu_cout = c.relu_cout;
+        d.in_mul = in_mul; d.in_add = in_add; d.in_relu = in_relu;
+        d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
+        d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
+        double rows = 0;
+        for (int l = 0; l < 3; ++l) rows += (double)B * H[l] * W[l];
+        const double fl = 2.0 * rows * (double)c.Cout * c.Cin * c.k * c.k;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        size_t ia = 0;
+        if (prof) { ia = e->ev_used; ea = e->next_event(); eb = e->next_event(); if (ea) (void)hipEventRecord(ea, st); }
+        rc = ore_conv2d_levels_fwd(&d, 3, H, W, ep_stride, st);
+        if (prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl}); }
+        flops += fl;
+    }
     void conv(const Conv& c, const float* in, int in_ld, int in_coff, int B, int H, int W, float* out, int out_ld,
               int out_coff, const float* in_mul = nullptr, const float* in_add = nullptr, int in_relu = 0,
-              const float* add = nullptr, int add_ld = 0, int add_coff = 0) {
+              const float* add = nullptr, int add_ld = 0, int add_coff = 0, float* colsum = nullptr, int* colsum_rows = nullptr) {
         if (rc) return;
         ore_conv_desc d{};
         d.in = in; d.in_ld = in_ld; d.in_coff = in_coff; d.B = B; d.H = H; d.W = W; d.Cin = c.Cin;
@@ -179,6 +203,10 @@ struct Run {
         d.add = add; d.add_ld = add_ld; d.add_coff = add_coff;
         d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
         d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
+        if (colsum) {
+            const int rows = ore_conv_colsum_rows(&d);
+            if ((size_t)rows * round_up(c.Cout, 16) <= e->colsum_floats) { d.colsum = colsum; *colsum_rows = rows; }
+        }
         const int Ho = (H + 2 * c.pad - c.k) / c.stride + 1, Wo = (W + 2 * c.pad - c.k) / c.stride + 1;
         const double fl = 2.0 * B * Ho * Wo * (double)c.Cout * c.Cin * c.k * c.k;
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -189,6 +217,12 @@ struct Run {
         flops += fl;
     }
 };
+
+int lvl_row0(const Geo& g, int l) {   // first row of pyramid level l (0 = p3) in the level-major matrices
+    int r = 0;
+    for (int j = 0; j < l; ++j) r += g.B * g.h[j + 3] * g.w[j + 3];
+    return r;
+}
 
 int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStream_t st, double* flops) {
     const ore_model_cfg& c = e->cfg;
@@ -214,10 +248,15 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
             r.conv(S.layer[i], cat.p, cat.ld, src, g.B, g.h[k], g.w[k], cat.p, cat.ld, dst);
             src = dst; dst += S.conv_ch;
         }
-        r.conv(S.concat, cat.p, cat.ld, 0, g.B, g.h[k], g.w[k], e->sout[s].p, e->sout[s].ld, 0);
+        int cs_rows = 0;
+        r.conv(S.concat, cat.p, cat.ld, 0, g.B, g.h[k], g.w[k], e->sout[s].p, e->sout[s].ld, 0, nullptr, nullptr, 0, nullptr, 0, 0,
+               g.B == 1 ? e->colsum : nullptr, &cs_rows);   // eSE average pool fused into the concat conv's epilogue
         if (r.rc) break;
-        r.rc = ore_ese_gate_fwd(e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s],
-                                e->ese_ws, st);
+        if (cs_rows > 0)
+            r.rc = ore_ese_gate_from_colsum_fwd(e->colsum, cs_rows, 1, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws, st);
+        else
+            r.rc = ore_ese_gate_fwd(e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s],
+                                    e->ese_ws, st);
     }
     // FPN top-down: level index 2 = p5, 1 = p4, 0 = p3; outputs land in the q half of pcat
     const int F = c.fpn_ch;
@@ -226,7 +265,7 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
         const float* add = l < 2 ? e->lat[l + 1].p : nullptr;
         r.conv(e->lateral[l], e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, e->gate[s], nullptr, 0,
                add, F, 0);
-        r.conv(e->output[l], e->lat[l].p, F, 0, g.B, g.h[k], g.w[k], e->pcat[l].p, 2 * F, F);
+        r.conv(e->output[l], e->lat[l].p, F, 0, g.B, g.h[k], g.w[k], e->pcat.p + (size_t)lvl_row0(g, l) * 2 * F, 2 * F, F);
     }
     *flops = r.flops;
     return r.rc;
@@ -237,20 +276,23 @@ int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
     const int F = c.fpn_ch;
     Run r{e, st};
     r.prof = e->profiling;
-    for (int l = 0; l < 3 && !r.rc; ++l) {
-        const int k = l + 3, H = g.h[k], W = g.w[k];
-        if (!e->support_set[l]) { ore_set_error("support prototype for level %d not set", k); return ORE_EINVAL; }
-        r.rc = ore_correlation_fwd(e->pcat[l].p, 2 * F, F, g.B, H, W, F, e->k11[l], e->k13[l], e->k31[l], e->pcat[l].p, 2 * F, 0, st);
-        if (r.rc) break;
-        r.flops += 2.0 * 8.0 * g.B * H * W * F;
-        r.conv(e->conv3, e->pcat[l].p, 2 * F, 0, g.B, H, W, e->pos[l].p, F, 0);
-        r.conv(e->tower, e->pos[l].p, F, 0, g.B, H, W, e->tow[l].p, F, 0);
-        if (r.rc) break;
-        r.rc = ore_groupnorm_affine_fwd(e->tow[l].p, F, 0, g.B, H * W, F, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->gn_mul[l],
-                                        e->gn_add[l], st);
-        if (r.rc) break;
-        r.conv(e->pred[l], e->tow[l].p, F, 0, g.B, H, W, e->head[l].p, 8, 0, e->gn_mul[l], e->gn_add[l], 1);
-    }
+    const int H[3] = {g.h[3], g.h[4], g.h[5]}, W[3] = {g.w[3], g.w[4], g.w[5]};
+    const int HW[3] = {H[0] * W[0], H[1] * W[1], H[2] * W[2]};
+    for (int l = 0; l < 3; ++l)
+        if (!e->support_set[l]) { ore_set_error("support prototype for level %d not set", l + 3); return ORE_EINVAL; }
+    // query<->support depthwise correlation, all levels: attn -> channels [0,F) of pcat (q sits in [F,2F))
+    r.rc = ore_correlation_levels_fwd(e->pcat.p, 2 * F, F, g.B, 3, H, W, F, e->k11, e->k13, e->k31, e->pcat.p, 2 * F, 0, st);
+    if (r.rc) return r.rc;
+    const double rows = (double)g.B * (HW[0] + HW[1] + HW[2]);
+    r.flops += 2.0 * 8.0 * rows * F;
+    r.conv_levels(e->conv3, e->pcat.p, 2 * F, 0, g.B, H, W, e->pos.p, F, 0);            // relu(conv3(cat(attn, q)))
+    r.conv_levels(e->tower, e->pos.p, F, 0, g.B, H, W, e->tow.p, F, 0);                 // bbox_tower conv (+bias)
+    if (r.rc) return r.rc;
+    r.rc = ore_groupnorm_affine_levels_fwd(e->tow.p, F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->gn_mul, e->gn_add,
+                                           e->gn_ws, st);
+    if (r.rc) return r.rc;
+    // (l,t,r,b | hm) conv with GN affine + ReLU on its input, per-level Scale in the epilogue
+    r.conv_levels(e->pred, e->tow.p, F, 0, g.B, H, W, e->head.p, 8, 0, 16, e->gn_mul, e->gn_add, 1);
     *flops = r.flops;
     return r.rc;
 }
@@ -259,7 +301,10 @@ int run_detect(ore_engine* e, const Geo& g, hipStream_t st) {
     const ore_model_cfg& c = e->cfg;
     ore_detect_desc d{};
     d.n_levels = 3; d.head_ld = 8;
-    for (int l = 0; l < 3; ++l) { d.head[l] = e->head[l].p; d.H[l] = g.h[l + 3]; d.W[l] = g.w[l + 3]; d.stride[l] = c.strides[l]; }
+    for (int l = 0; l < 3; ++l) {
+        d.head[l] = e->head.p + (size_t)lvl_row0(g, l) * 8;
+        d.H[l] = g.h[l + 3]; d.W[l] = g.w[l + 3]; d.stride[l] = c.strides[l];
+    }
     d.score_thresh = c.score_thresh; d.pre_topk = c.pre_topk; d.nms_thresh = c.nms_thresh; d.post_topk = c.post_topk;
     d.pre_boxes = e->pre_boxes; d.pre_scores = e->pre_scores; d.pre_loc = e->pre_loc; d.pre_level = e->pre_level;
     d.keep_idx = e->keep_idx; d.counts = e->counts; d.out_boxes = e->out_boxes; d.out_scores = e->out_scores;
@@ -314,7 +359,8 @@ extern "C" int ore_engine_set_support(ore_engine* e, int32_t level, const float*
         float* tmp = nullptr;
         ORE_HIP(hipMalloc((void**)&tmp, (size_t)C * s * s * sizeof(float)));
         hipError_t err = hipMemcpy(tmp, proto, (size_t)C * s * s * sizeof(float), hipMemcpyHostToDevice);
-        int rc = err == hipSuccess ? ore_support_kernels_fwd(tmp, C, s, e->k11[l], e->k13[l], e->k31[l], nullptr) : ORE_EHIP;
+        int rc = err == hipSuccess ? ore_support_kernels_fwd(tmp, C, s, e->k11 + (size_t)l * C, e->k13 + (size_t)l * C * 3,
+                                                             e->k31 + (size_t)l * C * 3, nullptr) : ORE_EHIP;
         hipDeviceSynchronize();
         hipFree(tmp);
         if (rc) return rc;
@@ -382,18 +428,19 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
         w5.insert(w5.end(), wh->v.begin(), wh->v.end());
         std::vector<float> packed(ore_packed_weight_floats(5, F, 3, 3));
         ore_pack_conv_weight_host(w5.data(), 5, F, 3, 3, packed.data());
-        float* wdev = nullptr;
-        if ((rc = e->upload(&wdev, packed))) return rc;
+        Conv& p = e->pred;
+        if ((rc = e->upload(&p.w, packed))) return rc;
+        p.Cin = F; p.Cout = 5; p.k = 3; p.stride = 1; p.pad = 1; p.relu_cout = 4;
+        std::vector<float> scale(3 * 16, 0.f), shift(3 * 16, 0.f);
         for (int l = 0; l < 3; ++l) {
             const HostTensor* sc;
             if ((rc = need(e, hp + "scales." + std::to_string(l) + ".scale", &sc, {1}))) return rc;
             const float s = sc->v[0];
             // reg = relu(scale_l * (conv + bias)); hm = conv + bias   (centernet_head.py:150-159)
-            std::vector<float> scale = {s, s, s, s, 1.0f}, shift = {br->v[0] * s, br->v[1] * s, br->v[2] * s, br->v[3] * s, bh->v[0]};
-            Conv& p = e->pred[l];
-            p.w = wdev; p.Cin = F; p.Cout = 5; p.k = 3; p.stride = 1; p.pad = 1; p.relu_cout = 4;
-            if ((rc = e->upload(&p.scale, scale)) || (rc = e->upload(&p.shift, shift))) return rc;
+            for (int j = 0; j < 4; ++j) { scale[l * 16 + j] = s; shift[l * 16 + j] = br->v[j] * s; }
+            scale[l * 16 + 4] = 1.0f; shift[l * 16 + 4] = bh->v[0];
         }
+        if ((rc = e->upload(&p.scale, scale)) || (rc = e->upload(&p.shift, shift))) return rc;
     }
     // ---- buffers for the largest padded geometry
     const Geo g = make_geo(c.max_batch, c.max_h, c.max_w);
@@ -403,38 +450,36 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
     e->allocs.push_back(e->img_in);
     if ((rc = alloc_buf(e, &e->s1, B * g.h[1] * g.w[1], c.stem_ch[0]))) return rc;
     if ((rc = alloc_buf(e, &e->s2, B * g.h[1] * g.w[1], c.stem_ch[1]))) return rc;
-    size_t ws_need = 0, cmax = 0;
-    auto plan = [&](size_t M, const Conv& cv) {
-        int BM, BN, S, cps;
-        ore_conv_plan((int)M, cv.Cout, cv.k * cv.k * cv.Cin / 16, 0, &BM, &BN, &S, &cps);
-        if (S > 1) { const size_t n = (size_t)S * M * round_up(cv.Cout, 16); if (n > ws_need) ws_need = n; }
-    };
-    plan(B * g.h[1] * g.w[1], e->stem2);
-    plan(B * g.h[2] * g.w[2], e->stem3);
+    size_t cmax = 0, cs_need = 0;
     for (int s = 0; s < 4; ++s) {
         const int k = s + 2;
         const size_t M = B * g.h[k] * g.w[k];
         if ((rc = alloc_buf(e, &e->cat[s], M, e->stage[s].cat_ch))) return rc;
         if ((rc = alloc_buf(e, &e->sout[s], M, e->stage[s].out_ch))) return rc;
         if ((rc = e->dalloc(&e->gate[s], B * e->stage[s].out_ch))) return rc;
-        for (int i = 0; i < c.layers_per_block; ++i) plan(M, e->stage[s].layer[i]);
-        plan(M, e->stage[s].concat);
         if ((size_t)e->stage[s].out_ch > cmax) cmax = e->stage[s].out_ch;
+        const size_t cs = (M / 16 + 1) * (size_t)e->stage[s].out_ch;     // worst case: 16-row tiles
+        if (cs > cs_need) cs_need = cs;
     }
+    size_t rows_all = 0;
     for (int l = 0; l < 3; ++l) {
         const int k = l + 3;
         const size_t M = B * g.h[k] * g.w[k];
-        if ((rc = alloc_buf(e, &e->lat[l], M, F)) || (rc = alloc_buf(e, &e->pcat[l], M, 2 * F)) || (rc = alloc_buf(e, &e->pos[l], M, F)) ||
-            (rc = alloc_buf(e, &e->tow[l], M, F)) || (rc = alloc_buf(e, &e->head[l], M, 8))) return rc;
-        if ((rc = e->dalloc(&e->gn_mul[l], B * F)) || (rc = e->dalloc(&e->gn_add[l], B * F))) return rc;
-        if ((rc = e->dalloc(&e->k11[l], (size_t)F)) || (rc = e->dalloc(&e->k13[l], (size_t)F * 3)) || (rc = e->dalloc(&e->k31[l], (size_t)F * 3))) return rc;
-        plan(M, e->lateral[l]); plan(M, e->output[l]); plan(M, e->conv3); plan(M, e->tower); plan(M, e->pred[l]);
-        ORE_HIP(hipMemset(e->head[l].p, 0, M * 8 * sizeof(float)));
+        rows_all += M;
+        if ((rc = alloc_buf(e, &e->lat[l], M, F))) return rc;
     }
-    if (ws_need < ((size_t)8 << 20)) ws_need = (size_t)8 << 20;  // smaller inputs may split deeper
-    e->ws_floats = ws_need;
-    if ((rc = e->dalloc(&e->ws, ws_need))) return rc;
-    if ((rc = e->dalloc(&e->ese_ws, B * ORE_ESE_PARTS * cmax))) return rc;
+    if ((rc = alloc_buf(e, &e->pcat, rows_all, 2 * F)) || (rc = alloc_buf(e, &e->pos, rows_all, F)) ||
+        (rc = alloc_buf(e, &e->tow, rows_all, F)) || (rc = alloc_buf(e, &e->head, rows_all, 8))) return rc;
+    ORE_HIP(hipMemset(e->head.p, 0, rows_all * 8 * sizeof(float)));
+    if ((rc = e->dalloc(&e->gn_mul, 3 * B * F)) || (rc = e->dalloc(&e->gn_add, 3 * B * F))) return rc;
+    if ((rc = e->dalloc(&e->k11, (size_t)3 * F)) || (rc = e->dalloc(&e->k13, (size_t)3 * F * 3)) || (rc = e->dalloc(&e->k31, (size_t)3 * F * 3))) return rc;
+    e->ws_floats = ore_conv_workspace_floats();
+    if ((rc = e->dalloc(&e->ws, e->ws_floats))) return rc;
+    ORE_HIP(hipMemset(e->ws, 0, e->ws_floats * sizeof(float)));   // arrival counters start at zero and reset themselves
+    if ((rc = e->dalloc(&e->ese_ws, B * (ORE_ESE_PARTS + 1) * cmax))) return rc;
+    e->colsum_floats = cs_need;
+    if ((rc = e->dalloc(&e->colsum, cs_need))) return rc;
+    if ((rc = e->dalloc(&e->gn_ws, (rows_all / 64 + 3 * B + 8) * 64 * 2))) return rc;
     const size_t cap = (size_t)3 * c.pre_topk;
     if ((rc = e->dalloc(&e->pre_boxes, cap * 4)) || (rc = e->dalloc(&e->pre_scores, cap)) || (rc = e->dalloc(&e->pre_loc, cap)) ||
         (rc = e->dalloc(&e->pre_level, cap)) || (rc = e->dalloc(&e->keep_idx, cap)) || (rc = e->dalloc(&e->counts, (size_t)4)) ||
@@ -562,12 +607,13 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
     for (int l = 0; l < 3; ++l) {
         const std::string k = std::to_string(l + 3);
         const int64_t rows = (int64_t)g.B * g.h[l + 3] * g.w[l + 3];
-        if (n == "p" + k) return set(e->pcat[l].p, rows, F, 2 * F, F);
-        if (n == "attn" + k) return set(e->pcat[l].p, rows, F, 2 * F, 0);
+        const size_t r0 = (size_t)lvl_row0(g, l);
+        if (n == "p" + k) return set(e->pcat.p + r0 * 2 * F, rows, F, 2 * F, F);
+        if (n == "attn" + k) return set(e->pcat.p + r0 * 2 * F, rows, F, 2 * F, 0);
         if (n == "lat" + k) return set(e->lat[l].p, rows, F, F, 0);
-        if (n == "pos" + k) return set(e->pos[l].p, rows, F, F, 0);
-        if (n == "tower" + k) return set(e->tow[l].p, rows, F, F, 0);
-        if (n == "head" + k) return set(e->head[l].p, rows, 5, 8, 0);
+        if (n == "pos" + k) return set(e->pos.p + r0 * F, rows, F, F, 0);
+        if (n == "tower" + k) return set(e->tow.p + r0 * F, rows, F, F, 0);
+        if (n == "head" + k) return set(e->head.p + r0 * 8, rows, 5, 8, 0);
     }
     if (n == "pre_boxes") return set(e->pre_boxes, cap, 4, 4, 0);
     if (n == "pre_scores") return set(e->pre_scores, cap, 1, 1, 0);

@@ -7,59 +7,77 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // stem_1: image [B][3][H][W] (u8 or f32 planar, BGR) -> (x-mean)/std, zero pad -> conv3x3 s2 p1 ->
-// FrozenBN -> ReLU -> NHWC.  Thread = (output pixel, 16-channel group); the 27 taps are registers,
-// the [27][Cout] weights sit in LDS (the 4 channel groups of a pixel read 4 distinct float4s).
+// FrozenBN -> ReLU -> NHWC, as a K=28 GEMM on v_mfma_f32_16x16x4_f32: each lane gathers only the 7 taps it
+// feeds to the matrix core, the weights live in registers for the whole wave.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B, int H, int W, int Ho, int Wo,
                                                float m0, float m1, float m2, float s0, float s1, float s2,
                                                const float* __restrict__ w, const float* __restrict__ scale,
                                                const float* __restrict__ shift, int Cout, float* __restrict__ out,
-                                               int out_ld, int out_coff) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [27][Cout]
-    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
-        const int n = i % Cout, k = i / Cout;
-        wl[i] = w[n * 27 + k];
+                                               int out_ld, int out_coff, int groups_per_wave) {
+    // GEMM view: M = output pixels (16 per MFMA tile), N = Cout (NT tiles of 16), K = 27 padded to 28 = 7 k-steps of 4.
+    // lane (i = lane&15, g = lane>>4) feeds A[pixel i][k = 4j+g] and B[k = 4j+g][n = i] in step j.
+    constexpr int MAXNT = NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    // per-lane tap decode for the 7 k-steps (independent of the pixel)
+    int kc[7], kdy[7], kdx[7];
+    bool kv[7];
+    float kmean[7], kstd[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = 4 * j + g;
+        kv[j] = k < 27;
+        const int kk = kv[j] ? k : 0;
+        kc[j] = kk / 9; kdy[j] = (kk % 9) / 3 - 1; kdx[j] = kk % 3 - 1;
+        kmean[j] = kc[j] == 0 ? m0 : (kc[j] == 1 ? m1 : m2);
+        kstd[j] = kc[j] == 0 ? s0 : (kc[j] == 1 ? s1 : s2);
     }
-    __syncthreads();
-    const int pix = blockIdx.x * 64 + (threadIdx.x >> 2);
-    const int cg = threadIdx.x & 3;
+    float bw[MAXNT][7];
+#pragma unroll
+    for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bw[t][j] = (t < NT && kv[j]) ? w[(t * 16 + li) * 27 + 4 * j + g] : 0.f;
     const int M = B * Ho * Wo;
-    if (pix >= M) return;
-    const int b = pix / (Ho * Wo), r = pix - b * Ho * Wo;
-    const int oy = r / Wo, ox = r - oy * Wo;
-    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
-    float x[27];
+    const int ngroups = (M + 15) >> 4;
+    const int gw0 = (blockIdx.x * 4 + wave) * groups_per_wave;
+    for (int gi = 0; gi < groups_per_wave; ++gi) {
+        const int grp = gw0 + gi;
+        if (grp >= ngroups) break;
+        const int pix = grp * 16 + li;
+        const bool pv = pix < M;
+        const int pp = pv ? pix : 0;
+        const int b = pp / (Ho * Wo), r = pp - b * Ho * Wo;
+        const int oy = r / Wo, ox = r - oy * Wo;
+        float a[7];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-                float v = 0.f;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    v = ((float)img[((size_t)(b * 3 + c) * H + iy) * W + ix] - mean[c]) / sd[c];
-                x[c * 9 + ky * 3 + kx] = v;
-            }
-    for (int cb = cg * 16; cb < Cout; cb += 64) {
-        f32x4 acc[4] = {};
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + k * Cout + cb + j * 4);
-                acc[j] += x[k] * wv;
-            }
+        for (int j = 0; j < 7; ++j) {
+            const int iy = oy * 2 + kdy[j], ix = ox * 2 + kdx[j];
+            float v = 0.f;
+            if (pv && kv[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = ((float)img[((size_t)(b * 3 + kc[j]) * H + iy) * W + ix] - kmean[j]) / kstd[j];
+            a[j] = v;
         }
-        float* o = out + (size_t)pix * out_ld + out_coff + cb;
+        f32x4 acc[MAXNT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cb + j * 4);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + cb + j * 4);
-            f32x4 v = acc[j] * sc + sh;
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            *reinterpret_cast<f32x4*>(o + j * 4) = v;
+        for (int t = 0; t < MAXNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int t = 0; t < MAXNT; ++t)
+                if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bw[t][j], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t) {
+            if (t < NT) {
+                const int n = t * 16 + li;
+                const float sc = scale[n], sh = shift[n];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int m = grp * 16 + g * 4 + rr;
+                    if (m < M) out[(size_t)m * out_ld + out_coff + n] = fmaxf(acc[t][rr] * sc + sh, 0.f);
+                }
+            }
         }
     }
 }
@@ -120,29 +138,43 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     }
 }
 
-// pass 2: mean -> fc (one wave per output channel, coalesced weight rows) -> hsigmoid.
-__global__ __launch_bounds__(256) void k_ese_gate(const float* __restrict__ part, int P, int HW, int C,
-                                                  const float* __restrict__ fw, const float* __restrict__ fb,
-                                                  float* __restrict__ gate) {
-    extern __shared__ float mean[];  // [C]
+// pass 2a: mean[b][c] = sum_p part[b][p][c] / HW.  One block per 16 channels: 4 float4 groups x 64 row slices, so a thread
+// has at most ceil(P/64) independent loads in flight and the whole reduction is one memory round trip.
+__global__ __launch_bounds__(256) void k_colmean(const float* __restrict__ part, int P, int HW, int C, float* __restrict__ mean) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
     const int b = blockIdx.y;
-    const float inv = 1.0f / (float)HW;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int p = 0; p < P; ++p) s += part[((size_t)(b * P + p)) * C + c];
-        mean[c] = s * inv;
-    }
+    const int cg = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 16 + cg * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (int p = sl; p < P; p += 64) a += *reinterpret_cast<const f32x4*>(part + ((size_t)b * P + p) * C + c);
+    *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = a;
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int o = blockIdx.x * 16 + wave; o < min((int)(blockIdx.x + 1) * 16, C); o += 4) {
-        float s = 0.f;
-        for (int k = lane; k < C; k += 64) s += fw[(size_t)o * C + k] * mean[k];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-        if (lane == 0) {
-            const float v = s + fb[o] + 3.0f;
-            gate[b * C + o] = fminf(fmaxf(v, 0.f), 6.0f) / 6.0f;
+    for (int h = 32; h > 0; h >>= 1) {      // fixed-order tree over the 64 slices: deterministic
+        if (sl < h) {
+            a = *reinterpret_cast<const f32x4*>(red + threadIdx.x * 4) + *reinterpret_cast<const f32x4*>(red + (threadIdx.x + h * 4) * 4);
+            *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = a;
         }
+        __syncthreads();
+    }
+    if (sl == 0 && c < C) *reinterpret_cast<f32x4*>(mean + (size_t)b * C + c) = a * (1.0f / (float)HW);
+}
+
+// pass 2b: gate = relu6(fc(mean) + 3) / 6; one wave per output channel (coalesced weight row), 4 outputs per block.
+__global__ __launch_bounds__(256) void k_ese_gate(const float* __restrict__ mean, int C, const float* __restrict__ fw,
+                                                  const float* __restrict__ fb, float* __restrict__ gate) {
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= C) return;
+    const float* m = mean + (size_t)b * C;
+    float s = 0.f;
+    for (int k = lane; k < C; k += 64) s += fw[(size_t)o * C + k] * m[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) {
+        const float v = s + fb[o] + 3.0f;
+        gate[b * C + o] = fminf(fmaxf(v, 0.f), 6.0f) / 6.0f;
     }
 }
 
@@ -165,16 +197,30 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_correlation(const float* __restrict__ q, int q_ld, int q_coff, int B, int H,
-                                                     int W, int C4, const float* __restrict__ k11,
-                                                     const float* __restrict__ k13, const float* __restrict__ k31,
-                                                     float* __restrict__ out, int out_ld, int out_coff) {
+struct CorrLv { int row0, H, W; };
+struct CorrP {
+    const float* q; int q_ld, q_coff; int B, C4, nlev; CorrLv lv[4]; int rows;
+    const float* k11; const float* k13; const float* k31; int kstride;   // per-level stride (in channels) of the kernels
+    float* out; int out_ld, out_coff;
+};
+
+__global__ __launch_bounds__(256) void k_correlation(CorrP p) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * H * W * C4) return;
-    const int c4 = idx % C4, pix = idx / C4;
-    const int b = pix / (H * W), r = pix - b * H * W;
-    const int y = r / W, x = r - y * W;
+    if (idx >= p.rows * p.C4) return;
+    const int c4 = idx % p.C4, row = idx / p.C4;
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (j < p.nlev && row >= p.lv[j].row0) l = j;
+    const int H = p.lv[l].H, W = p.lv[l].W;
+    const int r = row - p.lv[l].row0;
+    const int b = r / (H * W), rr = r - b * H * W;
+    const int y = rr / W, x = rr - y * W;
+    const int base = p.lv[l].row0 + b * H * W;
     const int c = c4 * 4;
+    const float* k11 = p.k11 + l * p.kstride;
+    const float* k13 = p.k13 + l * p.kstride * 3;
+    const float* k31 = p.k31 + l * p.kstride * 3;
     const f32x4 w11 = *reinterpret_cast<const f32x4*>(k11 + c);
     f32x4 w13[3], w31[3];
 #pragma unroll
@@ -184,7 +230,7 @@ __global__ __launch_bounds__(256) void k_correlation(const float* __restrict__ q
     }
     auto Q = [&](int yy, int xx) -> f32x4 {
         if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-            return *reinterpret_cast<const f32x4*>(q + (size_t)((b * H + yy) * W + xx) * q_ld + q_coff + c);
+            return *reinterpret_cast<const f32x4*>(p.q + (size_t)(base + yy * W + xx) * p.q_ld + p.q_coff + c);
         return f32x4{0.f, 0.f, 0.f, 0.f};
     };
     const f32x4 qc = Q(y, x);
@@ -199,7 +245,7 @@ __global__ __launch_bounds__(256) void k_correlation(const float* __restrict__ q
         }
     }
     const f32x4 res = a + relu4(bacc) + qc;
-    *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + out_coff + c) = res;
+    *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + p.out_coff + c) = res;
 }
 
 // support prototype [C][s][s] -> adaptive avg pools (1,1), (1,3), (3,1); one block per channel.
@@ -232,43 +278,105 @@ __global__ __launch_bounds__(64) void k_support_kernels(const float* __restrict_
     }
 }
 
-// GroupNorm statistics -> per-(b,c) affine.  One block per (group, b); two passes (mean, then
-// centred second moment) so there is no E[x^2]-E[x]^2 cancellation.
-__global__ __launch_bounds__(256) void k_groupnorm_affine(const float* __restrict__ x, int ld, int coff, int HW, int C,
-                                                          int G, float eps, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ mul,
-                                                          float* __restrict__ add) {
-    __shared__ float red[4];
-    __shared__ float bc;
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int cpg = C / G;
-    const int n = HW * cpg;
-    const float* base = x + (size_t)b * HW * ld + coff + g * cpg;
-    auto block_sum = [&](float v) -> float {
+// GroupNorm statistics -> per-(b,c) affine, deterministic and cancellation-free:
+//   pass 1: one block per (64-row chunk, b): coalesced [rows][C] reads, per-group (count, mean, M2) of the chunk;
+//   pass 2: one block per b: Chan's parallel-variance combine of the chunk statistics, then mul/add per channel.
+constexpr int GN_ROWS = 64;
+// segments = (level, image) pairs, level-major; seg s covers rows [seg_row0(s), +HW_l) and owns chunks [seg_chunk0(s), ...)
+struct GnSeg { int nlev, B; int HW[4]; int row0[4]; int chunk0[4]; int nchunk[4]; };
+
+__device__ __forceinline__ void gn_locate_chunk(const GnSeg& g, int chunk, int& seg, int& HW, int& row0, int& local) {
+    int l = 0;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
-        __syncthreads();
-        return bc;
-    };
+    for (int j = 1; j < 4; ++j)
+        if (j < g.nlev && chunk >= g.chunk0[j]) l = j;
+    const int within = chunk - g.chunk0[l];
+    const int b = within / g.nchunk[l];
+    local = within - b * g.nchunk[l];
+    HW = g.HW[l];
+    row0 = g.row0[l] + b * HW;
+    seg = l * g.B + b;
+}
+
+__global__ __launch_bounds__(256) void k_gn_chunk_stats(const float* __restrict__ x, int ld, int coff, GnSeg sg, int C, int G,
+                                                        float* __restrict__ stats /* [total chunks][G][2] */) {
+    __shared__ float red[256];
+    __shared__ float gmean[64];
+    int seg, HW, row0, chunk;
+    gn_locate_chunk(sg, blockIdx.x, seg, HW, row0, chunk);
+    const int cpg = C / G;
+    const int rpar = 256 / C;                    // host guarantees C <= 256 and 256 % C == 0
+    const int c = threadIdx.x % C, rr = threadIdx.x / C;
+    const int r0 = chunk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
+    const float* base = x + (size_t)row0 * ld + coff + c;
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += base[(size_t)(i / cpg) * ld + (i % cpg)];
-    const float mean = block_sum(s) / (float)n;
-    float v = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float d = base[(size_t)(i / cpg) * ld + (i % cpg)] - mean;
-        v += d * d;
+    for (int r = r0 + rr; r < r1; r += rpar) s += base[(size_t)r * ld];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t = 0.f;
+        for (int k = 0; k < rpar; ++k)
+            for (int j = 0; j < cpg; ++j) t += red[k * C + threadIdx.x * cpg + j];
+        gmean[threadIdx.x] = t / (float)((r1 - r0) * cpg);
     }
-    const float var = block_sum(v) / (float)n;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    if (threadIdx.x < cpg) {
-        const int c = g * cpg + threadIdx.x;
-        const float m = rstd * gamma[c];
+    __syncthreads();
+    const float mu = gmean[c / cpg];
+    float v = 0.f;
+    for (int r = r0 + rr; r < r1; r += rpar) { const float d = base[(size_t)r * ld] - mu; v += d * d; }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t = 0.f;
+        for (int k = 0; k < rpar; ++k)
+            for (int j = 0; j < cpg; ++j) t += red[k * C + threadIdx.x * cpg + j];
+        float* o = stats + ((size_t)blockIdx.x * G + threadIdx.x) * 2;
+        o[0] = gmean[threadIdx.x]; o[1] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_combine(const float* __restrict__ stats, GnSeg sg, int C, int G, float eps,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ mul, float* __restrict__ add) {
+    __shared__ float sn[8][64], sm[8][64], sq[8][64];
+    __shared__ float fmean[64], frstd[64];
+    const int b = blockIdx.x;                     // segment id = level*B + image
+    const int lvl = b / sg.B, img = b - lvl * sg.B;
+    const int nchunks = sg.nchunk[lvl], HW = sg.HW[lvl];
+    stats += (size_t)(sg.chunk0[lvl] + img * nchunks) * G * 2;
+    const int cpg = C / G;
+    const int g = threadIdx.x % 64, sl = threadIdx.x / 64;   // G <= 64; 4 slices of chunks
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (g < G)
+        for (int ch = sl; ch < nchunks; ch += 4) {
+            const float* o = stats + ((size_t)ch * G + g) * 2;
+            const float nb = (float)((min((ch + 1) * GN_ROWS, HW) - ch * GN_ROWS) * cpg);
+            const float mb = o[0], qb = o[1];
+            const float nt = n + nb, d = mb - mean;
+            mean += d * (nb / nt);
+            m2 += qb + d * d * (n * nb / nt);
+            n = nt;
+        }
+    sn[sl][g] = n; sm[sl][g] = mean; sq[sl][g] = m2;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float N = sn[0][g], M = sm[0][g], Q = sq[0][g];
+        for (int k = 1; k < 4; ++k) {
+            const float nb = sn[k][g];
+            if (nb > 0.f) {
+                const float nt = N + nb, d = sm[k][g] - M;
+                M += d * (nb / nt);
+                Q += sq[k][g] + d * d * (N * nb / nt);
+                N = nt;
+            }
+        }
+        fmean[g] = M;
+        frstd[g] = 1.0f / sqrtf(Q / N + eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float m = frstd[c / cpg] * gamma[c];
         mul[b * C + c] = m;
-        add[b * C + c] = beta[c] - mean * m;
+        add[b * C + c] = beta[c] - fmean[c / cpg] * m;
     }
 }
 
@@ -280,21 +388,26 @@ extern "C" int ore_stem1_fwd(const void* img, int32_t img_is_u8, int32_t B, int3
                              int32_t out_coff, void* stream) {
     ORE_CHECK_ARG(img && mean3 && std3 && w_oihw && scale && shift && out, "ore_stem1_fwd: null pointer");
     ORE_CHECK_ARG(B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W && Hp % 2 == 0 && Wp % 2 == 0, "ore_stem1_fwd: geometry");
-    ORE_CHECK_ARG(Cout % 16 == 0 && Cout <= 256 && out_coff % 4 == 0 && out_ld % 4 == 0 && out_coff + Cout <= out_ld,
+    ORE_CHECK_ARG(Cout % 16 == 0 && Cout <= 128 && out_coff % 4 == 0 && out_ld % 4 == 0 && out_coff + Cout <= out_ld,
                   "ore_stem1_fwd: Cout=%d ld=%d coff=%d", Cout, out_ld, out_coff);
     const int Ho = Hp / 2, Wo = Wp / 2;
     const int M = B * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)27 * Cout * sizeof(float);
     // mean/std are host-readable by contract (3 floats each)
-    if (img_is_u8)
-        hipLaunchKernelGGL(k_stem1<uint8_t>, dim3(ceil_div(M, 64)), dim3(256), lds, st, (const uint8_t*)img, B, H, W, Ho,
-                           Wo, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], w_oihw, scale, shift, Cout, out,
-                           out_ld, out_coff);
-    else
-        hipLaunchKernelGGL(k_stem1<float>, dim3(ceil_div(M, 64)), dim3(256), lds, st, (const float*)img, B, H, W, Ho, Wo,
-                           mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], w_oihw, scale, shift, Cout, out,
-                           out_ld, out_coff);
+    const int ngroups = ceil_div(M, 16);
+    const int gpw = ngroups >= 8192 ? 4 : 1;            // groups of 16 pixels per wave (amortises the weight registers)
+    const int blocks = ceil_div(ngroups, 4 * gpw);
+#define ORE_STEM1(T, NT)                                                                                              \
+    hipLaunchKernelGGL((k_stem1<T, NT>), dim3(blocks), dim3(256), 0, st, (const T*)img, B, H, W, Ho, Wo, mean3[0], mean3[1], \
+                       mean3[2], std3[0], std3[1], std3[2], w_oihw, scale, shift, Cout, out, out_ld, out_coff, gpw)
+    switch ((Cout >> 4) * 2 + (img_is_u8 ? 1 : 0)) {
+        case 2: ORE_STEM1(float, 1); break;     case 3: ORE_STEM1(uint8_t, 1); break;
+        case 4: ORE_STEM1(float, 2); break;     case 5: ORE_STEM1(uint8_t, 2); break;
+        case 8: ORE_STEM1(float, 4); break;     case 9: ORE_STEM1(uint8_t, 4); break;
+        case 16: ORE_STEM1(float, 8); break;    case 17: ORE_STEM1(uint8_t, 8); break;
+        default: ore_set_error("ore_stem1_fwd: Cout=%d not in {16,32,64,128}", Cout); return ORE_EINVAL;
+    }
+#undef ORE_STEM1
     return ore_launch_status("k_stem1");
 }
 
@@ -316,12 +429,27 @@ extern "C" int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_
     ORE_CHECK_ARG(x && fc_w && fc_b && gate && workspace, "ore_ese_gate_fwd: null pointer");
     ORE_CHECK_ARG(B > 0 && HW > 0 && C % 4 == 0 && C <= 4096 && ld % 4 == 0 && coff % 4 == 0, "ore_ese_gate_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    const int P = HW < ORE_ESE_PARTS ? HW : ORE_ESE_PARTS;
+    int P = ceil_div(HW, 32);                      // >= 32 rows per part; enough blocks to pull HBM bandwidth
+    if (P > ORE_ESE_PARTS) P = ORE_ESE_PARTS;
     hipLaunchKernelGGL(k_colsum_partial, dim3(P, B), dim3(256), 0, st, x, ld, coff, HW, C, workspace);
     int rc = ore_launch_status("k_colsum_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 16), B), dim3(256), (size_t)C * sizeof(float), st, workspace, P, HW, C,
-                       fc_w, fc_b, gate);
+    float* mean = workspace + (size_t)B * P * C;
+    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), B), dim3(256), 0, st, workspace, P, HW, C, mean);
+    if ((rc = ore_launch_status("k_colmean"))) return rc;
+    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean, C, fc_w, fc_b, gate);
+    return ore_launch_status("k_ese_gate");
+}
+
+extern "C" int ore_ese_gate_from_colsum_fwd(const float* part, int32_t P, int32_t B, int32_t HW, int32_t C, const float* fc_w,
+                                            const float* fc_b, float* gate, float* mean_ws, void* stream) {
+    ORE_CHECK_ARG(part && fc_w && fc_b && gate && mean_ws && P > 0 && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096,
+                  "ore_ese_gate_from_colsum_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), B), dim3(256), 0, st, part, P, HW, C, mean_ws);
+    int rc = ore_launch_status("k_colmean");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate);
     return ore_launch_status("k_ese_gate");
 }
 
@@ -341,9 +469,26 @@ extern "C" int ore_correlation_fwd(const float* q, int32_t q_ld, int32_t q_coff,
     ORE_CHECK_ARG(q && k11 && k13 && k31 && out, "ore_correlation_fwd: null pointer");
     ORE_CHECK_ARG(C % 4 == 0 && q_ld % 4 == 0 && q_coff % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0,
                   "ore_correlation_fwd: alignment");
-    const int total = B * H * W * (C / 4);
-    hipLaunchKernelGGL(k_correlation, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, q, q_ld, q_coff, B, H,
-                       W, C / 4, k11, k13, k31, out, out_ld, out_coff);
+    CorrP p{};
+    p.q = q; p.q_ld = q_ld; p.q_coff = q_coff; p.B = B; p.C4 = C / 4; p.nlev = 1; p.lv[0] = {0, H, W}; p.rows = B * H * W;
+    p.k11 = k11; p.k13 = k13; p.k31 = k31; p.kstride = 0; p.out = out; p.out_ld = out_ld; p.out_coff = out_coff;
+    hipLaunchKernelGGL(k_correlation, dim3(ceil_div(p.rows * p.C4, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return ore_launch_status("k_correlation");
+}
+
+extern "C" int ore_correlation_levels_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t n_levels,
+                                          const int32_t* H, const int32_t* W, int32_t C, const float* k11, const float* k13,
+                                          const float* k31, float* out, int32_t out_ld, int32_t out_coff, void* stream) {
+    ORE_CHECK_ARG(q && k11 && k13 && k31 && out && H && W && n_levels >= 1 && n_levels <= 4, "ore_correlation_levels_fwd: bad args");
+    ORE_CHECK_ARG(C % 4 == 0 && q_ld % 4 == 0 && q_coff % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0,
+                  "ore_correlation_levels_fwd: alignment");
+    CorrP p{};
+    p.q = q; p.q_ld = q_ld; p.q_coff = q_coff; p.B = B; p.C4 = C / 4; p.nlev = n_levels;
+    int rows = 0;
+    for (int l = 0; l < n_levels; ++l) { p.lv[l] = {rows, H[l], W[l]}; rows += B * H[l] * W[l]; }
+    p.rows = rows;
+    p.k11 = k11; p.k13 = k13; p.k31 = k31; p.kstride = C; p.out = out; p.out_ld = out_ld; p.out_coff = out_coff;
+    hipLaunchKernelGGL(k_correlation, dim3(ceil_div(p.rows * p.C4, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_correlation");
 }
 
@@ -354,12 +499,31 @@ extern "C" int ore_support_kernels_fwd(const float* proto_chw, int32_t C, int32_
     return ore_launch_status("k_support_kernels");
 }
 
+extern "C" int ore_groupnorm_affine_levels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
+                                               const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
+                                               const float* beta, float* mul, float* add, float* workspace, void* stream) {
+    ORE_CHECK_ARG(x && HW && gamma && beta && mul && add && workspace && n_levels >= 1 && n_levels <= 4 && groups > 0 && groups <= 64 &&
+                      C % groups == 0 && C <= 256 && 256 % C == 0, "ore_groupnorm_affine_levels_fwd: bad args (need C | 256, groups <= 64)");
+    GnSeg sg{};
+    sg.nlev = n_levels; sg.B = B;
+    int rows = 0, chunks = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        sg.HW[l] = HW[l]; sg.row0[l] = rows; sg.chunk0[l] = chunks; sg.nchunk[l] = ceil_div(HW[l], GN_ROWS);
+        rows += B * HW[l]; chunks += B * sg.nchunk[l];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gn_chunk_stats, dim3(chunks), dim3(256), 0, st, x, ld, coff, sg, C, groups, workspace);
+    int rc = ore_launch_status("k_gn_chunk_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gn_combine, dim3(n_levels * B), dim3(256), 0, st, workspace, sg, C, groups, eps, gamma, beta, mul, add);
+    return ore_launch_status("k_gn_combine");
+}
+
 extern "C" int ore_groupnorm_affine_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
                                         int32_t groups, float eps, const float* gamma, const float* beta, float* mul,
-                                        float* add, void* stream) {
-    ORE_CHECK_ARG(x && gamma && beta && mul && add && groups > 0 && C % groups == 0 && C / groups <= 256,
-                  "ore_groupnorm_affine_fwd: bad args");
-    hipLaunchKernelGGL(k_groupnorm_affine, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, x, ld, coff, HW, C, groups,
-                       eps, gamma, beta, mul, add);
-    return ore_launch_status("k_groupnorm_affine");
+                                        float* add, float* workspace, void* stream) {
+    ORE_CHECK_ARG(x && gamma && beta && mul && add && workspace && groups > 0 && groups <= 64 && C % groups == 0 && C <= 256 &&
+                      256 % C == 0, "ore_groupnorm_affine_fwd: bad args (need C | 256, groups <= 64)");
+    const int32_t hw1[1] = {HW};
+    return ore_groupnorm_affine_levels_fwd(x, ld, coff, B, 1, hw1, C, groups, eps, gamma, beta, mul, add, workspace, stream);
 }

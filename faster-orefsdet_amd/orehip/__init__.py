@@ -16,7 +16,7 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libore_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
-ESE_PARTS = 64
+ESE_PARTS = 512
 
 
 class OreError(RuntimeError):
@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
                 ("in_mul", C.c_void_p), ("in_add", C.c_void_p), ("in_relu", C.c_int32),
                 ("add", C.c_void_p), ("add_ld", C.c_int32), ("add_coff", C.c_int32),
                 ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_coff", C.c_int32),
-                ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t)]
+                ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("colsum", C.c_void_p)]
 
 
 class DetectDesc(C.Structure):
@@ -63,8 +63,9 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
-           "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+           "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_correlation_levels_fwd",
+           "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
@@ -81,6 +82,8 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         L.ore_last_error.restype = C.c_char_p
         L.ore_packed_weight_floats.restype = C.c_size_t
+        L.ore_conv_workspace_floats.restype = C.c_size_t
+        L.ore_conv_colsum_rows.restype = C.c_int32
         L.ore_detect_workspace_bytes.restype = C.c_size_t
         L.ore_nms_workspace_bytes.restype = C.c_size_t
         L.ore_engine_last_flops.restype = C.c_double
@@ -139,7 +142,7 @@ def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
 def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: int = 1, pad: Optional[int] = None, *,
            in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, relu_cout: int = 0, in_mul=None,
            in_add=None, in_relu: bool = False, add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           out_coff: int = 0, splitk: int = 0, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out_coff: int = 0, splitk: int = 0, workspace: Optional[torch.Tensor] = None, want_colsum: bool = False):
     """x: [B,H,W,ld] NHWC fp32.  Returns `out` ([B,Ho,Wo,out_ld]); only channels [out_coff, out_coff+Cout) are written."""
     _f32(x)
     B, H, W, ld = x.shape
@@ -167,8 +170,81 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
     d.splitk = splitk
     if workspace is not None:
         d.workspace, d.workspace_floats = _ptr(workspace), workspace.numel()
+    colsum = None
+    if want_colsum:
+        rows = lib().ore_conv_colsum_rows(C.byref(d))
+        colsum = torch.zeros(rows, (Cout + 15) // 16 * 16, device=x.device, dtype=torch.float32)
+        d.colsum = _ptr(colsum)
     _chk(lib().ore_conv2d_fwd(C.byref(d), _stream()), "ore_conv2d_fwd")
+    return (out, colsum) if want_colsum else out
+
+
+def conv2d_levels(x_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, w_packed: torch.Tensor, Cout: int, k: int, *,
+                  in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, ep_stride: int = 0, relu_cout: int = 0,
+                  in_mul=None, in_add=None, in_relu: bool = False, out: Optional[torch.Tensor] = None, out_coff: int = 0,
+                  splitk: int = 0) -> torch.Tensor:
+    """One launch over several pyramid levels: x_rows [sum_l B*H_l*W_l, ld] level-major."""
+    _f32(x_rows)
+    rows, ld = x_rows.shape
+    assert rows == sum(B * h * w for h, w in HW)
+    Cin = Cin if Cin is not None else ld - in_coff
+    if out is None:
+        out = torch.empty(rows, Cout, device=x_rows.device, dtype=torch.float32)
+    ws = _default_ws(x_rows.device)
+    d = ConvDesc()
+    d.in_, d.in_ld, d.in_coff = _ptr(x_rows), ld, in_coff
+    d.B, d.H, d.W, d.Cin = B, 0, 0, Cin
+    d.w = _ptr(_f32(w_packed))
+    d.Cout, d.kh, d.kw, d.stride, d.pad = Cout, k, k, 1, k // 2
+    d.scale, d.shift, d.relu_cout = _ptr(scale), _ptr(shift), relu_cout
+    d.in_mul, d.in_add, d.in_relu = _ptr(in_mul), _ptr(in_add), int(in_relu)
+    d.out, d.out_ld, d.out_coff = _ptr(_f32(out)), out.shape[-1], out_coff
+    d.splitk, d.workspace, d.workspace_floats = splitk, _ptr(ws), ws.numel()
+    L = len(HW)
+    Hs = (C.c_int32 * L)(*[h for h, _ in HW])
+    Ws = (C.c_int32 * L)(*[w for _, w in HW])
+    _chk(lib().ore_conv2d_levels_fwd(C.byref(d), L, Hs, Ws, ep_stride, _stream()), "ore_conv2d_levels_fwd")
     return out
+
+
+def correlation_levels(q_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, k11, k13, k31, Cc: int, q_coff: int = 0,
+                       out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+    _f32(q_rows)
+    if out is None:
+        out = torch.empty(q_rows.shape[0], Cc, device=q_rows.device, dtype=torch.float32)
+    L = len(HW)
+    Hs = (C.c_int32 * L)(*[h for h, _ in HW])
+    Ws = (C.c_int32 * L)(*[w for _, w in HW])
+    _chk(lib().ore_correlation_levels_fwd(C.c_void_p(_ptr(q_rows)), q_rows.shape[-1], q_coff, B, L, Hs, Ws, Cc,
+                                          C.c_void_p(_ptr(_f32(k11))), C.c_void_p(_ptr(_f32(k13))), C.c_void_p(_ptr(_f32(k31))),
+                                          C.c_void_p(_ptr(out)), out.shape[-1], out_coff, _stream()), "ore_correlation_levels_fwd")
+    return out
+
+
+def groupnorm_affine_levels(x_rows: torch.Tensor, HW: Sequence[int], B: int, groups: int, gamma, beta, eps: float = 1e-5):
+    _f32(x_rows)
+    Cc = x_rows.shape[-1]
+    L = len(HW)
+    mul = torch.empty(L * B, Cc, device=x_rows.device)
+    add = torch.empty(L * B, Cc, device=x_rows.device)
+    ws = torch.empty(sum(B * ((hw + 63) // 64) for hw in HW) * groups * 2 + 64, device=x_rows.device)
+    hws = (C.c_int32 * L)(*HW)
+    _chk(lib().ore_groupnorm_affine_levels_fwd(C.c_void_p(_ptr(x_rows)), Cc, 0, B, L, hws, Cc, groups, C.c_float(eps),
+                                               C.c_void_p(_ptr(_f32(gamma))), C.c_void_p(_ptr(_f32(beta))), C.c_void_p(_ptr(mul)),
+                                               C.c_void_p(_ptr(add)), C.c_void_p(_ptr(ws)), _stream()), "ore_groupnorm_affine_levels_fwd")
+    return mul, add
+
+
+def ese_gate_from_colsum(part: torch.Tensor, HW: int, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
+    """part [P, C] (B = 1): the fused column sums of the concat conv."""
+    _f32(part)
+    P, Cc = part.shape
+    gate = torch.empty(1, Cc, device=part.device, dtype=torch.float32)
+    mean_ws = torch.empty(Cc, device=part.device, dtype=torch.float32)
+    _chk(lib().ore_ese_gate_from_colsum_fwd(C.c_void_p(_ptr(part)), P, 1, HW, Cc, C.c_void_p(_ptr(_f32(fc_w.reshape(Cc, Cc)))),
+                                            C.c_void_p(_ptr(_f32(fc_b))), C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(mean_ws)), _stream()),
+         "ore_ese_gate_from_colsum_fwd")
+    return gate
 
 
 _WS: Dict[str, torch.Tensor] = {}
@@ -177,7 +253,7 @@ _WS: Dict[str, torch.Tensor] = {}
 def _default_ws(device) -> torch.Tensor:
     k = str(device)
     if k not in _WS:
-        _WS[k] = torch.empty(1 << 23, device=device, dtype=torch.float32)  # 32 MiB split-K slab space
+        _WS[k] = torch.zeros(lib().ore_conv_workspace_floats(), device=device, dtype=torch.float32)  # counters (zero) + slabs
     return _WS[k]
 
 
@@ -215,7 +291,7 @@ def ese_gate(x: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.T
     _f32(x)
     B, H, W, Cc = x.shape
     gate = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
-    ws = torch.empty(B * ESE_PARTS * Cc, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * (ESE_PARTS + 1) * Cc, device=x.device, dtype=torch.float32)
     _chk(lib().ore_ese_gate_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H * W, Cc, C.c_void_p(_ptr(_f32(fc_w.reshape(Cc, Cc)))),
                                 C.c_void_p(_ptr(_f32(fc_b))), C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(ws)), _stream()),
          "ore_ese_gate_fwd")
@@ -261,9 +337,10 @@ def groupnorm_affine(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: to
     B, H, W, Cc = x.shape
     mul = torch.empty(B, Cc, device=x.device)
     add = torch.empty(B, Cc, device=x.device)
+    ws = torch.empty(B * ((H * W + 63) // 64) * groups * 2, device=x.device)
     _chk(lib().ore_groupnorm_affine_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H * W, Cc, groups, C.c_float(eps),
                                         C.c_void_p(_ptr(_f32(gamma))), C.c_void_p(_ptr(_f32(beta))), C.c_void_p(_ptr(mul)),
-                                        C.c_void_p(_ptr(add)), _stream()), "ore_groupnorm_affine_fwd")
+                                        C.c_void_p(_ptr(add)), C.c_void_p(_ptr(ws)), _stream()), "ore_groupnorm_affine_fwd")
     return mul, add
 
 

@@ -45,7 +45,8 @@ int ore_version(void);
  *           d2z:modeling/backbone/vovnet.py:205-235 (conv3x3/conv1x1), d2z:modeling/backbone/fpn.py:126-145,
  *           ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:141-161.
  * Requirements: Cin % 16 == 0; weights packed by ore_pack_conv_weight_host ([Cout16][kh*kw*Cin], tap-major).
- * Split-K (splitk > 1) needs workspace >= splitk * M * Cout16 floats, M = B*Ho*Wo. */
+ * Split-K across blocks is reduced inside the launch (last-arriver slab reduction, deterministic); it needs the
+ * workspace described below. */
 typedef struct ore_conv_desc {
     const float* in;   int32_t in_ld, in_coff;
     int32_t B, H, W, Cin;
@@ -61,9 +62,25 @@ typedef struct ore_conv_desc {
     float* out;        int32_t out_ld, out_coff;
     int32_t splitk;       /* 0 = choose automatically, 1 = none */
     float* workspace;  size_t workspace_floats;
+    float* colsum;        /* optional [ore_conv_colsum_rows()][Cout16]: per-row-tile column sums of y (eSE average pool) */
 } ore_conv_desc;
 
+/* Workspace contract: the first ORE_CONV_CNT_INTS 32-bit words are split-K arrival counters and must be ZERO on entry;
+ * every launch leaves them zero again (the last arriver resets its counter).  The rest holds the fp32 partial slabs. */
+#define ORE_CONV_CNT_INTS 4096
+#define ORE_CONV_WS_FLOATS ((size_t)ORE_CONV_CNT_INTS + ((size_t)8 << 20))
+size_t ore_conv_workspace_floats(void);          /* recommended workspace size (floats) */
+int32_t ore_conv_colsum_rows(const ore_conv_desc* d);   /* number of row tiles (= rows of d->colsum) the plan will use */
+
 int ore_conv2d_fwd(const ore_conv_desc* d, void* stream);
+/* Tuning aid (tools/conv_tune.py): force the block tile (BM x BN, waves WGM x WGN x WGK) of subsequent conv calls;
+ * BM = 0 restores the automatic plan.  The product path never calls it. */
+int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK);
+/* The same 'same'-padded stride-1 conv over several pyramid levels in ONE launch (shared weights; CenterNet head / conv3):
+ * rows are level-major [level][b][y][x] in the input and output matrices (d->H, d->W ignored), scale/shift may differ per
+ * level (ep_stride floats apart, 0 = shared), in_mul/in_add are indexed [level*B + b][Cin]. */
+int ore_conv2d_levels_fwd(const ore_conv_desc* d, int32_t n_levels, const int32_t* H, const int32_t* W,
+                          int32_t ep_stride, void* stream);
 
 /* Host helper: OIHW fp32 -> packed [Cout16][kh][kw][Cin] (rows >= Cout zero). dst has ore_packed_weight_floats(). */
 size_t ore_packed_weight_floats(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw);
@@ -86,10 +103,15 @@ int ore_maxpool3x3s2_fwd(const float* in, int32_t in_ld, int32_t in_coff, int32_
                          void* stream);
 
 /* eSE gate: s[b][c] = relu6(fc(mean_hw(x))[c] + 3) / 6.   d2z:modeling/backbone/vovnet.py:238-260.
- * fc_w [C][C] (out,in), fc_b [C].  workspace >= B * ORE_ESE_PARTS * C floats. */
-#define ORE_ESE_PARTS 64
+ * fc_w [C][C] (out,in), fc_b [C].  workspace >= B * (ORE_ESE_PARTS + 1) * C floats. */
+#define ORE_ESE_PARTS 512
 int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
                      const float* fc_w, const float* fc_b, float* gate, float* workspace, void* stream);
+
+/* Same gate from partial column sums part[B][P][C] (e.g. the fused ore_conv_desc.colsum of the concat conv).
+ * mean_ws >= B*C floats. */
+int ore_ese_gate_from_colsum_fwd(const float* part, int32_t P, int32_t B, int32_t HW, int32_t C,
+                                 const float* fc_w, const float* fc_b, float* gate, float* mean_ws, void* stream);
 
 /* y = x * gate[b][c]  (materialises the eSE output; the fused engine folds the gate into consumers). */
 int ore_scale_channels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
@@ -103,16 +125,28 @@ int ore_correlation_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B,
                         const float* k11, const float* k13, const float* k31,
                         float* out, int32_t out_ld, int32_t out_coff, void* stream);
 
+/* All pyramid levels in one launch: rows level-major [level][b][y][x]; k11 [L][C], k13/k31 [L][C][3]. */
+int ore_correlation_levels_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t n_levels,
+                               const int32_t* H, const int32_t* W, int32_t C, const float* k11, const float* k13,
+                               const float* k31, float* out, int32_t out_ld, int32_t out_coff, void* stream);
+
 /* Support kernels from a prototype [C][s][s] (NCHW, as cached in support_feature.pkl):
  * adaptive avg pools (1,1), (1,3), (3,1).  ref:fewx/modeling/fsod/fsod_cen.py:457-459. */
 int ore_support_kernels_fwd(const float* proto_chw, int32_t C, int32_t s, float* k11, float* k13, float* k31,
                             void* stream);
 
 /* GroupNorm statistics folded to a per-(b,c) affine: mul = rstd*gamma, add = beta - mean*mul.
- * ref:...centernet_head.py:72-76 (nn.GroupNorm(32, C), eps 1e-5). */
+ * ref:...centernet_head.py:72-76 (nn.GroupNorm(32, C), eps 1e-5).  Needs C | 256, groups <= 64.
+ * workspace >= B * ceil(HW/64) * groups * 2 floats. */
 int ore_groupnorm_affine_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
                              int32_t groups, float eps, const float* gamma, const float* beta,
-                             float* mul, float* add, void* stream);
+                             float* mul, float* add, float* workspace, void* stream);
+
+/* Several pyramid levels in one launch: rows level-major, HW[l] pixels per image of level l; mul/add are
+ * [level*B + b][C]; workspace >= sum_l B*ceil(HW[l]/64) * groups * 2 floats. */
+int ore_groupnorm_affine_levels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
+                                    const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
+                                    const float* beta, float* mul, float* add, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------ detection tail ---------- */
 /* CenterNet.inference: sigmoid -> threshold -> per-level top-k -> decode -> NMS -> post-NMS top-k, all on

@@ -421,3 +421,85 @@ def test_detector_inference_proposals_vs_oracle(model, sd):
     assert props.pred_classes.dtype == torch.int64 and int(props.pred_classes.abs().sum()) == 0
     with pytest.raises(NotImplementedError):
         model([{"image": img}])  # the ROI-head stage is SURVEY 8f row 1 ("next"), it fails loudly, never silently
+
+
+# ------------------------------------------------------------------------------------------ batched-level / fused entry points
+def test_conv_fused_colsum_and_gate(ore):
+    """The concat conv's epilogue column sums (eSE average pool) + gate kernel == avgpool -> fc -> hsigmoid."""
+    g = torch.Generator().manual_seed(11)
+    for (H, W, Cin, Cout) in ((80, 80, 352, 256), (20, 20, 720, 512), (160, 160, 320, 112), (7, 9, 64, 48)):
+        x = torch.randn(1, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+        fw = torch.randn(Cout, Cout, 1, 1, generator=g) / Cout ** 0.5
+        fb = torch.randn(Cout, generator=g)
+        y_ref = F.relu(F.conv2d(x, w))
+        gate_ref = F.relu6(F.conv2d(F.adaptive_avg_pool2d(y_ref, 1), fw, fb) + 3.0) / 6.0
+        y, cs = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, 1, relu_cout=Cout, want_colsum=True)
+        assert rel_err(nchw(y).numpy(), y_ref.numpy()) < TOL
+        assert rel_err(cs.sum(0)[:Cout].cpu().numpy(), y_ref.sum((0, 2, 3)).numpy()) < 1e-5
+        gate = ore.ese_gate_from_colsum(cs[:, :Cout].contiguous(), H * W, dev(fw), dev(fb))
+        assert rel_err(gate.cpu().numpy(), gate_ref[:, :, 0, 0].numpy()) < 1e-5
+
+
+def test_levels_entry_points_match_per_level(ore, sd):
+    g = torch.Generator().manual_seed(12)
+    B, C = 2, 128
+    HW = [(20, 24), (10, 12), (5, 6)]
+    feats = [torch.randn(B, C, h, w, generator=g) for h, w in HW]
+    rows = torch.cat([nhwc(f).reshape(-1, C) for f in feats], 0).contiguous()
+    # 3x3 conv + per-level scale/shift + input affine/relu, one launch vs per level
+    w = torch.randn(5, C, 3, 3, generator=g) * 0.05
+    wp = ore.pack_conv_weight(w).cuda()
+    scale = torch.rand(3, 16, generator=g) + 0.5
+    shift = torch.randn(3, 16, generator=g)
+    mul = torch.rand(3 * B, C, generator=g) + 0.5
+    add = torch.randn(3 * B, C, generator=g) * 0.1
+    out = torch.zeros(rows.shape[0], 8).cuda()
+    ore.conv2d_levels(rows, HW, B, wp, 5, 3, scale=dev(scale), shift=dev(shift), ep_stride=16, relu_cout=4, in_mul=dev(mul),
+                      in_add=dev(add), in_relu=True, out=out)
+    r0 = 0
+    for l, (h, wd) in enumerate(HW):
+        xin = F.relu(feats[l] * mul[l * B:(l + 1) * B, :, None, None] + add[l * B:(l + 1) * B, :, None, None])
+        ref = F.conv2d(xin, w, None, 1, 1) * scale[l, :5].view(1, -1, 1, 1) + shift[l, :5].view(1, -1, 1, 1)
+        ref[:, :4] = F.relu(ref[:, :4])
+        got = out[r0:r0 + B * h * wd, :5].reshape(B, h, wd, 5).permute(0, 3, 1, 2).cpu()
+        assert rel_err(got.numpy(), ref.numpy()) < TOL, l
+        r0 += B * h * wd
+    # GroupNorm statistics over levels
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    m, a = ore.groupnorm_affine_levels(rows, [h * w for h, w in HW], B, 32, dev(gamma), dev(beta))
+    for l, f in enumerate(feats):
+        ref = F.group_norm(f, 32, gamma, beta, 1e-5)
+        got = f * m[l * B:(l + 1) * B].cpu()[:, :, None, None] + a[l * B:(l + 1) * B].cpu()[:, :, None, None]
+        assert rel_err(got.numpy(), ref.numpy()) < 1e-5
+    # correlation over levels
+    sup = R.synth_support(0)
+    ks = [R.support_kernels(sup[k]) for k in ("p3", "p4", "p5")]
+    k11 = torch.stack([k[0] for k in ks]); k13 = torch.stack([k[1] for k in ks]); k31 = torch.stack([k[2] for k in ks])
+    attn = ore.correlation_levels(rows, HW, B, dev(k11), dev(k13), dev(k31), C)
+    r0 = 0
+    for l, (h, wd) in enumerate(HW):
+        q = feats[l]
+        a1 = F.relu(F.conv2d(F.relu(F.conv2d(q, k11[l].view(C, 1, 1, 1), groups=C)), k11[l].view(C, 1, 1, 1), groups=C))
+        b1 = F.relu(F.conv2d(q, k13[l].view(C, 1, 1, 3), padding=(0, 1), groups=C))
+        b1 = F.relu(F.conv2d(b1, k31[l].view(C, 1, 3, 1), padding=(1, 0), groups=C))
+        ref = a1 + b1 + q
+        got = attn[r0:r0 + B * h * wd].reshape(B, h, wd, C).permute(0, 3, 1, 2).cpu()
+        assert rel_err(got.numpy(), ref.numpy()) < 1e-5
+        r0 += B * h * wd
+
+
+@pytest.mark.parametrize("M_hw,Cin,Cout,k,splitk", [((20, 20), 384, 112, 3, 4), ((20, 20), 512, 128, 1, 0), ((40, 40), 256, 96, 3, 3),
+                                                    ((40, 40), 544, 384, 1, 0), ((5, 5), 128, 128, 3, 0), ((80, 80), 112, 80, 3, 0)])
+def test_conv_inkernel_splitk_repeatable(ore, M_hw, Cin, Cout, k, splitk):
+    """In-kernel last-arriver split-K: correct, bitwise repeatable, and leaves the arrival counters at zero."""
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(1, Cin, *M_hw, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    ref = F.conv2d(x, w, None, 1, k // 2)
+    xd, wp = nhwc(x), ore.pack_conv_weight(w).cuda()
+    outs = [ore.conv2d(xd, wp, Cout, k, splitk=splitk).clone() for _ in range(3)]
+    assert rel_err(nchw(outs[0]).numpy(), ref.numpy()) < TOL
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    ws = ore._default_ws(xd.device)
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
