@@ -150,10 +150,9 @@ def main():
         eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from detectron2.utils import comm
+    elapsed = comm.max_over_ranks(elapsed, device)          # the slowest rank defines the job time
+    total_images = int(comm.sum_over_ranks(args.steps, device))
     n_prop = int(eng.buffer("counts")[1, 0].item())
 
     # per-image latency with a host sync after every image (the reference's inference_on_dataset protocol)
@@ -186,7 +185,6 @@ def main():
                 "kernel_ms_per_image": round(ms / max(args.profile_passes, 1), 4)}
 
     if rank == 0:
-        total_images = args.steps * world
         out = {
             "metric": "images/sec at 640x640 25-shot (eval FPS, bs=1 per GPU)",
             "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,

@@ -9,7 +9,7 @@
 // the output, WGK wave groups split every K step (BK = 16*WGK channels are staged per step, group kg consumes
 // slice kg) -- the small late-stage layers (M = 400..1600 rows at batch 1) get their parallelism from K, not M.
 // Per step the block stages an im2col tile A[BM][BK] (zero-filled at the border, optional per-(image,channel)
-// affine+ReLU on the fly) and a weight tile B[BN][BK] through registers into LDS (row stride BK+4 floats:
+// affine+ReLU on the fly) and a weight tile B[BN][BK] through registers into LDS (row stride BK+8 floats:
 // ds_read_b128 of 16 rows is bank-conflict-free), double-buffered, one barrier per step.
 // Split-K across blocks (grid.z) is reduced INSIDE the launch: every slice stores its fp32 tile to a slab, an
 // agent-scope release + ticket counter elects the last arriver, which acquires and sums the slabs in slice order
@@ -41,7 +41,9 @@ struct ConvP {
     float* ws; int* tile_cnt;
 };
 
-struct RowInfo { int sid, iy, ix, ibase; };   // sid = level*B + b ; ibase = first input row of that image
+// 16 bytes of zeros: the source of every out-of-image / out-of-range staging load, so that the loads themselves are
+// unconditional (no branch around a load => the compiler keeps them in flight behind counted vmcnt waits).
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 __device__ __forceinline__ void decode_row(const ConvP& p, int m, int& lvl, int& b, int& oy, int& ox) {
     lvl = 0;
@@ -67,10 +69,10 @@ __device__ __forceinline__ float epilogue_one(const ConvP& p, float acc, int m, 
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int WGK>
+template <int BM, int BN, int WGM, int WGN, int WGK, bool AFF>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
-    constexpr int BK = 16 * WGK, LD = BK + 4;
+    constexpr int BK = 16 * WGK, LD = BK + 8;   // +8: ds_read_b128 lane groups mix two k-offsets; BK+8 is conflict-free, BK+4 is 2-way
     static_assert(WGM * WGN * WGK == 4 && WM % 16 == 0 && WN % 16 == 0, "tile");
     constexpr int QPR = BK / 4;                                  // float4 per tile row
     constexpr int A_IT = (BM * QPR + 255) / 256, B_IT = (BN * QPR + 255) / 256;
@@ -91,29 +93,48 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     const int s_end = min(s_begin + p.steps_per_split, nsteps);
     const int cpt = p.Cin >> 4;                                  // chunks per tap
 
-    // ---- per-thread A rows: pixel coordinates are fixed across the K loop
-    int a_sid[A_IT], a_iy[A_IT], a_ix[A_IT], a_base[A_IT], a_H[A_IT], a_W[A_IT];
+    // ---- per-thread A rows, fixed across the K loop: pointer to the (top-left tap, channel 0) element of the row's
+    // receptive field, the row's image width, its segment id and a bitmask of the taps that fall inside the image.
+    const int my_q = tid % QPR, my_ks = my_q >> 2;               // QPR | 256: the same for all float4s of a thread
+    const float* a_ptr[A_IT];
+    int a_sid[A_IT], a_W[A_IT];
+    unsigned a_taps[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int f = tid + i * 256, row = f / QPR;
         const int m = m0 + row;
-        a_sid[i] = -1; a_iy[i] = a_ix[i] = a_base[i] = 0; a_H[i] = a_W[i] = 0;
-        if (f < BM * QPR && m < p.M) {
+        a_sid[i] = 0; a_W[i] = 0; a_taps[i] = 0u; a_ptr[i] = p.in;
+        if ((A_IT * 256 == BM * QPR || f < BM * QPR) && m < p.M) {
             int lvl, b, oy, ox;
             decode_row(p, m, lvl, b, oy, ox);
             const Lvl& L = p.lv[lvl];
             a_sid[i] = lvl * p.B + b;
-            a_iy[i] = oy * p.stride - p.pad; a_ix[i] = ox * p.stride - p.pad;
-            a_base[i] = L.irow0 + b * L.H * L.W; a_H[i] = L.H; a_W[i] = L.W;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            a_W[i] = L.W;
+            a_ptr[i] = p.in + ((ptrdiff_t)(L.irow0 + b * L.H * L.W) + (ptrdiff_t)iy0 * L.W + ix0) * p.in_ld + p.in_coff + (my_q & 3) * 4;
+            unsigned mask = 0u;
+            for (int dy = 0; dy < p.kh; ++dy)
+                for (int dx = 0; dx < p.kw; ++dx)
+                    if ((unsigned)(iy0 + dy) < (unsigned)L.H && (unsigned)(ix0 + dx) < (unsigned)L.W) mask |= 1u << (dy * p.kw + dx);
+            a_taps[i] = mask;
         }
     }
+    const float* b_ptr[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int f = tid + i * 256, n = n0 + f / QPR;
+        b_ok[i] = (B_IT * 256 == BN * QPR || f < BN * QPR) && n < p.Cout16;
+        b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + (my_q & 3) * 4;
+    }
     constexpr int PF = 3;                                        // register ring depth: a load has PF K-steps to land
+    constexpr int NAFF = AFF ? A_IT : 1;
+    constexpr bool A_FULL = (BM * QPR) % 256 == 0, B_FULL = (BN * QPR) % 256 == 0;   // every thread stores every float4
     f32x4 ra[PF][A_IT], rb[PF][B_IT];
+    f32x4 rmul[PF][NAFF], radd[PF][NAFF];                        // input affine operands travel with the data (AFF only)
+    unsigned rok[PF];                                            // bit i: float4 i of the slot is a real (in-image) element
 
-    // (dy, dx, c0) per float4 column group of the NEXT step, advanced incrementally (no divisions in the K loop).
-    // A thread's float4 sits in K-slice ks = q / 4 of the step, i.e. chunk (step*WGK + ks).
-    // QPR divides 256, so a thread's K-slice (tid % QPR) >> 2 is the same for all its float4s: one (dy, dx, c0) per thread.
-    const int my_q = tid % QPR, my_ks = my_q >> 2;
+    // (dy, dx, c0) of this thread's K-slice, advanced incrementally (no divisions, no branches in the K loop).
     int n_dy, n_dx, n_c0;
     {
         const int c = s_begin * WGK + my_ks;
@@ -121,50 +142,63 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         n_c0 = (c - tap * cpt) << 4;
         n_dy = tap / p.kw; n_dx = tap - n_dy * p.kw;
     }
-    auto gload = [&](int step, f32x4 (&ra)[A_IT], f32x4 (&rb)[B_IT]) {
+    const float* zero = g_zero16;
+    // branch-free pointer select (a ?: here is turned back into an exec-mask branch around the load by hipcc)
+    auto sel = [&](bool ok, const float* ptr) -> const f32x4* {
+        const uintptr_t m = (uintptr_t)0 - (uintptr_t)ok;
+        return reinterpret_cast<const f32x4*>(((uintptr_t)ptr & m) | ((uintptr_t)zero & ~m));
+    };
+    auto gload = [&](int step, f32x4 (&ra)[A_IT], f32x4 (&rb)[B_IT], f32x4 (&rmul)[NAFF], f32x4 (&radd)[NAFF], unsigned& okm) {
         const int c = step * WGK + my_ks;
         const int dy = n_dy, dx = n_dx, c0 = n_c0;
         n_c0 += BK;
-        while (n_c0 >= p.Cin) { n_c0 -= p.Cin; if (++n_dx == p.kw) { n_dx = 0; ++n_dy; } }
+#pragma unroll
+        for (int w = 0; w < WGK; ++w) {                           // BK = 16*WGK and Cin >= 16: at most WGK wraps, predicated
+            const bool wrap = n_c0 >= p.Cin;
+            n_c0 -= wrap ? p.Cin : 0;
+            n_dx += wrap ? 1 : 0;
+            const bool wy = n_dx == p.kw;
+            n_dx = wy ? 0 : n_dx;
+            n_dy += wy ? 1 : 0;
+        }
+        const bool cok = c < p.nchunks;
+        const unsigned tapbit = cok ? (1u << (dy * p.kw + dx)) : 0u;
+        okm = 0;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int f = tid + i * 256, q = my_q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f < BM * QPR && a_sid[i] >= 0 && c < p.nchunks) {
-                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-                if ((unsigned)iy < (unsigned)a_H[i] && (unsigned)ix < (unsigned)a_W[i]) {
-                    const int ch = c0 + (q & 3) * 4;
-                    v = *reinterpret_cast<const f32x4*>(p.in + (size_t)(a_base[i] + iy * a_W[i] + ix) * p.in_ld + p.in_coff + ch);
-                    if (p.in_mul) {
-                        v = v * *reinterpret_cast<const f32x4*>(p.in_mul + a_sid[i] * p.Cin + ch);
-                        if (p.in_add) v = v + *reinterpret_cast<const f32x4*>(p.in_add + a_sid[i] * p.Cin + ch);
-                        if (p.in_relu) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        }
-                    }
-                }
+            const bool ok = (a_taps[i] & tapbit) != 0u;
+            const float* src = a_ptr[i] + (dy * a_W[i] + dx) * p.in_ld + c0;
+            ra[i] = *sel(ok, src);
+            okm |= ok ? (1u << i) : 0u;
+            if (AFF) {
+                const int ch = a_sid[i] * p.Cin + c0 + (my_q & 3) * 4;
+                rmul[i] = *sel(ok, p.in_mul + ch);
+                radd[i] = *sel(ok && p.in_add != nullptr, p.in_add + ch);
             }
-            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int f = tid + i * 256, n = n0 + f / QPR, q = my_q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f < BN * QPR && n < p.Cout16 && c < p.nchunks)
-                v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + (c << 4) + (q & 3) * 4);
-            rb[i] = v;
+            const float* src = b_ptr[i] + (c << 4);
+            rb[i] = *sel(cok && b_ok[i], src);
         }
     };
-    auto lstore = [&](int buf, const f32x4 (&ra)[A_IT], const f32x4 (&rb)[B_IT]) {
+    auto lstore = [&](int buf, const f32x4 (&ra)[A_IT], const f32x4 (&rb)[B_IT], const f32x4 (&rmul)[NAFF], const f32x4 (&radd)[NAFF],
+                      unsigned okm) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int f = tid + i * 256;
-            if (f < BM * QPR) *reinterpret_cast<f32x4*>(As + buf * BM * LD + (f / QPR) * LD + (f % QPR) * 4) = ra[i];
+            f32x4 v = ra[i];
+            if (AFF) {                                            // relu?(x*mul + add) on real elements only (padding stays 0)
+                v = v * rmul[i] + radd[i];
+                if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (!((okm >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (A_FULL || f < BM * QPR) *reinterpret_cast<f32x4*>(As + buf * BM * LD + (f / QPR) * LD + (f % QPR) * 4) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int f = tid + i * 256;
-            if (f < BN * QPR) *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (f / QPR) * LD + (f % QPR) * 4) = rb[i];
+            if (B_FULL || f < BN * QPR) *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (f / QPR) * LD + (f % QPR) * 4) = rb[i];
         }
     };
 
@@ -175,38 +209,43 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fk = kg * 16 + (lane >> 4) * 4;
+    // one K step: (optionally) issue the loads of step st+PF into ring slot u, MFMA on LDS buffer `cur`, (optionally) park the
+    // step st+1 data (ring slot u+1, in flight for two steps already) in the other LDS buffer, barrier.
+#define ORE_STEP(u, st, DO_LOAD, DO_STORE)                                                                                      \
+    {                                                                                                                           \
+        const int cur = ((st) - s_begin) & 1;                                                                                   \
+        if (DO_LOAD) gload((st) + PF, ra[u], rb[u], rmul[u], radd[u], rok[u]);                                                  \
+        f32x4 af[TM], bf[TN];                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
+            af[i] = *reinterpret_cast<const f32x4*>(As + cur * BM * LD + (wm * WM + i * 16 + frow) * LD + fk);                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                          \
+            bf[j] = *reinterpret_cast<const f32x4*>(Bs + cur * BN * LD + (wn * WN + j * 16 + frow) * LD + fk);                  \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                           \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);                   \
+        if (DO_STORE)                                                                                                           \
+            lstore(cur ^ 1, ra[((u) + 1) % PF], rb[((u) + 1) % PF], rmul[((u) + 1) % PF], radd[((u) + 1) % PF], rok[((u) + 1) % PF]); \
+        __syncthreads();                                                                                                        \
+    }
     if (s_begin < s_end) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) gload(s_begin + u, ra[u], rb[u]);       // steps past s_end load zeros (c >= nchunks guard)
-        lstore(0, ra[0], rb[0]);
+        for (int u = 0; u < PF; ++u) gload(s_begin + u, ra[u], rb[u], rmul[u], radd[u], rok[u]);   // steps past the end load zeros
+        lstore(0, ra[0], rb[0], rmul[0], radd[0], rok[0]);
         __syncthreads();
-        for (int s0 = s_begin; s0 < s_end; s0 += PF) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {                                    // static ring slots (no runtime-indexed registers)
-                const int s = s0 + u;
-                if (s < s_end) {
-                    const int cur = (s - s_begin) & 1;
-                    if (s + PF < s_end) gload(s + PF, ra[u], rb[u]);          // slot u was stored to LDS one step ago: free
-                    f32x4 af[TM], bf[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        af[i] = *reinterpret_cast<const f32x4*>(As + cur * BM * LD + (wm * WM + i * 16 + frow) * LD + fk);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        bf[j] = *reinterpret_cast<const f32x4*>(Bs + cur * BN * LD + (wn * WN + j * 16 + frow) * LD + fk);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
-                    if (s + 1 < s_end) lstore(cur ^ 1, ra[(u + 1) % PF], rb[(u + 1) % PF]);
-                    __syncthreads();
-                }
-            }
+        int s0 = s_begin;
+        for (; s0 + 2 * PF <= s_end; s0 += PF) {      // steady state: no branch between a load and its use -> counted vmcnt waits
+            ORE_STEP(0, s0, true, true)
+            ORE_STEP(1, s0 + 1, true, true)
+            ORE_STEP(2, s0 + 2, true, true)
+        }
+        for (; s0 < s_end; s0 += PF) {                // tail (< 2*PF steps): loads past the end fetch the zero page, harmless
+            if (s0 < s_end) ORE_STEP(0, s0, true, s0 + 1 < s_end)
+            if (s0 + 1 < s_end) ORE_STEP(1, s0 + 1, true, s0 + 2 < s_end)
+            if (s0 + 2 < s_end) ORE_STEP(2, s0 + 2, true, s0 + 3 < s_end)
         }
     }
+#undef ORE_STEP
 
     // ---- in-block K reduction: groups kg>0 park their tiles in LDS, group 0 adds them in group order
     if (WGK > 1) {
@@ -327,7 +366,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 
 template <int BM, int BN, int WGM, int WGN, int WGK>
 void launch_conv(const ConvP& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK>), grid, dim3(256), 0, st, p);
+    if (p.in_mul) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, false>), grid, dim3(256), 0, st, p);
 }
 
 struct TileCfg { int BM, BN, WGM, WGN, WGK; };
@@ -377,7 +417,8 @@ void plan_conv(int M, int Cout, int nchunks, int req_splitk, TileCfg* t, int* S_
     // deepest K (stage-5 layer 0).
     int bn;
     if (M >= 16384) {
-        if (C16 % 64 == 0) *t = {32, 64, 2, 1, 2};
+        if (C16 == 64) { if (M >= 65536) *t = {32, 64, 2, 1, 2}; else *t = {64, 64, 4, 1, 1}; }
+        else if (C16 % 128 == 0) *t = {64, 128, 2, 2, 1};
         else *t = {64, C16 <= 128 ? C16 : 64, 4, 1, 1};
     } else if (M >= 2048) {
         if (C16 % 64 == 0) *t = {32, 64, 2, 1, 2};
@@ -471,7 +512,7 @@ static int conv_common_checks(const ore_conv_desc* d) {
     ORE_CHECK_ARG(d->in_ld % 4 == 0 && d->in_coff % 4 == 0 && d->in_coff + d->Cin <= d->in_ld,
                   "ore_conv2d_fwd: input slice ld=%d coff=%d Cin=%d", d->in_ld, d->in_coff, d->Cin);
     ORE_CHECK_ARG(d->out_coff + d->Cout <= d->out_ld && d->Cout > 0, "ore_conv2d_fwd: output slice");
-    ORE_CHECK_ARG(d->B > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "ore_conv2d_fwd: bad geometry");
+    ORE_CHECK_ARG(d->B > 0 && d->kh > 0 && d->kw > 0 && d->kh * d->kw <= 32 && d->stride > 0 && d->pad >= 0, "ore_conv2d_fwd: bad geometry (kernel up to 32 taps)");
     ORE_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "ore_conv2d_fwd: 16-byte alignment");
     ORE_CHECK_ARG(d->in_mul || !d->in_add, "ore_conv2d_fwd: in_add needs in_mul");
     return ORE_OK;

@@ -65,3 +65,34 @@ def reduce_dict(input_dict, average=True):
         if dist.get_rank() == 0 and average:
             values /= ws
         return dict(zip(names, values))
+
+
+# ---- data-parallel eval helpers: images are independent, so ranks share nothing on the data path ----------
+def shard_range(n_items: int, rank: int = None, world_size: int = None):
+    """Contiguous shard [begin, end) of n_items for this rank (d2z:data/samplers/distributed_sampler.py:191-194, InferenceSampler)."""
+    rank = get_rank() if rank is None else rank
+    world_size = get_world_size() if world_size is None else world_size
+    shard = (n_items - 1) // world_size + 1 if n_items > 0 else 0
+    begin = shard * rank
+    return min(begin, n_items), min(begin + shard, n_items)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX all-reduce of a host scalar (elapsed time): RCCL when the group is nccl, gloo on CPU."""
+    if get_world_size() == 1:
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device=None) -> float:
+    if get_world_size() == 1:
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
