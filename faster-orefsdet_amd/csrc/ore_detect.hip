@@ -498,9 +498,11 @@ extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
 
 // ---- stand-alone NMS (same kernels; scores sorted by the rank kernel through a 1-level DetP) -------
 namespace {
-__global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ boxes, const float* __restrict__ scores, int n,
-                                                  float* s_boxes, float* s_scores, int* s_order, int* n_out) {
+__global__ __launch_bounds__(256) void k_nms_prep(const float* __restrict__ boxes, const float* __restrict__ scores, int n_host,
+                                                  const int* __restrict__ n_dev, float* s_boxes, float* s_scores, int* s_order,
+                                                  int* n_out) {
     extern __shared__ float sc[];
+    const int n = n_dev ? *n_dev : n_host;
     for (int i = threadIdx.x; i < n; i += 256) sc[i] = scores[i];
     __syncthreads();
     const int e = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
@@ -541,9 +543,24 @@ NmsLayout nms_layout(int n) {
 
 extern "C" size_t ore_nms_workspace_bytes(int32_t n) { return nms_layout(n).total; }
 
+static int nms_pipeline(const float* boxes, const float* scores, int n, const int* n_devp, float thr, int64_t* keep_idx, int32_t* count,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int ore_nms_fwd(const float* boxes, const float* scores, int32_t n, float thr, int64_t* keep_idx, int32_t* count,
                            void* workspace, size_t workspace_bytes, void* stream) {
     ORE_CHECK_ARG(keep_idx && count && workspace && n >= 0, "ore_nms_fwd: bad args");
+    return nms_pipeline(boxes, scores, n, nullptr, thr, keep_idx, count, workspace, workspace_bytes, stream);
+}
+
+// Same, with the box count living on the device (capacity `cap`): no host sync between the producer and the NMS.
+extern "C" int ore_nms_device_n_fwd(const float* boxes, const float* scores, const int32_t* n_dev, int32_t cap, float thr,
+                                    int64_t* keep_idx, int32_t* count, void* workspace, size_t workspace_bytes, void* stream) {
+    ORE_CHECK_ARG(boxes && scores && n_dev && keep_idx && count && workspace && cap >= 1, "ore_nms_device_n_fwd: bad args");
+    return nms_pipeline(boxes, scores, cap, n_dev, thr, keep_idx, count, workspace, workspace_bytes, stream);
+}
+
+static int nms_pipeline(const float* boxes, const float* scores, int n, const int* n_devp, float thr, int64_t* keep_idx, int32_t* count,
+                        void* workspace, size_t workspace_bytes, void* stream) {
     const NmsLayout lay = nms_layout(n);
     if (workspace_bytes < lay.total) {
         ore_set_error("ore_nms_fwd: workspace %zu < %zu", workspace_bytes, lay.total);
@@ -560,7 +577,7 @@ extern "C" int ore_nms_fwd(const float* boxes, const float* scores, int32_t n, f
     const size_t sc_bytes = (size_t)(n > 0 ? n : 1) * 4;
     if (sc_bytes > 64 * 1024)
         ORE_HIP(hipFuncSetAttribute((const void*)k_nms_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_bytes));
-    hipLaunchKernelGGL(k_nms_prep, dim3(ceil_div(n > 0 ? n : 1, 16)), dim3(256), sc_bytes, st, boxes, scores, n, s_boxes,
+    hipLaunchKernelGGL(k_nms_prep, dim3(ceil_div(n > 0 ? n : 1, 16)), dim3(256), sc_bytes, st, boxes, scores, n, n_devp, s_boxes,
                        s_scores, s_order, n_dev);
     if ((rc = ore_launch_status("k_nms_prep"))) return rc;
     if (thr > 0.0f && n > 0) {

@@ -1,0 +1,261 @@
+// Second stage (CustomCascadeROIHeads, eval) on device, no host sync:
+//   k_roi_align      ROIPooler level assignment + ROIAlignV2 (aligned, sampling_ratio 0) 8x8 over p3..p5 -> [R][64][C]
+//                    (ref:fewx/modeling/fsod/fsod_roi_heads.py:459-470, d2z:modeling/poolers.py:22-58,190-250,
+//                     d2z:layers/roi_align.py:49-65 -> torchvision.ops.roi_align, un-vendored: restated from its published
+//                     algorithm -- roi*scale-0.5, bin = roi/pooled, grid = ceil(roi/pooled), bilinear with samples outside
+//                     [-1, size] = 0 and edge clamping, mean over samples)
+//   (GEMM)           support-guided mix (conv3(cat(x, s)) + cat(conv1(x), conv2(s))) -> flatten -> fc1 is LINEAR in the pooled
+//                    features, so it is pre-composed once per (weights, support set) into one [8192 -> 128] matrix and runs on
+//                    the implicit-GEMM conv kernel as a 1x1 conv (fsod_roi_heads.py:500-520, d2z:.../box_head.py)
+//   k_roi_predict    cls_score / bbox_pred, softmax, Box2BoxTransform.apply_deltas (weights 10,10,5,5, clamp log(1000/16)),
+//                    clip to the image, finite + score > thresh filter, ordered compaction
+//                    (custom_fast_rcnn.py:160-170, d2z:modeling/box_regression.py:77-115, d2z:.../fast_rcnn.py:118-171)
+//   then the NMS kernels of ore_detect.hip (thr 0.9) and keep[:topk].
+// Compiled with -ffp-contract=off like ore_detect.hip (same fixed expf) so the decode is bit-reproducible on the CPU twin.
+#include "ore_common.h"
+
+namespace {
+
+__device__ __forceinline__ float ore_expf(float x) {
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float e = fmaf(p, r * r, r) + 1.0f;
+    const int ni = (int)n;
+    return e * __uint_as_float((unsigned)(ni + 127) << 23);
+}
+
+struct RoiP {
+    const float* feat[4]; int ld[4], coff[4], H[4], W[4]; float scale[4];
+    int n_levels, min_level, C, pooled;
+    float canonical_size; int canonical_level;
+    const float* boxes; const int* n_ptr; int n_host; int cap;
+    float* out;
+};
+
+__device__ __forceinline__ f32x4 bilinear4(const float* f, int ld, int H, int W, float y, float x, int c) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return f32x4{0.f, 0.f, 0.f, 0.f};
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_low * W + x_low) * ld + c);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_low * W + x_high) * ld + c);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_high * W + x_low) * ld + c);
+    const f32x4 v4 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_high * W + x_high) * ld + c);
+    return (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
+}
+
+// one block per ROI; thread = (bin, 4 channels)
+__global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
+    const int r = blockIdx.x;
+    const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
+    const int P = p.pooled, C4 = p.C >> 2;
+    float* dst = p.out + (size_t)r * P * P * p.C;
+    if (r >= n) {   // keep the GEMM input finite
+        for (int i = threadIdx.x; i < P * P * C4; i += 256) *reinterpret_cast<f32x4*>(dst + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
+    // assign_boxes_to_levels (poolers.py:47-58)
+    const float size = sqrtf((b.z - b.x) * (b.w - b.y));
+    float lv = floorf((float)p.canonical_level + log2f(size / p.canonical_size + 1e-8f));
+    lv = fminf(fmaxf(lv, (float)p.min_level), (float)(p.min_level + p.n_levels - 1));
+    const int l = (int)lv - p.min_level;
+    const float sc = p.scale[l];
+    const int H = p.H[l], W = p.W[l], ld = p.ld[l];
+    const float* f = p.feat[l] + p.coff[l];
+    const float x0 = b.x * sc - 0.5f, y0 = b.y * sc - 0.5f, x1 = b.z * sc - 0.5f, y1 = b.w * sc - 0.5f;
+    const float rw = x1 - x0, rh = y1 - y0;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float cnt = (float)max(gh * gw, 1);
+    for (int i = threadIdx.x; i < P * P * C4; i += 256) {
+        const int c = (i % C4) * 4, bin = i / C4;
+        const int ph = bin / P, pw = bin - ph * P;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = y0 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = x0 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                acc += bilinear4(f, ld, H, W, y, x, c);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dst + (size_t)bin * p.C + c) = acc / cnt;
+    }
+}
+
+struct PredP {
+    const float* h; int C;                       // [cap][C] after fc1+ReLU
+    const float* cls_w; const float* cls_b;      // [K+1][C], [K+1]  (K = 1 foreground class)
+    const float* box_w; const float* box_b;      // [4][C], [4]
+    const float* boxes; const int* n_ptr; int n_host; int cap;
+    float wx, wy, ww, wh, scale_clamp;
+    float img_h, img_w, score_thresh;
+    float* raw_boxes; float* raw_scores;         // [cap] decoded, clipped (before the filter)
+    float* c_boxes; float* c_scores; int* c_src; int* c_count;   // compacted (filter_mask order)
+};
+
+// single block: one thread per ROI (cap <= 1024 per pass), ordered compaction by a block scan
+__global__ __launch_bounds__(1024) void k_roi_predict(PredP p) {
+    __shared__ int wsum[16];
+    __shared__ int base_sh;
+    const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n; r0 += 1024) {
+        const int r = r0 + tid;
+        bool ok = false;
+        float score = 0.f;
+        f32x4 ob = {0.f, 0.f, 0.f, 0.f};
+        if (r < n) {
+            const float* h = p.h + (size_t)r * p.C;
+            float l0 = p.cls_b[0], l1 = p.cls_b[1];
+            float d0 = p.box_b[0], d1 = p.box_b[1], d2 = p.box_b[2], d3 = p.box_b[3];
+            for (int c = 0; c < p.C; ++c) {
+                const float v = h[c];
+                l0 = fmaf(p.cls_w[c], v, l0); l1 = fmaf(p.cls_w[p.C + c], v, l1);
+                d0 = fmaf(p.box_w[c], v, d0); d1 = fmaf(p.box_w[p.C + c], v, d1);
+                d2 = fmaf(p.box_w[2 * p.C + c], v, d2); d3 = fmaf(p.box_w[3 * p.C + c], v, d3);
+            }
+            // softmax over (fg, bg); fast_rcnn_inference keeps scores[:, :-1] = the foreground column
+            const float m = fmaxf(l0, l1);
+            const float e0 = ore_expf(l0 - m), e1 = ore_expf(l1 - m);
+            score = e0 / (e0 + e1);
+            // Box2BoxTransform.apply_deltas
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
+            const float w = b.z - b.x, hgt = b.w - b.y;
+            const float cx = b.x + 0.5f * w, cy = b.y + 0.5f * hgt;
+            const float dx = d0 / p.wx, dy = d1 / p.wy;
+            const float dw = fminf(d2 / p.ww, p.scale_clamp), dh = fminf(d3 / p.wh, p.scale_clamp);
+            const float pcx = dx * w + cx, pcy = dy * hgt + cy;
+            const float pw = ore_expf(dw) * w, phh = ore_expf(dh) * hgt;
+            ob = f32x4{pcx - 0.5f * pw, pcy - 0.5f * phh, pcx + 0.5f * pw, pcy + 0.5f * phh};
+            const bool finite = isfinite(ob.x) && isfinite(ob.y) && isfinite(ob.z) && isfinite(ob.w) && isfinite(score);
+            // Boxes.clip
+            ob.x = fminf(fmaxf(ob.x, 0.f), p.img_w); ob.y = fminf(fmaxf(ob.y, 0.f), p.img_h);
+            ob.z = fminf(fmaxf(ob.z, 0.f), p.img_w); ob.w = fminf(fmaxf(ob.w, 0.f), p.img_h);
+            *reinterpret_cast<f32x4*>(p.raw_boxes + (size_t)r * 4) = ob;
+            p.raw_scores[r] = score;
+            ok = finite && score > p.score_thresh;
+        }
+        // ordered compaction
+        int inc = ok ? 1 : 0;
+        const int v = inc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = base_sh, tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { const int s = wsum[w2]; if (w2 < wave) base += s; tot += s; }
+        if (ok) {
+            const int pos = base + inc - v;
+            *reinterpret_cast<f32x4*>(p.c_boxes + (size_t)pos * 4) = ob;
+            p.c_scores[pos] = score;
+            p.c_src[pos] = r;
+        }
+        __syncthreads();
+        if (tid == 0) base_sh += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *p.c_count = base_sh;
+}
+
+// final gather: keep[:topk] of the NMS survivors -> detections
+__global__ __launch_bounds__(256) void k_roi_finalize(const long long* __restrict__ keep, const int* __restrict__ n_keep, int topk,
+                                                      const float* __restrict__ c_boxes, const float* __restrict__ c_scores,
+                                                      const int* __restrict__ c_src, float* __restrict__ det_boxes,
+                                                      float* __restrict__ det_scores, long long* __restrict__ det_src,
+                                                      int* __restrict__ det_count) {
+    int n = *n_keep;
+    if (topk >= 0 && n > topk) n = topk;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const long long k = keep[i];
+        *reinterpret_cast<f32x4*>(det_boxes + (size_t)i * 4) = *reinterpret_cast<const f32x4*>(c_boxes + (size_t)k * 4);
+        det_scores[i] = c_scores[k];
+        det_src[i] = (long long)c_src[k];
+    }
+    if (threadIdx.x == 0) *det_count = n;
+}
+
+}  // namespace
+
+extern "C" int ore_nms_device_n_fwd(const float* boxes, const float* scores, const int32_t* n_dev, int32_t cap, float thr,
+                                    int64_t* keep_idx, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
+
+extern "C" int ore_roi_align_fwd(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                                 const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                                 const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream) {
+    ORE_CHECK_ARG(feat && ld && coff && H && W && scales_host && boxes && out, "ore_roi_align_fwd: null pointer");
+    ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && C % 4 == 0 && pooled >= 1 && pooled <= 16 && cap >= 1, "ore_roi_align_fwd: bad args");
+    RoiP p{};
+    for (int l = 0; l < n_levels; ++l) {
+        ORE_CHECK_ARG(feat[l] && ld[l] % 4 == 0 && coff[l] % 4 == 0 && H[l] > 0 && W[l] > 0, "ore_roi_align_fwd: level %d", l);
+        p.feat[l] = feat[l]; p.ld[l] = ld[l]; p.coff[l] = coff[l]; p.H[l] = H[l]; p.W[l] = W[l]; p.scale[l] = scales_host[l];
+    }
+    p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
+    p.canonical_size = 224.0f; p.canonical_level = 4;      // ROIPooler defaults (poolers.py:96-97)
+    p.boxes = boxes; p.n_ptr = n_dev; p.n_host = n_host; p.cap = cap; p.out = out;
+    hipLaunchKernelGGL(k_roi_align, dim3(cap), dim3(256), 0, (hipStream_t)stream, p);
+    return ore_launch_status("k_roi_align");
+}
+
+extern "C" size_t ore_roi_predict_workspace_bytes(int32_t cap) {
+    const size_t c = (size_t)(cap > 0 ? cap : 1);
+    return 256 + c * 16 * 2 + c * 4 * 4 + c * 8 + ore_nms_workspace_bytes(cap) + 4096;
+}
+
+extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
+                                   const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
+                                   const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
+                                   int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    ORE_CHECK_ARG(h && cls_w && cls_b && box_w && box_b && boxes && reg_weights4_host && det_boxes && det_scores && det_src && det_count &&
+                      workspace, "ore_roi_predict_fwd: null pointer");
+    ORE_CHECK_ARG(cap >= 1 && C >= 1, "ore_roi_predict_fwd: bad args");
+    if (workspace_bytes < ore_roi_predict_workspace_bytes(cap)) {
+        ore_set_error("ore_roi_predict_fwd: workspace %zu < %zu", workspace_bytes, ore_roi_predict_workspace_bytes(cap));
+        return ORE_ENOMEM;
+    }
+    char* ws = (char*)workspace;
+    const size_t c = (size_t)cap;
+    size_t o = 0;
+    int* c_count = (int*)(ws + o); int* n_keep = c_count + 1; o += 256;
+    float* raw_boxes = (float*)(ws + o); o += c * 16;
+    float* c_boxes = (float*)(ws + o); o += c * 16;
+    float* raw_scores = (float*)(ws + o); o += c * 4;
+    float* c_scores = (float*)(ws + o); o += c * 4;
+    int* c_src = (int*)(ws + o); o += c * 4;
+    o += c * 4;
+    long long* keep = (long long*)(ws + o); o += c * 8;
+    o = (o + 255) & ~(size_t)255;
+    void* nms_ws = ws + o;
+    PredP p{};
+    p.h = h; p.C = C; p.cls_w = cls_w; p.cls_b = cls_b; p.box_w = box_w; p.box_b = box_b;
+    p.boxes = boxes; p.n_ptr = n_dev; p.n_host = n_host; p.cap = cap;
+    p.wx = reg_weights4_host[0]; p.wy = reg_weights4_host[1]; p.ww = reg_weights4_host[2]; p.wh = reg_weights4_host[3];
+    p.scale_clamp = logf(1000.0f / 16.0f);
+    p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh;
+    p.raw_boxes = raw_boxes; p.raw_scores = raw_scores; p.c_boxes = c_boxes; p.c_scores = c_scores; p.c_src = c_src; p.c_count = c_count;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_roi_predict, dim3(1), dim3(1024), 0, st, p);
+    int rc = ore_launch_status("k_roi_predict");
+    if (rc) return rc;
+    rc = ore_nms_device_n_fwd(c_boxes, c_scores, c_count, cap, nms_thresh, (int64_t*)keep, n_keep, nms_ws,
+                              workspace_bytes - o, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_roi_finalize, dim3(1), dim3(256), 0, st, keep, n_keep, topk, c_boxes, c_scores, c_src, det_boxes, det_scores,
+                       (long long*)det_src, det_count);
+    return ore_launch_status("k_roi_finalize");
+}

@@ -2,7 +2,7 @@
 
 CustomCascadeROIHeads is the second stage of Faster-OreFSDet ("next"): this round provides the module
 tree with the reference's parameter names/shapes (so checkpoints load and the DP gradient bucket has the right layout);
-its forward (ROIAlign + support-guided mixing + FC + box decode + NMS) is the next row to be built in HIP."""
+its eval forward (ROIAlign + support-guided mixing + FC + box decode + NMS) runs on the HIP kernels of csrc/ore_roi.hip."""
 import torch
 from torch import nn
 
@@ -34,6 +34,7 @@ class CustomCascadeROIHeads(nn.Module):
         self.test_nms_thresh = cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST
         self.test_topk = cfg.TEST.DETECTIONS_PER_IMAGE
         self.pooler_resolution, self.pooler_resolution2 = res, res2
+        self.bbox_reg_weights = tuple(cfg.MODEL.ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS[0])
         heads, preds = [], []
         for _ in range(n_stage):
             h = nn.Sequential()
@@ -55,9 +56,46 @@ class CustomCascadeROIHeads(nn.Module):
         self.conv2 = nn.Conv2d(C, C // 2, 1)
         self.conv3 = nn.Conv2d(2 * C, C, 1)
 
+    def composed(self, support_8):
+        """(W', b') of the linear chain DSA-mix -> flatten -> fc1, cached per (parameters, support features)."""
+        import orehip
+        key = tuple(p._version for p in self.parameters()) + (support_8.data_ptr(), support_8._version, str(support_8.device))
+        if getattr(self, "_comp", None) is None or self._comp[0] != key:
+            Wp, bp = orehip.compose_roi_head({"roi_heads." + k: v for k, v in self.state_dict().items()}, support_8)
+            dev = next(self.parameters()).device
+            self._comp = (key, Wp.to(dev), bp.to(dev))
+        return self._comp[1], self._comp[2]
+
+    @torch.no_grad()
     def forward(self, images, features, support_box_features, proposals, targets=None):
-        raise NotImplementedError("CustomCascadeROIHeads.forward (SURVEY 8f row 1: ROIAlign + DSA + FC + NMS) is the next row "
-                                  "to be built in HIP; use CenterNet2Detector.inference_proposals() for the built hot path")
+        """Eval second stage for one image on the HIP kernels: ROIAlign 8x8 over p3..p5 -> pre-composed [8192->128] GEMM + ReLU
+        -> cls/box -> softmax, apply_deltas, clip, score filter, NMS, keep[:topk].  (ref fsod_roi_heads.py:374-457; the second
+        `_forward_box` definition shadows the first, so MULT_PROPOSAL_SCORE is NOT applied -- SURVEY 8f row 1.)"""
+        import orehip
+        from detectron2.layers import nhwc_view
+        from detectron2.structures import Boxes, Instances
+        if self.training:
+            raise NotImplementedError("CustomCascadeROIHeads training (losses, sampling) is not built yet (SURVEY 8a rows a12/a13)")
+        assert len(proposals) == 1 and len(self.box_head) == 1, "one image, one cascade stage (finetune_vovnet.yaml)"
+        props = proposals[0]
+        boxes = props.proposal_boxes.tensor
+        feats = [nhwc_view(features[f]) for f in self.in_features]
+        strides = [8, 16, 32][: len(feats)]
+        Wp, bp = self.composed(support_box_features[0])
+        n = boxes.shape[0]
+        x = orehip.roi_align(feats, boxes, strides, self.pooler_resolution, cap=max(n, 1))
+        h = orehip.conv2d(x.view(1, 1, x.shape[0], x.shape[1]), Wp, Wp.shape[0], 1, shift=bp, relu_cout=Wp.shape[0])
+        h = h.view(x.shape[0], Wp.shape[0])
+        pr = self.box_predictor[0]
+        det = orehip.roi_predict(h, pr.cls_score.weight.detach().contiguous(), pr.cls_score.bias.detach().contiguous(),
+                                 pr.bbox_pred.weight.detach().contiguous(), pr.bbox_pred.bias.detach().contiguous(), boxes,
+                                 self.bbox_reg_weights, props.image_size, self.test_score_thresh, self.test_nms_thresh, self.test_topk)
+        k = int(det["count"].item())
+        res = Instances(props.image_size)
+        res.pred_boxes = Boxes(det["boxes"][:k])
+        res.scores = det["scores"][:k]
+        res.pred_classes = torch.zeros(k, dtype=torch.int64, device=boxes.device)
+        return [res], {}
 
 
 @ROI_HEADS_REGISTRY.register()

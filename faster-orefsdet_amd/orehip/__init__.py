@@ -67,7 +67,8 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
-           "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
+           "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
+           "ore_roi_predict_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
 
@@ -86,6 +87,7 @@ def lib() -> C.CDLL:
         L.ore_conv_colsum_rows.restype = C.c_int32
         L.ore_detect_workspace_bytes.restype = C.c_size_t
         L.ore_nms_workspace_bytes.restype = C.c_size_t
+        L.ore_roi_predict_workspace_bytes.restype = C.c_size_t
         L.ore_engine_last_flops.restype = C.c_double
         L.ore_engine_last_flops.argtypes = [C.c_void_p]
         L.ore_engine_destroy.argtypes = [C.c_void_p]
@@ -384,6 +386,75 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
     _chk(lib().ore_nms_fwd(C.c_void_p(_ptr(b)), C.c_void_p(_ptr(s)), n, C.c_float(thr), C.c_void_p(_ptr(keep)),
                            C.c_void_p(_ptr(cnt)), C.c_void_p(_ptr(ws)), C.c_size_t(wsb), _stream()), "ore_nms_fwd")
     return keep[: int(cnt.item())]
+
+
+def roi_align(feats: Sequence[torch.Tensor], boxes: torch.Tensor, strides: Sequence[int], pooled: int = 8,
+              n_dev: Optional[torch.Tensor] = None, cap: Optional[int] = None, min_level: int = 3) -> torch.Tensor:
+    """feats[l]: [1,H,W,C] NHWC (or a channel-slice view described by (tensor, coff, C)); boxes [n,4] -> [cap, pooled*pooled*C]."""
+    L = len(feats)
+    n = boxes.shape[0]
+    cap = cap or max(n, 1)
+    Cc = feats[0].shape[-1]
+    out = torch.empty(cap, pooled * pooled * Cc, device=boxes.device, dtype=torch.float32)
+    ptrs = (C.c_void_p * L)(*[_ptr(_f32(f)) for f in feats])
+    ld = (C.c_int32 * L)(*[f.shape[-1] for f in feats])
+    coff = (C.c_int32 * L)(*[0] * L)
+    Hs = (C.c_int32 * L)(*[f.shape[-3] for f in feats])
+    Ws = (C.c_int32 * L)(*[f.shape[-2] for f in feats])
+    sc = (C.c_float * L)(*[1.0 / s for s in strides])
+    b = boxes.float().contiguous() if n else torch.zeros(1, 4, device=boxes.device)
+    _chk(lib().ore_roi_align_fwd(ptrs, ld, coff, Hs, Ws, sc, L, min_level, Cc, pooled, C.c_void_p(_ptr(b)),
+                                 C.c_void_p(_ptr(n_dev)), n, cap, C.c_void_p(_ptr(out)), _stream()), "ore_roi_align_fwd")
+    return out
+
+
+def roi_predict(h: torch.Tensor, cls_w, cls_b, box_w, box_b, boxes: torch.Tensor, reg_weights, image_hw, score_thresh: float,
+                nms_thresh: float, topk: int, n_dev: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    cap, Cc = h.shape
+    n = boxes.shape[0]
+    dev = h.device
+    o = {"boxes": torch.zeros(cap, 4, device=dev), "scores": torch.zeros(cap, device=dev),
+         "src": torch.zeros(cap, dtype=torch.int64, device=dev), "count": torch.zeros(1, dtype=torch.int32, device=dev)}
+    wsb = lib().ore_roi_predict_workspace_bytes(cap)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rw = (C.c_float * 4)(*reg_weights)
+    b = boxes.float().contiguous() if n else torch.zeros(1, 4, device=dev)
+    _chk(lib().ore_roi_predict_fwd(C.c_void_p(_ptr(_f32(h))), Cc, C.c_void_p(_ptr(_f32(cls_w))), C.c_void_p(_ptr(_f32(cls_b))),
+                                   C.c_void_p(_ptr(_f32(box_w))), C.c_void_p(_ptr(_f32(box_b))), C.c_void_p(_ptr(b)),
+                                   C.c_void_p(_ptr(n_dev)), n, cap, rw, C.c_float(image_hw[0]), C.c_float(image_hw[1]),
+                                   C.c_float(score_thresh), C.c_float(nms_thresh), topk, C.c_void_p(_ptr(o["boxes"])),
+                                   C.c_void_p(_ptr(o["scores"])), C.c_void_p(_ptr(o["src"])), C.c_void_p(_ptr(o["count"])),
+                                   C.c_void_p(_ptr(ws)), C.c_size_t(wsb), _stream()), "ore_roi_predict_fwd")
+    o["_ws"] = ws
+    return o
+
+
+def compose_roi_head(sd, support_8: torch.Tensor, prefix: str = "roi_heads."):
+    """The eval second stage between ROIAlign and fc1's ReLU is linear in the pooled features:
+         a = conv3(cat(x, s)) + cat(conv1(x), conv2(s));  h = relu(fc1(flatten(a)))        (fsod_roi_heads.py:500-520)
+    so it folds, once per (weights, support set), into h = relu(W' x_flat + b') with x_flat ordered [pos][channel]
+    (the ROIAlign kernel's output order).  Returns (W' [fc, 64*C] fp32, b' [fc] fp32) on the CPU; done in fp64."""
+    f64 = torch.float64
+    W3 = sd[prefix + "conv3.weight"].detach().cpu().to(f64).flatten(1)
+    b3 = sd[prefix + "conv3.bias"].detach().cpu().to(f64)
+    W1 = sd[prefix + "conv1.weight"].detach().cpu().to(f64).flatten(1)
+    b1 = sd[prefix + "conv1.bias"].detach().cpu().to(f64)
+    W2 = sd[prefix + "conv2.weight"].detach().cpu().to(f64).flatten(1)
+    b2 = sd[prefix + "conv2.bias"].detach().cpu().to(f64)
+    fw = sd[prefix + "box_head.0.fc1.weight"].detach().cpu().to(f64)
+    fb = sd[prefix + "box_head.0.fc1.bias"].detach().cpu().to(f64)
+    Cc = W1.shape[1]
+    P = fw.shape[1] // Cc
+    s = support_8.detach().cpu().to(torch.float32).mean(0).to(f64).reshape(Cc, P)        # mean over shots in fp32 like the reference
+    Wc = W3[:, :Cc].clone()
+    Wc[: W1.shape[0]] += W1
+    const = W3[:, Cc:] @ s + b3[:, None]
+    const[: W1.shape[0]] += b1[:, None]
+    const[W1.shape[0]:] += W2 @ s + b2[:, None]
+    f3 = fw.reshape(fw.shape[0], Cc, P)                                                    # [o][c][pos]  (NCHW flatten)
+    Wp = torch.einsum("ocp,cd->opd", f3, Wc).reshape(fw.shape[0], P * Cc)                  # [o][pos*C + c']
+    bp = fb + torch.einsum("ocp,cp->o", f3, const)
+    return Wp.to(torch.float32).contiguous(), bp.to(torch.float32).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -173,6 +173,31 @@ size_t ore_nms_workspace_bytes(int32_t n);
 int ore_nms_fwd(const float* boxes, const float* scores, int32_t n, float thr, int64_t* keep_idx,
                 int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* NMS with the box count on the device (capacity cap): lets a producer kernel feed the NMS without a host sync. */
+int ore_nms_device_n_fwd(const float* boxes, const float* scores, const int32_t* n_dev, int32_t cap, float thr,
+                         int64_t* keep_idx, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ second stage (ROI heads, eval) ---------- */
+/* ROIPooler: FPN level assignment floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to the available levels, then
+ * ROIAlignV2 (aligned=True, sampling_ratio=0) pooled x pooled.  d2z:modeling/poolers.py:22-58,190-250,
+ * d2z:layers/roi_align.py:49-65 (torchvision.ops.roi_align, un-vendored, restated).
+ * feat[l]: NHWC level l (ld/coff slices), scales_host[l] = 1/stride; boxes [n][4] device; the count is *n_dev if n_dev
+ * is non-NULL else n_host; out [cap][pooled*pooled][C] (rows >= n are zero-filled). */
+int ore_roi_align_fwd(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                      const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                      const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream);
+/* Box predictor + fast_rcnn_inference for one image, class-agnostic box regression, one foreground class:
+ * logits = cls_w h + cls_b (2), deltas = box_w h + box_b (4); score = softmax(logits)[0]; Box2BoxTransform.apply_deltas
+ * (reg_weights4_host, clamp log(1000/16)); clip to (img_h, img_w); keep finite & score > score_thresh; NMS(nms_thresh);
+ * keep[:topk].  ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:160-170, d2z:modeling/box_regression.py:77-115,
+ * d2z:modeling/roi_heads/fast_rcnn.py:118-171.  det_src = index of the proposal each detection came from. */
+size_t ore_roi_predict_workspace_bytes(int32_t cap);
+int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
+                        const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
+                        const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
+                        int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ engine ------------------- */
 /* Whole eval hot path for one model instance: owns packed weights and all
  * intermediate buffers, replays a captured hipGraph per image.

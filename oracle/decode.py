@@ -91,6 +91,27 @@ def decode_nms(hm: Sequence[np.ndarray], reg: Sequence[np.ndarray], strides: Seq
             "pre_level": plv[:n].copy(), "keep": keep, "boxes": pb[:n][keep], "scores": ps[:n][keep]}
 
 
+def roi_predict(h, cls_w, cls_b, box_w, box_b, props, reg_weights, image_hw, score_thresh, nms_thresh, topk):
+    h = np.ascontiguousarray(h, np.float32)
+    n, Cc = h.shape
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (cls_w, cls_b, box_w, box_b, props)]
+    rw = np.asarray(reg_weights, np.float32)
+    cap = max(n, 1)
+    raw_b, raw_s = np.zeros((cap, 4), np.float32), np.zeros(cap, np.float32)
+    det_b, det_s = np.zeros((cap, 4), np.float32), np.zeros(cap, np.float32)
+    det_src = np.zeros(cap, np.int64)
+    cnt = ctypes.c_int32(0)
+    rc = lib().oracle_roi_predict(_p(h, ctypes.c_float), ctypes.c_int64(n), ctypes.c_int32(Cc), _p(arrs[0], ctypes.c_float),
+                                  _p(arrs[1], ctypes.c_float), _p(arrs[2], ctypes.c_float), _p(arrs[3], ctypes.c_float),
+                                  _p(arrs[4], ctypes.c_float), _p(rw, ctypes.c_float), ctypes.c_float(image_hw[0]),
+                                  ctypes.c_float(image_hw[1]), ctypes.c_float(score_thresh), ctypes.c_float(nms_thresh),
+                                  ctypes.c_int32(topk), _p(raw_b, ctypes.c_float), _p(raw_s, ctypes.c_float), _p(det_b, ctypes.c_float),
+                                  _p(det_s, ctypes.c_float), _p(det_src, ctypes.c_int64), ctypes.byref(cnt))
+    assert rc == 0
+    k = cnt.value
+    return {"raw_boxes": raw_b[:n], "raw_scores": raw_s[:n], "boxes": det_b[:k].copy(), "scores": det_s[:k].copy(), "src": det_src[:k].copy()}
+
+
 # ----------------------------------------------------------------------------------------------
 # Pure-numpy twin (small cases; mirrors ref_decode.c step for step, fp32 throughout).
 # ----------------------------------------------------------------------------------------------

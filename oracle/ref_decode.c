@@ -199,3 +199,60 @@ int64_t oracle_nms(const float* boxes, const float* scores, int64_t n, float thr
     free(o); free(dead);
     return nk;
 }
+
+
+/* ---- second stage predict + fast_rcnn_inference for one image (twin of csrc/ore_roi.hip:k_roi_predict + NMS + keep[:topk]).
+ * ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:160-170 (softmax), d2z:modeling/box_regression.py:77-115
+ * (apply_deltas), d2z:modeling/roi_heads/fast_rcnn.py:118-171 (clip, score filter, batched_nms, keep[:topk]).
+ * h [n][C] (fc1+ReLU output), cls_w [2][C], box_w [4][C], props [n][4].
+ * Outputs: raw_boxes [n][4] (decoded+clipped), raw_scores [n], det_* (capacity n), det_src = proposal index. */
+int oracle_roi_predict(const float* h, int64_t n, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
+                       const float* box_b, const float* props, const float* rw, float img_h, float img_w, float score_thresh,
+                       float nms_thresh, int32_t topk, float* raw_boxes, float* raw_scores, float* det_boxes, float* det_scores,
+                       int64_t* det_src, int32_t* det_count) {
+    const float scale_clamp = logf(1000.0f / 16.0f);
+    float* cb = (float*)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+    float* cs = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int64_t* csrc = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    int64_t* keep = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    if (!cb || !cs || !csrc || !keep) { free(cb); free(cs); free(csrc); free(keep); return -1; }
+    int64_t m = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        const float* hv = h + r * C;
+        float l0 = cls_b[0], l1 = cls_b[1], d0 = box_b[0], d1 = box_b[1], d2 = box_b[2], d3 = box_b[3];
+        for (int c = 0; c < C; ++c) {
+            const float v = hv[c];
+            l0 = fmaf(cls_w[c], v, l0); l1 = fmaf(cls_w[C + c], v, l1);
+            d0 = fmaf(box_w[c], v, d0); d1 = fmaf(box_w[C + c], v, d1);
+            d2 = fmaf(box_w[2 * C + c], v, d2); d3 = fmaf(box_w[3 * C + c], v, d3);
+        }
+        const float mx = fmaxf(l0, l1);
+        const float e0 = ore_expf(l0 - mx), e1 = ore_expf(l1 - mx);
+        const float score = e0 / (e0 + e1);
+        const float* b = props + 4 * r;
+        const float w = b[2] - b[0], hg = b[3] - b[1];
+        const float cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * hg;
+        const float dx = d0 / rw[0], dy = d1 / rw[1];
+        const float dw = fminf(d2 / rw[2], scale_clamp), dh = fminf(d3 / rw[3], scale_clamp);
+        const float pcx = dx * w + cx, pcy = dy * hg + cy;
+        const float pw = ore_expf(dw) * w, ph = ore_expf(dh) * hg;
+        float o[4] = {pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph};
+        const int finite = isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(o[3]) && isfinite(score);
+        o[0] = fminf(fmaxf(o[0], 0.f), img_w); o[1] = fminf(fmaxf(o[1], 0.f), img_h);
+        o[2] = fminf(fmaxf(o[2], 0.f), img_w); o[3] = fminf(fmaxf(o[3], 0.f), img_h);
+        memcpy(raw_boxes + 4 * r, o, sizeof(o));
+        raw_scores[r] = score;
+        if (finite && score > score_thresh) { memcpy(cb + 4 * m, o, sizeof(o)); cs[m] = score; csrc[m] = r; ++m; }
+    }
+    int64_t nk = oracle_nms(cb, cs, m, nms_thresh, keep);
+    if (nk < 0) { free(cb); free(cs); free(csrc); free(keep); return -1; }
+    if (topk >= 0 && nk > topk) nk = topk;
+    for (int64_t i = 0; i < nk; ++i) {
+        memcpy(det_boxes + 4 * i, cb + 4 * keep[i], 4 * sizeof(float));
+        det_scores[i] = cs[keep[i]];
+        det_src[i] = csrc[keep[i]];
+    }
+    *det_count = (int32_t)nk;
+    free(cb); free(cs); free(csrc); free(keep);
+    return 0;
+}

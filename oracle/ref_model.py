@@ -329,3 +329,116 @@ def synth_image(seed: int = 0, h: int = 640, w: int = 640) -> Tensor:
     x = x + 0.15 * (torch.rand(1, 3, h, w, generator=g) - 0.5)
     x = (x.clamp(0, 1) * 160 + 40).round().to(torch.uint8)
     return x[0]
+
+
+# --------------------------------------------------------------------------------------
+# f1  second stage, eval (CustomCascadeROIHeads): ref:fewx/modeling/fsod/fsod_roi_heads.py:404-520
+# --------------------------------------------------------------------------------------
+def assign_levels(boxes: Tensor, min_level: int = 3, max_level: int = 5, canonical_size: float = 224.0,
+                  canonical_level: int = 4) -> Tensor:
+    """d2z:modeling/poolers.py:22-58."""
+    sizes = torch.sqrt((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))
+    lv = torch.floor(canonical_level + torch.log2(sizes / canonical_size + 1e-8))
+    return torch.clamp(lv, min=min_level, max=max_level).to(torch.int64) - min_level
+
+
+def roi_align(feat: Tensor, boxes: Tensor, scale: float, pooled: int) -> Tensor:
+    """torchvision.ops.roi_align(aligned=True, sampling_ratio=0) restated from its published algorithm (torchvision 0.8.2 is an
+    un-vendored dependency of the reference: d2z:layers/roi_align.py:49-65).  feat [C,H,W], boxes [R,4] -> [R,C,pooled,pooled]."""
+    C, H, W = feat.shape
+    out = torch.zeros(len(boxes), C, pooled, pooled, dtype=torch.float32)
+    f32 = torch.float32
+    for r in range(len(boxes)):
+        b = boxes[r].to(f32) * scale - 0.5
+        x0, y0, x1, y1 = b[0], b[1], b[2], b[3]
+        rw, rh = x1 - x0, y1 - y0
+        bw, bh = rw / pooled, rh / pooled
+        gh, gw = int(math.ceil(float(rh) / pooled)), int(math.ceil(float(rw) / pooled))
+        cnt = max(gh * gw, 1)
+        if gh <= 0 or gw <= 0:
+            continue
+        ph = torch.arange(pooled, dtype=f32).view(-1, 1)
+        iy = torch.arange(gh, dtype=f32).view(1, -1)
+        ys = (y0 + ph * bh + (iy + 0.5) * bh / gh).reshape(-1)          # [pooled*gh]
+        pw = torch.arange(pooled, dtype=f32).view(-1, 1)
+        ix = torch.arange(gw, dtype=f32).view(1, -1)
+        xs = (x0 + pw * bw + (ix + 0.5) * bw / gw).reshape(-1)          # [pooled*gw]
+
+        def prep(v, size):
+            oob = (v < -1.0) | (v > size)
+            v = torch.clamp(v, min=0.0)
+            lo = v.to(torch.int64)
+            hi = lo + 1
+            edge = lo >= size - 1
+            lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
+            hi = torch.where(edge, torch.full_like(hi, size - 1), hi)
+            v = torch.where(edge, lo.to(f32), v)
+            l = v - lo.to(f32)
+            return oob, lo, hi, l, 1.0 - l
+        oy, yl, yh, ly, hy = prep(ys, H)
+        ox, xl, xh, lx, hx = prep(xs, W)
+        v1 = feat[:, yl][:, :, xl]
+        v2 = feat[:, yl][:, :, xh]
+        v3 = feat[:, yh][:, :, xl]
+        v4 = feat[:, yh][:, :, xh]
+        val = (hy.view(-1, 1) * hx.view(1, -1)) * v1 + (hy.view(-1, 1) * lx.view(1, -1)) * v2 + \
+              (ly.view(-1, 1) * hx.view(1, -1)) * v3 + (ly.view(-1, 1) * lx.view(1, -1)) * v4
+        val = val * (~oy).view(-1, 1).to(f32) * (~ox).view(1, -1).to(f32)
+        val = val.view(C, pooled, gh, pooled, gw).sum((2, 4)) / cnt
+        out[r] = val
+    return out
+
+
+def roi_pool_levels(feats: Sequence[Tensor], boxes: Tensor, pooled: int, strides=(8, 16, 32)) -> Tensor:
+    """ROIPooler.forward for one image (poolers.py:190-250).  feats[l] [1,C,H,W]."""
+    lv = assign_levels(boxes)
+    out = torch.zeros(len(boxes), feats[0].shape[1], pooled, pooled)
+    for l, f in enumerate(feats):
+        idx = torch.nonzero(lv == l).squeeze(1)
+        if len(idx):
+            out[idx] = roi_align(f[0], boxes[idx], 1.0 / strides[l], pooled)
+    return out
+
+
+def roi_head_features(box_feat: Tensor, support_8: Tensor, sd: SD, prefix: str = "roi_heads.") -> Tensor:
+    """_run_stage (fsod_roi_heads.py:459-520), the live branch: DSA mix with the mean support feature -> fc1 -> ReLU.
+    box_feat [R,C,8,8], support_8 [N,C,8,8].  (attn_4 / fc2 / fc3 are dead compute in the reference: SURVEY App. C.5.)"""
+    s = support_8.mean(0, True).expand_as(box_feat)
+    a = F.conv2d(torch.cat((box_feat, s), 1), sd[prefix + "conv3.weight"], sd[prefix + "conv3.bias"]) + \
+        torch.cat((F.conv2d(box_feat, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"]),
+                   F.conv2d(s, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])), 1)
+    return F.relu(F.linear(a.flatten(1), sd[prefix + "box_head.0.fc1.weight"], sd[prefix + "box_head.0.fc1.bias"]))
+
+
+def roi_head_eval(feats: Sequence[Tensor], proposals: Tensor, support_8: Tensor, sd: SD, image_hw: Tuple[int, int],
+                  score_thresh: float = 0.0, nms_thresh: float = 0.9, topk: int = 100, prefix: str = "roi_heads."):
+    """Whole second stage for one image; the predict/NMS part runs in oracle/ref_decode.c (bit-exact twin of the HIP kernel)."""
+    from . import decode as odec
+    x = roi_pool_levels(feats, proposals, 8)
+    h = roi_head_features(x, support_8, sd, prefix)
+    det = odec.roi_predict(h.numpy(), sd[prefix + "box_predictor.0.cls_score.weight"].numpy(),
+                           sd[prefix + "box_predictor.0.cls_score.bias"].numpy(),
+                           sd[prefix + "box_predictor.0.bbox_pred.weight"].numpy(),
+                           sd[prefix + "box_predictor.0.bbox_pred.bias"].numpy(), proposals.numpy(), (10.0, 10.0, 5.0, 5.0),
+                           image_hw, score_thresh, nms_thresh, topk)
+    det.update(box_features=x, h=h)
+    return det
+
+
+def synth_roi_state(sd: Dict[str, Tensor], seed: int = 0, C: int = 128) -> Dict[str, Tensor]:
+    """Adds seeded second-stage parameters (reference shapes) + rcnn_8 support features."""
+    g = torch.Generator().manual_seed(seed + 3000)
+
+    def u(*shape, b):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * b
+    p = "roi_heads."
+    sd = dict(sd)
+    sd[p + "conv1.weight"], sd[p + "conv1.bias"] = u(C // 2, C, 1, 1, b=C ** -0.5), u(C // 2, b=0.1)
+    sd[p + "conv2.weight"], sd[p + "conv2.bias"] = u(C // 2, C, 1, 1, b=C ** -0.5), u(C // 2, b=0.1)
+    sd[p + "conv3.weight"], sd[p + "conv3.bias"] = u(C, 2 * C, 1, 1, b=(2 * C) ** -0.5), u(C, b=0.1)
+    sd[p + "box_head.0.fc1.weight"], sd[p + "box_head.0.fc1.bias"] = u(128, C * 64, b=(C * 64) ** -0.5 * 3), u(128, b=0.1)
+    sd[p + "box_predictor.0.cls_score.weight"], sd[p + "box_predictor.0.cls_score.bias"] = u(2, 128, b=0.5), u(2, b=0.1)
+    sd[p + "box_predictor.0.bbox_pred.weight"], sd[p + "box_predictor.0.bbox_pred.bias"] = u(4, 128, b=0.3), u(4, b=0.1)
+    sd[p + "fc2.weight"], sd[p + "fc2.bias"] = u(128, C * 16, b=0.02), u(128, b=0.1)
+    sd[p + "fc3.weight"], sd[p + "fc3.bias"] = u(128, 256, b=0.06), u(128, b=0.1)
+    return sd
