@@ -5,9 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload at N=1 = BASELINE.json configs[1]: finetune_vovnet.yaml, 25-shot eval-only, bs=1, 640x640 synthetic image,
-cached support prototypes, random-init weights (no dataset / checkpoint exists offline).  One "step" = one pass of the
-hot path (fused preprocess + VoVNet-19-slim-eSE + FPN -> query<->support correlation ->
-CenterNet head -> sigmoid/top-k/decode/NMS) over one image that is already resident in HBM, replayed as a hipGraph.
+cached support prototypes, random-init weights (no dataset / checkpoint exists offline).  One "step" = one complete eval
+forward of the detector (fused preprocess + VoVNet-19-slim-eSE + FPN -> query<->support correlation ->
+CenterNet head -> sigmoid/top-k/decode/NMS proposals, then 8f row 1: ROIAlign -> support-guided mix + fc1 -> cls/box -> NMS ->
+top-100 detections) over one image that is already resident in HBM, replayed as ONE hipGraph.
 N>1: pure data parallel, every rank runs the same per-GPU work on its own images, no data-path collective (weak scaling);
 RCCL (backend "nccl") is used only for the barrier and the max-over-ranks of the elapsed time.
 
@@ -154,6 +155,7 @@ def main():
     elapsed = comm.max_over_ranks(elapsed, device)          # the slowest rank defines the job time
     total_images = int(comm.sum_over_ranks(args.steps, device))
     n_prop = int(eng.buffer("counts")[1, 0].item())
+    n_det = int(eng.buffer("det_count")[0, 0].item()) if getattr(eng, "has_roi", False) else None
 
     # per-image latency with a host sync after every image (the reference's inference_on_dataset protocol)
     lat = []
@@ -179,7 +181,7 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv, incl. split-K reduce)",
+                "kernel": "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv incl. in-kernel split-K; 28 convs + the ROI fc GEMM)",
                 "launches_per_image": nl // max(args.profile_passes, 1),
                 "gflop_per_image": round(fl / max(args.profile_passes, 1) / 1e9, 3),
                 "kernel_ms_per_image": round(ms / max(args.profile_passes, 1), 4)}
@@ -191,9 +193,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]): "
-                                   "preprocess+VoVNet-19-slim-eSE+FPN -> correlation -> CenterNet head -> top-k/NMS proposals",
+                                   "preprocess+VoVNet-19-slim-eSE+FPN -> correlation -> CenterNet head -> top-k/NMS proposals -> ROIAlign + cascade ROI head -> NMS -> detections",
                        "parallelism": f"dp{world} (images sharded, no data-path collective)", "hipgraph": use_graph,
-                       "proposals_last_image": n_prop},
+                       "proposals_last_image": n_prop, "detections_last_image": n_det},
             "latency_ms_host_sync": {"p50": round(lat[len(lat) // 2] * 1e3, 4), "min": round(lat[0] * 1e3, 4)},
             "roofline": roof,
         }

@@ -324,19 +324,30 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_bo
             // reached after (longest suppression chain) iterations, typically a handful instead of 64 serial steps.
             const unsigned long long cand = ~rem;
             unsigned long long kept = cand;
-            if (__ballot(diag != 0ull) != 0ull) {
+            const unsigned long long nz = __ballot(diag != 0ull);   // rows that suppress anything inside this block (usually few)
+            if (nz != 0ull) {
+                const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+                auto uni = [](unsigned long long v) -> unsigned long long {      // provably wave-uniform copy (SGPR pair)
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+                    return ((unsigned long long)hi << 32) | lo;
+                };
+                const unsigned long long cand_u = uni(cand), nz_u = uni(nz);
+                unsigned long long k_u = cand_u;
                 for (int it = 0; it < 64; ++it) {
-                    unsigned long long sup = ((kept >> lane) & 1ull) ? diag : 0ull;
-#pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) {
-                        const unsigned lo = __shfl_xor((unsigned)sup, d);
-                        const unsigned hi = __shfl_xor((unsigned)(sup >> 32), d);
+                    unsigned long long sup = 0ull, m = k_u & nz_u;   // scalar loop over the active suppressors only
+                    while (m) {
+                        const int t = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(dlo, t);   // readlane returns a signed int:
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane(dhi, t);   // go through unsigned, no sign extension
                         sup |= ((unsigned long long)hi << 32) | lo;
                     }
-                    const unsigned long long kn = cand & ~sup;
-                    if (kn == kept) break;
-                    kept = kn;
+                    const unsigned long long kn = cand_u & ~sup;
+                    if (kn == k_u) break;
+                    k_u = kn;
                 }
+                kept = k_u;
             }
             if (lane == 0) sh_kept = kept;
             if ((kept >> lane) & 1ull) {               // emit survivors of this block in order

@@ -61,6 +61,15 @@ struct ore_engine {
     float* pre_boxes = nullptr; float* pre_scores = nullptr; int64_t* pre_loc = nullptr; int32_t* pre_level = nullptr;
     int64_t* keep_idx = nullptr; int32_t* counts = nullptr; float* out_boxes = nullptr; float* out_scores = nullptr;
     void* det_ws = nullptr; size_t det_ws_bytes = 0;
+    // second stage (optional: ore_engine_set_roi_head)
+    bool roi_set = false;
+    int roi_cap = 320, roi_fc = 0, roi_pooled = 8, roi_topk = 100;
+    float roi_score_thresh = 0.f, roi_nms_thresh = 0.9f, roi_reg_w[4] = {10.f, 10.f, 5.f, 5.f};
+    float* roi_W = nullptr; float* roi_b = nullptr; float* roi_cls_w = nullptr; float* roi_cls_b = nullptr;
+    float* roi_box_w = nullptr; float* roi_box_b = nullptr;
+    float* roi_feat = nullptr; float* roi_h = nullptr;
+    float* det_boxes = nullptr; float* det_scores = nullptr; int64_t* det_src = nullptr; int32_t* det_count = nullptr;
+    void* roi_ws = nullptr; size_t roi_ws_bytes = 0;
     // graph cache
     hipStream_t cap_stream = nullptr;
     struct GraphKey { int u8, H, W; hipGraphExec_t exec; };
@@ -312,7 +321,69 @@ int run_detect(ore_engine* e, const Geo& g, hipStream_t st) {
     return ore_detect_fwd(&d, st);
 }
 
+int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
+    const ore_model_cfg& c = e->cfg;
+    const int F = c.fpn_ch;
+    const float* feat[3]; int ld[3], coff[3], H[3], W[3]; float sc[3];
+    for (int l = 0; l < 3; ++l) {
+        feat[l] = e->pcat.p + (size_t)lvl_row0(g, l) * 2 * F; ld[l] = 2 * F; coff[l] = F;
+        H[l] = g.h[l + 3]; W[l] = g.w[l + 3]; sc[l] = 1.0f / (float)c.strides[l];
+    }
+    int rc = ore_roi_align_fwd(feat, ld, coff, H, W, sc, 3, 3, F, e->roi_pooled, e->out_boxes, e->counts + 1, 0, e->roi_cap, e->roi_feat, st);
+    if (rc) return rc;
+    const int K = e->roi_pooled * e->roi_pooled * F;
+    Run r{e, st};
+    r.prof = e->profiling;
+    Conv fc{};
+    fc.w = e->roi_W; fc.scale = nullptr; fc.shift = e->roi_b; fc.Cin = K; fc.Cout = e->roi_fc; fc.k = 1; fc.stride = 1; fc.pad = 0;
+    fc.relu_cout = e->roi_fc;
+    r.conv(fc, e->roi_feat, K, 0, 1, 1, e->roi_cap, e->roi_h, e->roi_fc, 0);        // pre-composed DSA mix + flatten + fc1, ReLU
+    if (r.rc) return r.rc;
+    *flops = r.flops;
+    return ore_roi_predict_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, e->out_boxes, e->counts + 1, 0,
+                               e->roi_cap, e->roi_reg_w, (float)g.H, (float)g.W, e->roi_score_thresh, e->roi_nms_thresh, e->roi_topk,
+                               e->det_boxes, e->det_scores, e->det_src, e->det_count, e->roi_ws, e->roi_ws_bytes, st);
+}
+
 }  // namespace
+
+extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const float* b_host, int32_t fc_dim, int32_t pooled,
+                                       const float* cls_w_host, const float* cls_b_host, const float* box_w_host,
+                                       const float* box_b_host, const float* reg_weights4_host, float score_thresh, float nms_thresh,
+                                       int32_t topk) {
+    ORE_CHECK_ARG(e && e->finalized && W_host && b_host && cls_w_host && cls_b_host && box_w_host && box_b_host && reg_weights4_host,
+                  "ore_engine_set_roi_head: engine must be finalized, pointers non-null");
+    ORE_CHECK_ARG(fc_dim % 16 == 0 && fc_dim > 0 && pooled >= 1 && pooled <= 16 && nms_thresh > 0.f, "ore_engine_set_roi_head: bad args");
+    ORE_HIP(hipSetDevice(e->device));
+    const size_t K = (size_t)pooled * pooled * e->cfg.fpn_ch;
+    int rc;
+    auto up = [&](float** dst, const float* src, size_t n) -> int {
+        if (!*dst && (rc = e->dalloc(dst, n))) return rc;
+        ORE_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+        return ORE_OK;
+    };
+    if (e->roi_set && (e->roi_fc != fc_dim || e->roi_pooled != pooled)) { ore_set_error("ore_engine_set_roi_head: shape change not supported"); return ORE_EINVAL; }
+    if ((rc = up(&e->roi_W, W_host, (size_t)fc_dim * K)) || (rc = up(&e->roi_b, b_host, fc_dim)) || (rc = up(&e->roi_cls_w, cls_w_host, 2 * (size_t)fc_dim)) ||
+        (rc = up(&e->roi_cls_b, cls_b_host, 2)) || (rc = up(&e->roi_box_w, box_w_host, 4 * (size_t)fc_dim)) || (rc = up(&e->roi_box_b, box_b_host, 4)))
+        return rc;
+    if (!e->roi_set) {
+        const size_t cap = (size_t)e->roi_cap;
+        if ((rc = e->dalloc(&e->roi_feat, cap * K)) || (rc = e->dalloc(&e->roi_h, cap * fc_dim)) || (rc = e->dalloc(&e->det_boxes, cap * 4)) ||
+            (rc = e->dalloc(&e->det_scores, cap)) || (rc = e->dalloc(&e->det_src, cap)) || (rc = e->dalloc(&e->det_count, (size_t)4))) return rc;
+        e->roi_ws_bytes = ore_roi_predict_workspace_bytes(e->roi_cap);
+        char* w = nullptr;
+        if ((rc = e->dalloc(&w, e->roi_ws_bytes))) return rc;
+        e->roi_ws = w;
+        ORE_HIP(hipMemset(e->det_count, 0, 4 * sizeof(int32_t)));
+    }
+    e->roi_fc = fc_dim; e->roi_pooled = pooled; e->roi_topk = topk; e->roi_score_thresh = score_thresh; e->roi_nms_thresh = nms_thresh;
+    for (int i = 0; i < 4; ++i) e->roi_reg_w[i] = reg_weights4_host[i];
+    e->roi_set = true;
+    for (auto& gk : e->graphs) (void)hipGraphExecDestroy(gk.exec);   // captured graphs did not contain the second stage
+    e->graphs.clear();
+    ORE_HIP(hipDeviceSynchronize());
+    return ORE_OK;
+}
 
 extern "C" int ore_engine_create(const ore_model_cfg* cfg, int32_t device, ore_engine** out) {
     ORE_CHECK_ARG(cfg && out, "ore_engine_create: null");
@@ -532,9 +603,11 @@ extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8
     auto body = [&](hipStream_t s, double* fl) -> int {
         double f1 = 0, f2 = 0;
         int r = run_backbone(e, e->img_in, is_u8, g, s, &f1);
+        double f3 = 0;
         if (!r) r = run_heads(e, g, s, &f2);
         if (!r) r = run_detect(e, g, s);
-        *fl = f1 + f2;
+        if (!r && e->roi_set) r = run_roi(e, g, s, &f3);
+        *fl = f1 + f2 + f3;
         return r;
     };
     if (!use_graph) return body(st, &e->last_flops);
@@ -623,6 +696,13 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
     if (n == "counts") return set(e->counts, 4, 1, 1, 0);
     if (n == "out_boxes") return set(e->out_boxes, cap, 4, 4, 0);
     if (n == "out_scores") return set(e->out_scores, cap, 1, 1, 0);
+    if (e->roi_set) {
+        if (n == "det_boxes") return set(e->det_boxes, e->roi_cap, 4, 4, 0);
+        if (n == "det_scores") return set(e->det_scores, e->roi_cap, 1, 1, 0);
+        if (n == "det_src") return set(e->det_src, e->roi_cap, 1, 1, 0);
+        if (n == "det_count") return set(e->det_count, 4, 1, 1, 0);
+        if (n == "roi_h") return set(e->roi_h, e->roi_cap, e->roi_fc, e->roi_fc, 0);
+    }
     ore_set_error("ore_engine_buffer: unknown buffer '%s'", name);
     return ORE_ENOENT;
 }

@@ -106,28 +106,38 @@ struct PredP {
     float* c_boxes; float* c_scores; int* c_src; int* c_count;   // compacted (filter_mask order)
 };
 
-// single block: one thread per ROI (cap <= 1024 per pass), ordered compaction by a block scan
-__global__ __launch_bounds__(1024) void k_roi_predict(PredP p) {
-    __shared__ int wsum[16];
+// single block of 256 threads, 256 ROIs per pass: the fc1 rows are staged through LDS (coalesced global reads, row stride C+1
+// -> conflict-free per-thread row walks), each thread then runs the SAME sequential fma chain as the CPU twin (bit-exact),
+// ordered compaction by a block scan.
+__global__ __launch_bounds__(256) void k_roi_predict(PredP p) {
+    extern __shared__ float hs[];                 // [256][C+1] rows, then cls_w [2][C], box_w [4][C]
+    __shared__ int wsum[4];
     __shared__ int base_sh;
+    const int C = p.C, LDH = C + 1;
+    float* wl = hs + 256 * LDH;
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * C; i += 256) wl[i] = p.cls_w[i];
+    for (int i = tid; i < 4 * C; i += 256) wl[2 * C + i] = p.box_w[i];
     if (tid == 0) base_sh = 0;
     __syncthreads();
-    for (int r0 = 0; r0 < n; r0 += 1024) {
+    for (int r0 = 0; r0 < n; r0 += 256) {
+        const int rows = min(256, n - r0);
+        for (int i = tid; i < rows * C; i += 256) hs[(i / C) * LDH + (i % C)] = p.h[(size_t)r0 * C + i];
+        __syncthreads();
         const int r = r0 + tid;
         bool ok = false;
         float score = 0.f;
         f32x4 ob = {0.f, 0.f, 0.f, 0.f};
         if (r < n) {
-            const float* h = p.h + (size_t)r * p.C;
+            const float* h = hs + tid * LDH;
             float l0 = p.cls_b[0], l1 = p.cls_b[1];
             float d0 = p.box_b[0], d1 = p.box_b[1], d2 = p.box_b[2], d3 = p.box_b[3];
-            for (int c = 0; c < p.C; ++c) {
+            for (int c = 0; c < C; ++c) {
                 const float v = h[c];
-                l0 = fmaf(p.cls_w[c], v, l0); l1 = fmaf(p.cls_w[p.C + c], v, l1);
-                d0 = fmaf(p.box_w[c], v, d0); d1 = fmaf(p.box_w[p.C + c], v, d1);
-                d2 = fmaf(p.box_w[2 * p.C + c], v, d2); d3 = fmaf(p.box_w[3 * p.C + c], v, d3);
+                l0 = fmaf(wl[c], v, l0); l1 = fmaf(wl[C + c], v, l1);
+                d0 = fmaf(wl[2 * C + c], v, d0); d1 = fmaf(wl[3 * C + c], v, d1);
+                d2 = fmaf(wl[4 * C + c], v, d2); d3 = fmaf(wl[5 * C + c], v, d3);
             }
             // softmax over (fg, bg); fast_rcnn_inference keeps scores[:, :-1] = the foreground column
             const float m = fmaxf(l0, l1);
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(1024) void k_roi_predict(PredP p) {
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         int base = base_sh, tot = 0;
-        for (int w2 = 0; w2 < 16; ++w2) { const int s = wsum[w2]; if (w2 < wave) base += s; tot += s; }
+        for (int w2 = 0; w2 < 4; ++w2) { const int s = wsum[w2]; if (w2 < wave) base += s; tot += s; }
         if (ok) {
             const int pos = base + inc - v;
             *reinterpret_cast<f32x4*>(p.c_boxes + (size_t)pos * 4) = ob;
@@ -249,7 +259,10 @@ extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w
     p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh;
     p.raw_boxes = raw_boxes; p.raw_scores = raw_scores; p.c_boxes = c_boxes; p.c_scores = c_scores; p.c_src = c_src; p.c_count = c_count;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_roi_predict, dim3(1), dim3(1024), 0, st, p);
+    const size_t lds = ((size_t)256 * (C + 1) + 6 * (size_t)C) * sizeof(float);
+    ORE_CHECK_ARG(lds <= 150 * 1024, "ore_roi_predict_fwd: fc width %d too large", C);
+    if (lds > 48 * 1024) ORE_HIP(hipFuncSetAttribute((const void*)k_roi_predict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_roi_predict, dim3(1), dim3(256), lds, st, p);
     int rc = ore_launch_status("k_roi_predict");
     if (rc) return rc;
     rc = ore_nms_device_n_fwd(c_boxes, c_scores, c_count, cap, nms_thresh, (int64_t*)keep, n_keep, nms_ws,

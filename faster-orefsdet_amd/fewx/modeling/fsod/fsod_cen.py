@@ -153,6 +153,10 @@ class CenterNet2Detector(nn.Module):
             cls_id = list(self.support_dict["p3"].keys())[-1]   # the reference keeps only the last class
             e.set_support({k: self.support_dict[k][cls_id] for k in ("p3", "p4", "p5")})
             e.finalize()
+            rh = self.roi_heads
+            if "rcnn_8" in self.support_dict and hasattr(rh, "bbox_reg_weights"):
+                e.set_roi_head(self.state_dict(), self.support_dict["rcnn_8"][cls_id], rh.bbox_reg_weights, rh.test_score_thresh,
+                               rh.test_nms_thresh, rh.test_topk)
             self._engine, self._engine_key = e, key
         return self._engine
 
@@ -182,16 +186,29 @@ class CenterNet2Detector(nn.Module):
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
         assert not self.training
         self.init_model()
-        proposals = self.inference_proposals(batched_inputs)
-        e = self._engine
-        img = batched_inputs[0]["image"]
+        assert len(batched_inputs) == 1, "only 1 query image in test (ref fsod_cen.py:438-439)"
+        img = batched_inputs[0]["image"].to(self.device)
+        img = (img if img.dtype == torch.uint8 else img.float()).contiguous()
         H, W = img.shape[-2:]
-        Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
-        features = {f"p{l}": e.buffer(f"p{l}", (1, Hp >> l, Wp >> l)) for l in (3, 4, 5)}
-        cls_id = list(self.support_dict["p3"].keys())[-1]
-        support = [self.support_dict["rcnn_8"][cls_id], self.support_dict["rcnn_4"][cls_id]]
+        e = self.engine()
         images = ImageList(torch.empty(0), [(H, W)])
-        results, _ = self.roi_heads(images, features, support, proposals, None)
+        if getattr(e, "has_roi", False):
+            # both stages in ONE hipGraph replay; the only host sync is reading the detection count
+            from detectron2.structures import Boxes, Instances
+            e.eval_forward(img, use_graph=True)
+            boxes, scores, _ = e.detections()
+            res = Instances((H, W))
+            res.pred_boxes = Boxes(boxes.clone())
+            res.scores = scores.clone()
+            res.pred_classes = torch.zeros(len(scores), dtype=torch.int64, device=scores.device)
+            results = [res]
+        else:
+            proposals = self.inference_proposals(batched_inputs)
+            Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+            features = {f"p{l}": e.buffer(f"p{l}", (1, Hp >> l, Wp >> l)) for l in (3, 4, 5)}
+            cls_id = list(self.support_dict["p3"].keys())[-1]
+            support = [self.support_dict["rcnn_8"][cls_id], self.support_dict["rcnn_4"][cls_id]]
+            results, _ = self.roi_heads(images, features, support, proposals, None)
         if do_postprocess:
             return CenterNet2Detector._postprocess(results, batched_inputs, images.image_sizes)
         return results

@@ -69,7 +69,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
-           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
+           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
 
 _lib = None
@@ -512,6 +512,26 @@ class Engine:
     def finalize(self) -> None:
         _chk(lib().ore_engine_finalize(self._h), "ore_engine_finalize")
 
+    def set_roi_head(self, sd, support_8: torch.Tensor, reg_weights=(10.0, 10.0, 5.0, 5.0), score_thresh: float = 0.0,
+                     nms_thresh: float = 0.9, topk: int = 100, prefix: str = "roi_heads.") -> None:
+        """Second stage inside the engine graph: composes DSA-mix + flatten + fc1 once (compose_roi_head) and uploads it."""
+        Wp, bp = compose_roi_head(sd, support_8, prefix)
+        f = lambda k: sd[prefix + k].detach().float().cpu().contiguous()
+        cw, cb, bw, bb = f("box_predictor.0.cls_score.weight"), f("box_predictor.0.cls_score.bias"), f("box_predictor.0.bbox_pred.weight"), f("box_predictor.0.bbox_pred.bias")
+        assert cw.shape[0] == 2 and bw.shape[0] == 4, "one foreground class, class-agnostic box regression"
+        pooled = int(round((Wp.shape[1] // self.fpn_ch) ** 0.5))
+        rw = (C.c_float * 4)(*reg_weights)
+        _chk(lib().ore_engine_set_roi_head(self._h, C.c_void_p(Wp.data_ptr()), C.c_void_p(bp.data_ptr()), Wp.shape[0], pooled,
+                                           C.c_void_p(cw.data_ptr()), C.c_void_p(cb.data_ptr()), C.c_void_p(bw.data_ptr()),
+                                           C.c_void_p(bb.data_ptr()), rw, C.c_float(score_thresh), C.c_float(nms_thresh), topk),
+             "ore_engine_set_roi_head")
+        self.has_roi = True
+
+    def detections(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(boxes [k,4], scores [k], source proposal index [k]) of the second stage -- one sync to read the count."""
+        k = int(self.buffer("det_count")[0, 0].item())
+        return self.buffer("det_boxes")[:k], self.buffer("det_scores")[:k, 0], self.buffer("det_src")[:k, 0]
+
     def backbone(self, img: torch.Tensor) -> Dict[str, torch.Tensor]:
         """img [B,3,H,W] u8/f32 on device -> {'p3','p4','p5'} as logical NCHW views of engine-owned NHWC buffers."""
         assert img.is_cuda and img.is_contiguous()
@@ -546,7 +566,8 @@ class Engine:
         dims = (C.c_int64 * 4)()
         _chk(lib().ore_engine_buffer(self._h, name.encode(), C.byref(p), dims), f"ore_engine_buffer({name})")
         rows, ch, ld, coff = (int(x) for x in dims)
-        dt = {"pre_loc": torch.int64, "keep_idx": torch.int64, "pre_level": torch.int32, "counts": torch.int32}.get(name, torch.float32)
+        dt = {"pre_loc": torch.int64, "keep_idx": torch.int64, "pre_level": torch.int32, "counts": torch.int32, "det_src": torch.int64,
+              "det_count": torch.int32}.get(name, torch.float32)
         flat = _from_ptr(p.value, rows * ld, dt, self.device)
         t = flat.view(rows, ld)[:, coff:coff + ch]
         if bhw is not None:

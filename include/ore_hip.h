@@ -224,6 +224,14 @@ int ore_engine_set_tensor(ore_engine* e, const char* name, const float* data_hos
 /* Cached support prototypes [128][s][s] for level 3/4/5 (support_feature.pkl 'p3','p4','p5'), host. */
 int ore_engine_set_support(ore_engine* e, int32_t level, const float* proto_chw_host, int32_t C, int32_t s);
 int ore_engine_finalize(ore_engine* e);   /* fold BN, pack weights, upload */
+/* Optional second stage (CustomCascadeROIHeads, eval) inside the same forward/graph; call after finalize.  W_host [fc_dim]
+ * [pooled*pooled*fpn_ch] (k ordered [pos][channel]) and b_host [fc_dim] are the pre-composed DSA-mix + flatten + fc1 chain
+ * (ref:fewx/modeling/fsod/fsod_roi_heads.py:500-520; orehip.compose_roi_head builds them from the state_dict and the cached
+ * rcnn_8 support features); cls_* [2][fc_dim],[2]; box_* [4][fc_dim],[4].  Results: buffers "det_boxes","det_scores",
+ * "det_src","det_count".  At most 320 proposals enter the second stage (post-NMS top-256 plus up to 64 score ties). */
+int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const float* b_host, int32_t fc_dim, int32_t pooled,
+                            const float* cls_w_host, const float* cls_b_host, const float* box_w_host, const float* box_b_host,
+                            const float* reg_weights4_host, float score_thresh, float nms_thresh, int32_t topk);
 
 /* Backbone+FPN only: img [B][3][H][W] (u8 or f32, device) -> p3,p4,p5 NHWC device pointers owned by the engine. */
 int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W,

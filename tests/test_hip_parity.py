@@ -497,6 +497,18 @@ def test_detector_end_to_end(model, sd):
     assert inst.pred_classes.dtype == torch.int64
     b = inst.pred_boxes.tensor
     assert float(b.min()) >= 0 and float(b[:, 2].max()) <= 640 and float(b[:, 3].max()) <= 640
+    # the in-graph second stage (engine, 512-row GEMM) and the module-level forward (per-op calls, n-row GEMM -> another split-K
+    # plan) are the same kernels up to float summation order
+    assert getattr(e, "has_roi", False)
+    e.eval_forward(img.cuda(), use_graph=True)
+    eb, es, _ = e.detections()
+    from detectron2.structures import ImageList
+    proposals = model.inference_proposals([{"image": img}])
+    feats_d = {f"p{l}": e.buffer(f"p{l}", (1, 320 >> l, 320 >> l)) for l in (3, 4, 5)}
+    res, _ = model.roi_heads(ImageList(torch.empty(0), [(320, 320)]), feats_d, [rc8.cuda(), None], proposals, None)
+    assert len(es) == len(res[0].scores)
+    np.testing.assert_allclose(res[0].scores.cpu().numpy(), es.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res[0].pred_boxes.tensor.cpu().numpy(), eb.cpu().numpy(), rtol=1e-4, atol=1e-2)
 
 
 # ------------------------------------------------------------------------------------------ batched-level / fused entry points
