@@ -364,6 +364,170 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 "patch" kernel for the large-M layers (stem_2, stage-2 layers, FPN output3, head tower).
+// A block owns a TH x 16 pixel tile x 64 output channels.  Per 16 input channels it stages ONCE the (TH+2) x 18 halo patch of
+// the input and the 9 x 64 x 16 weight slab into LDS, then runs all 9 taps out of LDS: 9*TM*TN*4 MFMAs (288 for TH=8) per
+// barrier pair instead of 16..32, 9x fewer global A loads / address computations than the generic implicit-GEMM step.
+// The next slab is prefetched into registers while the current one is being multiplied (single LDS buffer, 72 KB -> two blocks
+// per CU overlap each other's staging phase).  wave w owns tile rows [w*TH/4, (w+1)*TH/4): an MFMA A fragment is one tile row of
+// 16 consecutive pixels, so the tap shift (dy, dx) is a plain LDS address offset.
+struct PatchP {
+    const float* in; int in_ld, in_coff;
+    int B, Cin, nlev; Lvl lv[4]; int tile0[5]; int tiles_x[4], tiles_y[4];
+    const float* w; int Cout, Cout16, K;
+    const float* scale; const float* shift; int ep_stride, relu_cout;
+    float* out; int out_ld, out_coff;
+};
+
+template <int TH>
+__global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
+    constexpr int TW = 16, BN = 64, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDA = 24;
+    constexpr int TM = TH / 4, TN = BN / 16;
+    constexpr int A_IT = (NPIX * 4 + 255) / 256, B_IT = 9;          // float4 slots per thread (B: tap j = slot j since BN*4 == 256)
+    extern __shared__ __attribute__((aligned(16))) float plds[];
+    float* As = plds;                       // [NPIX][LDA]
+    float* Bs = plds + NPIX * LDA;          // [9][BN][LDA]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- which tile
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+        if (l < p.nlev && (int)blockIdx.x >= p.tile0[l]) lvl = l;
+    const Lvl L = p.lv[lvl];
+    const int tl = blockIdx.x - p.tile0[lvl];
+    const int tpi = p.tiles_x[lvl] * p.tiles_y[lvl];
+    const int b = tl / tpi, tr = tl - b * tpi;
+    const int ty0 = (tr / p.tiles_x[lvl]) * TH, tx0 = (tr % p.tiles_x[lvl]) * TW;
+    const int n0 = blockIdx.y * BN;
+    const int ibase = L.irow0 + b * L.H * L.W, obase = L.orow0 + b * L.H * L.W;
+    const float* zero = g_zero16;
+    auto sel = [&](bool ok, const float* ptr) -> const f32x4* {
+        const uintptr_t m = (uintptr_t)0 - (uintptr_t)ok;
+        return reinterpret_cast<const f32x4*>(((uintptr_t)ptr & m) | ((uintptr_t)zero & ~m));
+    };
+    // ---- staging slots
+    const float* a_ptr[A_IT]; bool a_ok[A_IT]; int a_lds[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int f = tid + i * 256, pi = f >> 2, q = f & 3;
+        const int py = pi / PW, px = pi - py * PW;
+        const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+        a_ok[i] = pi < NPIX && (unsigned)gy < (unsigned)L.H && (unsigned)gx < (unsigned)L.W;
+        a_ptr[i] = p.in + (ptrdiff_t)(ibase + gy * L.W + gx) * p.in_ld + p.in_coff + q * 4;
+        a_lds[i] = pi < NPIX ? pi * LDA + q * 4 : -1;
+    }
+    const int bn = tid >> 2, bq = tid & 3;
+    const bool b_ok = n0 + bn < p.Cout16;
+    const float* b_ptr = p.w + (size_t)(b_ok ? n0 + bn : 0) * p.K + bq * 4;
+    const int b_lds = bn * LDA + bq * 4;
+    f32x4 ra[A_IT], rb[B_IT];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) ra[i] = *sel(a_ok[i], a_ptr[i] + c0);
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) rb[j] = *sel(b_ok, b_ptr + j * p.Cin + c0);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (a_lds[i] >= 0) *reinterpret_cast<f32x4*>(As + a_lds[i]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) *reinterpret_cast<f32x4*>(Bs + j * BN * LDA + b_lds) = rb[j];
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, g4 = (lane >> 4) * 4;
+    const int wrow = wave * TM;
+    gload(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += 16) {
+        lstore();
+        __syncthreads();
+        if (c0 + 16 < p.Cin) gload(c0 + 16);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const f32x4*>(As + ((wrow + i + dy) * PW + li + dx) * LDA + g4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + ((dy * 3 + dx) * BN + j * 16 + li) * LDA + g4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+    // ---- epilogue: accumulator (i, j, r): tile row wrow+i, column (lane>>4)*4 + r, channel n0 + j*16 + (lane&15)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 16 + li;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[lvl * p.ep_stride + n] : 1.0f;
+        const float sh = p.shift ? p.shift[lvl * p.ep_stride + n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int gy = ty0 + wrow + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gx = tx0 + g4 + r;
+                if (gy < L.H && gx < L.W) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (n < p.relu_cout) v = fmaxf(v, 0.f);
+                    p.out[(size_t)(obase + gy * L.W + gx) * p.out_ld + p.out_coff + n] = v;
+                }
+            }
+        }
+    }
+}
+
+int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH
+
+static int patch_launch(const ConvP& c, hipStream_t st) {
+    // returns ORE_OK if launched, 1 if the layer is not eligible (caller falls back to the generic kernel)
+    if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.Cout16 % 64 != 0 || c.in_mul || c.add || c.colsum) return 1;
+    if (g_patch_mode == 0) return 1;
+    int TH = g_patch_mode > 0 ? g_patch_mode : 4;
+    if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
+    PatchP p{};
+    p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = c.nlev;
+    int tiles = 0;
+    for (int l = 0; l < c.nlev; ++l) {
+        p.lv[l] = c.lv[l];
+        p.tiles_x[l] = ceil_div(c.lv[l].W, 16); p.tiles_y[l] = ceil_div(c.lv[l].H, TH);
+        p.tile0[l] = tiles;
+        tiles += c.B * p.tiles_x[l] * p.tiles_y[l];
+    }
+    p.tile0[c.nlev] = tiles;
+    p.w = c.w; p.Cout = c.Cout; p.Cout16 = c.Cout16; p.K = c.K;
+    p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
+    p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
+    const dim3 grid(tiles, c.Cout16 / 64);
+    if (TH == 8) {
+        const size_t lds = (size_t)(10 * 18 + 9 * 64) * 24 * sizeof(float);
+        static bool attr8 = false;
+        if (!attr8) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr8 = true; }
+        hipLaunchKernelGGL(k_conv3x3_patch<8>, grid, dim3(256), lds, st, p);
+    } else {
+        const size_t lds = (size_t)(6 * 18 + 9 * 64) * 24 * sizeof(float);
+        static bool attr4 = false;
+        if (!attr4) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr4 = true; }
+        hipLaunchKernelGGL(k_conv3x3_patch<4>, grid, dim3(256), lds, st, p);
+    }
+    return ore_launch_status("k_conv3x3_patch");
+}
+
 template <int BM, int BN, int WGM, int WGN, int WGK>
 void launch_conv(const ConvP& p, dim3 grid, hipStream_t st) {
     if (p.in_mul) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, true>), grid, dim3(256), 0, st, p);
@@ -468,6 +632,7 @@ extern "C" size_t ore_conv_workspace_floats(void) { return ORE_CONV_WS_FLOATS; }
 // Tuning aid (tools/conv_tune.py): force the tile configuration of subsequent ore_conv2d*_fwd calls; BM = 0 restores the
 // automatic plan.  Not used by the product path.
 extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK) {
+    if (BM == -1) { g_patch_mode = BN; g_override = {0, 0, 0, 0, 0}; return ORE_OK; }   // BM = -1: BN selects the 3x3 patch kernel mode
     g_override = {BM, BN, WGM, WGN, WGK};
     return ORE_OK;
 }
@@ -481,6 +646,10 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
 }
 
 static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t workspace_floats, hipStream_t st) {
+    if (g_override.BM == 0 && req_splitk <= 1) {
+        const int prc = patch_launch(p, st);
+        if (prc != 1) return prc;
+    }
     TileCfg t; int S, sps;
     plan_conv(p.M, p.Cout, p.nchunks, req_splitk, &t, &S, &sps);
     const int gx = ceil_div(p.M, t.BM), gy = ceil_div(p.Cout16, t.BN);

@@ -591,3 +591,44 @@ def test_conv_inkernel_splitk_repeatable(ore, M_hw, Cin, Cout, k, splitk):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     ws = ore._default_ws(xd.device)
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------ 3x3 patch kernel (forced on small shapes)
+@pytest.mark.parametrize("mode", [8, 4])
+def test_conv3x3_patch_kernel(ore, mode):
+    L = ore.lib()
+    g = torch.Generator().manual_seed(21 + mode)
+    try:
+        L.ore_conv_set_plan_override(-1, mode, 0, 0, 0)
+        for (B, H, W, Cin, Cout) in ((2, 17, 23, 32, 64), (1, 40, 40, 128, 128), (1, 9, 33, 16, 64), (1, 64, 48, 64, 192)):
+            x = torch.randn(B, Cin, H, W, generator=g)
+            w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+            sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+            ref = F.relu(F.conv2d(x, w, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+            # read a channel slice of a wider buffer, write a slice of a wider buffer (OSA concat usage)
+            xin = torch.zeros(B, H, W, Cin + 16).cuda()
+            xin[..., 16:] = nhwc(x)
+            out = torch.full((B, H, W, Cout + 32), -3.0).cuda()
+            ore.conv2d(xin, ore.pack_conv_weight(w).cuda(), Cout, 3, 1, in_coff=16, Cin=Cin, scale=dev(sc), shift=dev(sh), relu_cout=Cout,
+                       out=out, out_coff=32, splitk=1)
+            o = nchw(out)
+            assert rel_err(o[:, 32:].numpy(), ref.numpy()) < TOL, (mode, B, H, W, Cin, Cout)
+            assert (o[:, :32] == -3.0).all()
+        # multi-level (head tower shape): one launch over three levels with per-level epilogue parameters
+        B, C = 2, 64
+        HW = [(20, 24), (10, 12), (5, 6)]
+        feats = [torch.randn(B, C, h, w, generator=g) for h, w in HW]
+        rows = torch.cat([nhwc(f).reshape(-1, C) for f in feats], 0).contiguous()
+        w = torch.randn(128, C, 3, 3, generator=g) * 0.05
+        scale, shift = torch.rand(3, 128, generator=g) + 0.5, torch.randn(3, 128, generator=g)
+        out = ore.conv2d_levels(rows, HW, B, ore.pack_conv_weight(w).cuda(), 128, 3, scale=dev(scale), shift=dev(shift), ep_stride=128,
+                                relu_cout=100, splitk=1)
+        r0 = 0
+        for l, (h, wd) in enumerate(HW):
+            ref = F.conv2d(feats[l], w, None, 1, 1) * scale[l].view(1, -1, 1, 1) + shift[l].view(1, -1, 1, 1)
+            ref[:, :100] = F.relu(ref[:, :100])
+            got = out[r0:r0 + B * h * wd].reshape(B, h, wd, 128).permute(0, 3, 1, 2).cpu()
+            assert rel_err(got.numpy(), ref.numpy()) < TOL, (mode, l)
+            r0 += B * h * wd
+    finally:
+        L.ore_conv_set_plan_override(-1, -1, 0, 0, 0)

@@ -70,6 +70,21 @@ def main():
                 except orehip.OreError as ex:
                     pass
         L.ore_conv_set_plan_override(0, 0, 0, 0, 0)
+        if k == 3 and stride == 1 and C16 % 64 == 0:          # 3x3 "patch" kernel, tile height 8 / 4
+            for mode in (8, 4):
+                L.ore_conv_set_plan_override(-1, mode, 0, 0, 0)
+                for _ in range(3):
+                    orehip.conv2d(x, w, Cout, k, stride, out=out, splitk=1)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    orehip.conv2d(x, w, Cout, k, stride, out=out, splitk=1)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 30
+                print(f"     patch TH={mode}: {us:8.1f} us  {flops / us / 1e6:6.1f} TF/s")
+            L.ore_conv_set_plan_override(-1, 0, 0, 0, 0)       # generic kernels only for the sweep below / 'auto' = generic
         for _ in range(3):
             orehip.conv2d(x, w, Cout, k, stride, out=out)
         torch.cuda.synchronize()
@@ -80,6 +95,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         auto_us = e0.elapsed_time(e1) * 1e3 / 30
+        L.ore_conv_set_plan_override(-1, -1, 0, 0, 0)
         res.sort()
         print(f"== {name}: M={M} N={Cout} K={k * k * Cin}  {flops / 1e9:.2f} GF  ideal@155TF {flops / 155e6:.1f} us   auto={auto_us:.1f} us")
         for us, bm, bn, wgm, wgn, wgk, S, blocks in res[:6]:
