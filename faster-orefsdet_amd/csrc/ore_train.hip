@@ -1,0 +1,249 @@
+// CenterNet2 proposal-generator TRAINING targets and losses on device.
+//   k_cn_targets   per (level, image, location): Gaussian agnostic heatmap target exp(-min_n d2/r2) and the ltrb regression
+//                  target of the nearest object that owns the location (centre-3x3 AND size-of-interest), else -INF
+//                  ref:fewx/modeling/fsod/fsod_rpn.py:803-901 (_get_ground_truth), :959-989 (assign_reg_fpn), :992-1003
+//                  (_get_reg_targets), :1038-1046 (_create_agn_heatmaps_from_dist), :1049-1065 (get_center3x3)
+//   k_cn_pos_inds  positive location indices, one per (object, level that cares)   :904-956 (_get_label_inds), :959-975
+//   k_cn_losses    GIoU regression loss over locations with a target, binary heatmap focal loss (positives gathered by index,
+//                  negatives weighted (1-t)^beta, high-confidence negatives ignored), deterministic two-stage reduction
+//                  ref:fewx/modeling/fsod/fsod_rpn.py:702-779 (losses), ref:CenterNet2/centernet/modeling/layers/iou_loss.py:10-63,
+//                  heatmap_focal_loss.py:51-85
+// Rows are level-major [level][image][y][x] (the reference's `_transpose`d "level first" order).  Compiled with -ffp-contract=off:
+// the integer outputs (positive indices, which object owns a location) depend on exact fp32 comparisons.
+#include "ore_common.h"
+
+namespace {
+
+constexpr float CN_INF = 100000000.0f;   // fsod_rpn.py:490
+constexpr int MAXN = 128;                // objects per image held in LDS
+
+struct TgtP {
+    int n_levels, B, max_n;
+    int H[4], W[4], stride[4], row0[4];
+    float soi_lo[4], soi_hi[4];
+    const float* gt;          // [B][max_n][4]
+    const int* gt_count;      // [B]
+    float delta2x2, min_radius2;
+    float* reg_targets;       // [rows][4]
+    float* hm_targets;        // [rows]
+    int rows;
+};
+
+__global__ __launch_bounds__(256) void k_cn_targets(TgtP p) {
+    __shared__ float sb[MAXN * 4];
+    __shared__ float sr2[MAXN], scx[MAXN], scy[MAXN];
+    const int l = blockIdx.y / p.B, b = blockIdx.y % p.B;
+    const int HW = p.H[l] * p.W[l];
+    const int N = min(p.gt_count[b], min(p.max_n, MAXN));
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* g = p.gt + ((size_t)b * p.max_n + n) * 4;
+        const float x1 = g[0], y1 = g[1], x2 = g[2], y2 = g[3];
+        sb[n * 4 + 0] = x1; sb[n * 4 + 1] = y1; sb[n * 4 + 2] = x2; sb[n * 4 + 3] = y2;
+        const float area = (x2 - x1) * (y2 - y1);
+        sr2[n] = fmaxf(p.delta2x2 * area, p.min_radius2);
+        scx[n] = (x1 + x2) / 2.0f; scy[n] = (y1 + y2) / 2.0f;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const int st = p.stride[l];
+    const float fs = (float)st;
+    const float gx = (float)((i % p.W[l]) * st) + (float)(st / 2);
+    const float gy = (float)((i / p.W[l]) * st) + (float)(st / 2);
+    float best = CN_INF, hmin = CN_INF;
+    float bl = 0.f, bt = 0.f, br = 0.f, bb = 0.f;
+    bool any = false;
+    for (int n = 0; n < N; ++n) {
+        const float l_ = gx - sb[n * 4 + 0], t_ = gy - sb[n * 4 + 1], r_ = sb[n * 4 + 2] - gx, b_ = sb[n * 4 + 3] - gy;
+        // discretised centre of the object on this level
+        const float cdx = (float)((int)(scx[n] / fs)) * fs + fs / 2.0f;
+        const float cdy = (float)((int)(scy[n] / fs)) * fs + fs / 2.0f;
+        const float ddx = gx - cdx, ddy = gy - cdy;
+        const bool is_peak = (ddx * ddx + ddy * ddy) == 0.0f;
+        const bool in_box = fminf(fminf(l_, t_), fminf(r_, b_)) > 0.0f;
+        const bool c33 = fabsf(ddx) <= fs && fabsf(ddy) <= fs && in_box;
+        const float sw = l_ + r_, sh = t_ + b_;
+        const float crit = sqrtf(sw * sw + sh * sh) / 2.0f;
+        const bool cared = crit >= p.soi_lo[l] && crit <= p.soi_hi[l];
+        const float ex = gx - scx[n], ey = gy - scy[n];
+        float d2 = ex * ex + ey * ey;
+        if (is_peak) d2 = 0.0f;
+        const float wd = d2 / sr2[n];
+        hmin = fminf(hmin, wd);
+        const float dm = (c33 && cared) ? wd : CN_INF;
+        if (dm < best) { best = dm; bl = l_; bt = t_; br = r_; bb = b_; any = true; }   // strict <: first minimum wins (torch.min)
+    }
+    const size_t row = (size_t)p.row0[l] + (size_t)b * HW + i;
+    f32x4 rt;
+    if (any && best != CN_INF) rt = f32x4{bl / fs, bt / fs, br / fs, bb / fs};
+    else rt = f32x4{-CN_INF / fs, -CN_INF / fs, -CN_INF / fs, -CN_INF / fs};
+    *reinterpret_cast<f32x4*>(p.reg_targets + row * 4) = rt;
+    float hm = N > 0 ? expf(-hmin) : 0.0f;
+    if (hm < 1e-4f) hm = 0.0f;
+    p.hm_targets[row] = hm;
+}
+
+// positive indices in (image, object, level) order; one block, ordered compaction
+__global__ __launch_bounds__(1024) void k_cn_pos_inds(TgtP p, long long* __restrict__ pos_inds, int* __restrict__ pos_count) {
+    __shared__ int wsum[16];
+    __shared__ int base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    const int L = p.n_levels;
+    const int total = p.B * p.max_n * L;
+    for (int e0 = 0; e0 < total; e0 += 1024) {
+        const int e = e0 + tid;
+        bool ok = false;
+        long long idx = 0;
+        if (e < total) {
+            const int l = e % L, n = (e / L) % p.max_n, b = e / (L * p.max_n);
+            if (n < min(p.gt_count[b], p.max_n)) {
+                const float* g = p.gt + ((size_t)b * p.max_n + n) * 4;
+                const float w = g[2] - g[0], h = g[3] - g[1];
+                const float crit = sqrtf(w * w + h * h) / 2.0f;
+                ok = crit >= p.soi_lo[l] && crit <= p.soi_hi[l];
+                const float fs = (float)p.stride[l];
+                const long long cx = (long long)(((g[0] + g[2]) / 2.0f) / fs), cy = (long long)(((g[1] + g[3]) / 2.0f) / fs);
+                idx = (long long)p.row0[l] + (long long)b * p.H[l] * p.W[l] + cy * p.W[l] + cx;
+            }
+        }
+        int inc = ok ? 1 : 0;
+        const int v = inc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = base_sh, tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { const int s = wsum[w2]; if (w2 < wave) base += s; tot += s; }
+        if (ok) pos_inds[base + inc - v] = idx;
+        __syncthreads();
+        if (tid == 0) base_sh += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *pos_count = base_sh;
+}
+
+struct LossP {
+    const float* head; int head_ld;      // [rows][ld]: 0..3 = reg prediction (after Scale + ReLU), 4 = agnostic heatmap logit
+    const float* reg_targets; const float* hm_targets; int rows;
+    const long long* pos_inds; const int* pos_count;
+    float gamma, beta, clampv, ignore_high_fp;
+    float* partial;                      // [gridDim.x][4]: giou sum, #reg positives, neg-loss sum, (unused)
+    float* out;                          // [4]: giou sum, #reg positives, pos-loss sum (log p (1-p)^g), neg-loss sum
+};
+
+__device__ __forceinline__ float powi_like(float x, float e) { return powf(x, e); }
+
+__global__ __launch_bounds__(256) void k_cn_loss_partial(LossP p) {
+    __shared__ float red[3][4];
+    float giou = 0.f, cnt = 0.f, neg = 0.f;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < p.rows; r += gridDim.x * 256) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.reg_targets + (size_t)r * 4);
+        const float* h = p.head + (size_t)r * p.head_ld;
+        if (fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)) >= 0.0f) {            // reg_inds: reg_targets.max(dim=1) >= 0
+            const float pl = h[0], pt = h[1], pr = h[2], pb = h[3];
+            const float ta = (t.x + t.z) * (t.y + t.w), pa = (pl + pr) * (pt + pb);
+            const float wi = fminf(pl, t.x) + fminf(pr, t.z), hi = fminf(pb, t.w) + fminf(pt, t.y);
+            const float gw = fmaxf(pl, t.x) + fmaxf(pr, t.z), gh = fmaxf(pb, t.w) + fmaxf(pt, t.y);
+            const float ac = gw * gh, ai = wi * hi, au = ta + pa - ai;
+            const float iou = (ai + 1.0f) / (au + 1.0f);
+            giou += 1.0f - (iou - (ac - au) / ac);
+            cnt += 1.0f;
+        }
+        const float s = 1.0f / (1.0f + expf(-h[4]));
+        const float pred = fminf(fmaxf(s, p.clampv), 1.0f - p.clampv);
+        const float nw = powi_like(1.0f - p.hm_targets[r], p.beta);
+        float nl = logf(1.0f - pred) * powi_like(pred, p.gamma) * nw;
+        if (p.ignore_high_fp > 0.0f && !(pred < p.ignore_high_fp)) nl = 0.0f;
+        neg += nl;
+    }
+    // block reduction in a fixed order
+    float v[3] = {giou, cnt, neg};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v[k] += __shfl_xor(v[k], d);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) p.partial[blockIdx.x * 4 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(64) void k_cn_loss_final(LossP p, int nblocks) {
+    const int lane = threadIdx.x;
+    float v[3] = {0.f, 0.f, 0.f};
+    for (int b = lane; b < nblocks; b += 64)
+        for (int k = 0; k < 3; ++k) v[k] += p.partial[b * 4 + k];
+    float pos = 0.f;
+    const int np = *p.pos_count;
+    for (int i = lane; i < np; i += 64) {                                  // duplicates in pos_inds count once each, like the gather
+        const float* h = p.head + (size_t)p.pos_inds[i] * p.head_ld;
+        const float s = 1.0f / (1.0f + expf(-h[4]));
+        const float pred = fminf(fmaxf(s, p.clampv), 1.0f - p.clampv);
+        pos += logf(pred) * powi_like(1.0f - pred, p.gamma);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        for (int k = 0; k < 3; ++k) v[k] += __shfl_xor(v[k], d);
+        pos += __shfl_xor(pos, d);
+    }
+    if (lane == 0) { p.out[0] = v[0]; p.out[1] = v[1]; p.out[2] = pos; p.out[3] = v[2]; }
+}
+
+int fill_tgt(TgtP& p, int n_levels, const int32_t* H, const int32_t* W, const int32_t* stride, int B, int max_n, const float* soi_host) {
+    p.n_levels = n_levels; p.B = B; p.max_n = max_n;
+    int rows = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        p.H[l] = H[l]; p.W[l] = W[l]; p.stride[l] = stride[l]; p.row0[l] = rows;
+        p.soi_lo[l] = soi_host[2 * l]; p.soi_hi[l] = soi_host[2 * l + 1];
+        rows += B * H[l] * W[l];
+    }
+    p.rows = rows;
+    return rows;
+}
+
+}  // namespace
+
+extern "C" int ore_centernet_targets_fwd(int32_t n_levels, const int32_t* H, const int32_t* W, const int32_t* stride, int32_t B,
+                                         const float* gt_boxes, const int32_t* gt_count, int32_t max_n, const float* soi_host,
+                                         float hm_min_overlap, float min_radius, float* reg_targets, float* hm_targets,
+                                         int64_t* pos_inds, int32_t* pos_count, void* stream) {
+    ORE_CHECK_ARG(H && W && stride && gt_boxes && gt_count && soi_host && reg_targets && hm_targets && pos_inds && pos_count,
+                  "ore_centernet_targets_fwd: null pointer");
+    ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && B >= 1 && max_n >= 1 && max_n <= MAXN, "ore_centernet_targets_fwd: 1..4 levels, <= %d objects/image", MAXN);
+    TgtP p{};
+    fill_tgt(p, n_levels, H, W, stride, B, max_n, soi_host);
+    p.gt = gt_boxes; p.gt_count = gt_count;
+    const double delta = (1.0 - (double)hm_min_overlap) / (1.0 + (double)hm_min_overlap);    // fsod_rpn.py:579
+    p.delta2x2 = (float)(delta * delta * 2.0);
+    p.min_radius2 = (float)((double)min_radius * (double)min_radius);
+    p.reg_targets = reg_targets; p.hm_targets = hm_targets;
+    int maxhw = 0;
+    for (int l = 0; l < n_levels; ++l) maxhw = max(maxhw, H[l] * W[l]);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cn_targets, dim3(ceil_div(maxhw, 256), n_levels * B), dim3(256), 0, st, p);
+    int rc = ore_launch_status("k_cn_targets");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cn_pos_inds, dim3(1), dim3(1024), 0, st, p, (long long*)pos_inds, pos_count);
+    return ore_launch_status("k_cn_pos_inds");
+}
+
+extern "C" int ore_centernet_losses_fwd(const float* head, int32_t head_ld, const float* reg_targets, const float* hm_targets,
+                                        int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, float gamma, float beta,
+                                        float sigmoid_clamp, float ignore_high_fp, float* sums4, float* workspace, void* stream) {
+    ORE_CHECK_ARG(head && reg_targets && hm_targets && pos_inds && pos_count && sums4 && workspace && rows > 0 && head_ld >= 5,
+                  "ore_centernet_losses_fwd: bad args");
+    LossP p{};
+    p.head = head; p.head_ld = head_ld; p.reg_targets = reg_targets; p.hm_targets = hm_targets; p.rows = rows;
+    p.pos_inds = (const long long*)pos_inds; p.pos_count = pos_count;
+    p.gamma = gamma; p.beta = beta; p.clampv = sigmoid_clamp; p.ignore_high_fp = ignore_high_fp;
+    p.partial = workspace; p.out = sums4;
+    const int nb = min(ceil_div(rows, 256), 256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cn_loss_partial, dim3(nb), dim3(256), 0, st, p);
+    int rc = ore_launch_status("k_cn_loss_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cn_loss_final, dim3(1), dim3(64), 0, st, p, nb);
+    return ore_launch_status("k_cn_loss_final");
+}

@@ -68,7 +68,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
-           "ore_roi_predict_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
+           "ore_roi_predict_fwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
 
@@ -427,6 +427,47 @@ def roi_predict(h: torch.Tensor, cls_w, cls_b, box_w, box_b, boxes: torch.Tensor
                                    C.c_void_p(_ptr(ws)), C.c_size_t(wsb), _stream()), "ore_roi_predict_fwd")
     o["_ws"] = ws
     return o
+
+
+def centernet_targets(gt_boxes: Sequence[torch.Tensor], shapes: Sequence[Tuple[int, int]], strides=(8, 16, 32),
+                      soi=((0, 64), (48, 192), (128, 1000000)), hm_min_overlap: float = 0.8, min_radius: float = 4.0,
+                      device=None) -> Dict[str, torch.Tensor]:
+    """CenterNet._get_ground_truth (ref:fewx/modeling/fsod/fsod_rpn.py:803-901) on device.  gt_boxes: per image [N_i,4]."""
+    dev = torch.device(device or "cuda")
+    B, L = len(gt_boxes), len(strides)
+    max_n = max(1, max(int(b.shape[0]) for b in gt_boxes))
+    gt = torch.zeros(B, max_n, 4, dtype=torch.float32)
+    for i, b in enumerate(gt_boxes):
+        gt[i, :b.shape[0]] = b.detach().float().cpu()
+    cnt = torch.tensor([int(b.shape[0]) for b in gt_boxes], dtype=torch.int32)
+    gt, cnt = gt.to(dev), cnt.to(dev)
+    rows = sum(B * h * w for h, w in shapes)
+    o = {"reg_targets": torch.empty(rows, 4, device=dev), "hm_targets": torch.empty(rows, device=dev),
+         "pos_inds": torch.zeros(B * max_n * L, dtype=torch.int64, device=dev), "pos_count": torch.zeros(1, dtype=torch.int32, device=dev)}
+    Hs = (C.c_int32 * L)(*[h for h, _ in shapes]); Ws = (C.c_int32 * L)(*[w for _, w in shapes]); St = (C.c_int32 * L)(*strides)
+    so = (C.c_float * (2 * L))(*[float(v) for r in soi for v in r])
+    _chk(lib().ore_centernet_targets_fwd(L, Hs, Ws, St, B, C.c_void_p(_ptr(gt)), C.c_void_p(_ptr(cnt)), max_n, so,
+                                         C.c_float(hm_min_overlap), C.c_float(min_radius), C.c_void_p(_ptr(o["reg_targets"])),
+                                         C.c_void_p(_ptr(o["hm_targets"])), C.c_void_p(_ptr(o["pos_inds"])),
+                                         C.c_void_p(_ptr(o["pos_count"])), _stream()), "ore_centernet_targets_fwd")
+    o["_keep"] = (gt, cnt)
+    return o
+
+
+def centernet_loss_sums(head: torch.Tensor, reg_targets: torch.Tensor, hm_targets: torch.Tensor, pos_inds: torch.Tensor,
+                        pos_count: torch.Tensor, gamma: float = 2.0, beta: float = 4.0, sigmoid_clamp: float = 1e-4,
+                        ignore_high_fp: float = 0.85) -> torch.Tensor:
+    """[giou sum, #reg rows, pos focal sum, neg focal sum] of CenterNet.losses (ref:fewx/modeling/fsod/fsod_rpn.py:702-779).
+    head [rows, ld>=5]: cols 0..3 ltrb prediction, col 4 heatmap logit."""
+    rows, ld = head.shape
+    out = torch.zeros(4, device=head.device)
+    ws = torch.empty(4 * 256, device=head.device)
+    _chk(lib().ore_centernet_losses_fwd(C.c_void_p(_ptr(_f32(head))), ld, C.c_void_p(_ptr(_f32(reg_targets))),
+                                        C.c_void_p(_ptr(_f32(hm_targets))), rows, C.c_void_p(_ptr(pos_inds)),
+                                        C.c_void_p(_ptr(pos_count)), C.c_float(gamma), C.c_float(beta), C.c_float(sigmoid_clamp),
+                                        C.c_float(ignore_high_fp), C.c_void_p(_ptr(out)), C.c_void_p(_ptr(ws)), _stream()),
+         "ore_centernet_losses_fwd")
+    return out
 
 
 def compose_roi_head(sd, support_8: torch.Tensor, prefix: str = "roi_heads."):

@@ -199,6 +199,29 @@ int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const flo
                         int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ training targets / losses - */
+/* CenterNet2 proposal-generator ground truth for only_proposal=True (class-agnostic), on device.
+ * ref:fewx/modeling/fsod/fsod_rpn.py:803-901 (_get_ground_truth), :904-956 (_get_label_inds), :959-989 (assign_fpn_level /
+ * assign_reg_fpn), :992-1003 (_get_reg_targets), :1038-1046 (_create_agn_heatmaps_from_dist), :1049-1065 (get_center3x3).
+ * Rows are the reference's "level first" order [level][image][y][x].  gt_boxes [B][max_n][4] (x1,y1,x2,y2; max_n <= 128),
+ * gt_count [B] device; soi_host [n_levels][2].  Outputs: reg_targets [rows][4] (ltrb / stride, or -1e8/stride where no object
+ * owns the location), hm_targets [rows], pos_inds [<= B*max_n*n_levels] in (image, object, level) order, pos_count [1]. */
+int ore_centernet_targets_fwd(int32_t n_levels, const int32_t* H, const int32_t* W, const int32_t* stride, int32_t B,
+                              const float* gt_boxes, const int32_t* gt_count, int32_t max_n, const float* soi_host,
+                              float hm_min_overlap, float min_radius, float* reg_targets, float* hm_targets,
+                              int64_t* pos_inds, int32_t* pos_count, void* stream);
+/* Loss sums of CenterNet.losses (ref:fewx/modeling/fsod/fsod_rpn.py:702-779) with with_agn_hm + only_proposal:
+ * head [rows][head_ld]: columns 0..3 = ltrb prediction (after Scale + ReLU), column 4 = agnostic heatmap logit.
+ * sums4 = { sum GIoU loss over rows with max(reg_target) >= 0   (ref:CenterNet2/centernet/modeling/layers/iou_loss.py:10-63),
+ *           number of such rows,
+ *           sum_pos log(p)(1-p)^gamma over pos_inds, sum_all log(1-p) p^gamma (1-t)^beta [p < ignore_high_fp]
+ *           (ref:CenterNet2/centernet/modeling/layers/heatmap_focal_loss.py:51-85) }
+ * with p = clamp(sigmoid(logit), sigmoid_clamp, 1-sigmoid_clamp).  The caller applies the weights and the (all-reduced)
+ * normalisers.  Deterministic: fixed-order two-stage reduction.  workspace: >= 4*256 floats. */
+int ore_centernet_losses_fwd(const float* head, int32_t head_ld, const float* reg_targets, const float* hm_targets,
+                             int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, float gamma, float beta,
+                             float sigmoid_clamp, float ignore_high_fp, float* sums4, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ engine ------------------- */
 /* Whole eval hot path for one model instance: owns packed weights and all
  * intermediate buffers, replays a captured hipGraph per image.

@@ -442,3 +442,127 @@ def synth_roi_state(sd: Dict[str, Tensor], seed: int = 0, C: int = 128) -> Dict[
     sd[p + "fc2.weight"], sd[p + "fc2.bias"] = u(128, C * 16, b=0.02), u(128, b=0.1)
     sd[p + "fc3.weight"], sd[p + "fc3.bias"] = u(128, 256, b=0.06), u(128, b=0.1)
     return sd
+
+
+# --------------------------------------------------------------------------------------
+# a12  CenterNet training targets + losses (ref:fewx/modeling/fsod/fsod_rpn.py:702-779, 803-1065)
+# --------------------------------------------------------------------------------------
+CN_INF = 100000000
+
+
+def centernet_grids(shapes: Sequence[Tuple[int, int]], strides: Sequence[int]) -> List[Tensor]:
+    """compute_grids (fsod_rpn.py:782-800)."""
+    out = []
+    for (h, w), s in zip(shapes, strides):
+        ys = torch.arange(0, h * s, step=s, dtype=torch.float32)
+        xs = torch.arange(0, w * s, step=s, dtype=torch.float32)
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        out.append(torch.stack((xx.reshape(-1), yy.reshape(-1)), 1) + s // 2)
+    return out
+
+
+def centernet_targets(gt_boxes: Sequence[Tensor], shapes: Sequence[Tuple[int, int]], strides=(8, 16, 32),
+                      soi=((0, 64), (48, 192), (128, 1000000)), hm_min_overlap=0.8, min_radius=4):
+    """_get_ground_truth + _get_label_inds for only_proposal=True.  gt_boxes: per image [N_i,4].
+    Returns pos_inds [N'] int64, reg_targets [M*B,4], flattened_hms [M*B] in level-first order."""
+    L, B = len(strides), len(gt_boxes)
+    delta = (1 - hm_min_overlap) / (1 + hm_min_overlap)
+    grids_l = centernet_grids(shapes, strides)
+    nloc = [len(g) for g in grids_l]
+    strides_m = torch.cat([torch.full((nloc[l],), float(strides[l])) for l in range(L)])
+    ranges_m = torch.cat([torch.tensor(soi[l], dtype=torch.float32).view(1, 2).expand(nloc[l], 2) for l in range(L)])
+    grids = torch.cat(grids_l, 0)
+    M = grids.shape[0]
+    regs, hms = [], []
+    for boxes in gt_boxes:
+        N = boxes.shape[0]
+        if N == 0:
+            regs.append(torch.zeros(M, 4) - CN_INF)
+            hms.append(torch.zeros(M))
+            continue
+        area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+        l = grids[:, 0].view(M, 1) - boxes[:, 0].view(1, N)
+        t = grids[:, 1].view(M, 1) - boxes[:, 1].view(1, N)
+        r = boxes[:, 2].view(1, N) - grids[:, 0].view(M, 1)
+        b = boxes[:, 3].view(1, N) - grids[:, 1].view(M, 1)
+        reg = torch.stack([l, t, r, b], 2)
+        centers = (boxes[:, [0, 1]] + boxes[:, [2, 3]]) / 2
+        ce = centers.view(1, N, 2).expand(M, N, 2)
+        se = strides_m.view(M, 1, 1).expand(M, N, 2)
+        cd = ((ce / se).int() * se).float() + se / 2
+        ge = grids.view(M, 1, 2).expand(M, N, 2)
+        is_peak = ((ge - cd) ** 2).sum(2) == 0
+        in_box = reg.min(2)[0] > 0
+        c33 = ((ge[:, :, 0] - cd[:, :, 0]).abs() <= se[:, :, 0]) & ((ge[:, :, 1] - cd[:, :, 1]).abs() <= se[:, :, 0]) & in_box
+        crit = ((reg[:, :, :2] + reg[:, :, 2:]) ** 2).sum(2) ** 0.5 / 2
+        cared = (crit >= ranges_m[:, [0]]) & (crit <= ranges_m[:, [1]])
+        mask = c33 & cared
+        d2 = ((ge - ce) ** 2).sum(2)
+        d2[is_peak] = 0
+        r2 = torch.clamp(delta ** 2 * 2 * area, min=min_radius ** 2)
+        wd = d2 / r2.view(1, N).expand(M, N)
+        dm = wd.clone()
+        dm[mask == 0] = CN_INF * 1.0
+        mn, mi = dm.min(1)
+        rt = reg[range(M), mi]
+        rt[mn == CN_INF] = -CN_INF
+        hm = torch.exp(-wd.min(1)[0])
+        hm[hm < 1e-4] = 0
+        regs.append(rt)
+        hms.append(hm)
+    # level first
+    reg_lf = torch.cat([torch.cat([torch.split(x, nloc, 0)[l] for x in regs], 0) / float(strides[l]) for l in range(L)], 0)
+    hm_lf = torch.cat([torch.cat([torch.split(x, nloc, 0)[l] for x in hms], 0) for l in range(L)], 0)
+    # positive indices
+    loc = torch.tensor([h * w for h, w in shapes], dtype=torch.int64)
+    bases, s = [], 0
+    for l in range(L):
+        bases.append(s)
+        s += B * int(loc[l])
+    bases = torch.tensor(bases, dtype=torch.int64)
+    Ws = torch.tensor([w for _, w in shapes], dtype=torch.int64)
+    sr = torch.tensor(soi, dtype=torch.float32)
+    pos = []
+    for im, boxes in enumerate(gt_boxes):
+        n = boxes.shape[0]
+        if n == 0:
+            continue
+        c = ((boxes[:, [0, 1]] + boxes[:, [2, 3]]) / 2).view(n, 1, 2).expand(n, L, 2)
+        ci = (c / torch.tensor(strides, dtype=torch.float32).view(1, L, 1)).long()
+        ind = bases.view(1, L) + im * loc.view(1, L) + ci[:, :, 1] * Ws.view(1, L) + ci[:, :, 0]
+        crit = ((boxes[:, 2:] - boxes[:, :2]) ** 2).sum(1) ** 0.5 / 2
+        cared = (crit.view(n, 1) >= sr[:, 0].view(1, L)) & (crit.view(n, 1) <= sr[:, 1].view(1, L))
+        pos.append(ind[cared].view(-1))
+    pos = torch.cat(pos) if pos else torch.zeros(0, dtype=torch.int64)
+    return pos, reg_lf, hm_lf
+
+
+def centernet_losses(reg_pred: Tensor, hm_logit: Tensor, pos_inds: Tensor, reg_targets: Tensor, hms: Tensor, num_gpus: int = 1,
+                     reg_weight=1.0, pos_weight=0.5, neg_weight=0.5, alpha=0.25, beta=4, gamma=2.0, clamp=1e-4, ignore_high_fp=0.85):
+    """CenterNet.losses for only_proposal + with_agn_hm + not_norm_reg (fsod_rpn.py:702-779); world size 1.
+    reg_pred [M,4] (after Scale+ReLU), hm_logit [M].  Returns dict of the three scalar losses + the raw sums."""
+    num_pos_avg = max(pos_inds.numel() / num_gpus, 1.0)
+    idx = torch.nonzero(reg_targets.max(1)[0] >= 0).squeeze(1)
+    p, t = reg_pred[idx], reg_targets[idx]
+    ta = (t[:, 0] + t[:, 2]) * (t[:, 1] + t[:, 3])
+    pa = (p[:, 0] + p[:, 2]) * (p[:, 1] + p[:, 3])
+    wi = torch.min(p[:, 0], t[:, 0]) + torch.min(p[:, 2], t[:, 2])
+    hi = torch.min(p[:, 3], t[:, 3]) + torch.min(p[:, 1], t[:, 1])
+    gw = torch.max(p[:, 0], t[:, 0]) + torch.max(p[:, 2], t[:, 2])
+    gh = torch.max(p[:, 3], t[:, 3]) + torch.max(p[:, 1], t[:, 1])
+    ac, ai = gw * gh, wi * hi
+    au = ta + pa - ai
+    giou = (ai + 1.0) / (au + 1.0) - (ac - au) / ac
+    giou_sum = (1 - giou).sum()
+    reg_norm = max(float(len(idx)) / num_gpus, 1)
+    pred = torch.clamp(torch.sigmoid(hm_logit.float()), min=clamp, max=1 - clamp)
+    nw = torch.pow(1 - hms, beta)
+    pp = pred[pos_inds]
+    pos_sum = (torch.log(pp) * torch.pow(1 - pp, gamma)).sum()
+    nl = torch.log(1 - pred) * torch.pow(pred, gamma) * nw
+    nl = (pred < ignore_high_fp).float() * nl
+    neg_sum = nl.sum()
+    return {"loss_centernet_loc": reg_weight * giou_sum / reg_norm,
+            "loss_centernet_agn_pos": pos_weight * alpha * (-pos_sum) / num_pos_avg,
+            "loss_centernet_agn_neg": neg_weight * (1 - alpha) * (-neg_sum) / num_pos_avg,
+            "sums": torch.stack([giou_sum, torch.tensor(float(len(idx))), pos_sum, neg_sum])}

@@ -197,6 +197,40 @@ def main():
              **{f"reg{l}": np_(reg_l[l][0].permute(1, 2, 0).contiguous()) for l in range(3)},
              pre_boxes=np_(cap["pre_boxes"]), pre_scores=np_(cap["pre_scores"]),
              nms_boxes=np_(cap["nms_boxes"]), boxes=np_(boxes), scores=np_(scores))
+    # ---- CenterNet training targets + losses (ref fsod_rpn.py _get_ground_truth / losses executed), B=2 ----------------------
+    fh = _FakeHead()
+    cn = rpn.CenterNet(in_channels=128, num_classes=1, in_features=("p3", "p4", "p5"), strides=(8, 16, 32),
+                       score_thresh=1e-5, with_agn_hm=True, only_proposal=True, not_norm_reg=True,
+                       pre_nms_topk_train=4000, pre_nms_topk_test=1000, post_nms_topk_train=2000,
+                       post_nms_topk_test=256, nms_thresh_train=0.9, nms_thresh_test=0.6,
+                       pos_weight=0.5, neg_weight=0.5, ignore_high_fp=0.85, reg_weight=1.0, hm_focal_alpha=0.25,
+                       sizes_of_interest=[[0, 64], [48, 192], [128, 1000000]], centernet_head=fh)
+    cn.train()
+    Boxes = ns.boxes.Boxes
+    shapes = [(40, 48), (20, 24), (10, 12)]                       # a 320 x 384 image
+    gts = []
+    for n_obj in (17, 9):
+        ctr = torch.rand(n_obj, 2, generator=g) * torch.tensor([384.0, 320.0])
+        wh = torch.exp(torch.rand(n_obj, 2, generator=g) * 3.2 + 2.3)      # 10 .. 245 px
+        b = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).clamp(min=0)
+        b[:, 2].clamp_(max=384); b[:, 3].clamp_(max=320)
+        inst = Instances((320, 384))
+        inst.gt_boxes = Boxes(b)
+        inst.gt_classes = torch.zeros(n_obj, dtype=torch.int64)
+        gts.append(inst)
+    feats_t = [torch.zeros(2, 128, h, w) for h, w in shapes]
+    grids = cn.compute_grids(feats_t)
+    spl = grids[0].new_tensor(shapes)
+    with torch.no_grad():
+        pos_inds, labels, reg_targets, flattened_hms = cn._get_ground_truth(grids, spl, gts)
+        M2 = reg_targets.shape[0]
+        reg_pred = torch.relu(torch.randn(M2, 4, generator=g) * 1.5 + 2.5)
+        hm_logit = torch.randn(M2, generator=g) * 2.0 - 3.0
+        losses = cn.losses(pos_inds, labels, reg_targets, flattened_hms, None, reg_pred, hm_logit.clone())
+    save("cn_train_targets", gt0=np_(gts[0].gt_boxes.tensor), gt1=np_(gts[1].gt_boxes.tensor), shapes=np.array(shapes, np.int64),
+         pos_inds=np_(pos_inds), reg_targets=np_(reg_targets), hms=np_(flattened_hms[:, 0]), reg_pred=np_(reg_pred), hm_logit=np_(hm_logit),
+         loss_loc=np_(losses["loss_centernet_loc"]), loss_pos=np_(losses["loss_centernet_agn_pos"]),
+         loss_neg=np_(losses["loss_centernet_agn_neg"]))
     print("missing/unexpected:", missing)
 
 

@@ -1,0 +1,96 @@
+"""GPU parity of the training-side kernels against the oracle and the reference-run golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oh():
+    import orehip
+    orehip.lib()
+    return orehip
+
+
+def _rand_boxes(g, n, W, H, lo=2.3, span=3.2):
+    ctr = torch.rand(n, 2, generator=g) * torch.tensor([float(W), float(H)])
+    wh = torch.exp(torch.rand(n, 2, generator=g) * span + lo)
+    b = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).clamp(min=0)
+    b[:, 2].clamp_(max=W)
+    b[:, 3].clamp_(max=H)
+    return b
+
+
+def test_cn_targets_golden(oh, golden):
+    g = golden("cn_train_targets")
+    shapes = [tuple(int(v) for v in s) for s in g["shapes"]]
+    o = oh.centernet_targets([torch.from_numpy(g["gt0"]), torch.from_numpy(g["gt1"])], shapes)
+    n = int(o["pos_count"].item())
+    assert n == len(g["pos_inds"])
+    assert np.array_equal(o["pos_inds"][:n].cpu().numpy(), g["pos_inds"])                 # indices: bit-exact
+    assert np.array_equal(o["reg_targets"].cpu().numpy(), g["reg_targets"])               # ltrb/stride of the owning object: exact
+    hm = o["hm_targets"].cpu().numpy()
+    assert np.array_equal(hm == 0, g["hms"] == 0)
+    assert np.abs(hm - g["hms"]).max() <= 2e-7                                            # expf: <= 2 ulp at <= 1.0
+
+
+def test_cn_losses_golden(oh, golden):
+    g = golden("cn_train_targets")
+    dev = "cuda"
+    head = torch.zeros(len(g["hm_logit"]), 16, device=dev)
+    head[:, :4] = torch.from_numpy(g["reg_pred"]).to(dev)
+    head[:, 4] = torch.from_numpy(g["hm_logit"]).to(dev)
+    pos = torch.from_numpy(g["pos_inds"]).to(dev)
+    cnt = torch.tensor([len(pos)], dtype=torch.int32, device=dev)
+    s = oh.centernet_loss_sums(head, torch.from_numpy(g["reg_targets"]).to(dev), torch.from_numpy(g["hms"]).to(dev), pos, cnt).cpu()
+    npos = max(len(pos), 1)
+    loc = 1.0 * float(s[0]) / max(float(s[1]), 1.0)
+    lpos = 0.5 * 0.25 * (-float(s[2])) / npos
+    lneg = 0.5 * 0.75 * (-float(s[3])) / npos
+    for got, ref in ((loc, g["loss_loc"]), (lpos, g["loss_pos"]), (lneg, g["loss_neg"])):
+        assert abs(got - float(ref)) <= 2e-6 * abs(float(ref)), (got, float(ref))         # fp32 sums in a different order
+
+
+@pytest.mark.parametrize("B,n_obj,hw", [(1, 40, (640, 640)), (3, 128, (512, 704)), (2, 0, (320, 320)), (2, 1, (64, 96))])
+def test_cn_targets_vs_oracle(oh, B, n_obj, hw):
+    g = torch.Generator().manual_seed(100 + B + n_obj)
+    H, W = hw
+    shapes = [(H // s, W // s) for s in (8, 16, 32)]
+    gts = [_rand_boxes(g, n_obj if i != 1 else max(n_obj // 2, 0), W, H) for i in range(B)]
+    if n_obj >= 40:                     # degenerate cases: box centred exactly on a grid point / on a cell border, duplicate boxes
+        gts[0][0] = torch.tensor([100.0, 100.0, 140.0, 140.0])
+        gts[0][1] = torch.tensor([96.0, 96.0, 160.0, 160.0])
+        gts[0][2] = gts[0][1].clone()
+    pos, reg, hm = R.centernet_targets(gts, shapes)
+    o = oh.centernet_targets(gts, shapes)
+    n = int(o["pos_count"].item())
+    assert n == len(pos) and torch.equal(o["pos_inds"][:n].cpu(), pos)
+    assert torch.equal(o["reg_targets"].cpu(), reg)
+    hg = o["hm_targets"].cpu()
+    assert torch.equal(hg == 0, hm == 0) or (hg - hm).abs().max() < 1.1e-4              # the 1e-4 cut may flip within 1 ulp
+    assert (hg - hm).abs().max() <= 1.1e-4 and ((hg - hm).abs() > 2e-7).sum() <= 2
+
+
+def test_cn_losses_vs_oracle(oh):
+    g = torch.Generator().manual_seed(5)
+    H, W, B = 640, 640, 2
+    shapes = [(H // s, W // s) for s in (8, 16, 32)]
+    gts = [_rand_boxes(g, 30, W, H) for _ in range(B)]
+    pos, reg, hm = R.centernet_targets(gts, shapes)
+    M = reg.shape[0]
+    reg_pred = torch.relu(torch.randn(M, 4, generator=g) * 2 + 3)
+    logit = torch.randn(M, generator=g) * 3 - 2
+    ref = R.centernet_losses(reg_pred, logit, pos, reg, hm)["sums"]
+    head = torch.zeros(M, 16)
+    head[:, :4] = reg_pred
+    head[:, 4] = logit
+    s = oh.centernet_loss_sums(head.cuda(), reg.cuda(), hm.cuda(), pos.cuda(), torch.tensor([len(pos)], dtype=torch.int32).cuda()).cpu()
+    assert float(s[1]) == float(ref[1])
+    for k in (0, 2, 3):
+        assert abs(float(s[k]) - float(ref[k])) <= 3e-6 * abs(float(ref[k])), (k, float(s[k]), float(ref[k]))
+    # repeatable bit for bit (fixed-order reduction)
+    s2 = oh.centernet_loss_sums(head.cuda(), reg.cuda(), hm.cuda(), pos.cuda(), torch.tensor([len(pos)], dtype=torch.int32).cuda()).cpu()
+    assert torch.equal(s, s2)

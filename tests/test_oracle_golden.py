@@ -122,3 +122,16 @@ def test_nms_c_vs_numpy_edge_cases():
     assert list(odec.nms(boxes2, np.array([0.9, 0.8], np.float32), 0.5)) == [0, 1]
     assert list(odec.nms(boxes2, np.array([0.9, 0.8], np.float32), 0.49)) == [0]
     assert list(odec.nms(boxes, np.array([0.1, 0.8], np.float32), 0.3)) == [1]
+
+
+def test_centernet_train_targets_and_losses(golden):
+    """a12: the restated ground truth / losses equal the executed reference (fsod_rpn.py:702-779, 803-1065) on B=2."""
+    g = golden("cn_train_targets")
+    shapes = [tuple(int(v) for v in s) for s in g["shapes"]]
+    pos, reg, hm = R.centernet_targets([torch.from_numpy(g["gt0"]), torch.from_numpy(g["gt1"])], shapes)
+    assert np.array_equal(pos.numpy(), g["pos_inds"])
+    assert np.array_equal(reg.numpy(), g["reg_targets"])
+    assert np.array_equal(hm.numpy(), g["hms"])
+    ls = R.centernet_losses(torch.from_numpy(g["reg_pred"]), torch.from_numpy(g["hm_logit"]), pos, reg, hm)
+    for k, ref in (("loss_centernet_loc", "loss_loc"), ("loss_centernet_agn_pos", "loss_pos"), ("loss_centernet_agn_neg", "loss_neg")):
+        assert abs(float(ls[k]) - float(g[ref])) <= 1e-6 * abs(float(g[ref]))
