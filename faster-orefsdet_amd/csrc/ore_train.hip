@@ -191,6 +191,28 @@ __global__ __launch_bounds__(64) void k_cn_loss_final(LossP p, int nblocks) {
     if (lane == 0) { p.out[0] = v[0]; p.out[1] = v[1]; p.out[2] = pos; p.out[3] = v[2]; }
 }
 
+
+// ---- fused value-clip + SGD(momentum, weight decay) over the flat parameter bucket (row a13) -------------------------------
+// torch.nn.utils.clip_grad_value_ then torch.optim.SGD.step (ref:fewx/solver/build.py:18-60,110-139; d2z:engine/train_loop.py:258-294):
+//   g = clamp(grad_scale * grad, -clip, clip);  g += wd * p;  buf = momentum * buf + g;  p -= lr * buf
+// The bucket is cut into 256-element chunks that never straddle two parameters; chunk_lr / chunk_wd carry the parameter group.
+__global__ __launch_bounds__(256) void k_sgd_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  const float* __restrict__ chunk_lr, const float* __restrict__ chunk_wd,
+                                                  const float* __restrict__ lr_scale_dev, float lr_scale, float momentum,
+                                                  float clip, float grad_scale) {
+    const int c = blockIdx.x;
+    const size_t i = (size_t)c * 256 + threadIdx.x;
+    const float lr = chunk_lr[c] * (lr_scale_dev ? *lr_scale_dev : lr_scale);
+    const float wd = chunk_wd[c];
+    float gi = g[i] * grad_scale;
+    if (clip > 0.0f) gi = fminf(fmaxf(gi, -clip), clip);
+    const float pi = p[i];
+    gi = gi + wd * pi;
+    const float b = momentum * buf[i] + gi;
+    buf[i] = b;
+    p[i] = pi - lr * b;
+}
+
 int fill_tgt(TgtP& p, int n_levels, const int32_t* H, const int32_t* W, const int32_t* stride, int B, int max_n, const float* soi_host) {
     p.n_levels = n_levels; p.B = B; p.max_n = max_n;
     int rows = 0;
@@ -246,4 +268,14 @@ extern "C" int ore_centernet_losses_fwd(const float* head, int32_t head_ld, cons
     if (rc) return rc;
     hipLaunchKernelGGL(k_cn_loss_final, dim3(1), dim3(64), 0, st, p, nb);
     return ore_launch_status("k_cn_loss_final");
+}
+
+extern "C" int ore_sgd_step_fwd(float* params, const float* grads, float* momentum_buf, int64_t n_chunks, const float* chunk_lr,
+                                const float* chunk_wd, const float* lr_scale_dev, float lr_scale, float momentum, float clip_value,
+                                float grad_scale, void* stream) {
+    ORE_CHECK_ARG(params && grads && momentum_buf && chunk_lr && chunk_wd && n_chunks > 0 && n_chunks < (1ll << 31),
+                  "ore_sgd_step_fwd: bad args");
+    hipLaunchKernelGGL(k_sgd_step, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, chunk_lr,
+                       chunk_wd, lr_scale_dev, lr_scale, momentum, clip_value, grad_scale);
+    return ore_launch_status("k_sgd_step");
 }

@@ -1,0 +1,309 @@
+"""Optimizer / scheduler / data-parallel gradient exchange for the train step.
+
+Reference behaviour (ref:fewx/solver/build.py:18-60, :91-139, :142-170; d2z:engine/train_loop.py:258-294;
+d2z:engine/defaults.py:60-79 create_ddp_model; d2z:solver/lr_scheduler.py:132-164, :205-238):
+    losses.backward()  [DDP: bucketed gradient all-reduce, averaged, overlapped with backward]
+    clip_grad_value_(p, 1.0) per parameter;  torch.optim.SGD(momentum .9, wd 1e-4, box_predictor lr x2).step()
+    WarmupMultiStepLR(steps 10000/11000, gamma .1, linear warm-up 500 iters from factor 2.5e-4)
+
+MI355X design: every parameter that receives a gradient lives in ONE flat fp32 bucket (parameters, gradients and momentum are
+three parallel buffers cut into 256-float chunks; a parameter is padded to whole chunks).  `p.data` / `p.grad` are views, so
+  * backward accumulates straight into the bucket (no flatten/unflatten copies),
+  * the exchange is a handful of large RCCL all-reduces over contiguous slices (xGMI is per-link bound: few, big messages),
+    each launched as soon as every gradient of its slice has been produced (post-accumulate hooks), on torch's RCCL stream,
+  * clip + weight decay + momentum + update for the whole model is one HIP launch (ore_sgd_step_fwd), graph-capturable.
+Parameters that never receive a gradient (the reference's dead branches) stay outside the bucket: they
+are neither exchanged nor decayed -- torch.optim.SGD skips `grad is None` parameters the same way.
+"""
+from __future__ import annotations
+
+import bisect
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+CHUNK = 256
+
+# gradient-ready order of the detector (backward runs heads -> correlation -> support branch -> FPN -> stage5 -> stage4):
+# slices of the bucket are exchanged in this order while backward is still producing the later ones.
+_READY_ORDER = ("roi_heads.box_predictor", "roi_heads.box_head", "roi_heads.", "proposal_generator.", "conv3.", "vip_p", "conv",
+                "backbone.fpn_output", "backbone.fpn_lateral", "backbone.bottom_up.stage5", "backbone.bottom_up.stage4", "")
+
+
+def param_groups_like_reference(cfg, model) -> List[Tuple[str, torch.nn.Parameter, float, float]]:
+    """(name, parameter, lr, weight_decay) exactly as ref:fewx/solver/build.py:110-134 resolves them.
+
+    The reference walks `model.modules()` and, for each, `module.named_parameters()` RECURSIVELY (the `recurse=False` is commented
+    out), keeping the first visit of every parameter.  The root module comes first, so every parameter is resolved there with
+    its full dotted name: the norm-module test never fires (GroupNorm weights get the ordinary weight decay), `"bias" in key`
+    is a substring test on the full name, and `'box_predictor' in key` doubles the rate of the box predictor."""
+    out, memo = [], set()
+    for module in model.modules():
+        for key, value in module.named_parameters():
+            if not value.requires_grad or id(value) in memo:
+                continue
+            memo.add(id(value))
+            lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
+            if isinstance(module, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.GroupNorm, torch.nn.LayerNorm,
+                                   torch.nn.modules.instancenorm._InstanceNorm, torch.nn.LocalResponseNorm)):
+                wd = cfg.SOLVER.WEIGHT_DECAY_NORM
+            elif "bias" in key:
+                lr, wd = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR, cfg.SOLVER.WEIGHT_DECAY_BIAS
+            if "box_predictor" in key:
+                lr = cfg.SOLVER.BASE_LR * cfg.SOLVER.HEAD_LR_FACTOR
+            out.append((key, value, float(lr), float(wd)))
+    return out
+
+
+class FlatBucket:
+    """Re-homes parameters into one flat buffer with parallel gradient / momentum buffers (see module docstring)."""
+
+    def __init__(self, entries: Sequence[Tuple[str, torch.nn.Parameter, float, float]], n_slices: int = 4,
+                 min_slice_bytes: int = 1 << 20):
+        def order(e):
+            for i, pre in enumerate(_READY_ORDER):
+                if e[0].startswith(pre):
+                    return i
+            return len(_READY_ORDER)
+        entries = sorted(entries, key=order)          # stable: keeps definition order inside a group
+        assert entries, "no parameter to optimise"
+        dev = entries[0][1].device
+        self.names: List[str] = []
+        self.offsets: List[int] = []
+        self.numels: List[int] = []
+        self.base_lrs: List[float] = [e[2] for e in entries]
+        self.weight_decays: List[float] = [e[3] for e in entries]
+        off = 0
+        lr_c, wd_c = [], []
+        for name, p, lr, wd in entries:
+            assert p.dtype == torch.float32 and p.device == dev, name
+            n = p.numel()
+            chunks = (n + CHUNK - 1) // CHUNK
+            self.names.append(name); self.offsets.append(off); self.numels.append(n)
+            lr_c += [lr] * chunks; wd_c += [wd] * chunks
+            off += chunks * CHUNK
+        self.size = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.momentum = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.chunk_lr = torch.tensor(lr_c, dtype=torch.float32, device=dev)      # the group's base rate (before the schedule factor)
+        self.chunk_wd = torch.tensor(wd_c, dtype=torch.float32, device=dev)
+        self.tensors: List[torch.nn.Parameter] = []
+        for (name, p, _, _), o, n in zip(entries, self.offsets, self.numels):
+            with torch.no_grad():
+                self.params[o:o + n].copy_(p.detach().reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+            self.tensors.append(p)
+        # exchange slices: contiguous, chunk aligned, about equal bytes, never splitting a parameter
+        target = max(self.size // max(n_slices, 1), min_slice_bytes // 4)
+        self.slices: List[Tuple[int, int, int, int]] = []       # (begin, end, first_param, last_param+1)
+        b, first = 0, 0
+        for i in range(len(entries)):
+            end = self.offsets[i] + ((self.numels[i] + CHUNK - 1) // CHUNK) * CHUNK
+            if end - b >= target or i == len(entries) - 1:
+                self.slices.append((b, end, first, i + 1))
+                b, first = end, i + 1
+        self.param_slice = [0] * len(entries)
+        for s, (_, _, f, l) in enumerate(self.slices):
+            for i in range(f, l):
+                self.param_slice[i] = s
+
+    def zero_grad(self):
+        self.grads.zero_()
+        for p, o, n in zip(self.tensors, self.offsets, self.numels):      # a user may have set .grad = None
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
+                p.grad = self.grads[o:o + n].view(p.shape)
+
+    def nbytes_exchanged(self) -> int:
+        return 4 * self.size
+
+
+def get_bucket(model, cfg=None, entries=None) -> FlatBucket:
+    """One bucket per model, shared by the DP wrapper and the optimizer."""
+    b = getattr(model, "_ore_flat_bucket", None)
+    if b is None:
+        if entries is None:
+            entries = param_groups_like_reference(cfg, model)
+        dead = tuple(getattr(model, "gradless_parameter_prefixes", lambda: ())())
+        entries = [e for e in entries if not any(e[0].startswith(d) for d in dead)]
+        b = FlatBucket(entries)
+        object.__setattr__(model, "_ore_flat_bucket", b)
+    return b
+
+
+class FlatDataParallel(torch.nn.Module):
+    """Drop-in for DistributedDataParallel(model, broadcast_buffers=False) as d2z:engine/defaults.py:60-79 builds it.
+
+    forward = the wrapped model.  During backward, the moment the last gradient of an exchange slice has been accumulated its
+    all-reduce(SUM) is issued asynchronously; `finish()` (called by the optimizer) waits for all of them.  The 1/world_size
+    average is folded into the SGD kernel (grad_scale).  Ranks start from rank 0's parameters (one broadcast of the bucket)."""
+
+    def __init__(self, module: torch.nn.Module, cfg=None, process_group=None, entries=None, overlap: bool = True):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.bucket = get_bucket(module, cfg, entries)
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.overlap = overlap
+        self._pending = [0] * len(self.bucket.slices)
+        self._works: List = []
+        self._issued = [False] * len(self.bucket.slices)
+        self.bucket.grad_scale = 1.0 / self.world
+        self.bucket.finish = self.finish
+        if self.world > 1:
+            dist.broadcast(self.bucket.params, src=0, group=process_group)
+            inb = {id(p) for p in self.bucket.tensors}
+            for t in list(module.parameters()) + list(module.buffers()):     # DDP syncs the whole module state once at construction
+                if id(t) not in inb:
+                    dist.broadcast(t.data, src=0, group=process_group)
+            for i, p in enumerate(self.bucket.tensors):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self._reset()
+
+    def _reset(self):
+        for s, (_, _, f, l) in enumerate(self.bucket.slices):
+            self._pending[s] = l - f
+            self._issued[s] = False
+        self._works = []
+
+    def _make_hook(self, i: int) -> Callable:
+        s = self.bucket.param_slice[i]
+
+        def hook(_p):
+            self._pending[s] -= 1
+            if self._pending[s] == 0 and self.overlap:
+                self._issue(s)
+        return hook
+
+    def _issue(self, s: int):
+        if self._issued[s]:
+            return
+        b, e, _, _ = self.bucket.slices[s]
+        self._issued[s] = True
+        self._works.append(dist.all_reduce(self.bucket.grads[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Complete the exchange: issue whatever a skipped hook left behind (a parameter unused this iteration), wait for all."""
+        if self.world > 1:
+            for s in range(len(self.bucket.slices)):
+                self._issue(s)
+            for w in self._works:
+                w.wait()
+        self._reset()
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+class FlatSGD:
+    """torch.optim.SGD + clip_grad_value_ as one HIP launch over the flat bucket.  Keeps the parts of the torch.optim interface
+    the reference's trainer and checkpointer touch: param_groups (lr is read by the LR logger and written by the scheduler),
+    zero_grad(), step(), state_dict()/load_state_dict()."""
+
+    def __init__(self, bucket: FlatBucket, base_lr: float, momentum: float, clip_value: float, nesterov: bool = False,
+                 apply_fn: Optional[Callable] = None):
+        if nesterov:
+            raise NotImplementedError("SOLVER.NESTEROV is false in every reference config")
+        self.bucket = bucket
+        self.base_lr = float(base_lr)
+        self.momentum = float(momentum)
+        self.clip_value = float(clip_value)
+        self.lr_factor = 1.0                       # schedule factor; param_groups[i]["lr"] = group base x factor
+        self._apply = apply_fn
+        self.param_groups = []
+        for p, g, wd in zip(bucket.tensors, bucket.base_lrs, bucket.weight_decays):
+            self.param_groups.append({"params": [p], "lr": g, "initial_lr": g, "weight_decay": wd, "momentum": momentum})
+        self.defaults = {"lr": base_lr, "momentum": momentum}
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.bucket.zero_grad()
+
+    def set_lr_factor(self, f: float):
+        self.lr_factor = float(f)
+        for g in self.param_groups:
+            g["lr"] = g["initial_lr"] * self.lr_factor
+
+    def step(self, closure=None):
+        b = self.bucket
+        fin = getattr(b, "finish", None)
+        if fin is not None:
+            fin()
+        scale = getattr(b, "grad_scale", 1.0)
+        if self._apply is not None:                # tests on CPU inject the oracle's update here; the product path is the HIP kernel
+            self._apply(b, self.lr_factor, self.momentum, self.clip_value, scale)
+            return
+        import orehip
+        orehip.sgd_step(b.params, b.grads, b.momentum, b.chunk_lr, b.chunk_wd, lr_scale=self.lr_factor, momentum=self.momentum,
+                        clip_value=self.clip_value, grad_scale=scale)
+
+    def state_dict(self) -> Dict:
+        return {"momentum": self.bucket.momentum.detach().cpu(), "names": list(self.bucket.names), "lr_factor": self.lr_factor}
+
+    def load_state_dict(self, sd: Dict):
+        assert list(sd["names"]) == list(self.bucket.names), "optimizer state belongs to a different parameter set"
+        self.bucket.momentum.copy_(sd["momentum"])
+        self.set_lr_factor(sd.get("lr_factor", 1.0))
+
+
+def build_optimizer(cfg, model) -> FlatSGD:
+    """ref:fewx/solver/build.py:91-139.  `model` may be the FlatDataParallel wrapper or the bare detector."""
+    inner = model.module if isinstance(model, FlatDataParallel) else model
+    bucket = get_bucket(inner, cfg)
+    clip = cfg.SOLVER.CLIP_GRADIENTS
+    if clip.ENABLED and clip.CLIP_TYPE != "value":
+        raise NotImplementedError("only CLIP_TYPE=value is built (the reference configs use value clipping)")
+    return FlatSGD(bucket, cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM, clip.CLIP_VALUE if clip.ENABLED else 0.0, cfg.SOLVER.NESTEROV)
+
+
+def warmup_factor_at_iter(method: str, it: int, warmup_iters: int, warmup_factor: float) -> float:
+    """d2z:solver/lr_scheduler.py:205-238."""
+    if it >= warmup_iters:
+        return 1.0
+    if method == "constant":
+        return warmup_factor
+    if method == "linear":
+        alpha = it / warmup_iters
+        return warmup_factor * (1 - alpha) + alpha
+    raise ValueError("Unknown warmup method: {}".format(method))
+
+
+class WarmupMultiStepLR:
+    """d2z:solver/lr_scheduler.py:132-164 for FlatSGD: lr_i(t) = base_i * warmup(t) * gamma^(#milestones <= t)."""
+
+    def __init__(self, optimizer: FlatSGD, milestones: Sequence[int], gamma: float = 0.1, warmup_factor: float = 0.001,
+                 warmup_iters: int = 1000, warmup_method: str = "linear", last_epoch: int = -1):
+        if list(milestones) != sorted(milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(milestones))
+        self.optimizer, self.milestones, self.gamma = optimizer, list(milestones), gamma
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        self.last_epoch = last_epoch
+        self.step()
+
+    def factor(self, it: int) -> float:
+        return warmup_factor_at_iter(self.warmup_method, it, self.warmup_iters, self.warmup_factor) * \
+            self.gamma ** bisect.bisect_right(self.milestones, it)
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.set_lr_factor(self.factor(self.last_epoch))
+
+    def get_last_lr(self) -> List[float]:
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"]
+        self.optimizer.set_lr_factor(self.factor(self.last_epoch))
+
+
+def build_lr_scheduler(cfg, optimizer: FlatSGD):
+    """ref:fewx/solver/build.py:142-170."""
+    name = cfg.SOLVER.LR_SCHEDULER_NAME
+    if name != "WarmupMultiStepLR":
+        raise ValueError("Unknown LR scheduler: {}".format(name))
+    return WarmupMultiStepLR(optimizer, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, warmup_factor=cfg.SOLVER.WARMUP_FACTOR,
+                             warmup_iters=cfg.SOLVER.WARMUP_ITERS, warmup_method=cfg.SOLVER.WARMUP_METHOD)

@@ -68,7 +68,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
-           "ore_roi_predict_fwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
+           "ore_roi_predict_fwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_sgd_step_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
 
@@ -468,6 +468,20 @@ def centernet_loss_sums(head: torch.Tensor, reg_targets: torch.Tensor, hm_target
                                         C.c_float(ignore_high_fp), C.c_void_p(_ptr(out)), C.c_void_p(_ptr(ws)), _stream()),
          "ore_centernet_losses_fwd")
     return out
+
+
+def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: torch.Tensor, chunk_lr: torch.Tensor, chunk_wd: torch.Tensor,
+             lr_scale: float = 1.0, momentum: float = 0.9, clip_value: float = 1.0, grad_scale: float = 1.0,
+             lr_scale_dev: Optional[torch.Tensor] = None) -> None:
+    """In-place clip + SGD over a flat bucket of 256-float chunks (see ore_sgd_step_fwd)."""
+    n = params.numel()
+    assert n % 256 == 0 and grads.numel() == n and momentum_buf.numel() == n and chunk_lr.numel() == n // 256 == chunk_wd.numel()
+    for t in (params, grads, momentum_buf, chunk_lr, chunk_wd):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    _chk(lib().ore_sgd_step_fwd(C.c_void_p(_ptr(params)), C.c_void_p(_ptr(grads)), C.c_void_p(_ptr(momentum_buf)),
+                                C.c_int64(n // 256), C.c_void_p(_ptr(chunk_lr)), C.c_void_p(_ptr(chunk_wd)),
+                                C.c_void_p(_ptr(lr_scale_dev)), C.c_float(lr_scale), C.c_float(momentum), C.c_float(clip_value),
+                                C.c_float(grad_scale), _stream()), "ore_sgd_step_fwd")
 
 
 def compose_roi_head(sd, support_8: torch.Tensor, prefix: str = "roi_heads."):

@@ -222,6 +222,17 @@ int ore_centernet_losses_fwd(const float* head, int32_t head_ld, const float* re
                              int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, float gamma, float beta,
                              float sigmoid_clamp, float ignore_high_fp, float* sums4, float* workspace, void* stream);
 
+/* One launch of value-clip + SGD over the flat parameter bucket (row a13):
+ *   g = clamp(grad_scale*grad, -clip, clip) (clip <= 0: off); g += wd*p; buf = momentum*buf + g; p -= lr*buf
+ * = torch.nn.utils.clip_grad_value_ + torch.optim.SGD.step as wired by ref:fewx/solver/build.py:18-60,110-139 and
+ * d2z:engine/train_loop.py:258-294.  The bucket is n_chunks x 256 floats; a chunk never straddles two parameters (each
+ * parameter is padded to a multiple of 256) and chunk_lr[c]/chunk_wd[c] carry its parameter group.  The effective rate is
+ * chunk_lr[c] * (*lr_scale_dev if non-NULL else lr_scale): the scheduler factor can live on device so the step is
+ * hipGraph-capturable.  grad_scale = 1/world_size after a SUM all-reduce. */
+int ore_sgd_step_fwd(float* params, const float* grads, float* momentum_buf, int64_t n_chunks, const float* chunk_lr,
+                     const float* chunk_wd, const float* lr_scale_dev, float lr_scale, float momentum, float clip_value,
+                     float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------ engine ------------------- */
 /* Whole eval hot path for one model instance: owns packed weights and all
  * intermediate buffers, replays a captured hipGraph per image.

@@ -566,3 +566,19 @@ def centernet_losses(reg_pred: Tensor, hm_logit: Tensor, pos_inds: Tensor, reg_t
             "loss_centernet_agn_pos": pos_weight * alpha * (-pos_sum) / num_pos_avg,
             "loss_centernet_agn_neg": neg_weight * (1 - alpha) * (-neg_sum) / num_pos_avg,
             "sums": torch.stack([giou_sum, torch.tensor(float(len(idx))), pos_sum, neg_sum])}
+
+
+# --------------------------------------------------------------------------------------
+# a13  clip + SGD on a flat bucket (torch.nn.utils.clip_grad_value_ + torch.optim.SGD.step; ref:fewx/solver/build.py:18-60,110-139)
+# --------------------------------------------------------------------------------------
+def sgd_step_flat(params: Tensor, grads: Tensor, momentum_buf: Tensor, chunk_lr: Tensor, chunk_wd: Tensor, lr_scale: float,
+                  momentum: float, clip_value: float, grad_scale: float) -> None:
+    """In-place; chunk_* are per 256 elements."""
+    lr = (chunk_lr * lr_scale).repeat_interleave(256)
+    wd = chunk_wd.repeat_interleave(256)
+    g = grads * grad_scale
+    if clip_value > 0:
+        g = g.clamp(-clip_value, clip_value)
+    g = g + wd * params
+    momentum_buf.mul_(momentum).add_(g)
+    params.sub_(lr * momentum_buf)

@@ -94,3 +94,36 @@ def test_cn_losses_vs_oracle(oh):
     # repeatable bit for bit (fixed-order reduction)
     s2 = oh.centernet_loss_sums(head.cuda(), reg.cuda(), hm.cuda(), pos.cuda(), torch.tensor([len(pos)], dtype=torch.int32).cuda()).cpu()
     assert torch.equal(s, s2)
+
+
+def test_sgd_step_matches_torch_optim(oh):
+    """ore_sgd_step_fwd == clip_grad_value_ + torch.optim.SGD(momentum, per-group lr / weight decay) over 3 steps."""
+    import torch.nn as nn
+    from fewx.solver.build import FlatBucket, FlatSGD
+    torch.manual_seed(3)
+    shapes = [(300, 37), (300,), (5, 129), (129, 3, 3, 3), (1,)]
+    cpu_p = [nn.Parameter(torch.randn(*s)) for s in shapes]
+    lrs, wds = [0.01, 0.01, 0.02, 0.01, 0.02], [1e-4, 0.0, 1e-4, 1e-2, 1e-4]
+    ref = torch.optim.SGD([{"params": [p], "lr": lr, "weight_decay": wd} for p, lr, wd in zip(cpu_p, lrs, wds)], 0.01, momentum=0.9)
+    gpu_p = [nn.Parameter(p.detach().clone().cuda()) for p in cpu_p]
+    bucket = FlatBucket([("p%d" % i, p, lr, wd) for i, (p, lr, wd) in enumerate(zip(gpu_p, lrs, wds))], n_slices=2, min_slice_bytes=1024)
+    opt = FlatSGD(bucket, 0.01, 0.9, 1.0)
+    by_name = dict(zip(bucket.names, bucket.tensors))
+    for step in range(3):
+        f = [0.5, 1.0, 0.1][step]
+        opt.set_lr_factor(f)
+        for g, lr in zip(ref.param_groups, lrs):
+            g["lr"] = lr * f
+        opt.zero_grad()
+        for i, p in enumerate(cpu_p):
+            gr = torch.randn(p.shape) * 3.0                      # many entries beyond the clip value
+            p.grad = gr.clone()
+            by_name["p%d" % i].grad.add_(2.0 * gr.cuda())        # "sum over 2 ranks", averaged by grad_scale
+        bucket.grad_scale = 0.5
+        torch.nn.utils.clip_grad_value_(cpu_p, 1.0)
+        ref.step()
+        opt.step()
+        for i, p in enumerate(cpu_p):
+            got = by_name["p%d" % i].detach().cpu()
+            assert (got - p.detach()).abs().max() <= 2e-7 * max(1.0, float(p.detach().abs().max())), (step, i)
+    assert float(bucket.params[bucket.offsets[1] + 300:bucket.offsets[1] + 512].abs().max()) == 0.0      # padding never moves
