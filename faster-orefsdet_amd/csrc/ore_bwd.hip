@@ -1,0 +1,240 @@
+// Backward kernels of the trainable layers ("..._bwd counterparts for trainable layers", 8b).
+//   k_pack_weight      OIHW master weights -> the forward igemm layout, or the flipped/transposed layout that turns the forward
+//                      kernel into the data-gradient conv (dX = conv(dZ, W^T flipped)); runs on device once per optimizer step
+//   k_wgrad            weight gradient dW[co][ky][kx][ci] = sum_rows dZ[row][co] * X[row shifted by tap][ci] on fp32 MFMA,
+//                      rows split over blocks, partial slabs reduced in a fixed order by k_wgrad_reduce (deterministic)
+//   k_relu_affine_bwd  dZ = dY * (Y > 0) * scale[c]          (conv + FrozenBN + ReLU epilogue backward)
+//   k_colsum_*         bias gradient = column sums of dZ, two deterministic stages
+// What they replace: torch.autograd of F.conv2d / F.linear / F.relu / FrozenBatchNorm2d
+//   (d2z:layers/wrappers.py:48-91, d2z:layers/batch_norm.py:44-66) inside d2z:engine/train_loop.py:279 `losses.backward()`.
+#include "ore_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int Co, int Ci, int kh, int kw, int mode,
+                                                     float* __restrict__ dst, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int taps = kh * kw;
+    if (mode == 0) {                                   // [Co16][tap][Ci]
+        const int ci = (int)(i % Ci);
+        const int tap = (int)((i / Ci) % taps);
+        const int co = (int)(i / ((long long)Ci * taps));
+        dst[i] = co < Co ? w[((size_t)co * Ci + ci) * taps + tap] : 0.0f;
+    } else {                                           // [Ci16][flipped tap][Co16]
+        const int Co16 = (Co + 15) / 16 * 16;
+        const int co = (int)(i % Co16);
+        const int tap = (int)((i / Co16) % taps);
+        const int ci = (int)(i / ((long long)Co16 * taps));
+        dst[i] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * taps + (taps - 1 - tap)] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+struct WgradP {
+    const float* x; int x_ld, x_coff;
+    const float* dz; int dz_ld, dz_coff;
+    int B, H, W, Cin, Cout, kh, kw, pad;
+    int M, chunk;            // rows, rows per split (multiple of 16)
+    float* slab;             // [S][Cout][taps][Cin]
+};
+
+constexpr int WG_T = 64;     // block tile: 64 output channels x 64 input channels of one tap
+constexpr int WG_K = 16;     // rows per step
+constexpr int WG_LD = 80;    // LDS row stride: the 4 k-rows of an MFMA operand land 16 banks apart -> conflict-free ds_read_b32
+
+__global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
+    __shared__ float sA[2][WG_K][WG_LD];   // dZ rows x co
+    __shared__ float sB[2][WG_K][WG_LD];   // X  rows x ci
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_ci_tiles = (p.Cin + WG_T - 1) / WG_T;
+    const int co0 = blockIdx.x * WG_T;
+    const int ci0 = (blockIdx.y % n_ci_tiles) * WG_T;
+    const int tap = blockIdx.y / n_ci_tiles;
+    const int dy = tap / p.kw - p.pad, dx = tap % p.kw - p.pad;
+    const int m_begin = blockIdx.z * p.chunk, m_end = min(p.M, m_begin + p.chunk);
+
+    const int lr = tid >> 4, lc = (tid & 15) * 4;     // this thread stages row lr, columns lc..lc+3 of both tiles
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](int m0, f32x4& va, f32x4& vb) {
+        va = f32x4{0.f, 0.f, 0.f, 0.f};
+        vb = va;
+        const int m = m0 + lr;
+        if (m < m_end) {
+            if (co0 + lc < p.Cout) va = *reinterpret_cast<const f32x4*>(p.dz + (size_t)m * p.dz_ld + p.dz_coff + co0 + lc);
+            const int xq = m % p.W, yq = (m / p.W) % p.H;
+            const int ys = yq + dy, xs = xq + dx;
+            if (ci0 + lc < p.Cin && ys >= 0 && ys < p.H && xs >= 0 && xs < p.W)
+                vb = *reinterpret_cast<const f32x4*>(p.x + (size_t)(m + dy * p.W + dx) * p.x_ld + p.x_coff + ci0 + lc);
+        }
+    };
+    f32x4 va, vb;
+    load(m_begin, va, vb);
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+        *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
+        *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
+        __syncthreads();
+        if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb);          // next step's global loads fly under this step's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < WG_K / 4; ++kk) {
+            const int k = kk * 4 + (lane >> 4);
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = sA[buf][k][wm * 32 + t * 16 + (lane & 15)];
+                b[t] = sB[buf][k][wn * 32 + t * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        buf ^= 1;                                                // the other buffer was last read two barriers ago
+    }
+    // D: column = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
+    const int taps = p.kh * p.kw;
+    float* slab = p.slab + (size_t)blockIdx.z * p.Cout * taps * p.Cin;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int ci = ci0 + wn * 32 + tn * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 32 + tm * 16 + (lane >> 4) * 4 + r;
+                if (co < p.Cout && ci < p.Cin) slab[((size_t)co * taps + tap) * p.Cin + ci] = acc[tm][tn][r];
+            }
+        }
+}
+
+// dw_oihw[co][ci][tap] = beta * dw + sum_z slab[z][co][tap][ci]  (z ascending: fixed summation order)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cout, int taps, int Cin, float beta,
+                                                      float* __restrict__ dw) {
+    const long long n = (long long)Cout * taps * Cin;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slab[(size_t)z * n + i];
+    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % taps), co = (int)(i / ((long long)Cin * taps));
+    float* o = dw + ((size_t)co * Cin + ci) * taps + tap;
+    *o = beta != 0.0f ? beta * *o + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relu_affine_bwd(const float* __restrict__ dy, int dy_ld, int dy_coff, const float* __restrict__ y,
+                                                         int y_ld, int y_coff, const float* __restrict__ scale, long long rows, int C,
+                                                         float* __restrict__ dz, int dz_ld, int dz_coff) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c4n) return;
+    const long long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * dy_ld + dy_coff + c);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * y_ld + y_coff + c);
+    f32x4 s = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (scale) s = *reinterpret_cast<const f32x4*>(scale + c);
+    f32x4 o;
+    o.x = v.x > 0.f ? g.x * s.x : 0.f;
+    o.y = v.y > 0.f ? g.y * s.y : 0.f;
+    o.z = v.z > 0.f ? g.z * s.z : 0.f;
+    o.w = v.w > 0.f ? g.w * s.w : 0.f;
+    *reinterpret_cast<f32x4*>(dz + r * dz_ld + dz_coff + c) = o;
+}
+
+// column sums: stage 1 = 64-row chunks, stage 2 = chunks in order
+__global__ __launch_bounds__(256) void k_colsum_chunks(const float* __restrict__ x, int ld, int coff, long long rows, int C,
+                                                       float* __restrict__ part) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long r0 = (long long)blockIdx.x * 64, r1 = min(rows, r0 + 64);
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) s += x[r * ld + coff + c];
+    part[(size_t)blockIdx.x * C + c] = s;
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nchunks, int C, float beta, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * C + c];
+    out[c] = beta != 0.0f ? beta * out[c] + s : s;
+}
+
+}  // namespace
+
+extern "C" int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t dgrad,
+                                        float* dst, void* stream) {
+    ORE_CHECK_ARG(w_oihw && dst && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "ore_pack_conv_weight_fwd: bad args");
+    const int Co16 = round_up(Cout, 16), Ci16 = round_up(Cin, 16);
+    ORE_CHECK_ARG(dgrad || Cin % 16 == 0, "ore_pack_conv_weight_fwd: forward layout needs Cin %% 16 == 0");
+    const long long total = dgrad ? (long long)Ci16 * kh * kw * Co16 : (long long)Co16 * kh * kw * Cin;
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kh, kw,
+                       dgrad ? 1 : 0, dst, total);
+    return ore_launch_status("k_pack_weight");
+}
+
+extern "C" size_t ore_conv_wgrad_workspace_floats(int32_t rows, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw) {
+    const long long per = (long long)Cout * kh * kw * Cin;
+    const int tiles = ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T) * kh * kw;
+    int S = max(1, min(ceil_div(1024, tiles), ceil_div(rows, 64)));
+    return (size_t)(per * S);
+}
+
+extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff, const float* dz, int32_t dz_ld, int32_t dz_coff,
+                                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t pad,
+                                    float* dw_oihw, float beta, float* workspace, size_t workspace_floats, void* stream) {
+    ORE_CHECK_ARG(x && dz && dw_oihw && workspace, "ore_conv2d_wgrad_fwd: null pointer");
+    ORE_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && kh > 0 && kw > 0 && kh == 2 * pad + 1 && kw == 2 * pad + 1,
+                  "ore_conv2d_wgrad_fwd: stride-1 'same' convolutions only (k = 2*pad+1)");
+    ORE_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0 && x_ld % 4 == 0 && dz_ld % 4 == 0 && x_coff % 4 == 0 && dz_coff % 4 == 0 &&
+                  x_coff + Cin <= x_ld && dz_coff + Cout <= dz_ld, "ore_conv2d_wgrad_fwd: channel counts/offsets must be multiples of 4 and fit ld");
+    const long long M = (long long)B * H * W;
+    ORE_CHECK_ARG(M < (1ll << 31), "ore_conv2d_wgrad_fwd: too many rows");
+    const long long per = (long long)Cout * kh * kw * Cin;
+    const int tiles = ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T) * kh * kw;
+    int S = max(1, min(ceil_div(1024, tiles), ceil_div((int)M, 64)));
+    { const long long cap = (long long)(workspace_floats / (size_t)per); if (cap < S) S = (int)cap; }
+    if (S < 1) { ore_set_error("ore_conv2d_wgrad_fwd: workspace too small (%zu < %lld floats)", workspace_floats, per); return ORE_ENOMEM; }
+    WgradP p{};
+    p.x = x; p.x_ld = x_ld; p.x_coff = x_coff; p.dz = dz; p.dz_ld = dz_ld; p.dz_coff = dz_coff;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.kh = kh; p.kw = kw; p.pad = pad;
+    p.M = (int)M; p.chunk = round_up(ceil_div((int)M, S), WG_K);
+    S = ceil_div((int)M, p.chunk);
+    p.slab = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
+    int rc = ore_launch_status("k_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+    return ore_launch_status("k_wgrad_reduce");
+}
+
+extern "C" int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_coff, const float* y, int32_t y_ld, int32_t y_coff,
+                                   const float* scale, int64_t rows, int32_t C, float* dz, int32_t dz_ld, int32_t dz_coff, void* stream) {
+    ORE_CHECK_ARG(dy && y && dz && rows > 0 && C > 0 && C % 4 == 0 && dy_ld % 4 == 0 && y_ld % 4 == 0 && dz_ld % 4 == 0 &&
+                  dy_coff % 4 == 0 && y_coff % 4 == 0 && dz_coff % 4 == 0, "ore_relu_affine_bwd: bad args (channels multiple of 4)");
+    const long long n = rows * (C / 4);
+    hipLaunchKernelGGL(k_relu_affine_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dy_coff, y, y_ld,
+                       y_coff, scale, (long long)rows, C, dz, dz_ld, dz_coff);
+    return ore_launch_status("k_relu_affine_bwd");
+}
+
+extern "C" int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, float beta, float* out,
+                              float* workspace, size_t workspace_floats, void* stream) {
+    ORE_CHECK_ARG(x && out && workspace && rows > 0 && C > 0, "ore_colsum_fwd: bad args");
+    const long long nchunks = (rows + 63) / 64;
+    if ((size_t)(nchunks * C) > workspace_floats) { ore_set_error("ore_colsum_fwd: workspace too small"); return ORE_ENOMEM; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_colsum_chunks, dim3((unsigned)nchunks, ceil_div(C, 256)), dim3(256), 0, st, x, ld, coff, (long long)rows, C, workspace);
+    int rc = ore_launch_status("k_colsum_chunks");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(C, 256)), dim3(256), 0, st, workspace, (int)nchunks, C, beta, out);
+    return ore_launch_status("k_colsum_final");
+}

@@ -95,6 +95,67 @@ __global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
     }
 }
 
+// backward of k_roi_align: every sample scatters dOut/count with its 4 bilinear weights (fp32 hardware atomics; dfeat zeroed by the caller)
+__device__ __forceinline__ void bilinear4_scatter(float* f, int ld, int H, int W, float y, float x, int c, f32x4 g) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+    float* p1 = f + (size_t)(y_low * W + x_low) * ld + c;
+    float* p2 = f + (size_t)(y_low * W + x_high) * ld + c;
+    float* p3 = f + (size_t)(y_high * W + x_low) * ld + c;
+    float* p4 = f + (size_t)(y_high * W + x_high) * ld + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        atomicAdd(p1 + k, hy * hx * g[k]);
+        atomicAdd(p2 + k, hy * lx * g[k]);
+        atomicAdd(p3 + k, ly * hx * g[k]);
+        atomicAdd(p4 + k, ly * lx * g[k]);
+    }
+}
+
+struct RoiBwdP {
+    float* dfeat[4]; int ld[4], coff[4], H[4], W[4]; float scale[4];
+    int n_levels, min_level, C, pooled;
+    float canonical_size; int canonical_level;
+    const float* boxes; int n;
+    const float* dout;
+};
+
+__global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p) {
+    const int r = blockIdx.x;
+    const int P = p.pooled, C4 = p.C >> 2;
+    const float* src = p.dout + (size_t)r * P * P * p.C;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
+    const float size = sqrtf((b.z - b.x) * (b.w - b.y));
+    float lv = floorf((float)p.canonical_level + log2f(size / p.canonical_size + 1e-8f));
+    lv = fminf(fmaxf(lv, (float)p.min_level), (float)(p.min_level + p.n_levels - 1));
+    const int l = (int)lv - p.min_level;
+    const float sc = p.scale[l];
+    const int H = p.H[l], W = p.W[l], ld = p.ld[l];
+    float* f = p.dfeat[l] + p.coff[l];
+    const float x0 = b.x * sc - 0.5f, y0 = b.y * sc - 0.5f, x1 = b.z * sc - 0.5f, y1 = b.w * sc - 0.5f;
+    const float rw = x1 - x0, rh = y1 - y0;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float cnt = (float)max(gh * gw, 1);
+    for (int i = threadIdx.x; i < P * P * C4; i += 256) {
+        const int c = (i % C4) * 4, bin = i / C4;
+        const int ph = bin / P, pw = bin - ph * P;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(src + (size_t)bin * p.C + c) / cnt;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = y0 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = x0 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                bilinear4_scatter(f, ld, H, W, y, x, c, g);
+            }
+        }
+    }
+}
+
 struct PredP {
     const float* h; int C;                       // [cap][C] after fc1+ReLU
     const float* cls_w; const float* cls_b;      // [K+1][C], [K+1]  (K = 1 foreground class)
@@ -271,4 +332,21 @@ extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w
     hipLaunchKernelGGL(k_roi_finalize, dim3(1), dim3(256), 0, st, keep, n_keep, topk, c_boxes, c_scores, c_src, det_boxes, det_scores,
                        (long long*)det_src, det_count);
     return ore_launch_status("k_roi_finalize");
+}
+
+extern "C" int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                                 const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                                 const float* boxes, int32_t n, const float* dout, void* stream) {
+    ORE_CHECK_ARG(dfeat && ld && coff && H && W && scales_host && boxes && dout, "ore_roi_align_bwd: null pointer");
+    ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && C % 4 == 0 && pooled >= 1 && pooled <= 16 && n >= 1, "ore_roi_align_bwd: bad args");
+    RoiBwdP p{};
+    for (int l = 0; l < n_levels; ++l) {
+        ORE_CHECK_ARG(dfeat[l] && ld[l] % 4 == 0 && coff[l] % 4 == 0 && H[l] > 0 && W[l] > 0, "ore_roi_align_bwd: level %d", l);
+        p.dfeat[l] = dfeat[l]; p.ld[l] = ld[l]; p.coff[l] = coff[l]; p.H[l] = H[l]; p.W[l] = W[l]; p.scale[l] = scales_host[l];
+    }
+    p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
+    p.canonical_size = 224.0f; p.canonical_level = 4;
+    p.boxes = boxes; p.n = n; p.dout = dout;
+    hipLaunchKernelGGL(k_roi_align_bwd, dim3(n), dim3(256), 0, (hipStream_t)stream, p);
+    return ore_launch_status("k_roi_align_bwd");
 }

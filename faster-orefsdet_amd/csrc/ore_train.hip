@@ -213,6 +213,62 @@ __global__ __launch_bounds__(256) void k_sgd_step(float* __restrict__ p, const f
     p[i] = pi - lr * b;
 }
 
+// ---- gradient of the three CenterNet losses w.r.t. the head outputs --------------------------------------------------------
+// coef (device) = { reg_weight / reg_norm, pos_weight*alpha / num_pos_avg, neg_weight*(1-alpha) / num_pos_avg } * upstream grad.
+// min/max ties split the gradient like torch.minimum/maximum; clamp passes the gradient on the closed interval like torch.clamp.
+__device__ __forceinline__ float dmin_dp(float p, float t) { return p < t ? 1.0f : (p == t ? 0.5f : 0.0f); }
+__device__ __forceinline__ float dmax_dp(float p, float t) { return p > t ? 1.0f : (p == t ? 0.5f : 0.0f); }
+
+__global__ __launch_bounds__(256) void k_cn_loss_grad(LossP p, const float* __restrict__ coef, float* __restrict__ dhead, int dhead_ld) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= p.rows) return;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p.reg_targets + (size_t)r * 4);
+    const float* h = p.head + (size_t)r * p.head_ld;
+    float* d = dhead + (size_t)r * dhead_ld;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)) >= 0.0f) {
+        const float pl = h[0], pt = h[1], pr = h[2], pb = h[3];
+        const float ta = (t.x + t.z) * (t.y + t.w), pa = (pl + pr) * (pt + pb);
+        const float wi = fminf(pl, t.x) + fminf(pr, t.z), hi = fminf(pb, t.w) + fminf(pt, t.y);
+        const float gw = fmaxf(pl, t.x) + fmaxf(pr, t.z), gh = fmaxf(pb, t.w) + fmaxf(pt, t.y);
+        const float ac = gw * gh, ai = wi * hi, au = ta + pa - ai;
+        // L = 2 - (ai+1)/(au+1) - au/ac
+        const float inv_u = 1.0f / (au + 1.0f), inv_c = 1.0f / ac;
+        const float dL_dai = -inv_u;                                   // through the numerator of iou
+        const float dL_dau = (ai + 1.0f) * inv_u * inv_u - inv_c;      // iou denominator and au/ac
+        const float dL_dac = au * inv_c * inv_c;
+        const float c0 = coef[0];
+        // per variable: d pa, d ai, d ac
+        auto gradv = [&](float dpa, float dai, float dac) { return c0 * (dL_dai * dai + dL_dau * (dpa - dai) + dL_dac * dac); };
+        g0 = gradv(pt + pb, hi * dmin_dp(pl, t.x), gh * dmax_dp(pl, t.x));
+        g2 = gradv(pt + pb, hi * dmin_dp(pr, t.z), gh * dmax_dp(pr, t.z));
+        g1 = gradv(pl + pr, wi * dmin_dp(pt, t.y), gw * dmax_dp(pt, t.y));
+        g3 = gradv(pl + pr, wi * dmin_dp(pb, t.w), gw * dmax_dp(pb, t.w));
+    }
+    d[0] = g0; d[1] = g1; d[2] = g2; d[3] = g3;
+    const float s = 1.0f / (1.0f + expf(-h[4]));
+    const bool inside = s >= p.clampv && s <= 1.0f - p.clampv;
+    const float pred = fminf(fmaxf(s, p.clampv), 1.0f - p.clampv);
+    float gx = 0.f;
+    if (inside && !(p.ignore_high_fp > 0.0f && !(pred < p.ignore_high_fp))) {
+        const float nw = powf(1.0f - p.hm_targets[r], p.beta);
+        const float dg = nw * (-powf(pred, p.gamma) / (1.0f - pred) + p.gamma * powf(pred, p.gamma - 1.0f) * logf(1.0f - pred));
+        gx = -coef[2] * dg * s * (1.0f - s);
+    }
+    d[4] = gx;
+}
+
+__global__ __launch_bounds__(256) void k_cn_loss_grad_pos(LossP p, const float* __restrict__ coef, float* __restrict__ dhead, int dhead_ld) {
+    const int np = *p.pos_count;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < np; i += gridDim.x * 256) {
+        const long long r = p.pos_inds[i];
+        const float s = 1.0f / (1.0f + expf(-p.head[(size_t)r * p.head_ld + 4]));
+        if (s < p.clampv || s > 1.0f - p.clampv) continue;
+        const float df = powf(1.0f - s, p.gamma) / s - p.gamma * logf(s) * powf(1.0f - s, p.gamma - 1.0f);
+        atomicAdd(dhead + (size_t)r * dhead_ld + 4, -coef[1] * df * s * (1.0f - s));
+    }
+}
+
 int fill_tgt(TgtP& p, int n_levels, const int32_t* H, const int32_t* W, const int32_t* stride, int B, int max_n, const float* soi_host) {
     p.n_levels = n_levels; p.B = B; p.max_n = max_n;
     int rows = 0;
@@ -278,4 +334,22 @@ extern "C" int ore_sgd_step_fwd(float* params, const float* grads, float* moment
     hipLaunchKernelGGL(k_sgd_step, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, chunk_lr,
                        chunk_wd, lr_scale_dev, lr_scale, momentum, clip_value, grad_scale);
     return ore_launch_status("k_sgd_step");
+}
+
+extern "C" int ore_centernet_losses_bwd(const float* head, int32_t head_ld, const float* reg_targets, const float* hm_targets,
+                                        int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, int32_t max_pos, float gamma,
+                                        float beta, float sigmoid_clamp, float ignore_high_fp, const float* coef3, float* dhead,
+                                        int32_t dhead_ld, void* stream) {
+    ORE_CHECK_ARG(head && reg_targets && hm_targets && pos_inds && pos_count && coef3 && dhead && rows > 0 && head_ld >= 5 && dhead_ld >= 5,
+                  "ore_centernet_losses_bwd: bad args");
+    LossP p{};
+    p.head = head; p.head_ld = head_ld; p.reg_targets = reg_targets; p.hm_targets = hm_targets; p.rows = rows;
+    p.pos_inds = (const long long*)pos_inds; p.pos_count = pos_count;
+    p.gamma = gamma; p.beta = beta; p.clampv = sigmoid_clamp; p.ignore_high_fp = ignore_high_fp;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cn_loss_grad, dim3(ceil_div(rows, 256)), dim3(256), 0, st, p, coef3, dhead, dhead_ld);
+    int rc = ore_launch_status("k_cn_loss_grad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cn_loss_grad_pos, dim3(max(1, min(ceil_div(max_pos, 256), 64))), dim3(256), 0, st, p, coef3, dhead, dhead_ld);
+    return ore_launch_status("k_cn_loss_grad_pos");
 }

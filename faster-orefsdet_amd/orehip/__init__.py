@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -68,7 +68,8 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
-           "ore_roi_predict_fwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_sgd_step_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
+           "ore_roi_predict_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
+           "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
 
@@ -88,6 +89,7 @@ def lib() -> C.CDLL:
         L.ore_detect_workspace_bytes.restype = C.c_size_t
         L.ore_nms_workspace_bytes.restype = C.c_size_t
         L.ore_roi_predict_workspace_bytes.restype = C.c_size_t
+        L.ore_conv_wgrad_workspace_floats.restype = C.c_size_t
         L.ore_engine_last_flops.restype = C.c_double
         L.ore_engine_last_flops.argtypes = [C.c_void_p]
         L.ore_engine_destroy.argtypes = [C.c_void_p]
@@ -408,6 +410,28 @@ def roi_align(feats: Sequence[torch.Tensor], boxes: torch.Tensor, strides: Seque
     return out
 
 
+def roi_align_bwd(dout: torch.Tensor, feats_like: Sequence[torch.Tensor], boxes: torch.Tensor, strides=(8, 16, 32), min_level: int = 3,
+                  pooled: int = 8, dfeats: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+    """dout [n, pooled*pooled*C]; returns/accumulates into per-level gradient buffers shaped like feats_like ([H,W,ld] NHWC)."""
+    L = len(feats_like)
+    n = boxes.shape[0]
+    if dfeats is None:
+        dfeats = [torch.zeros_like(f) for f in feats_like]
+    Cc = dfeats[0].shape[-1]
+    assert dout.numel() == n * pooled * pooled * Cc
+    if n == 0:
+        return list(dfeats)
+    ptrs = (C.c_void_p * L)(*[_ptr(_f32(f)) for f in dfeats])
+    ld = (C.c_int32 * L)(*[f.shape[-1] for f in dfeats])
+    coff = (C.c_int32 * L)(*[0] * L)
+    Hs = (C.c_int32 * L)(*[f.shape[-3] for f in dfeats])
+    Ws = (C.c_int32 * L)(*[f.shape[-2] for f in dfeats])
+    sc = (C.c_float * L)(*[1.0 / s for s in strides])
+    _chk(lib().ore_roi_align_bwd(ptrs, ld, coff, Hs, Ws, sc, L, min_level, Cc, pooled, C.c_void_p(_ptr(_f32(boxes.float().contiguous()))),
+                                 n, C.c_void_p(_ptr(_f32(dout))), _stream()), "ore_roi_align_bwd")
+    return list(dfeats)
+
+
 def roi_predict(h: torch.Tensor, cls_w, cls_b, box_w, box_b, boxes: torch.Tensor, reg_weights, image_hw, score_thresh: float,
                 nms_thresh: float, topk: int, n_dev: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     cap, Cc = h.shape
@@ -470,6 +494,20 @@ def centernet_loss_sums(head: torch.Tensor, reg_targets: torch.Tensor, hm_target
     return out
 
 
+def centernet_loss_grad(head: torch.Tensor, reg_targets: torch.Tensor, hm_targets: torch.Tensor, pos_inds: torch.Tensor,
+                        pos_count: torch.Tensor, coef3: torch.Tensor, gamma: float = 2.0, beta: float = 4.0, sigmoid_clamp: float = 1e-4,
+                        ignore_high_fp: float = 0.85) -> torch.Tensor:
+    """d(losses)/d(head[:, :5]) for coef3 = [reg_w/reg_norm, pos_w*alpha/num_pos_avg, neg_w*(1-alpha)/num_pos_avg] (device)."""
+    rows, ld = head.shape
+    dhead = torch.zeros(rows, ld, device=head.device, dtype=torch.float32)
+    _chk(lib().ore_centernet_losses_bwd(C.c_void_p(_ptr(_f32(head))), ld, C.c_void_p(_ptr(_f32(reg_targets))),
+                                        C.c_void_p(_ptr(_f32(hm_targets))), rows, C.c_void_p(_ptr(pos_inds)), C.c_void_p(_ptr(pos_count)),
+                                        int(pos_inds.numel()), C.c_float(gamma), C.c_float(beta), C.c_float(sigmoid_clamp),
+                                        C.c_float(ignore_high_fp), C.c_void_p(_ptr(_f32(coef3))), C.c_void_p(_ptr(dhead)), ld, _stream()),
+         "ore_centernet_losses_bwd")
+    return dhead
+
+
 def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: torch.Tensor, chunk_lr: torch.Tensor, chunk_wd: torch.Tensor,
              lr_scale: float = 1.0, momentum: float = 0.9, clip_value: float = 1.0, grad_scale: float = 1.0,
              lr_scale_dev: Optional[torch.Tensor] = None) -> None:
@@ -482,6 +520,81 @@ def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: torch.Tens
                                 C.c_int64(n // 256), C.c_void_p(_ptr(chunk_lr)), C.c_void_p(_ptr(chunk_wd)),
                                 C.c_void_p(_ptr(lr_scale_dev)), C.c_float(lr_scale), C.c_float(momentum), C.c_float(clip_value),
                                 C.c_float(grad_scale), _stream()), "ore_sgd_step_fwd")
+
+
+def pack_conv_weight_dev(w_oihw: torch.Tensor, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device-side repack of OIHW master weights (runs every optimizer step): forward layout [Cout16][tap][Cin], or the
+    data-gradient layout [Cin16][flipped tap][Cout16]."""
+    w = _f32(w_oihw.detach())
+    co, ci, kh, kw = w.shape
+    co16, ci16 = (co + 15) // 16 * 16, (ci + 15) // 16 * 16
+    n = ci16 * kh * kw * co16 if dgrad else co16 * kh * kw * ci
+    if out is None:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    assert out.numel() == n
+    _chk(lib().ore_pack_conv_weight_fwd(C.c_void_p(_ptr(w)), co, ci, kh, kw, int(dgrad), C.c_void_p(_ptr(out)), _stream()),
+         "ore_pack_conv_weight_fwd")
+    return out
+
+
+_WGWS: Dict[str, torch.Tensor] = {}
+
+
+def _wgrad_ws(device, n: int) -> torch.Tensor:
+    k = str(device)
+    if k not in _WGWS or _WGWS[k].numel() < n:
+        _WGWS[k] = torch.empty(max(n, 16 << 20), device=device, dtype=torch.float32)
+    return _WGWS[k]
+
+
+def conv2d_wgrad(x: torch.Tensor, dz: torch.Tensor, k: int, *, x_coff: int = 0, Cin: Optional[int] = None, dz_coff: int = 0,
+                 Cout: Optional[int] = None, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    """x [B,H,W,x_ld], dz [B,H,W,dz_ld] NHWC -> dW [Cout,Cin,k,k] (OIHW); stride 1, pad k//2."""
+    _f32(x); _f32(dz)
+    B, H, W, xld = x.shape
+    dld = dz.shape[-1]
+    assert dz.shape[:3] == (B, H, W)
+    Cin = Cin if Cin is not None else xld - x_coff
+    Cout = Cout if Cout is not None else dld - dz_coff
+    if out is None:
+        out = torch.empty(Cout, Cin, k, k, device=x.device, dtype=torch.float32)
+        beta = 0.0
+    assert out.shape == (Cout, Cin, k, k) and out.is_contiguous()
+    n = lib().ore_conv_wgrad_workspace_floats(B * H * W, Cin, Cout, k, k)
+    ws = _wgrad_ws(x.device, n)
+    _chk(lib().ore_conv2d_wgrad_fwd(C.c_void_p(_ptr(x)), xld, x_coff, C.c_void_p(_ptr(dz)), dld, dz_coff, B, H, W, Cin, Cout, k, k,
+                                    k // 2, C.c_void_p(_ptr(out)), C.c_float(beta), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()),
+                                    _stream()), "ore_conv2d_wgrad_fwd")
+    return out
+
+
+def relu_affine_bwd(dy: torch.Tensor, y: torch.Tensor, scale: Optional[torch.Tensor] = None, *, dy_coff: int = 0, y_coff: int = 0,
+                    Cc: Optional[int] = None, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+    """dZ = dY * (Y > 0) * scale over channel slices of NHWC/row-major buffers (last dim = ld)."""
+    _f32(dy); _f32(y)
+    Cc = Cc if Cc is not None else y.shape[-1] - y_coff
+    rows = y.numel() // y.shape[-1]
+    if out is None:
+        out = torch.empty(*y.shape[:-1], Cc, device=y.device, dtype=torch.float32)
+    _chk(lib().ore_relu_affine_bwd(C.c_void_p(_ptr(dy)), dy.shape[-1], dy_coff, C.c_void_p(_ptr(y)), y.shape[-1], y_coff,
+                                   C.c_void_p(_ptr(scale)), C.c_int64(rows), Cc, C.c_void_p(_ptr(_f32(out))), out.shape[-1], out_coff,
+                                   _stream()), "ore_relu_affine_bwd")
+    return out
+
+
+def colsum(x: torch.Tensor, *, coff: int = 0, Cc: Optional[int] = None, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    """Bias gradient: sums over all leading dims of x[..., coff:coff+Cc]."""
+    _f32(x)
+    ld = x.shape[-1]
+    Cc = Cc if Cc is not None else ld - coff
+    rows = x.numel() // ld
+    if out is None:
+        out = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        beta = 0.0
+    ws = _wgrad_ws(x.device, ((rows + 63) // 64) * Cc)
+    _chk(lib().ore_colsum_fwd(C.c_void_p(_ptr(x)), ld, coff, C.c_int64(rows), Cc, C.c_float(beta), C.c_void_p(_ptr(out)),
+                              C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_colsum_fwd")
+    return out
 
 
 def compose_roi_head(sd, support_8: torch.Tensor, prefix: str = "roi_heads."):

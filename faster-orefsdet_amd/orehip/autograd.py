@@ -1,0 +1,215 @@
+"""torch.autograd bindings of the HIP forward/backward kernels.
+
+torch.autograd is used as the TAPE only: it records which kernels ran and replays their backward entry points in reverse
+order (what `losses.backward()` does in d2z:engine/train_loop.py:279).  Every FLOP-carrying node is a libore_hip.so call:
+    ConvFn      conv/linear (+ FrozenBN scale/shift or bias, + ReLU): ore_conv2d_fwd | ore_relu_affine_bwd, ore_conv2d_fwd with
+                the data-gradient weight layout, ore_conv2d_wgrad_fwd, ore_colsum_fwd
+    OSAFn       one whole OSA block over its concat buffer (d2z:modeling/backbone/vovnet.py:310-332): layers write channel
+                slices, the backward walks the slices of ONE gradient buffer (no torch.cat / split)
+    RoiAlignFn  ore_roi_align_fwd | ore_roi_align_bwd
+    CenterNetLossFn  ore_centernet_losses_fwd | ore_centernet_losses_bwd (normalisers stay on device)
+Weights are repacked on device (ore_pack_conv_weight_fwd) at most once per optimizer step and layout.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+import orehip
+
+_EPOCH = [0]
+_PACK = {}
+
+
+def weights_changed() -> None:
+    """Called by the optimizer after it rewrote the flat parameter bucket: packed copies are stale."""
+    _EPOCH[0] += 1
+
+
+def packed(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
+    key = (id(w), bool(dgrad))
+    tag = (_EPOCH[0], w.data_ptr(), w._version, tuple(w.shape))
+    e = _PACK.get(key)
+    if e is None or e[0] != tag:
+        buf = e[1] if e is not None and e[0][3] == tag[3] else None
+        _PACK[key] = (tag, orehip.pack_conv_weight_dev(w.detach().contiguous(), dgrad, out=buf))
+    return _PACK[key][1]
+
+
+def _c16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def _conv_backward(x, x_coff, Cin, weight, dz, k, need_x: bool, need_w: bool, need_b: bool):
+    """dz [B,H,W,Cout16] contiguous -> (dX [B,H,W,Cin] | None, dW | None, db | None)."""
+    Cout = weight.shape[0]
+    gx = gw = gb = None
+    if need_x:
+        gx = orehip.conv2d(dz, packed(weight, True), Cin, k, 1, k // 2)
+    if need_w:
+        gw = orehip.conv2d_wgrad(x, dz, k, x_coff=x_coff, Cin=Cin)[:Cout]
+    if need_b:
+        gb = orehip.colsum(dz)[:Cout]
+    return gx, gw, gb
+
+
+class ConvFn(Function):
+    """y = act(conv(x, W) * scale + shift) or act(conv(x, W) + bias);  x [B,H,W,Cin] NHWC, W OIHW, stride 1, pad k//2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, shift, relu: bool):
+        x = x.contiguous()
+        Cout, Cin, k, _ = weight.shape
+        co16 = _c16(Cout)
+        out = torch.empty(*x.shape[:3], co16, device=x.device, dtype=torch.float32) if co16 != Cout else None
+        sh = shift if shift is not None else (bias.detach().contiguous() if bias is not None else None)
+        if out is not None:
+            out.zero_()
+        y = orehip.conv2d(x, packed(weight, False), Cout, k, 1, k // 2, scale=scale, shift=sh, relu_cout=Cout if relu else 0, out=out)
+        ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.meta = (k, relu, bias is not None, Cout, Cin, co16)
+        return y if co16 == Cout else y[..., :Cout]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, scale, y = ctx.saved_tensors
+        k, relu, has_bias, Cout, Cin, co16 = ctx.meta
+        if co16 != Cout:
+            dz = torch.zeros(*dy.shape[:3], co16, device=dy.device, dtype=torch.float32)
+            dz[..., :Cout] = dy
+        else:
+            dz = dy.contiguous()
+        if relu:
+            dz = orehip.relu_affine_bwd(dz, y, scale)
+        elif scale is not None:
+            dz = dz * scale
+        gx, gw, gb = _conv_backward(x, 0, Cin, weight, dz, k, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                    has_bias and ctx.needs_input_grad[2])
+        return gx, gw, gb, None, None, None
+
+
+def conv(x, weight, bias=None, scale=None, shift=None, relu=False):
+    return ConvFn.apply(x, weight, bias, scale, shift, relu)
+
+
+def linear(x2d, weight, bias=None, relu=False):
+    """F.linear (+ReLU) on rows: x2d [N, in] -> [N, out]."""
+    N, cin = x2d.shape
+    y = ConvFn.apply(x2d.reshape(1, 1, N, cin), weight.reshape(weight.shape[0], cin, 1, 1), bias, None, None, relu)
+    return y.reshape(N, weight.shape[0])
+
+
+class OSAFn(Function):
+    """One OSA block up to (not including) eSE: n x [conv3x3 + FrozenBN + ReLU] chained through channel slices of one concat
+    buffer, then conv1x1 + FrozenBN + ReLU over the whole buffer.  args: x_in, then per layer (weight, scale, shift), then the
+    concat conv's (weight, scale, shift).  d2z:modeling/backbone/vovnet.py:310-332."""
+
+    @staticmethod
+    def forward(ctx, x_in, *args):
+        n = len(args) // 3 - 1
+        ws, scs, shs = args[0::3], args[1::3], args[2::3]
+        x_in = x_in.contiguous()
+        B, H, W, in_ch = x_in.shape
+        stage_ch = ws[0].shape[0]
+        cat_ch = in_ch + n * stage_ch
+        cat = torch.empty(B, H, W, cat_ch, device=x_in.device, dtype=torch.float32)
+        cat[..., :in_ch] = x_in
+        src, cin, dst = 0, in_ch, in_ch
+        for i in range(n):
+            orehip.conv2d(cat, packed(ws[i], False), stage_ch, 3, 1, 1, in_coff=src, Cin=cin, scale=scs[i], shift=shs[i],
+                          relu_cout=stage_ch, out=cat, out_coff=dst)
+            src, cin, dst = dst, stage_ch, dst + stage_ch
+        y = orehip.conv2d(cat, packed(ws[n], False), ws[n].shape[0], 1, 1, 0, scale=scs[n], shift=shs[n], relu_cout=ws[n].shape[0])
+        ctx.save_for_backward(cat, y, *ws, *scs)
+        ctx.meta = (n, in_ch, stage_ch)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, in_ch, stage_ch = ctx.meta
+        saved = ctx.saved_tensors
+        cat, y = saved[0], saved[1]
+        ws, scs = saved[2:2 + n + 1], saved[3 + n:3 + n + n + 1]
+        grads: List[Optional[torch.Tensor]] = [None] * (3 * (n + 1))
+        dz = orehip.relu_affine_bwd(dy.contiguous(), y, scs[n])
+        if ctx.needs_input_grad[1 + 3 * n]:
+            grads[3 * n] = orehip.conv2d_wgrad(cat, dz, 1)
+        dcat = orehip.conv2d(dz, packed(ws[n], True), cat.shape[-1], 1, 1, 0)          # gradient of every concat slice
+        for i in range(n - 1, -1, -1):
+            dst = in_ch + i * stage_ch
+            src, cin = (0, in_ch) if i == 0 else (dst - stage_ch, stage_ch)
+            dzi = orehip.relu_affine_bwd(dcat, cat, scs[i], dy_coff=dst, y_coff=dst, Cc=stage_ch)
+            if ctx.needs_input_grad[1 + 3 * i]:
+                grads[3 * i] = orehip.conv2d_wgrad(cat, dzi, 3, x_coff=src, Cin=cin)
+            if i > 0 or ctx.needs_input_grad[0]:
+                dcat[..., src:src + cin] += orehip.conv2d(dzi, packed(ws[i], True), cin, 3, 1, 1)
+        gx = dcat[..., :in_ch].contiguous() if ctx.needs_input_grad[0] else None
+        return (gx, *grads)
+
+
+def osa_block(x_in, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]):
+    flat = [t for tri in layers for t in tri]
+    return OSAFn.apply(x_in, *flat)
+
+
+class RoiAlignFn(Function):
+    """ROIPooler(8x8, ROIAlignV2, sampling_ratio 0) of ONE image's pyramid: feats[l] [H,W,C] NHWC -> [n, 64, C]."""
+
+    @staticmethod
+    def forward(ctx, boxes, strides, pooled, *feats):
+        feats = [f.contiguous() for f in feats]
+        out = orehip.roi_align(feats, boxes, strides=strides, pooled=pooled)
+        ctx.save_for_backward(boxes, *feats)
+        ctx.meta = (tuple(strides), pooled)
+        return out[:boxes.shape[0]]
+
+    @staticmethod
+    def backward(ctx, dout):
+        boxes, feats = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        strides, pooled = ctx.meta
+        d = orehip.roi_align_bwd(dout.contiguous(), feats, boxes, strides=strides, pooled=pooled)
+        return (None, None, None, *d)
+
+
+def roi_align(feats: Sequence[torch.Tensor], boxes: torch.Tensor, strides=(8, 16, 32), pooled: int = 8) -> torch.Tensor:
+    return RoiAlignFn.apply(boxes.detach().float().contiguous(), tuple(strides), pooled, *feats)
+
+
+class CenterNetLossFn(Function):
+    """head [rows, ld>=5] (cols 0..3 ltrb after Scale+ReLU, col 4 heatmap logit) -> [loss_loc, loss_agn_pos, loss_agn_neg]
+    (ref:fewx/modeling/fsod/fsod_rpn.py:702-779).  The two normalisers are summed over ranks on device."""
+
+    @staticmethod
+    def forward(ctx, head, reg_targets, hm_targets, pos_inds, pos_count, hp):
+        head = head.contiguous()
+        sums = orehip.centernet_loss_sums(head, reg_targets, hm_targets, pos_inds, pos_count, hp["gamma"], hp["beta"],
+                                          hp["sigmoid_clamp"], hp["ignore_high_fp"])
+        norm = torch.stack([sums[1], pos_count[0].to(torch.float32)])
+        world = 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            dist.all_reduce(norm)                                     # the only other exchange of the step: 2 scalars
+        norm = torch.clamp(norm / world, min=1.0)
+        coef = torch.stack([hp["reg_weight"] / norm[0], hp["pos_weight"] * hp["alpha"] / norm[1],
+                            hp["neg_weight"] * (1.0 - hp["alpha"]) / norm[1]])
+        ctx.save_for_backward(head, reg_targets, hm_targets, pos_inds, pos_count, coef)
+        ctx.hp = hp
+        return torch.stack([coef[0] * sums[0], -coef[1] * sums[2], -coef[2] * sums[3]])
+
+    @staticmethod
+    def backward(ctx, g):
+        head, reg_targets, hm_targets, pos_inds, pos_count, coef = ctx.saved_tensors
+        hp = ctx.hp
+        d = orehip.centernet_loss_grad(head, reg_targets, hm_targets, pos_inds, pos_count, (coef * g).contiguous(), hp["gamma"],
+                                       hp["beta"], hp["sigmoid_clamp"], hp["ignore_high_fp"])
+        return d, None, None, None, None, None
+
+
+CN_HP = dict(gamma=2.0, beta=4.0, sigmoid_clamp=1e-4, ignore_high_fp=0.85, alpha=0.25, pos_weight=0.5, neg_weight=0.5, reg_weight=1.0)
+
+
+def centernet_losses(head, reg_targets, hm_targets, pos_inds, pos_count, hp=None):
+    return CenterNetLossFn.apply(head, reg_targets, hm_targets, pos_inds, pos_count, hp or CN_HP)

@@ -192,6 +192,10 @@ int ore_roi_align_fwd(const float* const* feat, const int32_t* ld, const int32_t
  * (reg_weights4_host, clamp log(1000/16)); clip to (img_h, img_w); keep finite & score > score_thresh; NMS(nms_thresh);
  * keep[:topk].  ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:160-170, d2z:modeling/box_regression.py:77-115,
  * d2z:modeling/roi_heads/fast_rcnn.py:118-171.  det_src = index of the proposal each detection came from. */
+/* Backward of ore_roi_align_fwd: dfeat[l] += scatter of dout [n][pooled*pooled][C] (fp32 atomics; the caller zeroes dfeat). */
+int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                      const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                      const float* boxes, int32_t n, const float* dout, void* stream);
 size_t ore_roi_predict_workspace_bytes(int32_t cap);
 int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
                         const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
@@ -222,6 +226,13 @@ int ore_centernet_losses_fwd(const float* head, int32_t head_ld, const float* re
                              int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, float gamma, float beta,
                              float sigmoid_clamp, float ignore_high_fp, float* sums4, float* workspace, void* stream);
 
+/* Gradient of the three losses w.r.t. head columns 0..4 (written to dhead[rows][dhead_ld], columns 0..4; every row is written).
+ * coef3 (device) = { reg_weight/reg_norm, pos_weight*alpha/num_pos_avg, neg_weight*(1-alpha)/num_pos_avg } times the upstream
+ * gradient, so the normalisers (all-reduced over ranks, fsod_rpn.py:719-726,751-754) never visit the host. */
+int ore_centernet_losses_bwd(const float* head, int32_t head_ld, const float* reg_targets, const float* hm_targets,
+                             int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, int32_t max_pos, float gamma,
+                             float beta, float sigmoid_clamp, float ignore_high_fp, const float* coef3, float* dhead,
+                             int32_t dhead_ld, void* stream);
 /* One launch of value-clip + SGD over the flat parameter bucket (row a13):
  *   g = clamp(grad_scale*grad, -clip, clip) (clip <= 0: off); g += wd*p; buf = momentum*buf + g; p -= lr*buf
  * = torch.nn.utils.clip_grad_value_ + torch.optim.SGD.step as wired by ref:fewx/solver/build.py:18-60,110-139 and
@@ -232,6 +243,28 @@ int ore_centernet_losses_fwd(const float* head, int32_t head_ld, const float* re
 int ore_sgd_step_fwd(float* params, const float* grads, float* momentum_buf, int64_t n_chunks, const float* chunk_lr,
                      const float* chunk_wd, const float* lr_scale_dev, float lr_scale, float momentum, float clip_value,
                      float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ backward of trainable layers */
+/* What torch.autograd does for F.conv2d / F.linear / ReLU / FrozenBN inside `losses.backward()` (d2z:engine/train_loop.py:279;
+ * layers d2z:layers/wrappers.py:48-91, d2z:layers/batch_norm.py:44-66), as explicit entry points:
+ *   data gradient   = ore_conv2d_fwd over dZ with weights packed by ore_pack_conv_weight_fwd(dgrad=1)
+ *                     ([Cin16][flipped tap][Cout16]; the conv then has Cin' = Cout16, Cout' = Cin, same k / pad, stride 1)
+ *   weight gradient = ore_conv2d_wgrad_fwd (fp32 MFMA, rows split across blocks, slabs reduced in a fixed order)
+ *   bias gradient   = ore_colsum_fwd over dZ
+ *   epilogue        = ore_relu_affine_bwd: dZ = dY * (Y > 0) * scale[c]  (scale NULL = 1; in place allowed) */
+int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t dgrad,
+                             float* dst, void* stream);
+size_t ore_conv_wgrad_workspace_floats(int32_t rows, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw);
+/* dw_oihw[co][ci][ky][kx] = beta * dw_oihw + sum_{b,y,x} dz[b,y,x,co] * x[b,y+ky-pad,x+kx-pad,ci]   (stride 1, k = 2*pad+1).
+ * Cin, Cout, ld, coff multiples of 4. */
+int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff, const float* dz, int32_t dz_ld, int32_t dz_coff,
+                         int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t pad,
+                         float* dw_oihw, float beta, float* workspace, size_t workspace_floats, void* stream);
+int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_coff, const float* y, int32_t y_ld, int32_t y_coff,
+                        const float* scale, int64_t rows, int32_t C, float* dz, int32_t dz_ld, int32_t dz_coff, void* stream);
+/* out[c] = beta * out[c] + sum_rows x[row][coff + c]; workspace >= ceil(rows/64) * C floats. */
+int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, float beta, float* out,
+                   float* workspace, size_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------ engine ------------------- */
 /* Whole eval hot path for one model instance: owns packed weights and all
