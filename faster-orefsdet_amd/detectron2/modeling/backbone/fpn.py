@@ -53,6 +53,17 @@ class FPN(Backbone):
         _require_gpu(x, "FPN")
         feats = self.bottom_up(x)
         results, prev = [], None
+        if torch.is_grad_enabled() and any(p.requires_grad for c in self.lateral_convs + self.output_convs for p in c.parameters()):
+            from orehip import autograd as A
+            for idx, (lateral, output) in enumerate(zip(self.lateral_convs, self.output_convs)):
+                f = nhwc_view(feats[self.in_features[-idx - 1]])
+                lat = A.conv(f, lateral.weight, lateral.bias)
+                if prev is not None:                                       # F.interpolate(scale_factor=2, mode="nearest") + sum (fpn.py:136-141)
+                    up = prev.repeat_interleave(2, 1).repeat_interleave(2, 2)
+                    lat = lat + up[:, : lat.shape[1], : lat.shape[2]]
+                prev = lat
+                results.insert(0, A.conv(prev, output.weight, output.bias).permute(0, 3, 1, 2))
+            return dict(zip(self._out_features, results))
         for idx, (lateral, output) in enumerate(zip(self.lateral_convs, self.output_convs)):
             f = nhwc_view(feats[self.in_features[-idx - 1]])
             prev = lateral.forward_nhwc(f, add=prev)          # conv + bias (+ nearest2x(prev)) in one launch

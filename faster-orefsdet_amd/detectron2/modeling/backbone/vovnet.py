@@ -167,46 +167,87 @@ class VoVNet(Backbone):
         return self._stem_units[name]
 
     def forward(self, x):
+        """Frozen stages run as plain HIP launches; stages with trainable parameters (FREEZE_AT < stage) run through the autograd
+        bindings (orehip.autograd.OSAFn: forward + data/weight-gradient kernels) when gradients are enabled."""
         import orehip
         _require_gpu(x, "VoVNet")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("training through the HIP backbone is not built yet (round 1 covers the eval path)")
+        grad_on = torch.is_grad_enabled()
         outputs = {}
-        y = self.stem_hip(x)
-        y = self._unit("stem_2").hip(y)
-        first = getattr(self, "stage2").blocks()[0]
-        B, H, W, _ = y.shape
-        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        cat = torch.empty(B, Ho, Wo, first.cat_ch, device=x.device, dtype=torch.float32)
-        self._unit("stem_3").hip(y, out=cat, out_coff=0)
+        with torch.no_grad():
+            y = self.stem_hip(x)
+            y = self._unit("stem_2").hip(y)
+            first = getattr(self, "stage2").blocks()[0]
+            B, H, W, _ = y.shape
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            cat = torch.empty(B, Ho, Wo, first.cat_ch, device=x.device, dtype=torch.float32)
+            self._unit("stem_3").hip(y, out=cat, out_coff=0)
         if "stem" in self._out_features:
             outputs["stem"] = cat[..., : first.in_ch].permute(0, 3, 1, 2)
-        prev, gate = None, None
+        prev, gate, full = None, None, None      # prev = pre-gate block output (frozen path), full = gated output (train path)
         for name in self.stage_names:
             stage = getattr(self, name)
             blocks = stage.blocks()
-            for bi, blk in enumerate(blocks):
-                if prev is not None:
-                    if bi == 0 and stage.pool:
-                        pooled = orehip.maxpool3x3s2(prev, gate)          # gate folded: max commutes with the positive scale
-                        B, H, W, _ = pooled.shape
-                        cat = torch.empty(B, H, W, blk.cat_ch, device=x.device, dtype=torch.float32)
-                        cat[..., : blk.in_ch] = pooled
-                        ident = None
-                    else:
-                        full = orehip.scale_channels(prev, gate) if gate is not None else prev
-                        cat = torch.empty(*full.shape[:3], blk.cat_ch, device=x.device, dtype=torch.float32)
-                        cat[..., : blk.in_ch] = full
-                        ident = full
-                y, g = blk.hip(cat)
-                if blk.identity:
-                    y = orehip.scale_channels(y, g) + ident
-                    g = None
-                prev, gate = y, g
-            if name in self._out_features:
-                full = orehip.scale_channels(prev, gate) if gate is not None else prev
-                outputs[name] = full.permute(0, 3, 1, 2)
+            train = grad_on and any(p.requires_grad for p in stage.parameters())
+            if train:
+                full = self._stage_train(stage, blocks, cat if prev is None and full is None else None, prev, gate, full)
+                prev, gate = None, None
+                if name in self._out_features:
+                    outputs[name] = full.permute(0, 3, 1, 2)
+                continue
+            assert full is None, "a frozen stage after a trainable one is not a configuration of the reference (FREEZE_AT)"
+            with torch.no_grad():
+                for bi, blk in enumerate(blocks):
+                    if prev is not None:
+                        if bi == 0 and stage.pool:
+                            pooled = orehip.maxpool3x3s2(prev, gate)          # gate folded: max commutes with the positive scale
+                            B, H, W, _ = pooled.shape
+                            cat = torch.empty(B, H, W, blk.cat_ch, device=x.device, dtype=torch.float32)
+                            cat[..., : blk.in_ch] = pooled
+                            ident = None
+                        else:
+                            fullp = orehip.scale_channels(prev, gate) if gate is not None else prev
+                            cat = torch.empty(*fullp.shape[:3], blk.cat_ch, device=x.device, dtype=torch.float32)
+                            cat[..., : blk.in_ch] = fullp
+                            ident = fullp
+                    y, g = blk.hip(cat)
+                    if blk.identity:
+                        y = orehip.scale_channels(y, g) + ident
+                        g = None
+                    prev, gate = y, g
+                if name in self._out_features:
+                    fullp = orehip.scale_channels(prev, gate) if gate is not None else prev
+                    outputs[name] = fullp.permute(0, 3, 1, 2)
         return outputs
+
+    def _stage_train(self, stage, blocks, cat0, prev, gate, full):
+        """One trainable stage: max-pool, OSA blocks through OSAFn, eSE.  The input comes either from a frozen stage
+        (prev, gate: no gradient needed) or from the previous trainable stage (`full`, carries gradient)."""
+        import orehip
+        import torch.nn.functional as F
+        from orehip import autograd as A
+        for bi, blk in enumerate(blocks):
+            if bi == 0:
+                if full is not None:
+                    x_in = F.max_pool2d(full.permute(0, 3, 1, 2), 3, 2, ceil_mode=True).permute(0, 2, 3, 1).contiguous() if stage.pool else full
+                elif prev is not None:
+                    with torch.no_grad():
+                        x_in = orehip.maxpool3x3s2(prev, gate) if stage.pool else (orehip.scale_channels(prev, gate) if gate is not None else prev)
+                else:
+                    x_in = cat0[..., : blk.in_ch].contiguous()
+            else:
+                x_in = full
+            layers = []
+            for unit in list(blk.layers) + [blk.concat]:
+                conv, bn = unit.parts()
+                sc, sh = bn.scale_shift()
+                layers.append((conv.weight, sc.contiguous(), sh.contiguous()))
+            y = A.osa_block(x_in, layers)
+            C = y.shape[-1]
+            m = y.mean((1, 2))                                                                   # eSE (vovnet.py:238-260)
+            g = F.relu6(F.linear(m, blk.ese.fc.weight.view(C, C), blk.ese.fc.bias) + 3.0) / 6.0
+            out = y * g[:, None, None, :]
+            full = out + x_in if blk.identity else out
+        return full
 
 
 @BACKBONE_REGISTRY.register()

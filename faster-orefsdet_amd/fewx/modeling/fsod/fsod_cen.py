@@ -32,6 +32,10 @@ class MLP(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if x.is_cuda:                                   # the two Linears on the MFMA GEMM kernel (autograd bindings when training)
+            from orehip import autograd as A
+            h = self.drop(self.act(A.linear(x.contiguous(), self.fc1.weight, self.fc1.bias)))
+            return self.drop(A.linear(h.contiguous(), self.fc2.weight, self.fc2.bias))
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
@@ -59,8 +63,8 @@ class SM_Block(nn.Module):
 
     def forward(self, x):
         _require_gpu(x, "SM_Block")
-        if self.training:
-            raise NotImplementedError("SM_Block training (dropout + backward) is not built yet (round 1 covers the eval path)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(x)
         B, H, W, C = x.shape
         S = C // self.seg_dim
         h = x.reshape(B, H, W, self.seg_dim, S).permute(0, 3, 2, 1, 4).reshape(-1, H * S)
@@ -71,6 +75,25 @@ class SM_Block(nn.Module):
         a = self.reweighting(a).reshape(B, C, 2).permute(2, 0, 1).softmax(0).unsqueeze(2).unsqueeze(2)
         y = w * a[0] + h * a[1]
         return _hip_linear(y.reshape(-1, C), self.proj.weight, self.proj.bias).reshape(B, H, W, C)
+
+
+def _sm_block_train(self, x):
+    """Same arithmetic as the eval forward with the Linears going through orehip.autograd (forward, data- and weight-gradient
+    kernels); permutes / softmax / GELU / dropout stay torch tensor ops on the device (ref fsod_cen.py:584-630)."""
+    from orehip import autograd as A
+    B, H, W, C = x.shape
+    S = C // self.seg_dim
+    h = x.reshape(B, H, W, self.seg_dim, S).permute(0, 3, 2, 1, 4).reshape(-1, H * S)
+    h = A.linear(h, self.mlp_h.weight, self.mlp_h.bias).reshape(B, self.seg_dim, W, H, S).permute(0, 3, 2, 1, 4).reshape(B, H, W, C)
+    w = x.reshape(B, H, W, self.seg_dim, S).permute(0, 3, 1, 2, 4).reshape(-1, W * S)
+    w = A.linear(w, self.mlp_w.weight, self.mlp_w.bias).reshape(B, self.seg_dim, H, W, S).permute(0, 2, 3, 1, 4).reshape(B, H, W, C)
+    a = (h + w).permute(0, 3, 1, 2).flatten(2).mean(2)
+    a = self.reweighting(a).reshape(B, C, 2).permute(2, 0, 1).softmax(0).unsqueeze(2).unsqueeze(2)
+    y = w * a[0] + h * a[1]
+    return self.proj_drop(A.linear(y.reshape(-1, C), self.proj.weight, self.proj.bias).reshape(B, H, W, C))
+
+
+SM_Block._forward_train = _sm_block_train
 
 
 @META_ARCH_REGISTRY.register()
@@ -165,8 +188,17 @@ class CenterNet2Detector(nn.Module):
         if not self.training:
             self.init_model()
             return self.inference(batched_inputs)
-        raise NotImplementedError("CenterNet2Detector training step (SURVEY 8a rows a12/a13) is not built yet; "
-                                  "round 1 covers the eval hot path")
+        from .train_forward import train_forward
+        for x in batched_inputs:                                  # gt_classes forced to 0 (ref fsod_cen.py:158-159)
+            if "instances" in x and x["instances"].has("gt_classes"):
+                x["instances"].gt_classes = torch.zeros_like(x["instances"].gt_classes)
+        return train_forward(self, batched_inputs)
+
+    @staticmethod
+    def gradless_parameter_prefixes():
+        """Parameters of the reference's dead branches: they exist for checkpoint compatibility, never receive
+        a gradient, and therefore stay out of the gradient bucket / optimizer like `grad is None` parameters do in torch."""
+        return ("conv1.", "conv2.", "roi_heads.fc2.", "roi_heads.fc3.")
 
     @torch.no_grad()
     def inference_proposals(self, batched_inputs, use_graph=True):

@@ -34,6 +34,10 @@ class CustomCascadeROIHeads(nn.Module):
         self.test_nms_thresh = cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST
         self.test_topk = cfg.TEST.DETECTIONS_PER_IMAGE
         self.pooler_resolution, self.pooler_resolution2 = res, res2
+        self.batch_size_per_image = cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE
+        self.positive_fraction = cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION
+        self.iou_threshold = cfg.MODEL.ROI_BOX_CASCADE_HEAD.IOUS[0]
+        self.proposal_append_gt = cfg.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT
         self.bbox_reg_weights = tuple(cfg.MODEL.ROI_BOX_CASCADE_HEAD.BBOX_REG_WEIGHTS[0])
         heads, preds = [], []
         for _ in range(n_stage):
@@ -75,7 +79,8 @@ class CustomCascadeROIHeads(nn.Module):
         from detectron2.layers import nhwc_view
         from detectron2.structures import Boxes, Instances
         if self.training:
-            raise NotImplementedError("CustomCascadeROIHeads training (losses, sampling) is not built yet (SURVEY 8a rows a12/a13)")
+            raise NotImplementedError("in training the second stage runs inside fewx.modeling.fsod.train_forward.train_forward "
+                                      "(sampling, ROIAlign fwd/bwd, DSA mix, losses); call the detector")
         assert len(proposals) == 1 and len(self.box_head) == 1, "one image, one cascade stage (finetune_vovnet.yaml)"
         props = proposals[0]
         boxes = props.proposal_boxes.tensor

@@ -29,18 +29,20 @@ class CenterNet(nn.Module):
         self.only_proposal, self.with_agn_hm, self.not_nms = c.ONLY_PROPOSAL, c.WITH_AGN_HM, c.NOT_NMS
         if not (self.only_proposal and self.with_agn_hm) or self.not_nms or c.CENTER_NMS or c.MORE_POS:
             raise NotImplementedError("CenterNet: only ONLY_PROPOSAL + WITH_AGN_HM with NMS is built (finetune_vovnet.yaml)")
-        # training-side hyper-parameters (losses/targets are SURVEY 8a row a12, built after the eval path)
+        # training-side hyper-parameters (fewx/modeling/fsod/train_forward.py)
         self.hm_focal_alpha, self.hm_focal_beta, self.loss_gamma = c.HM_FOCAL_ALPHA, c.HM_FOCAL_BETA, c.LOSS_GAMMA
         self.reg_weight, self.not_norm_reg, self.pos_weight, self.neg_weight = c.REG_WEIGHT, c.NOT_NORM_REG, c.POS_WEIGHT, c.NEG_WEIGHT
         self.sigmoid_clamp, self.ignore_high_fp, self.min_radius = c.SIGMOID_CLAMP, c.IGNORE_HIGH_FP, c.MIN_RADIUS
         self.sizes_of_interest, self.no_reduce = c.SOI, c.NO_REDUCE
+        self.hm_min_overlap = c.HM_MIN_OVERLAP
         self.delta = (1 - c.HM_MIN_OVERLAP) / (1 + c.HM_MIN_OVERLAP)
         shapes = [input_shape[f] for f in self.in_features]
         self.centernet_head = CenterNetHead(**CenterNetHead.from_config(cfg, shapes))
 
     def forward(self, images, features_dict, gt_instances=None):
         if self.training:
-            raise NotImplementedError("CenterNet training targets/losses (SURVEY 8a row a12) are not built yet")
+            raise NotImplementedError("in training the proposal generator runs inside fewx.modeling.fsod.train_forward.train_forward "
+                                      "(head -> ore_centernet_targets_fwd / ore_centernet_losses_fwd -> proposals); call the detector")
         feats = [features_dict[f] for f in self.in_features]
         for f in feats:
             _require_gpu(f, "CenterNet")

@@ -1,0 +1,184 @@
+"""Training forward of CenterNet2Detector: returns the reference's loss dict with an autograd tape whose
+FLOP-carrying nodes are libore_hip.so kernels (orehip.autograd).
+
+Reference flow restated here (one query image + its support set per call; the reference trains with IMS_PER_BATCH = 1 per GPU):
+    ref:fewx/modeling/fsod/fsod_cen.py:151-308     CenterNet2Detector.forward, training branch
+    ref:fewx/modeling/fsod/fsod_rpn.py:644-700     CenterNet.forward: head -> targets -> 3 losses -> proposals (*_TRAIN thresholds)
+    d2z:modeling/roi_heads/roi_heads.py:181-295    label_and_sample_proposals (append gt, IoU matcher 0.6, 128 samples, <= 50 % fg)
+    ref:fewx/modeling/fsod/fsod_roi_heads.py:404-520  _forward_box / _run_stage (the second, live definition)
+    ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:52-81,131-157   losses
+What runs where: convs / linears (forward, data gradient, weight gradient), ROIAlign fwd/bwd, CenterNet targets + losses + their
+gradient, top-k / decode / NMS are HIP kernels.  Still torch tensor ops on the device this round (small, listed in DESIGN.md):
+the depthwise correlation and its gradient, GroupNorm, eSE gate, max-pool backward, SM_Block pointwise math, the two ROI losses.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from detectron2.layers import nhwc_view
+
+LEVELS = ("p3", "p4", "p5")
+
+
+def _normalise_pad(imgs: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, div: int) -> torch.Tensor:
+    """(x - mean) / std, then zero-pad bottom/right to a multiple of `div` (fsod_cen.py:540-551).  imgs [N,3,H,W]."""
+    x = (imgs.float() - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1)
+    H, W = x.shape[-2:]
+    return F.pad(x, (0, (W + div - 1) // div * div - W, 0, (H + div - 1) // div * div - H)).contiguous()
+
+
+def _correlation(q: torch.Tensor, proto: torch.Tensor) -> torch.Tensor:
+    """fsod_cen.py:229-245: q [1,C,H,W], proto [1,C,s,s] -> attn [1,C,H,W] (before conv3)."""
+    C = q.shape[1]
+    k11 = F.adaptive_avg_pool2d(proto, (1, 1)).permute(1, 0, 2, 3)
+    k13 = F.adaptive_avg_pool2d(proto, (1, 3)).permute(1, 0, 2, 3)
+    k31 = F.adaptive_avg_pool2d(proto, (3, 1)).permute(1, 0, 2, 3)
+    a = F.relu(F.conv2d(q, k11, padding=(0, 0), groups=C))
+    a = F.relu(F.conv2d(a, k11, padding=(0, 0), groups=C))
+    b = F.relu(F.conv2d(q, k13, padding=(0, 1), groups=C))
+    b = F.relu(F.conv2d(b, k31, padding=(1, 0), groups=C))
+    return a + b + q
+
+
+def pairwise_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """d2z:structures/boxes.py:286-310."""
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    wh = (torch.min(a[:, None, 2:], b[:, 2:]) - torch.max(a[:, None, :2], b[:, :2])).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return torch.where(inter > 0, inter / (area_a[:, None] + area_b - inter), torch.zeros(1, device=a.device))
+
+
+def get_deltas(src: torch.Tensor, tgt: torch.Tensor, weights) -> torch.Tensor:
+    """Box2BoxTransform.get_deltas (d2z:modeling/box_regression.py:41-75)."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+    tx, ty = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+    wx, wy, ww, wh = weights
+    return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), 1)
+
+
+def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
+    """CenterNetHead.forward with gradients: per level [1,H,W,128] -> [1,H,W,16] (0..3 ltrb after Scale+ReLU, 4 logit, rest 0).
+    ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:141-161."""
+    from orehip import autograd as A
+    tower, gn = head.bbox_tower[0], head.bbox_tower[1]
+    w5 = torch.cat([head.bbox_pred.weight, head.agn_hm.weight], 0)
+    b5 = torch.cat([head.bbox_pred.bias, head.agn_hm.bias], 0)
+    outs = []
+    for l, x in enumerate(feats_nhwc):
+        t = A.conv(x, tower.weight, tower.bias)
+        t = F.relu(F.group_norm(t.permute(0, 3, 1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)).permute(0, 2, 3, 1).contiguous()
+        o = A.conv(t, w5, b5)
+        reg = F.relu(o[..., :4] * head.scales[l].scale)
+        outs.append(torch.cat([reg, o[..., 4:5], torch.zeros(*o.shape[:3], 11, device=o.device)], -1))
+    return outs
+
+
+def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Tensor]] = None, return_aux: bool = False,
+                  roi_override: Optional[Dict[str, torch.Tensor]] = None):
+    """model: CenterNet2Detector in training mode.  batched_inputs[i]: image [3,H,W] (uint8/float BGR), instances (gt_boxes),
+    support_images [N,3,h,w], support_bboxes [N,4].  Returns the 5 losses (mean over the images of the call).
+    `perm(n)` replaces torch.randperm in the fg/bg subsampling; `roi_override` = {boxes, labels, gt} replaces the sampled set
+    altogether (parity tests pin the second stage on the oracle's sample so a 1-ulp heatmap difference cannot change the batch)."""
+    import orehip
+    from orehip import autograd as A
+    dev = model.device
+    pg, rh = model.proposal_generator, model.roi_heads
+    mean, std = model.pixel_mean.view(-1), model.pixel_std.view(-1)
+    div = model.backbone.size_divisibility
+    if perm is None:
+        perm = lambda n: torch.randperm(n, device=dev)          # noqa: E731  (subsample_labels, d2z:modeling/sampling.py:49-50)
+    acc: Dict[str, List[torch.Tensor]] = {}
+    aux = {}
+    for item in batched_inputs:
+        img = item["image"].to(dev)
+        H, W = img.shape[-2:]
+        inst = item["instances"]
+        gt_boxes = (inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes).to(dev).float()
+        sup = item["support_images"].to(dev)
+        sboxes = torch.as_tensor(item["support_bboxes"], dtype=torch.float32, device=dev)
+        assert sup.shape[0] == model.support_way * model.support_shot, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
+        assert model.support_way == 1
+        feats = model.backbone(_normalise_pad(img[None], mean, std, div))
+        sfeats = model.backbone(_normalise_pad(sup, mean, std, div))
+        # ---- support prototypes: avg-pool to 32/16/8, SM_Block, the reference's H<->W swapping permute, mean over shots
+        pos = []
+        for i, k in enumerate(LEVELS):
+            size = (32, 16, 8)[i]
+            sf = sfeats[k]
+            if sf.shape[-2:] != (size, size):
+                sf = F.adaptive_avg_pool2d(sf, (size, size))
+            v = getattr(model, f"vip_p{3 + i}")(nhwc_view(sf)).permute(0, 3, 2, 1)
+            proto = v.mean(0, True)
+            q = feats[k]
+            attn = _correlation(q, proto)
+            cat = torch.cat((attn, q), 1).permute(0, 2, 3, 1).contiguous()
+            pos.append(A.conv(cat, model.conv3.weight, model.conv3.bias, None, None, True))
+        # ---- CenterNet head, ground truth, losses
+        heads = head_train(pg.centernet_head, pos)
+        shapes = [tuple(h.shape[1:3]) for h in heads]
+        rows = torch.cat([h.reshape(-1, h.shape[-1]) for h in heads], 0)
+        tg = orehip.centernet_targets([gt_boxes], shapes, pg.strides, pg.sizes_of_interest, pg.hm_min_overlap, pg.min_radius, device=dev)
+        hp = dict(gamma=pg.loss_gamma, beta=pg.hm_focal_beta, sigmoid_clamp=pg.sigmoid_clamp, ignore_high_fp=pg.ignore_high_fp,
+                  alpha=pg.hm_focal_alpha, pos_weight=pg.pos_weight, neg_weight=pg.neg_weight, reg_weight=pg.reg_weight)
+        l3 = A.centernet_losses(rows, tg["reg_targets"], tg["hm_targets"], tg["pos_inds"], tg["pos_count"], hp)
+        # ---- proposals with the training thresholds; labels and samples (no gradient)
+        with torch.no_grad():
+            o = orehip.detect([h[0].detach().contiguous() for h in heads], pg.strides, pg.score_thresh, pg.pre_nms_topk_train,
+                              pg.nms_thresh_train, pg.post_nms_topk_train)
+            n = int(o["counts"][1].item())
+            proposals = o["out_boxes"][:n]
+            boxes = torch.cat([proposals, gt_boxes], 0)                                   # proposal_append_gt
+            if gt_boxes.shape[0]:
+                vals, midx = pairwise_iou(gt_boxes, boxes).max(0)
+                labels = torch.where(vals >= rh.iou_threshold, torch.zeros_like(midx), torch.ones_like(midx))
+            else:
+                midx = torch.zeros(len(boxes), dtype=torch.int64, device=dev)
+                labels = torch.ones(len(boxes), dtype=torch.int64, device=dev)
+            p_idx = torch.nonzero(labels == 0).squeeze(1)
+            n_idx = torch.nonzero(labels == 1).squeeze(1)
+            n_pos = min(p_idx.numel(), int(rh.batch_size_per_image * rh.positive_fraction))
+            n_neg = min(n_idx.numel(), rh.batch_size_per_image - n_pos)
+            sampled = torch.cat([p_idx[perm(p_idx.numel()).to(dev)[:n_pos]], n_idx[perm(n_idx.numel()).to(dev)[:n_neg]]], 0)
+            roi_boxes, roi_labels = boxes[sampled].contiguous(), labels[sampled]
+            roi_gt = gt_boxes[midx[sampled]] if gt_boxes.shape[0] else roi_boxes
+            if roi_override is not None:
+                roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
+                roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
+        # ---- second stage
+        qf = [nhwc_view(feats[k])[0] for k in LEVELS]
+        R = roi_boxes.shape[0]
+        C = qf[0].shape[-1]
+        P = rh.pooler_resolution
+        x = A.roi_align(qf, roi_boxes, pg.strides, P).reshape(R * P * P, C)                # rows ordered [roi][pos], channels last
+        sup8 = torch.cat([A.roi_align([nhwc_view(sfeats[k])[j] for k in LEVELS], sboxes[j:j + 1], pg.strides, P)
+                          for j in range(sup.shape[0])], 0)
+        s = sup8.mean(0, True).reshape(P * P, C)
+        s_exp = s.unsqueeze(0).expand(R, P * P, C).reshape(R * P * P, C)
+        a = A.linear(torch.cat((x, s_exp), 1), rh.conv3.weight.flatten(1), rh.conv3.bias) + \
+            torch.cat((A.linear(x, rh.conv1.weight.flatten(1), rh.conv1.bias),
+                       A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).unsqueeze(0).expand(R, P * P, C // 2).reshape(R * P * P, C // 2)), 1)
+        a = a.reshape(R, P * P, C).permute(0, 2, 1).reshape(R, C * P * P)                   # NCHW flatten order of fc1's weight
+        fc1 = rh.box_head[0].fc1
+        h = A.linear(a.contiguous(), fc1.weight, fc1.bias, True)
+        pr = rh.box_predictor[0]
+        scores = A.linear(h, pr.cls_score.weight, pr.cls_score.bias)
+        deltas = A.linear(h, pr.bbox_pred.weight, pr.bbox_pred.bias)
+        loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
+        fg = torch.nonzero(roi_labels == 0).squeeze(1)
+        tgt = get_deltas(roi_boxes[fg], roi_gt[fg], rh.bbox_reg_weights)
+        loss_box = (deltas[fg] - tgt).abs().sum() / max(roi_labels.numel(), 1)               # smooth_l1, beta = 0
+        for k, v in (("loss_cls_stage0", loss_cls), ("loss_box_reg_stage0", loss_box), ("loss_centernet_loc", l3[0]),
+                     ("loss_centernet_agn_pos", l3[1]), ("loss_centernet_agn_neg", l3[2])):
+            acc.setdefault(k, []).append(v)
+        if return_aux:
+            aux = dict(proposals=proposals, sampled=sampled, roi_boxes=roi_boxes, roi_labels=roi_labels, pos_inds=tg["pos_inds"],
+                       pos_count=tg["pos_count"], features=feats, pos_features=pos, heads=heads, scores=scores, deltas=deltas, h=h)
+    losses = {k: (v[0] if len(v) == 1 else torch.stack(v).mean()) for k, v in acc.items()}
+    return (losses, aux) if return_aux else losses

@@ -270,3 +270,79 @@ def test_centernet_loss_fn_backward(oh):
     _close(head.grad[:, :4], reg_pred.grad, tol=1e-5)
     _close(head.grad[:, 4], logit.grad, tol=1e-5)
     assert float(head.grad[:, 5:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the whole training iteration: CenterNet2Detector.forward (training) on the HIP kernels vs oracle/ref_train.py (torch CPU autograd)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _train_model(shots):
+    import os
+    from conftest import PKG
+    from fewx.config import get_cfg
+    from detectron2.modeling import build_model
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(PKG, "configs", "fsod", "finetune_vovnet.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "INPUT.FS.SUPPORT_SHOT", shots])
+    cfg.freeze()
+    torch.manual_seed(0)
+    m = build_model(cfg)
+    sd = R.synth_roi_state(R.synth_state_dict(0), 0)
+    sd["roi_heads.box_head.0.fc1.weight"] = sd["roi_heads.box_head.0.fc1.weight"] * 0.02
+    sd["proposal_generator.centernet_head.agn_hm.bias"] = torch.full((1,), -2.0)       # more candidates than the -4.6 init
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m.train()
+    for lvl in (3, 4, 5):
+        getattr(m, f"vip_p{lvl}").reweighting.drop.p = 0.0                             # the oracle has no dropout
+    return m, sd, cfg
+
+
+def test_train_iteration_losses_and_gradients_vs_oracle(oh):
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod.train_forward import train_forward
+    shots = 4
+    m, sd, cfg = _train_model(shots)
+    img, gt, sup, sbox = T.synth_train_inputs(0, (320, 384), n_gt=9, shots=shots, support_hw=112)
+    # ---- oracle
+    leaf = T.leaf_state(sd)
+    g = torch.Generator().manual_seed(11)
+    ref = T.train_iteration(leaf, img, gt, sup, sbox, lambda n: torch.randperm(n, generator=g))
+    sum(ref["losses"].values()).backward()
+    # ---- product
+    inst = Instances((320, 384))
+    inst.gt_boxes = Boxes(gt)
+    inst.gt_classes = torch.zeros(len(gt), dtype=torch.int64)
+    item = {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+    over = {"boxes": ref["roi_boxes"], "labels": ref["roi_labels"], "gt": ref["roi_gt"]}
+    losses, aux = train_forward(m, [item], return_aux=True, roi_override=over)
+    # proposals: same top-k / NMS kernels as the eval path, here with the *_TRAIN thresholds on the training head
+    pb, rb = aux["proposals"].cpu(), ref["proposals"]
+    assert abs(len(pb) - len(rb)) <= 2, (len(pb), len(rb))
+    d = (pb[:, None, :] - rb[None, :, :]).abs().amax(2).min(1)[0]       # order may swap on 1-ulp score ties: compare as sets
+    assert float((d < 1e-2).float().mean()) >= 0.99, float((d < 1e-2).float().mean())
+    assert int(aux["pos_count"].item()) == len(ref["pos_inds"])
+    assert torch.equal(aux["pos_inds"][: len(ref["pos_inds"])].cpu(), ref["pos_inds"])
+    for k, v in ref["losses"].items():
+        assert abs(float(losses[k].detach()) - float(v.detach())) <= 2e-4 * max(abs(float(v.detach())), 1e-3), (k, float(losses[k]), float(v))
+    sum(losses.values()).backward()
+    named = dict(m.named_parameters())
+    dead = set()
+    worst = []
+    for k, t in leaf.items():
+        if not t.requires_grad:
+            continue
+        p = named[k]
+        if t.grad is None:
+            dead.add(k)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        err = float((p.grad.cpu() - t.grad).abs().max())
+        scale = max(float(t.grad.abs().max()), 1e-8)
+        worst.append((err / scale, k))
+        assert err <= 2e-3 * scale, (k, err, scale)
+    assert dead == {"conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "roi_heads.fc2.weight", "roi_heads.fc2.bias",
+                    "roi_heads.fc3.weight", "roi_heads.fc3.bias"}
+    assert all(any(k.startswith(pre) for pre in m.gradless_parameter_prefixes()) for k in dead)
+    print("worst relative gradient errors:", sorted(worst)[-3:])
