@@ -1,0 +1,168 @@
+"""The slice of d2z:engine the reference's training script touches (ref:fsod_train_net.py:12-17,36-73,96-118), on the
+flat-bucket data-parallel step of fewx.solver:
+
+    SimpleTrainer.run_step   d2z:engine/train_loop.py:258-294   data -> model(data) -> sum(losses) -> zero_grad -> backward
+                             [gradient exchange overlapped] -> optimizer.step() (one fused clip+SGD launch)
+    create_ddp_model         d2z:engine/defaults.py:60-79       FlatDataParallel instead of DistributedDataParallel
+    DefaultTrainer           d2z:engine/defaults.py:300-560     build_model / build_optimizer / build_lr_scheduler / train()
+    launch                   d2z:engine/launch.py:24-83          one process per GPU, RCCL ("nccl") process group, 127.0.0.1
+Dataset registration, evaluators, hooks for periodic checkpoint/eval belong to the data/evaluation side.
+"""
+import argparse
+import logging
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from detectron2.utils import comm
+from detectron2.utils.events import EventStorage
+
+__all__ = ["SimpleTrainer", "DefaultTrainer", "create_ddp_model", "default_argument_parser", "default_setup", "launch"]
+
+
+def create_ddp_model(model, cfg=None, **kwargs):
+    if comm.get_world_size() == 1:
+        return model
+    from fewx.solver import FlatDataParallel
+    return FlatDataParallel(model, cfg, **kwargs)
+
+
+class SimpleTrainer:
+    def __init__(self, model, data_loader, optimizer):
+        model.train()
+        self.model, self.data_loader, self.optimizer = model, data_loader, optimizer
+        self._data_loader_iter = iter(data_loader)
+        self.iter = 0
+        self.storage = None
+        self.last_losses = None
+
+    def run_step(self):
+        assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        data = next(self._data_loader_iter)
+        data_time = time.perf_counter() - start
+        loss_dict = self.model(data)
+        losses = loss_dict if isinstance(loss_dict, torch.Tensor) else sum(loss_dict.values())
+        self.optimizer.zero_grad()
+        losses.backward()
+        self.last_losses = {k: v.detach() for k, v in loss_dict.items()} if not isinstance(loss_dict, torch.Tensor) else {"total_loss": losses.detach()}
+        self.last_data_time = data_time
+        self.optimizer.step()
+
+
+class DefaultTrainer(SimpleTrainer):
+    def __init__(self, cfg):
+        logging.getLogger("detectron2")
+        model = self.build_model(cfg)
+        model = create_ddp_model(model, cfg)
+        optimizer = self.build_optimizer(cfg, model)
+        data_loader = self.build_train_loader(cfg)
+        super().__init__(model, data_loader, optimizer)
+        self.scheduler = self.build_lr_scheduler(cfg, optimizer)
+        self.cfg = cfg
+        self.start_iter, self.max_iter = 0, cfg.SOLVER.MAX_ITER
+        from detectron2.checkpoint import DetectionCheckpointer
+        self.checkpointer = DetectionCheckpointer(model.module if hasattr(model, "module") else model, cfg.OUTPUT_DIR,
+                                                  optimizer=optimizer, scheduler=self.scheduler)
+
+    @classmethod
+    def build_model(cls, cfg):
+        from detectron2.modeling import build_model
+        return build_model(cfg)
+
+    @classmethod
+    def build_optimizer(cls, cfg, model):
+        from fewx.solver import build_optimizer
+        return build_optimizer(cfg, model)
+
+    @classmethod
+    def build_lr_scheduler(cls, cfg, optimizer):
+        from fewx.solver import build_lr_scheduler
+        return build_lr_scheduler(cfg, optimizer)
+
+    @classmethod
+    def build_train_loader(cls, cfg):
+        raise NotImplementedError("dataset loading (fewx.data.build / DatasetMapperWithSupport) is SURVEY 8f row 3; override "
+                                  "build_train_loader, e.g. with an iterator of synthetic batches (tools/bench_train.py)")
+
+    @classmethod
+    def build_test_loader(cls, cfg, dataset_name):
+        raise NotImplementedError("dataset loading is SURVEY 8f row 3")
+
+    @classmethod
+    def build_evaluator(cls, cfg, dataset_name, output_folder=None):
+        raise NotImplementedError("COCO evaluation is outside the hot path (SURVEY 8f)")
+
+    def resume_or_load(self, resume=True):
+        self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
+        if resume and self.checkpointer.has_checkpoint():
+            self.start_iter = self.scheduler.last_epoch
+
+    def train(self):
+        with EventStorage(self.start_iter) as self.storage:
+            for self.iter in range(self.start_iter, self.max_iter):
+                self.run_step()
+                self.scheduler.step()
+                period = self.cfg.SOLVER.CHECKPOINT_PERIOD
+                if comm.is_main_process() and period > 0 and (self.iter + 1) % period == 0:
+                    self.checkpointer.save("model_{:07d}".format(self.iter), iteration=self.iter)
+            if comm.is_main_process():
+                self.checkpointer.save("model_final", iteration=self.max_iter - 1)
+
+
+def default_argument_parser(epilog=None):
+    """d2z:engine/defaults.py:82-127 (same flags)."""
+    p = argparse.ArgumentParser(epilog=epilog, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--config-file", default="", metavar="FILE")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--eval-only", action="store_true")
+    p.add_argument("--num-gpus", type=int, default=1)
+    p.add_argument("--num-machines", type=int, default=1)
+    p.add_argument("--machine-rank", type=int, default=0)
+    port = 2 ** 15 + 2 ** 14 + hash(os.getuid() if hasattr(os, "getuid") else 1) % 2 ** 14
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:{}".format(port))
+    p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
+    return p
+
+
+def default_setup(cfg, args):
+    """d2z:engine/defaults.py:130-178: output dir, logger, seed, config dump."""
+    from detectron2.utils.env import seed_all_rng
+    from detectron2.utils.logger import setup_logger
+    out = cfg.OUTPUT_DIR
+    if comm.is_main_process() and out:
+        os.makedirs(out, exist_ok=True)
+    setup_logger(out, distributed_rank=comm.get_rank())
+    seed_all_rng(None if cfg.SEED < 0 else cfg.SEED + comm.get_rank())
+    if comm.is_main_process() and out:
+        with open(os.path.join(out, "config.yaml"), "w") as f:
+            f.write(cfg.dump())
+
+
+def _worker(local_rank, main_func, world, gpus_per_machine, machine_rank, dist_url, args):
+    assert torch.cuda.is_available(), "training runs on the MI355X only"
+    rank = machine_rank * gpus_per_machine + local_rank
+    os.environ.setdefault("LOCAL_RANK", str(local_rank))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", init_method=dist_url, world_size=world, rank=rank)      # "nccl" is RCCL on ROCm
+    try:
+        comm.synchronize()
+        main_func(*args)
+    finally:
+        dist.destroy_process_group()
+
+
+def launch(main_func, num_gpus_per_machine, num_machines=1, machine_rank=0, dist_url=None, args=()):
+    """One process per GPU (d2z:engine/launch.py:24-83)."""
+    world = num_machines * num_gpus_per_machine
+    if world <= 1:
+        return main_func(*args)
+    import torch.multiprocessing as mp
+    if dist_url in (None, "auto"):
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        dist_url = "tcp://127.0.0.1:{}".format(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_worker, nprocs=num_gpus_per_machine, args=(main_func, world, num_gpus_per_machine, machine_rank, dist_url, args), daemon=False)

@@ -235,8 +235,10 @@ class FlatSGD:
             self._apply(b, self.lr_factor, self.momentum, self.clip_value, scale)
             return
         import orehip
+        from orehip import autograd as A
         orehip.sgd_step(b.params, b.grads, b.momentum, b.chunk_lr, b.chunk_wd, lr_scale=self.lr_factor, momentum=self.momentum,
                         clip_value=self.clip_value, grad_scale=scale)
+        A.weights_changed()                         # packed weight layouts are rebuilt lazily by the next forward
 
     def state_dict(self) -> Dict:
         return {"momentum": self.bucket.momentum.detach().cpu(), "names": list(self.bucket.names), "lr_factor": self.lr_factor}

@@ -346,3 +346,52 @@ def test_train_iteration_losses_and_gradients_vs_oracle(oh):
                     "roi_heads.fc3.weight", "roi_heads.fc3.bias"}
     assert all(any(k.startswith(pre) for pre in m.gradless_parameter_prefixes()) for k in dead)
     print("worst relative gradient errors:", sorted(worst)[-3:])
+
+
+def test_train_step_updates_match_oracle_sgd(oh):
+    """fwd + bwd + flat-bucket clip/SGD (one process): parameter deltas after one step equal clip_grad_value_ + torch.optim.SGD on
+    the oracle's gradients with the reference's parameter groups; dead-branch parameters do not move."""
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod.train_forward import train_forward
+    from fewx.solver import build_optimizer, param_groups_like_reference
+    shots = 4
+    m, sd, cfg = _train_model(shots)
+    img, gt, sup, sbox = T.synth_train_inputs(1, (256, 320), n_gt=7, shots=shots, support_hw=96)
+    leaf = T.leaf_state(sd)
+    g = torch.Generator().manual_seed(3)
+    ref = T.train_iteration(leaf, img, gt, sup, sbox, lambda n: torch.randperm(n, generator=g))
+    sum(ref["losses"].values()).backward()
+    groups = {n: (lr, wd) for n, _, lr, wd in param_groups_like_reference(cfg, m)}
+    live = [k for k, t in leaf.items() if t.requires_grad and t.grad is not None]
+    ropt = torch.optim.SGD([{"params": [leaf[k]], "lr": groups[k][0], "weight_decay": groups[k][1]} for k in live], cfg.SOLVER.BASE_LR,
+                           momentum=cfg.SOLVER.MOMENTUM)
+    before = {k: leaf[k].detach().clone() for k in leaf}
+    torch.nn.utils.clip_grad_value_([leaf[k] for k in live], cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE)
+    ropt.step()
+    opt = build_optimizer(cfg, m)
+    assert sorted(opt.bucket.names) == sorted(live)                      # the bucket holds exactly the parameters that get gradients
+    assert 4 * sum(opt.bucket.numels) == 4 * 4086478                      # 16.3 MB exchanged per step (SURVEY 8e)
+    inst = Instances((256, 320))
+    inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+    item = {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+    over = {"boxes": ref["roi_boxes"], "labels": ref["roi_labels"], "gt": ref["roi_gt"]}
+    losses = train_forward(m, [item], roi_override=over)
+    opt.zero_grad()
+    sum(losses.values()).backward()
+    opt.step()
+    named = dict(m.named_parameters())
+    for k in leaf:
+        if k not in named:
+            continue
+        d_ref = leaf[k].detach() - before[k]
+        d_got = named[k].detach().cpu() - before[k]
+        if k in live:
+            assert float(d_ref.abs().max()) > 0
+            ulp = 1.2e-7 * float(before[k].abs().max())                 # the update is rounded into the fp32 parameter
+            assert float((d_got - d_ref).abs().max()) <= 2e-3 * float(d_ref.abs().max()) + 2 * ulp + 1e-9, k
+        else:
+            assert float(d_got.abs().max()) == 0.0, k
+    # a second forward sees the updated weights (packed layouts are rebuilt after the step)
+    l2 = train_forward(m, [item], roi_override=over)
+    assert abs(float(sum(l2.values()).detach()) - float(sum(losses.values()).detach())) > 0
