@@ -167,6 +167,116 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
     out[c] = beta != 0.0f ? beta * out[c] + s : s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Depthwise support correlation with gradients (ref:fewx/modeling/fsod/fsod_cen.py:229-245, training branch):
+//   a2 = relu(k11 * relu(k11 * q));  t = relu(conv1x3(q, k13));  u = conv3x1(t, k31);  attn = a2 + relu(u) + q
+// Forward (training) writes [attn | q] into the 2C-wide input of conv3 and keeps t, u.  Backward in two passes so that every
+// neighbourhood is a 3-tap read: pass A: dT = [t>0] * conv3x1^T(dU), per-row products for dk31; pass B: dq and the per-row products
+// for dk13 / dk11.  The per-row products are then column-summed (ore_colsum_fwd) -- deterministic.
+struct CorrT {
+    const float* q; int q_ld, q_coff;
+    int H, W, C4, rows;
+    const float* k11; const float* k13; const float* k31;   // [C], [C][3], [C][3]
+};
+__device__ __forceinline__ f32x4 relu4b(f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
+__device__ __forceinline__ f32x4 gt0(f32x4 v, f32x4 g) { return f32x4{v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f}; }
+__device__ __forceinline__ void ld3(const float* k, int c, f32x4* w) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w[j] = f32x4{k[(c + 0) * 3 + j], k[(c + 1) * 3 + j], k[(c + 2) * 3 + j], k[(c + 3) * 3 + j]};
+}
+
+__global__ __launch_bounds__(256) void k_corr_fwd_train(CorrT p, float* __restrict__ cat, float* __restrict__ T, float* __restrict__ U) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.rows * p.C4) return;
+    const int c = (idx % p.C4) * 4, row = idx / p.C4;
+    const int C = p.C4 * 4, H = p.H, W = p.W;
+    const int b = row / (H * W), rr = row - b * H * W, y = rr / W, x = rr - y * W, base = b * H * W;
+    const f32x4 w11 = *reinterpret_cast<const f32x4*>(p.k11 + c);
+    f32x4 w13[3], w31[3];
+    ld3(p.k13, c, w13); ld3(p.k31, c, w31);
+    auto Q = [&](int yy, int xx) -> f32x4 {
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+            return *reinterpret_cast<const f32x4*>(p.q + (size_t)(base + yy * W + xx) * p.q_ld + p.q_coff + c);
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    const f32x4 qc = Q(y, x);
+    const f32x4 a = relu4b(w11 * relu4b(w11 * qc));
+    f32x4 u = {0.f, 0.f, 0.f, 0.f}, tc = u;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy < (unsigned)H) {
+            const f32x4 t = relu4b(w13[0] * Q(yy, x - 1) + w13[1] * (dy == 0 ? qc : Q(yy, x)) + w13[2] * Q(yy, x + 1));
+            u += w31[dy + 1] * t;
+            if (dy == 0) tc = t;
+        }
+    }
+    *reinterpret_cast<f32x4*>(cat + (size_t)row * 2 * C + c) = a + relu4b(u) + qc;
+    *reinterpret_cast<f32x4*>(cat + (size_t)row * 2 * C + C + c) = qc;
+    *reinterpret_cast<f32x4*>(T + (size_t)row * C + c) = tc;
+    *reinterpret_cast<f32x4*>(U + (size_t)row * C + c) = u;
+}
+
+// g = dcat[..., :C] (row stride 2C)
+__global__ __launch_bounds__(256) void k_corr_bwd_a(CorrT p, const float* __restrict__ dcat, const float* __restrict__ T,
+                                                    const float* __restrict__ U, float* __restrict__ DT, float* __restrict__ P31) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.rows * p.C4) return;
+    const int c = (idx % p.C4) * 4, row = idx / p.C4;
+    const int C = p.C4 * 4, H = p.H, W = p.W;
+    const int rr = row % (H * W), y = rr / W;
+    f32x4 w31[3];
+    ld3(p.k31, c, w31);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    auto DU = [&](int dy) -> f32x4 {                                    // dU at (y+dy, x)
+        if ((unsigned)(y + dy) >= (unsigned)H) return z;
+        const size_t r2 = (size_t)(row + dy * W);
+        return gt0(*reinterpret_cast<const f32x4*>(U + r2 * C + c), *reinterpret_cast<const f32x4*>(dcat + r2 * 2 * C + c));
+    };
+    auto TT = [&](int dy) -> f32x4 {
+        if ((unsigned)(y + dy) >= (unsigned)H) return z;
+        return *reinterpret_cast<const f32x4*>(T + (size_t)(row + dy * W) * C + c);
+    };
+    const f32x4 du0 = DU(0), tc = TT(0);
+    const f32x4 dt = w31[0] * DU(1) + w31[1] * du0 + w31[2] * DU(-1);
+    *reinterpret_cast<f32x4*>(DT + (size_t)row * C + c) = gt0(tc, dt);
+    *reinterpret_cast<f32x4*>(P31 + (size_t)row * 3 * C + 0 * C + c) = du0 * TT(-1);
+    *reinterpret_cast<f32x4*>(P31 + (size_t)row * 3 * C + 1 * C + c) = du0 * tc;
+    *reinterpret_cast<f32x4*>(P31 + (size_t)row * 3 * C + 2 * C + c) = du0 * TT(1);
+}
+
+__global__ __launch_bounds__(256) void k_corr_bwd_b(CorrT p, const float* __restrict__ dcat, const float* __restrict__ DT,
+                                                    float* __restrict__ dq, float* __restrict__ P13, float* __restrict__ P11) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.rows * p.C4) return;
+    const int c = (idx % p.C4) * 4, row = idx / p.C4;
+    const int C = p.C4 * 4, W = p.W;
+    const int x = row % W;
+    const f32x4 w11 = *reinterpret_cast<const f32x4*>(p.k11 + c);
+    f32x4 w13[3];
+    ld3(p.k13, c, w13);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    auto Qx = [&](int dx) -> f32x4 {
+        if ((unsigned)(x + dx) >= (unsigned)W) return z;
+        return *reinterpret_cast<const f32x4*>(p.q + (size_t)(row + dx) * p.q_ld + p.q_coff + c);
+    };
+    auto D = [&](int dx) -> f32x4 {
+        if ((unsigned)(x + dx) >= (unsigned)W) return z;
+        return *reinterpret_cast<const f32x4*>(DT + (size_t)(row + dx) * C + c);
+    };
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dcat + (size_t)row * 2 * C + c);
+    const f32x4 g2 = *reinterpret_cast<const f32x4*>(dcat + (size_t)row * 2 * C + C + c);
+    const f32x4 qc = Qx(0), dtc = D(0);
+    const f32x4 s1 = w11 * qc, a1 = relu4b(s1);
+    const f32x4 da2 = gt0(w11 * a1, g);
+    const f32x4 da1 = gt0(s1, da2 * w11);
+    *reinterpret_cast<f32x4*>(P11 + (size_t)row * C + c) = da2 * a1 + da1 * qc;
+    *reinterpret_cast<f32x4*>(dq + (size_t)row * C + c) = g + g2 + da1 * w11 + w13[0] * D(1) + w13[1] * dtc + w13[2] * D(-1);
+    *reinterpret_cast<f32x4*>(P13 + (size_t)row * 3 * C + 0 * C + c) = dtc * Qx(-1);
+    *reinterpret_cast<f32x4*>(P13 + (size_t)row * 3 * C + 1 * C + c) = dtc * qc;
+    *reinterpret_cast<f32x4*>(P13 + (size_t)row * 3 * C + 2 * C + c) = dtc * Qx(1);
+}
+
 }  // namespace
 
 extern "C" int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t dgrad,
@@ -237,4 +347,48 @@ extern "C" int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t 
     if (rc) return rc;
     hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(C, 256)), dim3(256), 0, st, workspace, (int)nchunks, C, beta, out);
     return ore_launch_status("k_colsum_final");
+}
+
+static int corr_fill(CorrT& p, const float* q, int q_ld, int q_coff, int B, int H, int W, int C, const float* k11, const float* k13,
+                     const float* k31) {
+    p.q = q; p.q_ld = q_ld; p.q_coff = q_coff; p.H = H; p.W = W; p.C4 = C / 4; p.rows = B * H * W;
+    p.k11 = k11; p.k13 = k13; p.k31 = k31;
+    return ceil_div(p.rows * p.C4, 256);
+}
+
+extern "C" int ore_correlation_train_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                                         const float* k11, const float* k13, const float* k31, float* cat2c, float* t_save,
+                                         float* u_save, void* stream) {
+    ORE_CHECK_ARG(q && k11 && k13 && k31 && cat2c && t_save && u_save && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && q_ld % 4 == 0 &&
+                  q_coff % 4 == 0, "ore_correlation_train_fwd: bad args");
+    CorrT p{};
+    const int nb = corr_fill(p, q, q_ld, q_coff, B, H, W, C, k11, k13, k31);
+    hipLaunchKernelGGL(k_corr_fwd_train, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, cat2c, t_save, u_save);
+    return ore_launch_status("k_corr_fwd_train");
+}
+
+extern "C" int ore_correlation_train_bwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                                         const float* k11, const float* k13, const float* k31, const float* dcat2c,
+                                         const float* t_save, const float* u_save, float* dq, float* dk11, float* dk13_3c,
+                                         float* dk31_3c, float* workspace, size_t workspace_floats, void* stream) {
+    ORE_CHECK_ARG(q && k11 && k13 && k31 && dcat2c && t_save && u_save && dq && dk11 && dk13_3c && dk31_3c && workspace && B > 0 && H > 0 &&
+                  W > 0 && C > 0 && C % 4 == 0 && q_ld % 4 == 0 && q_coff % 4 == 0, "ore_correlation_train_bwd: bad args");
+    const size_t rows = (size_t)B * H * W;
+    const size_t need = rows * C * 8 + ((rows + 63) / 64) * 3 * C;
+    if (workspace_floats < need) { ore_set_error("ore_correlation_train_bwd: workspace %zu < %zu floats", workspace_floats, need); return ORE_ENOMEM; }
+    float* DT = workspace; float* P31 = DT + rows * C; float* P13 = P31 + rows * 3 * C; float* P11 = P13 + rows * 3 * C;
+    float* cs = P11 + rows * C;
+    const size_t cs_floats = workspace_floats - rows * C * 8;
+    CorrT p{};
+    const int nb = corr_fill(p, q, q_ld, q_coff, B, H, W, C, k11, k13, k31);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_corr_bwd_a, dim3(nb), dim3(256), 0, st, p, dcat2c, t_save, u_save, DT, P31);
+    int rc = ore_launch_status("k_corr_bwd_a");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_corr_bwd_b, dim3(nb), dim3(256), 0, st, p, dcat2c, DT, dq, P13, P11);
+    rc = ore_launch_status("k_corr_bwd_b");
+    if (rc) return rc;
+    if ((rc = ore_colsum_fwd(P11, C, 0, (int64_t)rows, C, 0.f, dk11, cs, cs_floats, stream))) return rc;
+    if ((rc = ore_colsum_fwd(P13, 3 * C, 0, (int64_t)rows, 3 * C, 0.f, dk13_3c, cs, cs_floats, stream))) return rc;
+    return ore_colsum_fwd(P31, 3 * C, 0, (int64_t)rows, 3 * C, 0.f, dk31_3c, cs, cs_floats, stream);
 }

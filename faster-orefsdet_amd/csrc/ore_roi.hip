@@ -39,6 +39,7 @@ struct RoiP {
     float canonical_size; int canonical_level;
     const float* boxes; const int* n_ptr; int n_host; int cap;
     float* out;
+    const int* bidx;      // optional image index per box (features are [B][H][W][ld]); NULL = one image
 };
 
 __device__ __forceinline__ f32x4 bilinear4(const float* f, int ld, int H, int W, float y, float x, int c) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
     const int l = (int)lv - p.min_level;
     const float sc = p.scale[l];
     const int H = p.H[l], W = p.W[l], ld = p.ld[l];
-    const float* f = p.feat[l] + p.coff[l];
+    const float* f = p.feat[l] + p.coff[l] + (p.bidx ? (size_t)p.bidx[r] * H * W * ld : 0);
     const float x0 = b.x * sc - 0.5f, y0 = b.y * sc - 0.5f, x1 = b.z * sc - 0.5f, y1 = b.w * sc - 0.5f;
     const float rw = x1 - x0, rh = y1 - y0;
     const float bw = rw / (float)P, bh = rh / (float)P;
@@ -123,6 +124,7 @@ struct RoiBwdP {
     float canonical_size; int canonical_level;
     const float* boxes; int n;
     const float* dout;
+    const int* bidx;
 };
 
 __global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p) {
     const int l = (int)lv - p.min_level;
     const float sc = p.scale[l];
     const int H = p.H[l], W = p.W[l], ld = p.ld[l];
-    float* f = p.dfeat[l] + p.coff[l];
+    float* f = p.dfeat[l] + p.coff[l] + (p.bidx ? (size_t)p.bidx[r] * H * W * ld : 0);
     const float x0 = b.x * sc - 0.5f, y0 = b.y * sc - 0.5f, x1 = b.z * sc - 0.5f, y1 = b.w * sc - 0.5f;
     const float rw = x1 - x0, rh = y1 - y0;
     const float bw = rw / (float)P, bh = rh / (float)P;
@@ -265,9 +267,28 @@ __global__ __launch_bounds__(256) void k_roi_finalize(const long long* __restric
 extern "C" int ore_nms_device_n_fwd(const float* boxes, const float* scores, const int32_t* n_dev, int32_t cap, float thr,
                                     int64_t* keep_idx, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
 
+static int roi_align_fwd_impl(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                              const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                              const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream,
+                              const int32_t* box_image);
+
 extern "C" int ore_roi_align_fwd(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                                  const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
                                  const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream) {
+    return roi_align_fwd_impl(feat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, n_dev, n_host, cap, out, stream, nullptr);
+}
+
+extern "C" int ore_roi_align_batched_fwd(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                                         const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                                         const float* boxes, const int32_t* box_image, int32_t n, float* out, void* stream) {
+    ORE_CHECK_ARG(box_image, "ore_roi_align_batched_fwd: null box_image");
+    return roi_align_fwd_impl(feat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, nullptr, n, n, out, stream, box_image);
+}
+
+static int roi_align_fwd_impl(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                              const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                              const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream,
+                              const int32_t* box_image) {
     ORE_CHECK_ARG(feat && ld && coff && H && W && scales_host && boxes && out, "ore_roi_align_fwd: null pointer");
     ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && C % 4 == 0 && pooled >= 1 && pooled <= 16 && cap >= 1, "ore_roi_align_fwd: bad args");
     RoiP p{};
@@ -277,7 +298,7 @@ extern "C" int ore_roi_align_fwd(const float* const* feat, const int32_t* ld, co
     }
     p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
     p.canonical_size = 224.0f; p.canonical_level = 4;      // ROIPooler defaults (poolers.py:96-97)
-    p.boxes = boxes; p.n_ptr = n_dev; p.n_host = n_host; p.cap = cap; p.out = out;
+    p.boxes = boxes; p.n_ptr = n_dev; p.n_host = n_host; p.cap = cap; p.out = out; p.bidx = box_image;
     hipLaunchKernelGGL(k_roi_align, dim3(cap), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_roi_align");
 }
@@ -336,7 +357,7 @@ extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w
 
 extern "C" int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                                  const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
-                                 const float* boxes, int32_t n, const float* dout, void* stream) {
+                                 const float* boxes, const int32_t* box_image, int32_t n, const float* dout, void* stream) {
     ORE_CHECK_ARG(dfeat && ld && coff && H && W && scales_host && boxes && dout, "ore_roi_align_bwd: null pointer");
     ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && C % 4 == 0 && pooled >= 1 && pooled <= 16 && n >= 1, "ore_roi_align_bwd: bad args");
     RoiBwdP p{};
@@ -346,7 +367,7 @@ extern "C" int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const i
     }
     p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
     p.canonical_size = 224.0f; p.canonical_level = 4;
-    p.boxes = boxes; p.n = n; p.dout = dout;
+    p.boxes = boxes; p.n = n; p.dout = dout; p.bidx = box_image;
     hipLaunchKernelGGL(k_roi_align_bwd, dim3(n), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_roi_align_bwd");
 }

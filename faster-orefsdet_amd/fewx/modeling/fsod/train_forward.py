@@ -8,8 +8,8 @@ Reference flow restated here (one query image + its support set per call; the re
     ref:fewx/modeling/fsod/fsod_roi_heads.py:404-520  _forward_box / _run_stage (the second, live definition)
     ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:52-81,131-157   losses
 What runs where: convs / linears (forward, data gradient, weight gradient), ROIAlign fwd/bwd, CenterNet targets + losses + their
-gradient, top-k / decode / NMS are HIP kernels.  Still torch tensor ops on the device this round (small, listed in DESIGN.md):
-the depthwise correlation and its gradient, GroupNorm, eSE gate, max-pool backward, SM_Block pointwise math, the two ROI losses.
+gradient, the depthwise correlation fwd/bwd, top-k / decode / NMS are HIP kernels.  Still torch tensor ops on the device this round (small, listed in DESIGN.md):
+GroupNorm, eSE gate, max-pool backward, SM_Block pointwise math, the two ROI losses.
 """
 from __future__ import annotations
 
@@ -116,9 +116,10 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
                 sf = F.adaptive_avg_pool2d(sf, (size, size))
             v = getattr(model, f"vip_p{3 + i}")(nhwc_view(sf)).permute(0, 3, 2, 1)
             proto = v.mean(0, True)
-            q = feats[k]
-            attn = _correlation(q, proto)
-            cat = torch.cat((attn, q), 1).permute(0, 2, 3, 1).contiguous()
+            k11 = F.adaptive_avg_pool2d(proto, (1, 1))[0, :, 0, 0]                  # support kernels (fsod_cen.py:229-231)
+            k13 = F.adaptive_avg_pool2d(proto, (1, 3))[0, :, 0, :]
+            k31 = F.adaptive_avg_pool2d(proto, (3, 1))[0, :, :, 0]
+            cat = A.correlation_cat(nhwc_view(feats[k]), k11, k13, k31)            # [1,H,W,2C] = [attn | q]
             pos.append(A.conv(cat, model.conv3.weight, model.conv3.bias, None, None, True))
         # ---- CenterNet head, ground truth, losses
         heads = head_train(pg.centernet_head, pos)
@@ -157,8 +158,8 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
         C = qf[0].shape[-1]
         P = rh.pooler_resolution
         x = A.roi_align(qf, roi_boxes, pg.strides, P).reshape(R * P * P, C)                # rows ordered [roi][pos], channels last
-        sup8 = torch.cat([A.roi_align([nhwc_view(sfeats[k])[j] for k in LEVELS], sboxes[j:j + 1], pg.strides, P)
-                          for j in range(sup.shape[0])], 0)
+        sup8 = A.roi_align_batched([nhwc_view(sfeats[k]) for k in LEVELS], sboxes,
+                                   torch.arange(sup.shape[0], dtype=torch.int32, device=dev), pg.strides, P)   # one box per support crop
         s = sup8.mean(0, True).reshape(P * P, C)
         s_exp = s.unsqueeze(0).expand(R, P * P, C).reshape(R * P * P, C)
         a = A.linear(torch.cat((x, s_exp), 1), rh.conv3.weight.flatten(1), rh.conv3.bias) + \

@@ -68,8 +68,8 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
-           "ore_roi_predict_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
-           "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
+           "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
+           "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
 
@@ -410,8 +410,27 @@ def roi_align(feats: Sequence[torch.Tensor], boxes: torch.Tensor, strides: Seque
     return out
 
 
+def roi_align_batched(feats: Sequence[torch.Tensor], boxes: torch.Tensor, box_image: torch.Tensor, strides=(8, 16, 32), pooled: int = 8,
+                      min_level: int = 3) -> torch.Tensor:
+    """feats[l] [B,H,W,C]; box i pools image box_image[i] (int32) -> [n, pooled*pooled*C]."""
+    L = len(feats)
+    n = boxes.shape[0]
+    Cc = feats[0].shape[-1]
+    out = torch.empty(max(n, 1), pooled * pooled * Cc, device=boxes.device, dtype=torch.float32)
+    ptrs = (C.c_void_p * L)(*[_ptr(_f32(f)) for f in feats])
+    ld = (C.c_int32 * L)(*[f.shape[-1] for f in feats])
+    coff = (C.c_int32 * L)(*[0] * L)
+    Hs = (C.c_int32 * L)(*[f.shape[-3] for f in feats])
+    Ws = (C.c_int32 * L)(*[f.shape[-2] for f in feats])
+    sc = (C.c_float * L)(*[1.0 / s for s in strides])
+    assert box_image.dtype == torch.int32 and box_image.numel() == n
+    _chk(lib().ore_roi_align_batched_fwd(ptrs, ld, coff, Hs, Ws, sc, L, min_level, Cc, pooled, C.c_void_p(_ptr(_f32(boxes))),
+                                         C.c_void_p(_ptr(box_image)), n, C.c_void_p(_ptr(out)), _stream()), "ore_roi_align_batched_fwd")
+    return out[:n]
+
+
 def roi_align_bwd(dout: torch.Tensor, feats_like: Sequence[torch.Tensor], boxes: torch.Tensor, strides=(8, 16, 32), min_level: int = 3,
-                  pooled: int = 8, dfeats: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+                  pooled: int = 8, dfeats: Optional[Sequence[torch.Tensor]] = None, box_image: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """dout [n, pooled*pooled*C]; returns/accumulates into per-level gradient buffers shaped like feats_like ([H,W,ld] NHWC)."""
     L = len(feats_like)
     n = boxes.shape[0]
@@ -428,7 +447,7 @@ def roi_align_bwd(dout: torch.Tensor, feats_like: Sequence[torch.Tensor], boxes:
     Ws = (C.c_int32 * L)(*[f.shape[-2] for f in dfeats])
     sc = (C.c_float * L)(*[1.0 / s for s in strides])
     _chk(lib().ore_roi_align_bwd(ptrs, ld, coff, Hs, Ws, sc, L, min_level, Cc, pooled, C.c_void_p(_ptr(_f32(boxes.float().contiguous()))),
-                                 n, C.c_void_p(_ptr(_f32(dout))), _stream()), "ore_roi_align_bwd")
+                                 C.c_void_p(_ptr(box_image)), n, C.c_void_p(_ptr(_f32(dout))), _stream()), "ore_roi_align_bwd")
     return list(dfeats)
 
 
@@ -595,6 +614,36 @@ def colsum(x: torch.Tensor, *, coff: int = 0, Cc: Optional[int] = None, out: Opt
     _chk(lib().ore_colsum_fwd(C.c_void_p(_ptr(x)), ld, coff, C.c_int64(rows), Cc, C.c_float(beta), C.c_void_p(_ptr(out)),
                               C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_colsum_fwd")
     return out
+
+
+def correlation_train_fwd(q: torch.Tensor, k11: torch.Tensor, k13: torch.Tensor, k31: torch.Tensor):
+    """q [B,H,W,C] -> (cat [B,H,W,2C] = [attn | q], t, u)."""
+    _f32(q)
+    B, H, W, Cc = q.shape
+    cat = torch.empty(B, H, W, 2 * Cc, device=q.device, dtype=torch.float32)
+    t = torch.empty(B, H, W, Cc, device=q.device, dtype=torch.float32)
+    u = torch.empty_like(t)
+    _chk(lib().ore_correlation_train_fwd(C.c_void_p(_ptr(q)), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(_f32(k11))), C.c_void_p(_ptr(_f32(k13))),
+                                         C.c_void_p(_ptr(_f32(k31))), C.c_void_p(_ptr(cat)), C.c_void_p(_ptr(t)), C.c_void_p(_ptr(u)),
+                                         _stream()), "ore_correlation_train_fwd")
+    return cat, t, u
+
+
+def correlation_train_bwd(q, k11, k13, k31, dcat, t, u):
+    """-> dq [B,H,W,C], dk11 [C], dk13 [C,3], dk31 [C,3]."""
+    B, H, W, Cc = q.shape
+    rows = B * H * W
+    dq = torch.empty_like(q)
+    dk11 = torch.empty(Cc, device=q.device, dtype=torch.float32)
+    d13 = torch.empty(3, Cc, device=q.device, dtype=torch.float32)
+    d31 = torch.empty(3, Cc, device=q.device, dtype=torch.float32)
+    ws = _wgrad_ws(q.device, rows * Cc * 8 + ((rows + 63) // 64) * 3 * Cc)
+    _chk(lib().ore_correlation_train_bwd(C.c_void_p(_ptr(_f32(q))), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(_f32(k11))),
+                                         C.c_void_p(_ptr(_f32(k13))), C.c_void_p(_ptr(_f32(k31))), C.c_void_p(_ptr(_f32(dcat))),
+                                         C.c_void_p(_ptr(t)), C.c_void_p(_ptr(u)), C.c_void_p(_ptr(dq)), C.c_void_p(_ptr(dk11)),
+                                         C.c_void_p(_ptr(d13)), C.c_void_p(_ptr(d31)), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()),
+                                         _stream()), "ore_correlation_train_bwd")
+    return dq, dk11, d13.t().contiguous(), d31.t().contiguous()
 
 
 def compose_roi_head(sd, support_8: torch.Tensor, prefix: str = "roi_heads."):

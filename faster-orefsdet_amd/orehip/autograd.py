@@ -32,6 +32,8 @@ def packed(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
     key = (id(w), bool(dgrad))
     tag = (_EPOCH[0], w.data_ptr(), w._version, tuple(w.shape))
     e = _PACK.get(key)
+    if e is None and len(_PACK) > 512:               # temporaries (e.g. the concatenated head weight) come and go: bound the cache
+        _PACK.clear()
     if e is None or e[0] != tag:
         buf = e[1] if e is not None and e[0][3] == tag[3] else None
         _PACK[key] = (tag, orehip.pack_conv_weight_dev(w.detach().contiguous(), dgrad, out=buf))
@@ -154,6 +156,27 @@ def osa_block(x_in, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Ten
     return OSAFn.apply(x_in, *flat)
 
 
+class CorrelationFn(Function):
+    """Depthwise support correlation (fsod_cen.py:229-245): q [1,H,W,C], k11 [C], k13 [C,3], k31 [C,3] -> [1,H,W,2C] = [attn | q],
+    the input of conv3 (no torch.cat)."""
+
+    @staticmethod
+    def forward(ctx, q, k11, k13, k31):
+        q, k11, k13, k31 = q.contiguous(), k11.contiguous(), k13.contiguous(), k31.contiguous()
+        cat, t, u = orehip.correlation_train_fwd(q, k11, k13, k31)
+        ctx.save_for_backward(q, k11, k13, k31, t, u)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        q, k11, k13, k31, t, u = ctx.saved_tensors
+        return orehip.correlation_train_bwd(q, k11, k13, k31, dcat.contiguous(), t, u)
+
+
+def correlation_cat(q, k11, k13, k31):
+    return CorrelationFn.apply(q, k11, k13, k31)
+
+
 class RoiAlignFn(Function):
     """ROIPooler(8x8, ROIAlignV2, sampling_ratio 0) of ONE image's pyramid: feats[l] [H,W,C] NHWC -> [n, 64, C]."""
 
@@ -175,6 +198,29 @@ class RoiAlignFn(Function):
 
 def roi_align(feats: Sequence[torch.Tensor], boxes: torch.Tensor, strides=(8, 16, 32), pooled: int = 8) -> torch.Tensor:
     return RoiAlignFn.apply(boxes.detach().float().contiguous(), tuple(strides), pooled, *feats)
+
+
+class RoiAlignBatchedFn(Function):
+    """One box per image of a batch (the support crops): feats[l] [B,H,W,C], boxes [n,4], box_image [n] int32 -> [n, P*P*C]."""
+
+    @staticmethod
+    def forward(ctx, boxes, box_image, strides, pooled, *feats):
+        feats = [f.contiguous() for f in feats]
+        out = orehip.roi_align_batched(feats, boxes, box_image, strides=strides, pooled=pooled)
+        ctx.save_for_backward(boxes, box_image, *feats)
+        ctx.meta = (tuple(strides), pooled)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        boxes, box_image, feats = ctx.saved_tensors[0], ctx.saved_tensors[1], ctx.saved_tensors[2:]
+        strides, pooled = ctx.meta
+        d = orehip.roi_align_bwd(dout.contiguous(), feats, boxes, strides=strides, pooled=pooled, box_image=box_image)
+        return (None, None, None, None, *d)
+
+
+def roi_align_batched(feats, boxes, box_image, strides=(8, 16, 32), pooled: int = 8):
+    return RoiAlignBatchedFn.apply(boxes.detach().float().contiguous(), box_image, tuple(strides), pooled, *feats)
 
 
 class CenterNetLossFn(Function):

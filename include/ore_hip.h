@@ -192,10 +192,16 @@ int ore_roi_align_fwd(const float* const* feat, const int32_t* ld, const int32_t
  * (reg_weights4_host, clamp log(1000/16)); clip to (img_h, img_w); keep finite & score > score_thresh; NMS(nms_thresh);
  * keep[:topk].  ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:160-170, d2z:modeling/box_regression.py:77-115,
  * d2z:modeling/roi_heads/fast_rcnn.py:118-171.  det_src = index of the proposal each detection came from. */
-/* Backward of ore_roi_align_fwd: dfeat[l] += scatter of dout [n][pooled*pooled][C] (fp32 atomics; the caller zeroes dfeat). */
+/* The same pooling over a BATCH of images ([B][H][W][ld] per level; box i reads image box_image[i]): the 24 support crops of a
+ * training step in one launch (ref:fewx/modeling/fsod/fsod_cen.py:196-200). */
+int ore_roi_align_batched_fwd(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                              const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                              const float* boxes, const int32_t* box_image, int32_t n, float* out, void* stream);
+/* Backward of both: dfeat[l] += scatter of dout [n][pooled*pooled][C] (fp32 atomics; the caller zeroes dfeat).
+ * box_image may be NULL (one image). */
 int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                       const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
-                      const float* boxes, int32_t n, const float* dout, void* stream);
+                      const float* boxes, const int32_t* box_image, int32_t n, const float* dout, void* stream);
 size_t ore_roi_predict_workspace_bytes(int32_t cap);
 int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
                         const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
@@ -265,6 +271,18 @@ int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_coff, const f
 /* out[c] = beta * out[c] + sum_rows x[row][coff + c]; workspace >= ceil(rows/64) * C floats. */
 int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, float beta, float* out,
                    float* workspace, size_t workspace_floats, void* stream);
+
+/* Depthwise support correlation with gradients (ref:fewx/modeling/fsod/fsod_cen.py:229-245, training branch).
+ * fwd: cat2c [rows][2C] = [attn | q] (the input of conv3), t_save / u_save [rows][C] kept for the backward.
+ * bwd: dcat2c [rows][2C] -> dq [rows][C] (both halves), dk11 [C], dk13_3c / dk31_3c [3][C] (tap-major; the kernels are [C][3]).
+ * workspace >= rows*C*8 + ceil(rows/64)*3*C floats.  Deterministic (per-row products + ordered column sums). */
+int ore_correlation_train_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                              const float* k11, const float* k13, const float* k31, float* cat2c, float* t_save,
+                              float* u_save, void* stream);
+int ore_correlation_train_bwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                              const float* k11, const float* k13, const float* k31, const float* dcat2c,
+                              const float* t_save, const float* u_save, float* dq, float* dk11, float* dk13_3c,
+                              float* dk31_3c, float* workspace, size_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------ engine ------------------- */
 /* Whole eval hot path for one model instance: owns packed weights and all

@@ -395,3 +395,31 @@ def test_train_step_updates_match_oracle_sgd(oh):
     # a second forward sees the updated weights (packed layouts are rebuilt after the step)
     l2 = train_forward(m, [item], roi_override=over)
     assert abs(float(sum(l2.values()).detach()) - float(sum(losses.values()).detach())) > 0
+
+
+def test_correlation_fn_backward(oh):
+    """HIP depthwise correlation (forward + both backward passes) vs torch autograd of the oracle's depthwise convs."""
+    import torch.nn.functional as F
+    from orehip import autograd as A
+    g = torch.Generator().manual_seed(8)
+    for (H, W, s) in ((20, 24, 16), (7, 5, 8)):
+        C = 128
+        q = torch.randn(1, C, H, W, generator=g).requires_grad_(True)
+        proto = (torch.randn(1, C, s, s, generator=g) * 0.7).requires_grad_(True)
+        w3 = (torch.randn(C, 2 * C, 1, 1, generator=g) / 16).requires_grad_(True)
+        b3 = torch.randn(C, generator=g).requires_grad_(True)
+        ref = R.correlation(q, proto, w3, b3)
+        up = torch.randn(ref.shape, generator=g)
+        (ref * up).sum().backward()
+        qg = _nhwc(q.detach()).cuda().requires_grad_(True)
+        pg = proto.detach().cuda().requires_grad_(True)
+        wg, bg = w3.detach().cuda().requires_grad_(True), b3.detach().cuda().requires_grad_(True)
+        k11 = F.adaptive_avg_pool2d(pg, (1, 1))[0, :, 0, 0]
+        k13 = F.adaptive_avg_pool2d(pg, (1, 3))[0, :, 0, :]
+        k31 = F.adaptive_avg_pool2d(pg, (3, 1))[0, :, :, 0]
+        y = A.conv(A.correlation_cat(qg, k11, k13, k31), wg, bg, None, None, True)
+        _close(y.permute(0, 3, 1, 2), ref)
+        (y * _nhwc(up).cuda()).sum().backward()
+        _close(qg.grad.permute(0, 3, 1, 2), q.grad)
+        _close(pg.grad, proto.grad)
+        _close(wg.grad, w3.grad)
