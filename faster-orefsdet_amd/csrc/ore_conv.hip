@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         b_ok[i] = (B_IT * 256 == BN * QPR || f < BN * QPR) && n < p.Cout16;
         b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + (my_q & 3) * 4;
     }
-    constexpr int PF = 3;                                        // register ring depth: a load has PF K-steps to land
+#ifndef ORE_PF
+#define ORE_PF 3
+#endif
+    constexpr int PF = ORE_PF;                                   // register ring depth: a load has PF K-steps to land
     constexpr int NAFF = AFF ? A_IT : 1;
     constexpr bool A_FULL = (BM * QPR) % 256 == 0, B_FULL = (BN * QPR) % 256 == 0;   // every thread stores every float4
     f32x4 ra[PF][A_IT], rb[PF][B_IT];
@@ -235,14 +238,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         __syncthreads();
         int s0 = s_begin;
         for (; s0 + 2 * PF <= s_end; s0 += PF) {      // steady state: no branch between a load and its use -> counted vmcnt waits
-            ORE_STEP(0, s0, true, true)
-            ORE_STEP(1, s0 + 1, true, true)
-            ORE_STEP(2, s0 + 2, true, true)
+#pragma unroll
+            for (int u = 0; u < PF; ++u) ORE_STEP(u, s0 + u, true, true)
         }
         for (; s0 < s_end; s0 += PF) {                // tail (< 2*PF steps): loads past the end fetch the zero page, harmless
-            if (s0 < s_end) ORE_STEP(0, s0, true, s0 + 1 < s_end)
-            if (s0 + 1 < s_end) ORE_STEP(1, s0 + 1, true, s0 + 2 < s_end)
-            if (s0 + 2 < s_end) ORE_STEP(2, s0 + 2, true, s0 + 3 < s_end)
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+                if (s0 + u < s_end) ORE_STEP(u, s0 + u, true, s0 + u + 1 < s_end)
         }
     }
 #undef ORE_STEP

@@ -154,33 +154,38 @@ class CenterNet2Detector(nn.Module):
     def _state_key(self):
         return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
 
-    def engine(self):
+    def make_engine(self):
+        """A fresh engine (own buffers, own hipGraph) for the current parameters and support set.  `engine()` caches one; a server
+        that keeps several images in flight on separate streams makes one per stream (bench.py --inflight)."""
         import orehip
         from detectron2.modeling.backbone.vovnet import _STAGE_SPECS
+        c = self._cfg_engine
+        spec = _STAGE_SPECS[c["body"]]
+        assert all(b == 1 for b in spec["block_per_stage"]), "the fused engine covers one OSA block per stage (V-19 bodies)"
+        dev = self.device
+        assert dev.type == "cuda", "CenterNet2Detector inference runs on the MI355X only"
+        e = orehip.Engine(stem=spec["stem"], conv=spec["stage_conv_ch"], out=spec["stage_out_ch"], layers=spec["layer_per_block"],
+                          fpn_ch=c["fpn_ch"], strides=c["strides"], pixel_mean=c["pixel_mean"], pixel_std=c["pixel_std"],
+                          score_thresh=c["score_thresh"], pre_topk=c["pre_topk"], nms_thresh=c["nms_thresh"],
+                          post_topk=c["post_topk"], max_batch=1, max_h=self.max_hw[0], max_w=self.max_hw[1],
+                          device=dev.index or 0)
+        e.load_state_dict(self.state_dict())
+        assert self.support_dict is not None, "support prototypes not set (init_model / set_support_dict)"
+        cls_id = list(self.support_dict["p3"].keys())[-1]   # the reference keeps only the last class (SURVEY App. C.4)
+        e.set_support({k: self.support_dict[k][cls_id] for k in ("p3", "p4", "p5")})
+        e.finalize()
+        rh = self.roi_heads
+        if "rcnn_8" in self.support_dict and hasattr(rh, "bbox_reg_weights"):
+            e.set_roi_head(self.state_dict(), self.support_dict["rcnn_8"][cls_id], rh.bbox_reg_weights, rh.test_score_thresh,
+                           rh.test_nms_thresh, rh.test_topk)
+        return e
+
+    def engine(self):
         key = (self._state_key(), str(self.device))
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
-            c = self._cfg_engine
-            spec = _STAGE_SPECS[c["body"]]
-            assert all(b == 1 for b in spec["block_per_stage"]), "the fused engine covers one OSA block per stage (V-19 bodies)"
-            dev = self.device
-            assert dev.type == "cuda", "CenterNet2Detector inference runs on the MI355X only"
-            e = orehip.Engine(stem=spec["stem"], conv=spec["stage_conv_ch"], out=spec["stage_out_ch"], layers=spec["layer_per_block"],
-                              fpn_ch=c["fpn_ch"], strides=c["strides"], pixel_mean=c["pixel_mean"], pixel_std=c["pixel_std"],
-                              score_thresh=c["score_thresh"], pre_topk=c["pre_topk"], nms_thresh=c["nms_thresh"],
-                              post_topk=c["post_topk"], max_batch=1, max_h=self.max_hw[0], max_w=self.max_hw[1],
-                              device=dev.index or 0)
-            e.load_state_dict(self.state_dict())
-            assert self.support_dict is not None, "support prototypes not set (init_model / set_support_dict)"
-            cls_id = list(self.support_dict["p3"].keys())[-1]   # the reference keeps only the last class
-            e.set_support({k: self.support_dict[k][cls_id] for k in ("p3", "p4", "p5")})
-            e.finalize()
-            rh = self.roi_heads
-            if "rcnn_8" in self.support_dict and hasattr(rh, "bbox_reg_weights"):
-                e.set_roi_head(self.state_dict(), self.support_dict["rcnn_8"][cls_id], rh.bbox_reg_weights, rh.test_score_thresh,
-                               rh.test_nms_thresh, rh.test_topk)
-            self._engine, self._engine_key = e, key
+            self._engine, self._engine_key = self.make_engine(), key
         return self._engine
 
     # ---- forward ------------------------------------------------------------------------------------------------

@@ -632,3 +632,28 @@ def test_conv3x3_patch_kernel(ore, mode):
             r0 += B * h * wd
     finally:
         L.ore_conv_set_plan_override(-1, -1, 0, 0, 0)
+
+
+def test_engines_on_concurrent_streams_are_bit_identical(model):
+    """bench.py keeps several bs=1 forwards in flight, each on its own engine + stream: every engine must produce what a single
+    sequential engine produces (no shared scratch, split-K counters or graphs between engines)."""
+    e0 = model.engine()
+    engines = [e0] + [model.make_engine() for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in engines]
+    imgs = [R.synth_image(20 + i, 320, 320).cuda() for i in range(4)]
+    want = []
+    for im in imgs:
+        e0.eval_forward(im)
+        torch.cuda.synchronize()
+        want.append([t.clone() for t in e0.proposals()] + [t.clone() for t in e0.detections()])
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, (e, s) in enumerate(zip(engines, streams)):
+            with torch.cuda.stream(s):
+                e.eval_forward(imgs[(k + rep) % 4])
+        torch.cuda.synchronize()
+        for k, e in enumerate(engines):
+            got = list(e.proposals()) + list(e.detections())
+            assert all(torch.equal(a, b) for a, b in zip(got, want[(k + rep) % 4])), (rep, k)
+    for e in engines[1:]:
+        e.close()
