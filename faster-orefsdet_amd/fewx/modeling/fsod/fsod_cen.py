@@ -140,15 +140,67 @@ class CenterNet2Detector(nn.Module):
 
     def init_model(self, support_file="./support_dir/support_feature.pkl"):
         """ref fsod_cen.py:313-415, minus its two defects: the pickle is read once (not per forward) and tensors go to
-        self.device (not a hard-coded .cuda()).  Generating the pickle from a support dataframe needs the ore dataset
-         and is not built."""
+        self.device (not a hard-coded .cuda()).  Reading the support dataframe + images needs the ore dataset (SURVEY 8f row
+        3); the compute it feeds is compute_support_dict()."""
         if self.support_dict is not None:
             return
         if not os.path.exists(support_file):
             raise FileNotFoundError(f"{support_file} not found: generating support features needs the few-shot support set "
-                                    "(datasets/coco/*_shot_support_df.pkl, SURVEY 8f row 3); call set_support_dict() instead")
+                                    "(datasets/coco/*_shot_support_df.pkl, SURVEY 8f row 3): call compute_support_dict(images, boxes) "
+                                    "+ save_support_file(), or set_support_dict()")
         with open(support_file, "rb") as f:
             self.set_support_dict(pickle.load(f, encoding="latin1"))
+
+    @torch.no_grad()
+    def compute_support_dict(self, support_images, support_boxes, cls_id=0, merge=True):
+        """The compute half of the reference's init_model (ref fsod_cen.py:345-392) for one class, on the HIP kernels:
+        support crops -> backbone/FPN -> rcnn_8 / rcnn_4 = ROIAlign (8x8, 4x4) of every crop's own box; p3..p5 prototypes =
+        avg-pool to 32/16/8 -> SM_Block -> permute(0,3,2,1) (H<->W swap preserved) -> mean over the shots.
+        support_images: list of [3,h,w] (or one [N,3,h,w]) uint8/float BGR; support_boxes [N,4].  Returns the dict in the layout of
+        support_feature.pkl (CPU tensors) and, with merge=True, installs it (set_support_dict)."""
+        import torch.nn.functional as F
+        import orehip
+        from detectron2.layers import nhwc_view
+        dev = self.device
+        imgs = list(support_images) if not torch.is_tensor(support_images) else [x for x in support_images]
+        div = self.backbone.size_divisibility
+        H = (max(int(x.shape[-2]) for x in imgs) + div - 1) // div * div
+        W = (max(int(x.shape[-1]) for x in imgs) + div - 1) // div * div
+        mean, std = self.pixel_mean.view(-1, 1, 1), self.pixel_std.view(-1, 1, 1)
+        batch = torch.zeros(len(imgs), 3, H, W, device=dev)
+        for i, x in enumerate(imgs):                                            # ImageList.from_tensors: normalise, zero-pad bottom/right
+            x = (x.to(dev).float() - mean) / std
+            batch[i, :, : x.shape[-2], : x.shape[-1]] = x
+        boxes = torch.as_tensor(support_boxes, dtype=torch.float32, device=dev).reshape(-1, 4).contiguous()
+        assert boxes.shape[0] == len(imgs)
+        feats = self.backbone(batch)
+        levels = [nhwc_view(feats[f]) for f in self.in_features]
+        strides = self._cfg_engine["strides"]
+        bidx = torch.arange(len(imgs), dtype=torch.int32, device=dev)
+        C = levels[0].shape[-1]
+        out = {}
+        for key, P in (("rcnn_8", self.roi_heads.pooler_resolution), ("rcnn_4", self.roi_heads.pooler_resolution2)):
+            r = orehip.roi_align_batched(levels, boxes, bidx, strides, P)        # [N, P*P*C] ordered [pos][c]
+            out[key] = {cls_id: r.reshape(len(imgs), P, P, C).permute(0, 3, 1, 2).contiguous().cpu()}
+        for i, f in enumerate(self.in_features):
+            size = (32, 16, 8)[i]
+            sf = feats[f]
+            if sf.shape[-2:] != (size, size):
+                sf = F.adaptive_avg_pool2d(sf, (size, size))
+            v = getattr(self, f"vip_p{3 + i}")(nhwc_view(sf)).permute(0, 3, 2, 1)
+            out[f"p{3 + i}"] = {cls_id: v.mean(0, True).contiguous().cpu()}
+        if merge:
+            cur = {k: dict(v) for k, v in (self.support_dict or {}).items()}
+            for k, v in out.items():
+                cur.setdefault(k, {}).update(v)
+            self.set_support_dict(cur)
+        return out
+
+    def save_support_file(self, support_file="./support_dir/support_feature.pkl"):
+        """Writes self.support_dict in the reference's pickle layout (CPU tensors keyed by level then class id)."""
+        os.makedirs(os.path.dirname(support_file) or ".", exist_ok=True)
+        with open(support_file, "wb") as f:
+            pickle.dump({k: {c: t.detach().cpu() for c, t in v.items()} for k, v in self.support_dict.items()}, f)
 
     # ---- engine -------------------------------------------------------------------------------------------------
     def _state_key(self):

@@ -657,3 +657,28 @@ def test_engines_on_concurrent_streams_are_bit_identical(model):
             assert all(torch.equal(a, b) for a, b in zip(got, want[(k + rep) % 4])), (rep, k)
     for e in engines[1:]:
         e.close()
+
+
+def test_compute_support_dict_vs_oracle(model, sd, tmp_path):
+    """init_model's compute (support crops -> prototypes + rcnn_8/rcnn_4) on the HIP kernels vs the oracle; pickle round trip."""
+    from oracle import ref_train as T
+    import pickle
+    old = model.support_dict
+    try:
+        _, _, sup, sbox = T.synth_train_inputs(3, (64, 64), n_gt=1, shots=5, support_hw=144)
+        out = model.compute_support_dict(sup, sbox, cls_id=7, merge=True)
+        sf = R.backbone_fpn(T.preprocess_batch(sup), sd)
+        for i, k in enumerate(("p3", "p4", "p5")):
+            ref = R.support_prototype(sf[k], sd, 3 + i)
+            assert tuple(out[k][7].shape) == tuple(ref.shape)
+            assert rel_err(out[k][7].numpy(), ref.numpy()) < TOL, k
+        for key, P in (("rcnn_8", 8), ("rcnn_4", 4)):
+            ref = torch.cat([R.roi_pool_levels([sf[k][n:n + 1] for k in ("p3", "p4", "p5")], sbox[n:n + 1], P) for n in range(5)], 0)
+            assert rel_err(out[key][7].numpy(), ref.numpy()) < TOL, key
+        f = str(tmp_path / "support_dir" / "support_feature.pkl")
+        model.save_support_file(f)
+        with open(f, "rb") as fh:
+            back = pickle.load(fh)
+        assert set(back) == {"p3", "p4", "p5", "rcnn_8", "rcnn_4"} and torch.equal(back["p4"][7], out["p4"][7])
+    finally:
+        model.set_support_dict({k: {c: t.cpu() for c, t in v.items()} for k, v in old.items()})
