@@ -216,8 +216,18 @@ def main():
         ms, fl, nl = eng.read_profile()
         eng.set_profiling(False)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None                                  # HBM bytes of the conv launches of one image, from the committed PMC passes
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                with open(tf) as f:
+                    traffic = float(json.load(f)["conv_hbm_bytes_per_image"])
+            except Exception:
+                traffic = None
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "bytes per image over the same conv launches: (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc "
+                                "passes (tools/pmc_pass.py, profiles/r01_pmc_traffic.json); 0.58 GB in 0.82 ms = 0.7 TB/s << 8 TB/s",
                 "kernel": "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv incl. in-kernel split-K; 28 convs + the ROI fc GEMM)",
                 "launches_per_image": nl // max(args.profile_passes, 1),
                 "gflop_per_image": round(fl / max(args.profile_passes, 1) / 1e9, 3),
