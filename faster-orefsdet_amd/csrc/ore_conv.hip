@@ -211,6 +211,18 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // epilogue operands fetched NOW, under the K loop's loads (a dependent global load after the last MFMA costs ~1 us of pure
+    // latency on the small layers); per-level scale/shift (ep_stride != 0) keep the late path
+    float pre_sc[TN], pre_sh[TN];
+    const bool ep_pre = p.ep_stride == 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + (lane & 15);
+        const bool okn = ep_pre && n < p.Cout;
+        pre_sc[j] = (okn && p.scale) ? p.scale[n] : 1.0f;
+        pre_sh[j] = (okn && p.shift) ? p.shift[n] : 0.0f;
+    }
+
     const int frow = lane & 15, fk = kg * 16 + (lane >> 4) * 4;
     // one K step: (optionally) issue the loads of step st+PF into ring slot u, MFMA on LDS buffer `cur`, (optionally) park the
     // step st+1 data (ring slot u+1, in flight for two steps already) in the other LDS buffer, barrier.
@@ -330,7 +342,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
                 if (m < p.M && n < p.Cout) {
-                    const float v = epilogue_one(p, acc[i][j][r], m, n);
+                    float v;
+                    if (ep_pre && !p.add) {
+                        v = acc[i][j][r] * pre_sc[j] + pre_sh[j];
+                        if (n < p.relu_cout) v = fmaxf(v, 0.0f);
+                    } else {
+                        v = epilogue_one(p, acc[i][j][r], m, n);
+                    }
                     p.out[(size_t)m * p.out_ld + p.out_coff + n] = v;
                     csum[j] += v;
                 }
