@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     constexpr int QPR = BK / 4;                                  // float4 per tile row
     constexpr int A_IT = (BM * QPR + 255) / 256, B_IT = (BN * QPR + 255) / 256;
     constexpr int STAGE = 2 * (BM + BN) * LD;                    // staging floats (double buffered)
-    constexpr int RED = (WGK - 1) * BM * BN;                     // in-block K reduction scratch
+    constexpr int RED = WGK > 1 ? WGK * BM * BN : 0;             // in-block K reduction scratch (all k-groups park their tiles)
     constexpr int LDSF = STAGE > RED ? STAGE : RED;
     __shared__ __attribute__((aligned(16))) float lds[LDSF + 8];
     float* As = lds;
@@ -261,7 +261,48 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
 #undef ORE_STEP
 
-    // ---- in-block K reduction: groups kg>0 park their tiles in LDS, group 0 adds them in group order
+    // ---- in-block K reduction.
+    // Fast path (no cross-block split-K, no fused column sums): every k-group parks its tiles in LDS and then ALL WGK waves share
+    // the epilogue -- wave kg finishes accumulator registers r = kg, kg+WGK, ... of every tile (same group order of the sum as
+    // the slow path: bit-identical).  With one wave doing all the stores (slow path) the store phase of the small layers ran at a
+    // quarter of the CU's wave parallelism: +3 us per launch at M=6400, +11 us at M=25600 (tools/conv_fixed_cost2.py).
+    if (WGK > 1 && p.splitk <= 1 && !p.colsum) {
+        constexpr int RALL = WGK * (WGM * WGN) * TM * TN * 256;
+        static_assert(WGK == 1 || RALL <= LDSF, "LDS too small for the distributed K reduction");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<f32x4*>(lds + ((kg * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4) = acc[i][j];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + (lane & 15);
+#pragma unroll
+                for (int rr = 0; rr < 4 / WGK; ++rr) {
+                    const int r = kg + rr * WGK;
+                    float a = lds[((0 * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4 + r];
+#pragma unroll
+                    for (int g = 1; g < WGK; ++g) a += lds[((g * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4 + r];
+                    const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+                    if (m < p.M && n < p.Cout) {
+                        float v;
+                        if (ep_pre && !p.add) {
+                            v = a * pre_sc[j] + pre_sh[j];
+                            if (n < p.relu_cout) v = fmaxf(v, 0.0f);
+                        } else {
+                            v = epilogue_one(p, a, m, n);
+                        }
+                        p.out[(size_t)m * p.out_ld + p.out_coff + n] = v;
+                    }
+                }
+            }
+        return;
+    }
+    // Slow path: groups kg>0 park their tiles in LDS, group 0 adds them in group order and carries on alone
     if (WGK > 1) {
         __syncthreads();
         if (kg > 0) {
