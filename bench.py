@@ -110,6 +110,53 @@ def cpu_baseline(model, img, budget_s=12.0):
                       f"torch {torch.__version__} CPU, {el:.1f} s)"}
 
 
+def train_leg(device, steps=5, warmup=2, size=640, shots=24):
+    """SURVEY 8d metric (ii), single GPU: forward + backward + clip/SGD of finetune_vovnet.yaml on one query + 24 support crops
+    (tools/bench_train.py is the stand-alone / multi-GPU version).  Reported beside the headline, never as `value`."""
+    from detectron2.structures import Boxes, Instances
+    from fewx.solver import build_lr_scheduler, build_optimizer
+    model, cfg = build_model(device)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():                                   # second-stage weights: small, so the synthetic losses stay finite
+        for n, p in model.named_parameters():
+            if n.startswith("roi_heads.") and p.dim() > 1:
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).to(device) * (p[0].numel() ** -0.5))
+    opt = build_optimizer(cfg, model)
+    sched = build_lr_scheduler(cfg, opt)
+    wh = torch.rand(17, 2, generator=g) * 120 + 30
+    ctr = torch.rand(17, 2, generator=g) * (size - wh) + wh / 2
+    inst = Instances((size, size))
+    inst.gt_boxes = Boxes(torch.cat([ctr - wh / 2, ctr + wh / 2], 1).to(device))
+    inst.gt_classes = torch.zeros(17, dtype=torch.int64, device=device)
+    sup = torch.stack([synth_image(100 + i, 240, 240) for i in range(shots)]).to(device)
+    side = torch.rand(shots, 2, generator=g) * 120 + 80
+    c = torch.rand(shots, 2, generator=g) * (240 - side) + side / 2
+    item = {"image": synth_image(7, size, size).to(device), "instances": inst, "support_images": sup,
+            "support_bboxes": torch.cat([c - side / 2, c + side / 2], 1).numpy()}
+
+    def step():
+        losses = model([item])
+        opt.zero_grad()
+        sum(losses.values()).backward()
+        opt.step()
+        sched.step()
+        return losses
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"images_per_s": round(steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
+            "workload": "finetune_vovnet.yaml train step on 1 GPU: 1 query %dx%d + %d support 240x240, fwd + bwd (HIP backward kernels) + "
+                        "flat-bucket clip/SGD, FREEZE_AT=3" % (size, size, shots),
+            "exchanged_bytes_per_step_if_dp": 4 * opt.bucket.size, "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +164,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the single-GPU train-step measurement printed as \"train_step\"")
     ap.add_argument("--profile-passes", type=int, default=20)
     ap.add_argument("--inflight", type=int, default=4,
                     help="images kept in flight per GPU, each a bs=1 forward on its own engine + HIP stream (bs=1 leaves most of "
@@ -226,8 +274,8 @@ def main():
                 traffic = None
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes per image over the same conv launches: (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc "
-                                "passes (tools/pmc_pass.py, profiles/r01_pmc_traffic.json); 0.58 GB in 0.82 ms = 0.7 TB/s << 8 TB/s",
+                "traffic_note": "HBM-side bytes per image over the same conv launches: (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 "
+                                "--pmc passes (tools/pmc_pass.py -> profiles/r01_pmc_traffic.json); ~0.7 TB/s, far below the 8 TB/s roof",
                 "kernel": "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv incl. in-kernel split-K; 28 convs + the ROI fc GEMM)",
                 "launches_per_image": nl // max(args.profile_passes, 1),
                 "gflop_per_image": round(fl / max(args.profile_passes, 1) / 1e9, 3),
@@ -252,6 +300,11 @@ def main():
             "latency_ms_host_sync": {"p50": round(lat[len(lat) // 2] * 1e3, 4), "min": round(lat[0] * 1e3, 4)},
             "roofline": roof,
         }
+        if not args.no_train_leg and world == 1:
+            try:
+                out["train_step"] = train_leg(device)
+            except Exception as ex:                         # the headline line must survive a failure of the side measurement
+                out["train_step"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, imgs[0].cpu())
         print(json.dumps(out), flush=True)
