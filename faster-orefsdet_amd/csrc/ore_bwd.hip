@@ -149,21 +149,33 @@ __global__ __launch_bounds__(256) void k_relu_affine_bwd(const float* __restrict
     *reinterpret_cast<f32x4*>(dz + r * dz_ld + dz_coff + c) = o;
 }
 
-// column sums: stage 1 = 64-row chunks, stage 2 = chunks in order
+// column sums: stage 1 = 256-row chunks (64 channels x 4 row lanes per block, lanes combined in fixed order through LDS),
+// stage 2 = chunks in order.  Deterministic.
+constexpr int CS_ROWS = 256;
 __global__ __launch_bounds__(256) void k_colsum_chunks(const float* __restrict__ x, int ld, int coff, long long rows, int C,
                                                        float* __restrict__ part) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
-    const long long r0 = (long long)blockIdx.x * 64, r1 = min(rows, r0 + 64);
-    float s = 0.f;
-    for (long long r = r0; r < r1; ++r) s += x[r * ld + coff + c];
-    part[(size_t)blockIdx.x * C + c] = s;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long long r0 = (long long)blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        long long r = r0 + rl;
+        for (; r + 4 < r1; r += 8) { s0 += x[r * ld + coff + c]; s1 += x[(r + 4) * ld + coff + c]; }
+        if (r < r1) s0 += x[r * ld + coff + c];
+    }
+    red[rl][cl] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && c < C) part[(size_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nchunks, int C, float beta, float* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * C + c];
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < nchunks; k += 2) { s0 += part[(size_t)k * C + c]; s1 += part[(size_t)(k + 1) * C + c]; }
+    if (k < nchunks) s0 += part[(size_t)k * C + c];
+    const float s = s0 + s1;
     out[c] = beta != 0.0f ? beta * out[c] + s : s;
 }
 
@@ -277,6 +289,160 @@ __global__ __launch_bounds__(256) void k_corr_bwd_b(CorrT p, const float* __rest
     *reinterpret_cast<f32x4*>(P13 + (size_t)row * 3 * C + 2 * C + c) = dtc * Qx(1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small HBM-bound training ops (float4 per thread, NHWC rows x C):
+//   GroupNorm(+ReLU) of the head tower with gradients; eSE scale with gradients; ceil-mode 3x3/s2 max-pool backward;
+//   2x2 sum-pool (backward of the FPN's nearest-2x top-down add).
+// xhat = x * r[c] + a[c] with r = rstd of the channel's group, a = -mean * rstd (from ore_groupnorm_affine_fwd with gamma=1, beta=0).
+__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, int ld, int coff, long long rows, int C,
+                                                  const float* __restrict__ r, const float* __restrict__ a, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int relu, float* __restrict__ y) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c4n) return;
+    const long long row = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ld + coff + c);
+    const f32x4 rr = *reinterpret_cast<const f32x4*>(r + c), aa = *reinterpret_cast<const f32x4*>(a + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o = (v * rr + aa) * g + b;
+    if (relu) o = relu4b(o);
+    *reinterpret_cast<f32x4*>(y + row * C + c) = o;
+}
+
+// P[row][0:C] = dy' = dy * [y > 0 or !relu],  P[row][C:2C] = dy' * xhat
+__global__ __launch_bounds__(256) void k_gn_bwd_prod(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, int ld,
+                                                     int coff, long long rows, int C, const float* __restrict__ r, const float* __restrict__ a,
+                                                     int relu, float* __restrict__ P) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c4n) return;
+    const long long row = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * C + c);
+    if (relu) g = gt0(*reinterpret_cast<const f32x4*>(y + row * C + c), g);
+    const f32x4 xh = *reinterpret_cast<const f32x4*>(x + row * ld + coff + c) * *reinterpret_cast<const f32x4*>(r + c) +
+                     *reinterpret_cast<const f32x4*>(a + c);
+    *reinterpret_cast<f32x4*>(P + row * 2 * C + c) = g;
+    *reinterpret_cast<f32x4*>(P + row * 2 * C + C + c) = g * xh;
+}
+
+// dx = r * (gamma * dy' - (S1_g + xhat * S2_g) / n),  S1_g = sum_{c in g} gamma_c dbeta_c,  S2_g = sum_{c in g} gamma_c dgamma_c
+__global__ __launch_bounds__(256) void k_gn_bwd_dx(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, int ld,
+                                                   int coff, long long rows, int C, int cpg, const float* __restrict__ r,
+                                                   const float* __restrict__ a, const float* __restrict__ gamma,
+                                                   const float* __restrict__ sums /* [2C]: dbeta | dgamma */, int relu, float* __restrict__ dx) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * c4n) return;
+    const long long row = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const float inv_n = 1.0f / ((float)rows * (float)cpg);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * C + c);
+    if (relu) g = gt0(*reinterpret_cast<const f32x4*>(y + row * C + c), g);
+    const f32x4 rr = *reinterpret_cast<const f32x4*>(r + c);
+    const f32x4 xh = *reinterpret_cast<const f32x4*>(x + row * ld + coff + c) * rr + *reinterpret_cast<const f32x4*>(a + c);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int g0 = ((c + k) / cpg) * cpg;
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = 0; q < cpg; ++q) { s1 += gamma[g0 + q] * sums[g0 + q]; s2 += gamma[g0 + q] * sums[C + g0 + q]; }
+        o[k] = rr[k] * (gm[k] * g[k] - (s1 + xh[k] * s2) * inv_n);
+    }
+    *reinterpret_cast<f32x4*>(dx + row * C + c) = o;
+}
+
+// out[b][row][c] = p[b][row][c] * q[b][row][c]  (product fed to the segmented column sum: d gate = sum_hw dy * x)
+__global__ __launch_bounds__(256) void k_prod(const float* __restrict__ p, const float* __restrict__ q, long long n4, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(p)[i] * reinterpret_cast<const f32x4*>(q)[i];
+}
+
+// per-image column sums: x [B][rows][C] -> out [B][C]; one block = 64 channels x 4 row lanes of one image, fixed order
+__global__ __launch_bounds__(256) void k_colsum_seg(const float* __restrict__ x, int rows, int C, float scale, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const float* xb = x + (size_t)b * rows * C;
+    float s = 0.f;
+    if (c < C)
+        for (int r = rl; r < rows; r += 4) s += xb[(size_t)r * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) out[(size_t)b * C + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * scale;
+}
+
+// out[b][row][c] = x[b][row][c] * s[b][c] + v[b][c]   (v may be NULL)
+__global__ __launch_bounds__(256) void k_scale_add(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ v,
+                                                   int B, int rows, int C, float* __restrict__ out) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * rows * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    const int b = (int)(i / ((long long)rows * c4n));
+    f32x4 o = reinterpret_cast<const f32x4*>(x)[i] * *reinterpret_cast<const f32x4*>(sc + (size_t)b * C + c);
+    if (v) o += *reinterpret_cast<const f32x4*>(v + (size_t)b * C + c);
+    reinterpret_cast<f32x4*>(out)[i] = o;
+}
+
+// MaxPool2d(3, 2, ceil_mode=True) backward: the first maximum in (ky, kx) scan order owns the window (ATen's max_pool2d)
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int Ho,
+                                                     int Wo, int C, float* __restrict__ dx) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * H * W * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    long long t = i / c4n;
+    const int xq = (int)(t % W); t /= W;
+    const int yq = (int)(t % H);
+    const int b = (int)(t / H);
+    const float* xb = x + (size_t)b * H * W * C;
+    const f32x4 me = *reinterpret_cast<const f32x4*>(xb + ((size_t)yq * W + xq) * C + c);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oy0 = max(0, (yq - 1) / 2), oy1 = min(Ho - 1, yq / 2), ox0 = max(0, (xq - 1) / 2), ox1 = min(Wo - 1, xq / 2);
+    for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            if (oy * 2 > yq || oy * 2 + 2 < yq || ox * 2 > xq || ox * 2 + 2 < xq) continue;
+            // is (yq, xq) the first maximum of window (oy, ox)?
+            bool own[4] = {true, true, true, true};
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = oy * 2 + ky, xx = ox * 2 + kx;
+                    if (yy >= H || xx >= W || (yy == yq && xx == xq)) continue;
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(xb + ((size_t)yy * W + xx) * C + c);
+                    const bool before = yy < yq || (yy == yq && xx < xq);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) own[k] = own[k] && (before ? o[k] < me[k] : o[k] <= me[k]);
+                }
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (own[k]) acc[k] += g[k];
+        }
+    reinterpret_cast<f32x4*>(dx)[i] = acc;
+}
+
+// out[b][y][x][c] = sum of the (up to) 2x2 block of in[b][2y..2y+1][2x..2x+1][c]: backward of nearest-2x upsample (cropped to H x W)
+__global__ __launch_bounds__(256) void k_sumpool2(const float* __restrict__ in, int ld, int B, int H, int W, int C, float* __restrict__ out) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * Ho * Wo * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    long long t = i / c4n;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int y = oy * 2 + dy, x = ox * 2 + dx;
+            if (y < H && x < W) s += *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + y) * W + x) * ld + c);
+        }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
 }  // namespace
 
 extern "C" int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t dgrad,
@@ -339,10 +505,10 @@ extern "C" int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_co
 extern "C" int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, float beta, float* out,
                               float* workspace, size_t workspace_floats, void* stream) {
     ORE_CHECK_ARG(x && out && workspace && rows > 0 && C > 0, "ore_colsum_fwd: bad args");
-    const long long nchunks = (rows + 63) / 64;
+    const long long nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
     if ((size_t)(nchunks * C) > workspace_floats) { ore_set_error("ore_colsum_fwd: workspace too small"); return ORE_ENOMEM; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_colsum_chunks, dim3((unsigned)nchunks, ceil_div(C, 256)), dim3(256), 0, st, x, ld, coff, (long long)rows, C, workspace);
+    hipLaunchKernelGGL(k_colsum_chunks, dim3((unsigned)nchunks, ceil_div(C, 64)), dim3(256), 0, st, x, ld, coff, (long long)rows, C, workspace);
     int rc = ore_launch_status("k_colsum_chunks");
     if (rc) return rc;
     hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(C, 256)), dim3(256), 0, st, workspace, (int)nchunks, C, beta, out);
@@ -391,4 +557,77 @@ extern "C" int ore_correlation_train_bwd(const float* q, int32_t q_ld, int32_t q
     if ((rc = ore_colsum_fwd(P11, C, 0, (int64_t)rows, C, 0.f, dk11, cs, cs_floats, stream))) return rc;
     if ((rc = ore_colsum_fwd(P13, 3 * C, 0, (int64_t)rows, 3 * C, 0.f, dk13_3c, cs, cs_floats, stream))) return rc;
     return ore_colsum_fwd(P31, 3 * C, 0, (int64_t)rows, 3 * C, 0.f, dk31_3c, cs, cs_floats, stream);
+}
+
+extern "C" int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, const float* rstd_c,
+                                       const float* shift_c, const float* gamma, const float* beta, int32_t relu, float* y, void* stream) {
+    ORE_CHECK_ARG(x && rstd_c && shift_c && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && coff % 4 == 0,
+                  "ore_groupnorm_apply_fwd: bad args");
+    const long long n = rows * (C / 4);
+    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, coff, (long long)rows, C, rstd_c,
+                       shift_c, gamma, beta, relu, y);
+    return ore_launch_status("k_gn_apply");
+}
+
+extern "C" int ore_groupnorm_bwd(const float* dy, const float* y, const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C,
+                                 int32_t groups, const float* rstd_c, const float* shift_c, const float* gamma, int32_t relu, float* dx,
+                                 float* dbeta_dgamma_2c, float* workspace, size_t workspace_floats, void* stream) {
+    ORE_CHECK_ARG(dy && y && x && rstd_c && shift_c && gamma && dx && dbeta_dgamma_2c && workspace && rows > 0 && C > 0 && C % 4 == 0 &&
+                  groups > 0 && C % groups == 0 && ld % 4 == 0 && coff % 4 == 0, "ore_groupnorm_bwd: bad args");
+    const size_t need = (size_t)rows * 2 * C + (size_t)((rows + CS_ROWS - 1) / CS_ROWS) * 2 * C;
+    if (workspace_floats < need) { ore_set_error("ore_groupnorm_bwd: workspace %zu < %zu floats", workspace_floats, need); return ORE_ENOMEM; }
+    float* P = workspace;
+    float* cs = P + (size_t)rows * 2 * C;
+    const long long n = rows * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gn_bwd_prod, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, x, ld, coff, (long long)rows, C, rstd_c, shift_c, relu, P);
+    int rc = ore_launch_status("k_gn_bwd_prod");
+    if (rc) return rc;
+    if ((rc = ore_colsum_fwd(P, 2 * C, 0, rows, 2 * C, 0.f, dbeta_dgamma_2c, cs, workspace_floats - (size_t)rows * 2 * C, stream))) return rc;
+    hipLaunchKernelGGL(k_gn_bwd_dx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, x, ld, coff, (long long)rows, C, C / groups, rstd_c,
+                       shift_c, gamma, dbeta_dgamma_2c, relu, dx);
+    return ore_launch_status("k_gn_bwd_dx");
+}
+
+extern "C" int ore_prod_colsum_fwd(const float* p, const float* q, int32_t B, int32_t rows, int32_t C, float scale, float* out_bc,
+                                   float* workspace, size_t workspace_floats, void* stream) {
+    ORE_CHECK_ARG(p && out_bc && workspace && B > 0 && rows > 0 && C > 0 && C % 4 == 0, "ore_prod_colsum_fwd: bad args");
+    const float* src = p;
+    hipStream_t st = (hipStream_t)stream;
+    if (q) {
+        const size_t n = (size_t)B * rows * C;
+        if (workspace_floats < n) { ore_set_error("ore_prod_colsum_fwd: workspace too small"); return ORE_ENOMEM; }
+        hipLaunchKernelGGL(k_prod, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, p, q, (long long)(n / 4), workspace);
+        int rc = ore_launch_status("k_prod");
+        if (rc) return rc;
+        src = workspace;
+    }
+    hipLaunchKernelGGL(k_colsum_seg, dim3(ceil_div(C, 64), B), dim3(256), 0, st, src, rows, C, scale, out_bc);
+    return ore_launch_status("k_colsum_seg");
+}
+
+extern "C" int ore_scale_add_channels_fwd(const float* x, const float* scale_bc, const float* add_bc, int32_t B, int32_t rows, int32_t C,
+                                          float* out, void* stream) {
+    ORE_CHECK_ARG(x && scale_bc && out && B > 0 && rows > 0 && C > 0 && C % 4 == 0, "ore_scale_add_channels_fwd: bad args");
+    const long long n = (long long)B * rows * (C / 4);
+    hipLaunchKernelGGL(k_scale_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, scale_bc, add_bc, B, rows, C, out);
+    return ore_launch_status("k_scale_add");
+}
+
+extern "C" int ore_maxpool3x3s2_bwd(const float* x, const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream) {
+    ORE_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ore_maxpool3x3s2_bwd: bad args");
+    // ceil mode: out = ceil((H - 3) / 2) + 1, and the last window must start inside the input
+    int ho = (H - 3 + 1) / 2 + 1, wo = (W - 3 + 1) / 2 + 1;
+    if ((ho - 1) * 2 >= H) --ho;
+    if ((wo - 1) * 2 >= W) --wo;
+    const long long n = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, ho, wo, C, dx);
+    return ore_launch_status("k_maxpool_bwd");
+}
+
+extern "C" int ore_sumpool2x2_fwd(const float* in, int32_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* stream) {
+    ORE_CHECK_ARG(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "ore_sumpool2x2_fwd: bad args");
+    const long long n = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL(k_sumpool2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, ld, B, H, W, C, out);
+    return ore_launch_status("k_sumpool2");
 }

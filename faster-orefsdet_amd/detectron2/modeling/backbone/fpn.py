@@ -57,11 +57,9 @@ class FPN(Backbone):
             from orehip import autograd as A
             for idx, (lateral, output) in enumerate(zip(self.lateral_convs, self.output_convs)):
                 f = nhwc_view(feats[self.in_features[-idx - 1]])
-                lat = A.conv(f, lateral.weight, lateral.bias)
-                if prev is not None:                                       # F.interpolate(scale_factor=2, mode="nearest") + sum (fpn.py:136-141)
-                    up = prev.repeat_interleave(2, 1).repeat_interleave(2, 2)
-                    lat = lat + up[:, : lat.shape[1], : lat.shape[2]]
-                prev = lat
+                # lateral 1x1 + bias with F.interpolate(scale_factor=2, "nearest") + sum (fpn.py:136-141) fused in its epilogue;
+                # the backward of the add is a 2x2 sum-pool of the lateral's gradient (ore_sumpool2x2_fwd)
+                prev = A.conv(f, lateral.weight, lateral.bias, None, None, False, prev)
                 results.insert(0, A.conv(prev, output.weight, output.bias).permute(0, 3, 1, 2))
             return dict(zip(self._out_features, results))
         for idx, (lateral, output) in enumerate(zip(self.lateral_convs, self.output_convs)):

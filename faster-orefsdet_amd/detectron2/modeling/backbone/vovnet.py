@@ -228,7 +228,7 @@ class VoVNet(Backbone):
         for bi, blk in enumerate(blocks):
             if bi == 0:
                 if full is not None:
-                    x_in = F.max_pool2d(full.permute(0, 3, 1, 2), 3, 2, ceil_mode=True).permute(0, 2, 3, 1).contiguous() if stage.pool else full
+                    x_in = A.maxpool(full) if stage.pool else full
                 elif prev is not None:
                     with torch.no_grad():
                         x_in = orehip.maxpool3x3s2(prev, gate) if stage.pool else (orehip.scale_channels(prev, gate) if gate is not None else prev)
@@ -242,10 +242,7 @@ class VoVNet(Backbone):
                 sc, sh = bn.scale_shift()
                 layers.append((conv.weight, sc.contiguous(), sh.contiguous()))
             y = A.osa_block(x_in, layers)
-            C = y.shape[-1]
-            m = y.mean((1, 2))                                                                   # eSE (vovnet.py:238-260)
-            g = F.relu6(F.linear(m, blk.ese.fc.weight.view(C, C), blk.ese.fc.bias) + 3.0) / 6.0
-            out = y * g[:, None, None, :]
+            out = A.ese(y, blk.ese.fc.weight, blk.ese.fc.bias)                                   # eSE (vovnet.py:238-260)
             full = out + x_in if blk.identity else out
         return full
 

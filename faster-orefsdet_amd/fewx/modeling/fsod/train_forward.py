@@ -8,8 +8,9 @@ Reference flow restated here (one query image + its support set per call; the re
     ref:fewx/modeling/fsod/fsod_roi_heads.py:404-520  _forward_box / _run_stage (the second, live definition)
     ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:52-81,131-157   losses
 What runs where: convs / linears (forward, data gradient, weight gradient), ROIAlign fwd/bwd, CenterNet targets + losses + their
-gradient, the depthwise correlation fwd/bwd, top-k / decode / NMS are HIP kernels.  Still torch tensor ops on the device this round (small, listed in DESIGN.md):
-GroupNorm, eSE gate, max-pool backward, SM_Block pointwise math, the two ROI losses.
+gradient, the depthwise correlation fwd/bwd, GroupNorm fwd/bwd, the eSE scale and its gradient, max-pool fwd/bwd, the FPN top-down
+add and its gradient, top-k / decode / NMS are HIP kernels.  Still torch tensor ops on the device this round (small, listed in
+DESIGN.md): the [B,C]-sized gate algebra of eSE, SM_Block pointwise math, proposal matching/sampling, the two ROI losses.
 """
 from __future__ import annotations
 
@@ -73,7 +74,7 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
     outs = []
     for l, x in enumerate(feats_nhwc):
         t = A.conv(x, tower.weight, tower.bias)
-        t = F.relu(F.group_norm(t.permute(0, 3, 1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)).permute(0, 2, 3, 1).contiguous()
+        t = A.group_norm_relu(t, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
         o = A.conv(t, w5, b5)
         reg = F.relu(o[..., :4] * head.scales[l].scale)
         outs.append(torch.cat([reg, o[..., 4:5], torch.zeros(*o.shape[:3], 11, device=o.device)], -1))

@@ -69,7 +69,8 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
-           "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
+           "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
+           "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
 
@@ -644,6 +645,72 @@ def correlation_train_bwd(q, k11, k13, k31, dcat, t, u):
                                          C.c_void_p(_ptr(d13)), C.c_void_p(_ptr(d31)), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()),
                                          _stream()), "ore_correlation_train_bwd")
     return dq, dk11, d13.t().contiguous(), d31.t().contiguous()
+
+
+def groupnorm_apply(x: torch.Tensor, rstd_c: torch.Tensor, shift_c: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, relu: bool):
+    """x [1,H,W,C] (one image) -> relu?((x*rstd_c + shift_c)*gamma + beta)."""
+    _f32(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    _chk(lib().ore_groupnorm_apply_fwd(C.c_void_p(_ptr(x)), Cc, 0, C.c_int64(rows), Cc, C.c_void_p(_ptr(_f32(rstd_c))), C.c_void_p(_ptr(_f32(shift_c))),
+                                       C.c_void_p(_ptr(_f32(gamma))), C.c_void_p(_ptr(_f32(beta))), int(relu), C.c_void_p(_ptr(y)), _stream()),
+         "ore_groupnorm_apply_fwd")
+    return y
+
+
+def groupnorm_bwd(dy, y, x, groups: int, rstd_c, shift_c, gamma, relu: bool):
+    """-> dx like x, dbeta [C], dgamma [C]."""
+    _f32(dy); _f32(y); _f32(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx = torch.empty_like(x)
+    sums = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
+    ws = _wgrad_ws(x.device, rows * 2 * Cc + ((rows + 255) // 256) * 2 * Cc)
+    _chk(lib().ore_groupnorm_bwd(C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(y)), C.c_void_p(_ptr(x)), Cc, 0, C.c_int64(rows), Cc, groups,
+                                 C.c_void_p(_ptr(_f32(rstd_c))), C.c_void_p(_ptr(_f32(shift_c))), C.c_void_p(_ptr(_f32(gamma))), int(relu),
+                                 C.c_void_p(_ptr(dx)), C.c_void_p(_ptr(sums)), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()),
+         "ore_groupnorm_bwd")
+    return dx, sums[:Cc], sums[Cc:]
+
+
+def prod_colsum(p: torch.Tensor, q: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+    """p (, q) [B,H,W,C] -> [B,C]: per-image sum over pixels of p (* q), times scale."""
+    _f32(p)
+    B, Cc = p.shape[0], p.shape[-1]
+    rows = p.numel() // (B * Cc)
+    out = torch.empty(B, Cc, device=p.device, dtype=torch.float32)
+    ws = _wgrad_ws(p.device, p.numel())
+    _chk(lib().ore_prod_colsum_fwd(C.c_void_p(_ptr(p)), C.c_void_p(_ptr(_f32(q)) if q is not None else None), B, rows, Cc, C.c_float(scale),
+                                   C.c_void_p(_ptr(out)), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_prod_colsum_fwd")
+    return out
+
+
+def scale_add_channels(x: torch.Tensor, scale_bc: torch.Tensor, add_bc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _f32(x)
+    B, Cc = x.shape[0], x.shape[-1]
+    rows = x.numel() // (B * Cc)
+    out = torch.empty_like(x)
+    _chk(lib().ore_scale_add_channels_fwd(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(_f32(scale_bc))),
+                                          C.c_void_p(_ptr(_f32(add_bc)) if add_bc is not None else None), B, rows, Cc, C.c_void_p(_ptr(out)),
+                                          _stream()), "ore_scale_add_channels_fwd")
+    return out
+
+
+def maxpool3x3s2_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _f32(x); _f32(dy)
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    _chk(lib().ore_maxpool3x3s2_bwd(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(dy)), B, H, W, Cc, C.c_void_p(_ptr(dx)), _stream()), "ore_maxpool3x3s2_bwd")
+    return dx
+
+
+def sumpool2x2(x: torch.Tensor) -> torch.Tensor:
+    _f32(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, Cc, device=x.device, dtype=torch.float32)
+    _chk(lib().ore_sumpool2x2_fwd(C.c_void_p(_ptr(x)), Cc, B, H, W, Cc, C.c_void_p(_ptr(out)), _stream()), "ore_sumpool2x2_fwd")
+    return out
 
 
 def compose_roi_head(sd, support_8: torch.Tensor, prefix: str = "roi_heads."):

@@ -61,7 +61,8 @@ class ConvFn(Function):
     """y = act(conv(x, W) * scale + shift) or act(conv(x, W) + bias);  x [B,H,W,Cin] NHWC, W OIHW, stride 1, pad k//2."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, relu: bool):
+    def forward(ctx, x, weight, bias, scale, shift, relu: bool, add=None):
+        """add: optional [B,ceil(H/2),ceil(W/2),Cout] summed in nearest-2x upsampled (the FPN top-down path) in the conv epilogue."""
         x = x.contiguous()
         Cout, Cin, k, _ = weight.shape
         co16 = _c16(Cout)
@@ -69,9 +70,12 @@ class ConvFn(Function):
         sh = shift if shift is not None else (bias.detach().contiguous() if bias is not None else None)
         if out is not None:
             out.zero_()
-        y = orehip.conv2d(x, packed(weight, False), Cout, k, 1, k // 2, scale=scale, shift=sh, relu_cout=Cout if relu else 0, out=out)
+        assert add is None or (co16 == Cout and not relu)
+        y = orehip.conv2d(x, packed(weight, False), Cout, k, 1, k // 2, scale=scale, shift=sh, relu_cout=Cout if relu else 0, out=out,
+                          add=add.contiguous() if add is not None else None)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
         ctx.meta = (k, relu, bias is not None, Cout, Cin, co16)
+        ctx.has_add = add is not None
         return y if co16 == Cout else y[..., :Cout]
 
     @staticmethod
@@ -89,17 +93,18 @@ class ConvFn(Function):
             dz = dz * scale
         gx, gw, gb = _conv_backward(x, 0, Cin, weight, dz, k, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                     has_bias and ctx.needs_input_grad[2])
-        return gx, gw, gb, None, None, None
+        gadd = orehip.sumpool2x2(dz) if (ctx.has_add and ctx.needs_input_grad[6]) else None
+        return gx, gw, gb, None, None, None, gadd
 
 
-def conv(x, weight, bias=None, scale=None, shift=None, relu=False):
-    return ConvFn.apply(x, weight, bias, scale, shift, relu)
+def conv(x, weight, bias=None, scale=None, shift=None, relu=False, add=None):
+    return ConvFn.apply(x, weight, bias, scale, shift, relu, add)
 
 
 def linear(x2d, weight, bias=None, relu=False):
     """F.linear (+ReLU) on rows: x2d [N, in] -> [N, out]."""
     N, cin = x2d.shape
-    y = ConvFn.apply(x2d.reshape(1, 1, N, cin), weight.reshape(weight.shape[0], cin, 1, 1), bias, None, None, relu)
+    y = ConvFn.apply(x2d.reshape(1, 1, N, cin), weight.reshape(weight.shape[0], cin, 1, 1), bias, None, None, relu, None)
     return y.reshape(N, weight.shape[0])
 
 
@@ -154,6 +159,87 @@ class OSAFn(Function):
 def osa_block(x_in, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]):
     flat = [t for tri in layers for t in tri]
     return OSAFn.apply(x_in, *flat)
+
+
+class GroupNormReluFn(Function):
+    """relu?(GroupNorm(x)) for ONE image x [1,H,W,C] (head tower: GN(32,128) + ReLU).  Statistics by the engine's Chan-combine
+    kernels (ore_groupnorm_affine_fwd with unit gamma), apply + backward in ore_groupnorm_apply_fwd / ore_groupnorm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups: int, eps: float, relu: bool):
+        assert x.shape[0] == 1, "one image per call (statistics are per image)"
+        x = x.contiguous()
+        C = x.shape[-1]
+        one, zero = torch.ones(C, device=x.device), torch.zeros(C, device=x.device)
+        r, a = orehip.groupnorm_affine(x, groups, one, zero, eps)              # [1,C]: rstd, -mean*rstd of the channel's group
+        r, a = r.reshape(C).contiguous(), a.reshape(C).contiguous()
+        y = orehip.groupnorm_apply(x, r, a, gamma.detach().contiguous(), beta.detach().contiguous(), relu)
+        ctx.save_for_backward(x, y, r, a, gamma)
+        ctx.meta = (groups, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, r, a, gamma = ctx.saved_tensors
+        groups, relu = ctx.meta
+        dx, dbeta, dgamma = orehip.groupnorm_bwd(dy.contiguous(), y, x, groups, r, a, gamma.detach().contiguous(), relu)
+        return dx, dgamma, dbeta, None, None, None
+
+
+def group_norm_relu(x, gamma, beta, groups, eps=1e-5, relu=True):
+    return GroupNormReluFn.apply(x, gamma, beta, groups, eps, relu)
+
+
+class EseFn(Function):
+    """eSE (d2z:modeling/backbone/vovnet.py:238-260): y = x * hsigmoid(fc(mean_hw(x))).  x [B,H,W,C]; fc_w [C,C,1,1]; fc_b [C].
+    Pixel-sized work (average pool, x*gate, sum_hw dy*x, dy*gate + const) runs in HIP kernels; the [B,C]-sized vector algebra of
+    the gate (a C x C mat-vec and its transpose) stays on torch tensors."""
+
+    @staticmethod
+    def forward(ctx, x, fc_w, fc_b):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        m = orehip.prod_colsum(x, None, 1.0 / (H * W))                                 # [B,C] average pool
+        z = torch.addmm(fc_b, m, fc_w.reshape(C, C).t())
+        g = torch.clamp(z + 3.0, 0.0, 6.0) / 6.0
+        y = orehip.scale_add_channels(x, g.contiguous(), None)
+        ctx.save_for_backward(x, fc_w, m, z, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, fc_w, m, z, g = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dy = dy.contiguous()
+        dg = orehip.prod_colsum(dy, x, 1.0)                                            # [B,C] = sum_hw dy * x
+        dz = dg * ((z > -3.0) & (z < 3.0)).to(dg.dtype) / 6.0
+        Wm = fc_w.reshape(C, C)
+        dm = dz @ Wm                                                                   # [B,C]
+        dx = orehip.scale_add_channels(dy, g.contiguous(), (dm / (H * W)).contiguous())
+        return dx, (dz.t() @ m).reshape(fc_w.shape), dz.sum(0)
+
+
+def ese(x, fc_w, fc_b):
+    return EseFn.apply(x, fc_w, fc_b)
+
+
+class MaxPoolFn(Function):
+    """MaxPool2d(3, 2, ceil_mode=True) on NHWC: ore_maxpool3x3s2_fwd | ore_maxpool3x3s2_bwd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return orehip.maxpool3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return orehip.maxpool3x3s2_bwd(x, dy.contiguous())
+
+
+def maxpool(x):
+    return MaxPoolFn.apply(x)
 
 
 class CorrelationFn(Function):

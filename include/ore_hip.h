@@ -284,6 +284,27 @@ int ore_correlation_train_bwd(const float* q, int32_t q_ld, int32_t q_coff, int3
                               const float* t_save, const float* u_save, float* dq, float* dk11, float* dk13_3c,
                               float* dk31_3c, float* workspace, size_t workspace_floats, void* stream);
 
+/* Small HBM-bound training ops (NHWC fp32, channels multiple of 4), all deterministic:
+ *   GroupNorm(+ReLU) with gradients (head tower, ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:86-100; torch
+ *     F.group_norm backward).  rstd_c / shift_c [C] = per-channel rstd and -mean*rstd of the channel's group for ONE image: what
+ *     ore_groupnorm_affine_fwd returns for gamma = 1, beta = 0.  ore_groupnorm_bwd writes dx [rows][C] and (dbeta | dgamma) [2C];
+ *     workspace >= rows*2*C + ceil(rows/256)*2*C floats.
+ *   eSE (d2z:modeling/backbone/vovnet.py:238-260) pieces: ore_prod_colsum_fwd = per-image column sums of p*q (q NULL: of p) times
+ *     `scale` -> [B][C] (average pool, and d gate = sum_hw dy*x); ore_scale_add_channels_fwd = x*s[b][c] + v[b][c].
+ *   ore_maxpool3x3s2_bwd: MaxPool2d(3, 2, ceil_mode=True) backward, first maximum in scan order owns the window (ATen).
+ *   ore_sumpool2x2_fwd: backward of the FPN's nearest-2x top-down add (d2z:modeling/backbone/fpn.py:136-141). */
+int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, const float* rstd_c,
+                            const float* shift_c, const float* gamma, const float* beta, int32_t relu, float* y, void* stream);
+int ore_groupnorm_bwd(const float* dy, const float* y, const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C,
+                      int32_t groups, const float* rstd_c, const float* shift_c, const float* gamma, int32_t relu, float* dx,
+                      float* dbeta_dgamma_2c, float* workspace, size_t workspace_floats, void* stream);
+int ore_prod_colsum_fwd(const float* p, const float* q, int32_t B, int32_t rows, int32_t C, float scale, float* out_bc,
+                        float* workspace, size_t workspace_floats, void* stream);
+int ore_scale_add_channels_fwd(const float* x, const float* scale_bc, const float* add_bc, int32_t B, int32_t rows, int32_t C,
+                               float* out, void* stream);
+int ore_maxpool3x3s2_bwd(const float* x, const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
+int ore_sumpool2x2_fwd(const float* in, int32_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* stream);
+
 /* ------------------------------------------------------------------ engine ------------------- */
 /* Whole eval hot path for one model instance: owns packed weights and all
  * intermediate buffers, replays a captured hipGraph per image.
