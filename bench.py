@@ -191,7 +191,12 @@ def main():
     eng = model.engine()
     use_graph = not args.no_graph
     engines = [eng] + [model.make_engine() for _ in range(max(args.inflight, 1) - 1)]
-    streams = [torch.cuda.Stream(device) for _ in engines] if len(engines) > 1 else [None]
+    prio = os.environ.get("ORE_BENCH_STREAM_PRIO")          # experiment knob: comma list of stream priorities (e.g. "0,-1")
+    if len(engines) > 1:
+        pl = [int(v) for v in prio.split(",")] if prio else [0]
+        streams = [torch.cuda.Stream(device, priority=pl[i % len(pl)]) for i in range(len(engines))]
+    else:
+        streams = [None]
 
     def run_step(i):
         e, s = engines[i % len(engines)], streams[i % len(engines)]

@@ -504,6 +504,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, g4 = (lane >> 4) * 4;
     const int wrow = wave * TM;
+    float pre_sc[TN], pre_sh[TN];                              // epilogue operands fetched under the main loop's loads
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 16 + li;
+        pre_sc[j] = (p.scale && n < p.Cout) ? p.scale[lvl * p.ep_stride + n] : 1.0f;
+        pre_sh[j] = (p.shift && n < p.Cout) ? p.shift[lvl * p.ep_stride + n] : 0.0f;
+    }
     gload(0);
     for (int c0 = 0; c0 < p.Cin; c0 += 16) {
         lstore();
@@ -535,8 +542,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 16 + li;
         if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[lvl * p.ep_stride + n] : 1.0f;
-        const float sh = p.shift ? p.shift[lvl * p.ep_stride + n] : 0.0f;
+        const float sc = pre_sc[j], sh = pre_sh[j];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int gy = ty0 + wrow + i;
