@@ -14,7 +14,6 @@ DESIGN.md): the [B,C]-sized gate algebra of eSE, SM_Block pointwise math, propos
 """
 from __future__ import annotations
 
-import math
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -30,19 +29,6 @@ def _normalise_pad(imgs: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, di
     x = (imgs.float() - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1)
     H, W = x.shape[-2:]
     return F.pad(x, (0, (W + div - 1) // div * div - W, 0, (H + div - 1) // div * div - H)).contiguous()
-
-
-def _correlation(q: torch.Tensor, proto: torch.Tensor) -> torch.Tensor:
-    """fsod_cen.py:229-245: q [1,C,H,W], proto [1,C,s,s] -> attn [1,C,H,W] (before conv3)."""
-    C = q.shape[1]
-    k11 = F.adaptive_avg_pool2d(proto, (1, 1)).permute(1, 0, 2, 3)
-    k13 = F.adaptive_avg_pool2d(proto, (1, 3)).permute(1, 0, 2, 3)
-    k31 = F.adaptive_avg_pool2d(proto, (3, 1)).permute(1, 0, 2, 3)
-    a = F.relu(F.conv2d(q, k11, padding=(0, 0), groups=C))
-    a = F.relu(F.conv2d(a, k11, padding=(0, 0), groups=C))
-    b = F.relu(F.conv2d(q, k13, padding=(0, 1), groups=C))
-    b = F.relu(F.conv2d(b, k31, padding=(1, 0), groups=C))
-    return a + b + q
 
 
 def pairwise_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -18,7 +18,7 @@ are neither exchanged nor decayed -- torch.optim.SGD skips `grad is None` parame
 from __future__ import annotations
 
 import bisect
-from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
