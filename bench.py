@@ -110,7 +110,7 @@ def cpu_baseline(model, img, budget_s=12.0):
                       f"torch {torch.__version__} CPU, {el:.1f} s)"}
 
 
-def train_leg(device, steps=5, warmup=2, size=640, shots=24):
+def train_leg(device, steps=8, warmup=4, size=640, shots=24):
     """SURVEY 8d metric (ii), single GPU: forward + backward + clip/SGD of finetune_vovnet.yaml on one query + 24 support crops
     (tools/bench_train.py is the stand-alone / multi-GPU version).  Reported beside the headline, never as `value`."""
     from detectron2.structures import Boxes, Instances
