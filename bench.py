@@ -117,6 +117,7 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24):
     from fewx.solver import build_lr_scheduler, build_optimizer
     model, cfg = build_model(device)
     model.train()
+    model.train_graph = True        # the shape-static dense part (fwd + bwd) replays as two hipGraphs; falls back to eager if capture fails
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():                                   # second-stage weights: small, so the synthetic losses stay finite
         for n, p in model.named_parameters():
@@ -154,6 +155,7 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24):
     return {"images_per_s": round(steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
             "workload": "finetune_vovnet.yaml train step on 1 GPU: 1 query %dx%d + %d support 240x240, fwd + bwd (HIP backward kernels) + "
                         "flat-bucket clip/SGD, FREEZE_AT=3" % (size, size, shots),
+            "dense_part_hipgraph": model.__dict__.get("_ore_train_graph_error") is None,
             "exchanged_bytes_per_step_if_dp": 4 * opt.bucket.size, "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
 
 

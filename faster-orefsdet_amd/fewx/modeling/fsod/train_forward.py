@@ -67,6 +67,61 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
     return outs
 
 
+def dense_part(model, xq: torch.Tensor, xs: torch.Tensor):
+    """The shape-static part of a training iteration: query and support pyramids, support prototypes, correlation, conv3, head.
+    xq [1,3,H,W], xs [N,3,h,w] normalised + padded.  Returns (q3, q4, q5, s3, s4, s5 as NHWC, head3, head4, head5 [1,H,W,16])."""
+    from orehip import autograd as A
+    feats = model.backbone(xq)
+    sfeats = model.backbone(xs)
+    pos = []
+    for i, k in enumerate(LEVELS):
+        size = (32, 16, 8)[i]
+        sf = sfeats[k]
+        if sf.shape[-2:] != (size, size):
+            sf = F.adaptive_avg_pool2d(sf, (size, size))
+        # support prototypes: avg-pool to 32/16/8, SM_Block, the reference's H<->W swapping permute, mean over shots
+        v = getattr(model, f"vip_p{3 + i}")(nhwc_view(sf)).permute(0, 3, 2, 1)
+        proto = v.mean(0, True)
+        k11 = F.adaptive_avg_pool2d(proto, (1, 1))[0, :, 0, 0]                  # support kernels (fsod_cen.py:229-231)
+        k13 = F.adaptive_avg_pool2d(proto, (1, 3))[0, :, 0, :]
+        k31 = F.adaptive_avg_pool2d(proto, (3, 1))[0, :, :, 0]
+        cat = A.correlation_cat(nhwc_view(feats[k]), k11, k13, k31)            # [1,H,W,2C] = [attn | q]
+        pos.append(A.conv(cat, model.conv3.weight, model.conv3.bias, None, None, True))
+    heads = head_train(model.proposal_generator.centernet_head, pos)
+    return tuple(nhwc_view(feats[k]) for k in LEVELS) + tuple(nhwc_view(sfeats[k]) for k in LEVELS) + tuple(heads)
+
+
+class _DensePart(torch.nn.Module):
+    """dense_part as a Module so torch.cuda.make_graphed_callables can capture its forward AND backward into two hipGraphs
+    (one replay each per iteration instead of ~1000 launches).  The weight repacks are forced inside the capture so the replay
+    always repacks from the current parameters."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, xq, xs):
+        from orehip import autograd as A
+        A.weights_changed()
+        return dense_part(self.model, xq, xs)
+
+
+def graphed_dense_part(model, xq, xs):
+    """Cached hipGraph capture of dense_part for these input shapes (opt-in: model.train_graph = True).  Falls back to the eager
+    path (and remembers why) if the capture fails."""
+    key = (tuple(xq.shape), tuple(xs.shape))
+    cache = model.__dict__.setdefault("_ore_train_graphs", {})
+    if key not in cache:
+        try:
+            mod = _DensePart(model)
+            cache[key] = torch.cuda.make_graphed_callables(mod, (xq.clone(), xs.clone()), num_warmup_iters=3, allow_unused_input=True)
+        except Exception as ex:                                   # noqa: BLE001 -- capture is an optimisation, never a requirement
+            cache[key] = None
+            model.__dict__["_ore_train_graph_error"] = repr(ex)[:500]
+    g = cache[key]
+    return g(xq, xs) if g is not None else dense_part(model, xq, xs)
+
+
 def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Tensor]] = None, return_aux: bool = False,
                   roi_override: Optional[Dict[str, torch.Tensor]] = None):
     """model: CenterNet2Detector in training mode.  batched_inputs[i]: image [3,H,W] (uint8/float BGR), instances (gt_boxes),
@@ -92,24 +147,10 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
         sboxes = torch.as_tensor(item["support_bboxes"], dtype=torch.float32, device=dev)
         assert sup.shape[0] == model.support_way * model.support_shot, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
         assert model.support_way == 1
-        feats = model.backbone(_normalise_pad(img[None], mean, std, div))
-        sfeats = model.backbone(_normalise_pad(sup, mean, std, div))
-        # ---- support prototypes: avg-pool to 32/16/8, SM_Block, the reference's H<->W swapping permute, mean over shots
-        pos = []
-        for i, k in enumerate(LEVELS):
-            size = (32, 16, 8)[i]
-            sf = sfeats[k]
-            if sf.shape[-2:] != (size, size):
-                sf = F.adaptive_avg_pool2d(sf, (size, size))
-            v = getattr(model, f"vip_p{3 + i}")(nhwc_view(sf)).permute(0, 3, 2, 1)
-            proto = v.mean(0, True)
-            k11 = F.adaptive_avg_pool2d(proto, (1, 1))[0, :, 0, 0]                  # support kernels (fsod_cen.py:229-231)
-            k13 = F.adaptive_avg_pool2d(proto, (1, 3))[0, :, 0, :]
-            k31 = F.adaptive_avg_pool2d(proto, (3, 1))[0, :, :, 0]
-            cat = A.correlation_cat(nhwc_view(feats[k]), k11, k13, k31)            # [1,H,W,2C] = [attn | q]
-            pos.append(A.conv(cat, model.conv3.weight, model.conv3.bias, None, None, True))
-        # ---- CenterNet head, ground truth, losses
-        heads = head_train(pg.centernet_head, pos)
+        xq, xs = _normalise_pad(img[None], mean, std, div), _normalise_pad(sup, mean, std, div)
+        outs = graphed_dense_part(model, xq, xs) if getattr(model, "train_graph", False) else dense_part(model, xq, xs)
+        qf, sf_levels, heads = list(outs[0:3]), list(outs[3:6]), list(outs[6:9])
+        # ---- CenterNet ground truth, losses
         shapes = [tuple(h.shape[1:3]) for h in heads]
         rows = torch.cat([h.reshape(-1, h.shape[-1]) for h in heads], 0)
         tg = orehip.centernet_targets([gt_boxes], shapes, pg.strides, pg.sizes_of_interest, pg.hm_min_overlap, pg.min_radius, device=dev)
@@ -140,12 +181,12 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
                 roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
                 roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
         # ---- second stage
-        qf = [nhwc_view(feats[k])[0] for k in LEVELS]
+        qf = [f[0] for f in qf]
         R = roi_boxes.shape[0]
         C = qf[0].shape[-1]
         P = rh.pooler_resolution
         x = A.roi_align(qf, roi_boxes, pg.strides, P).reshape(R * P * P, C)                # rows ordered [roi][pos], channels last
-        sup8 = A.roi_align_batched([nhwc_view(sfeats[k]) for k in LEVELS], sboxes,
+        sup8 = A.roi_align_batched(sf_levels, sboxes,
                                    torch.arange(sup.shape[0], dtype=torch.int32, device=dev), pg.strides, P)   # one box per support crop
         s = sup8.mean(0, True).reshape(P * P, C)
         s_exp = s.unsqueeze(0).expand(R, P * P, C).reshape(R * P * P, C)
@@ -167,6 +208,7 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
             acc.setdefault(k, []).append(v)
         if return_aux:
             aux = dict(proposals=proposals, sampled=sampled, roi_boxes=roi_boxes, roi_labels=roi_labels, pos_inds=tg["pos_inds"],
-                       pos_count=tg["pos_count"], features=feats, pos_features=pos, heads=heads, scores=scores, deltas=deltas, h=h)
+                       pos_count=tg["pos_count"], features={k: f.permute(2, 0, 1)[None] for k, f in zip(LEVELS, qf)}, heads=heads,
+                       scores=scores, deltas=deltas, h=h)
     losses = {k: (v[0] if len(v) == 1 else torch.stack(v).mean()) for k, v in acc.items()}
     return (losses, aux) if return_aux else losses

@@ -561,3 +561,39 @@ def test_small_training_ops_backward(oh):
     _close(y.permute(0, 3, 1, 2), ref)
     (y * _nhwc(up).cuda()).sum().backward()
     _close(fg.grad.permute(0, 3, 1, 2), f.grad); _close(tg.grad.permute(0, 3, 1, 2), top.grad); _close(wg.grad, w.grad); _close(bg.grad, b.grad)
+
+
+def test_graph_captured_dense_part_matches_eager(oh):
+    """model.train_graph = True replays the shape-static dense part (forward and backward) as hipGraphs: losses, gradients and
+    the parameters after two optimizer steps must equal the eager path (same kernels, same order)."""
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod.train_forward import train_forward
+    from fewx.solver import build_optimizer
+    shots = 4
+    img, gt, sup, sbox = T.synth_train_inputs(2, (256, 320), n_gt=6, shots=shots, support_hw=96)
+    res = {}
+    for mode in ("eager", "graph"):
+        m, sd, cfg = _train_model(shots)
+        m.train_graph = mode == "graph"
+        opt = build_optimizer(cfg, m)
+        inst = Instances((256, 320))
+        inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+        item = {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+        out = []
+        for step in range(3):
+            g = torch.Generator().manual_seed(5 + step)
+            losses = train_forward(m, [item], perm=lambda n: torch.randperm(n, generator=g))
+            opt.zero_grad()
+            sum(losses.values()).backward()
+            out.append(({k: float(v.detach()) for k, v in losses.items()}, opt.bucket.grads.clone()))
+            opt.step()
+        assert m.__dict__.get("_ore_train_graph_error") is None, m.__dict__.get("_ore_train_graph_error")
+        res[mode] = (out, opt.bucket.params.clone())
+    for step in range(3):
+        le, ge = res["eager"][0][step]
+        lg, gg = res["graph"][0][step]
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-5 * max(abs(le[k]), 1e-3), (step, k, le[k], lg[k])
+        assert float((ge - gg).abs().max()) <= 1e-4 * float(ge.abs().max()), (step, float((ge - gg).abs().max()), float(ge.abs().max()))
+    assert float((res["eager"][1] - res["graph"][1]).abs().max()) <= 1e-5        # ROIAlign backward uses fp32 atomics: order differs run to run

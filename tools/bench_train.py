@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--shots", type=int, default=24)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the shape-static dense part (fwd + bwd) into hipGraphs")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -50,6 +51,7 @@ def main():
     sd["roi_heads.box_head.0.fc1.weight"] *= 0.02
     m.load_state_dict(sd, strict=False)
     m.train()
+    m.train_graph = bool(a.graph)
     model = FlatDataParallel(m, cfg, overlap=not a.no_overlap) if world > 1 else m
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
@@ -88,6 +90,7 @@ def main():
                           "scaling": "weak", "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "finetune_vovnet.yaml train step, 1 query %dx%d + %d support 240x240 per GPU" % (a.size, a.size, a.shots),
                                      "bucket_bytes": 4 * opt.bucket.size},
+                          "train_graph": bool(a.graph), "train_graph_error": m.__dict__.get("_ore_train_graph_error"),
                           "losses": {k: float(v.detach()) for k, v in losses.items()}}))
     if world > 1:
         dist.destroy_process_group()
