@@ -38,6 +38,7 @@ struct WgradP {
     int B, H, W, Cin, Cout, kh, kw, pad;
     int M, chunk;            // rows, rows per split (multiple of 16)
     float* slab;             // [S][Cout][taps][Cin]
+    float* dw; float beta;   // S == 1: write OIHW directly (no slab, no reduce launch)
 };
 
 constexpr int WG_T = 64;     // block tile: 64 output channels x 64 input channels of one tap
@@ -110,7 +111,14 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wm * 32 + tm * 16 + (lane >> 4) * 4 + r;
-                if (co < p.Cout && ci < p.Cin) slab[((size_t)co * taps + tap) * p.Cin + ci] = acc[tm][tn][r];
+                if (co < p.Cout && ci < p.Cin) {
+                    if (p.dw) {
+                        float* o = p.dw + ((size_t)co * p.Cin + ci) * taps + tap;
+                        *o = p.beta != 0.0f ? p.beta * *o + acc[tm][tn][r] : acc[tm][tn][r];
+                    } else {
+                        slab[((size_t)co * taps + tap) * p.Cin + ci] = acc[tm][tn][r];
+                    }
+                }
             }
         }
 }
@@ -459,7 +467,7 @@ extern "C" int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32
 extern "C" size_t ore_conv_wgrad_workspace_floats(int32_t rows, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw) {
     const long long per = (long long)Cout * kh * kw * Cin;
     const int tiles = ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T) * kh * kw;
-    int S = max(1, min(ceil_div(1024, tiles), ceil_div(rows, 64)));
+    int S = max(1, min(ceil_div(512, tiles), ceil_div(rows, 128)));
     return (size_t)(per * S);
 }
 
@@ -475,7 +483,7 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     ORE_CHECK_ARG(M < (1ll << 31), "ore_conv2d_wgrad_fwd: too many rows");
     const long long per = (long long)Cout * kh * kw * Cin;
     const int tiles = ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T) * kh * kw;
-    int S = max(1, min(ceil_div(1024, tiles), ceil_div((int)M, 64)));
+    int S = max(1, min(ceil_div(512, tiles), ceil_div((int)M, 128)));
     { const long long cap = (long long)(workspace_floats / (size_t)per); if (cap < S) S = (int)cap; }
     if (S < 1) { ore_set_error("ore_conv2d_wgrad_fwd: workspace too small (%zu < %lld floats)", workspace_floats, per); return ORE_ENOMEM; }
     WgradP p{};
@@ -484,10 +492,11 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     p.M = (int)M; p.chunk = round_up(ceil_div((int)M, S), WG_K);
     S = ceil_div((int)M, p.chunk);
     p.slab = workspace;
+    if (S == 1) { p.dw = dw_oihw; p.beta = beta; }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
     int rc = ore_launch_status("k_wgrad");
-    if (rc) return rc;
+    if (rc || S == 1) return rc;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
     return ore_launch_status("k_wgrad_reduce");
 }
