@@ -597,3 +597,34 @@ def test_graph_captured_dense_part_matches_eager(oh):
             assert abs(le[k] - lg[k]) <= 1e-5 * max(abs(le[k]), 1e-3), (step, k, le[k], lg[k])
         assert float((ge - gg).abs().max()) <= 1e-4 * float(ge.abs().max()), (step, float((ge - gg).abs().max()), float(ge.abs().max()))
     assert float((res["eager"][1] - res["graph"][1]).abs().max()) <= 1e-5        # ROIAlign backward uses fp32 atomics: order differs run to run
+
+
+def test_train_forward_batch_and_empty_gt(oh):
+    """A list of several images averages the per-image losses (documented deviation from the reference, which returns the last
+    image's: SURVEY App. C.1); an image without ground truth trains on background only (finite losses, no box-regression term)."""
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    shots = 4
+    m, sd, cfg = _train_model(shots)
+
+    def item(seed, n_gt):
+        img, gt, sup, sbox = T.synth_train_inputs(seed, (256, 320), n_gt=max(n_gt, 1), shots=shots, support_hw=96)
+        gt = gt[:n_gt]
+        inst = Instances((256, 320))
+        inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.ones(len(gt), dtype=torch.int64)     # forced to class 0 by the detector
+        return {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+    a, b = item(1, 5), item(2, 0)
+    torch.manual_seed(0)
+    la = m([a])
+    torch.manual_seed(0)
+    lb = m([b])
+    assert float(lb["loss_box_reg_stage0"]) == 0.0 and all(torch.isfinite(v) for v in lb.values())
+    assert float(lb["loss_centernet_agn_pos"]) == 0.0 and float(lb["loss_centernet_loc"]) == 0.0
+    assert int(a["instances"].gt_classes.sum()) == 0                                           # gt_classes forced to 0 (fsod_cen.py:158-159)
+    torch.manual_seed(0)
+    lab = m([a, b])
+    for k in la:
+        if k.startswith("loss_centernet"):                                                      # deterministic part (no sampling)
+            assert abs(float(lab[k]) - 0.5 * (float(la[k]) + float(lb[k]))) <= 1e-5 * max(abs(float(lab[k])), 1e-3), k
+    sum(lab.values()).backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
