@@ -628,3 +628,52 @@ def test_train_forward_batch_and_empty_gt(oh):
             assert abs(float(lab[k]) - 0.5 * (float(la[k]) + float(lb[k]))) <= 1e-5 * max(abs(float(lab[k])), 1e-3), k
     sum(lab.values()).backward()
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_default_trainer_loop_with_synthetic_loader(oh, tmp_path):
+    """The reference's training protocol end to end (ref:fsod_train_net.py:36-73,96-118): a DefaultTrainer subclass with a synthetic
+    loader runs run_step + scheduler + periodic checkpoint, then resumes from the checkpoint (model, momentum, iteration)."""
+    import os
+    from conftest import PKG
+    from oracle import ref_train as T
+    from detectron2.engine import DefaultTrainer
+    from detectron2.structures import Boxes, Instances
+    from fewx.config import get_cfg
+    shots = 4
+
+    def batches():
+        i = 0
+        while True:
+            img, gt, sup, sbox = T.synth_train_inputs(30 + i % 3, (256, 320), n_gt=5, shots=shots, support_hw=96)
+            inst = Instances((256, 320))
+            inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+            yield [{"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}]
+            i += 1
+
+    class Trainer(DefaultTrainer):
+        @classmethod
+        def build_train_loader(cls, cfg):
+            return batches()
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(PKG, "configs", "fsod", "finetune_vovnet.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "INPUT.FS.SUPPORT_SHOT", shots, "SOLVER.MAX_ITER", 4, "SOLVER.CHECKPOINT_PERIOD", 2,
+                         "OUTPUT_DIR", str(tmp_path), "MODEL.WEIGHTS", ""])
+    cfg.freeze()
+    torch.manual_seed(0)
+    tr = Trainer(cfg)
+    tr.resume_or_load(resume=False)
+    w0 = tr.model.conv3.weight.detach().clone()
+    tr.train()
+    assert tr.iter == 3 and all(torch.isfinite(v) for v in tr.last_losses.values())
+    assert set(tr.last_losses) == {"loss_cls_stage0", "loss_box_reg_stage0", "loss_centernet_loc", "loss_centernet_agn_pos", "loss_centernet_agn_neg"}
+    assert not torch.equal(tr.model.conv3.weight.detach(), w0)
+    g0 = tr.optimizer.param_groups[0]
+    assert abs(g0["lr"] - g0["initial_lr"] * tr.scheduler.factor(4)) < 1e-12 and g0["initial_lr"] in (0.001, 0.002)
+    files = sorted(os.listdir(tmp_path))
+    assert "model_0000001.pth" in files and "model_0000003.pth" in files and "model_final.pth" in files and "last_checkpoint" in files
+    w_end, mom_end = tr.model.conv3.weight.detach().clone(), tr.optimizer.bucket.momentum.clone()
+    tr2 = Trainer(cfg)
+    tr2.resume_or_load(resume=True)
+    assert torch.equal(tr2.model.conv3.weight.detach(), w_end) and torch.equal(tr2.optimizer.bucket.momentum, mom_end)
+    assert tr2.start_iter == 4
