@@ -504,13 +504,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, g4 = (lane >> 4) * 4;
     const int wrow = wave * TM;
-    float pre_sc[TN], pre_sh[TN];                              // epilogue operands fetched under the main loop's loads
+    f32x4 pre_sc4[TN], pre_sh4[TN];                            // epilogue operands fetched under the main loop's loads
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 16 + li;
-        pre_sc[j] = (p.scale && n < p.Cout) ? p.scale[lvl * p.ep_stride + n] : 1.0f;
-        pre_sh[j] = (p.shift && n < p.Cout) ? p.shift[lvl * p.ep_stride + n] : 0.0f;
-    }
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + j * 16 + g4 + r;
+            pre_sc4[j][r] = (p.scale && n < p.Cout) ? p.scale[lvl * p.ep_stride + n] : 1.0f;
+            pre_sh4[j][r] = (p.shift && n < p.Cout) ? p.shift[lvl * p.ep_stride + n] : 0.0f;
+        }
     gload(0);
     for (int c0 = 0; c0 < p.Cin; c0 += 16) {
         lstore();
@@ -533,26 +535,31 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);   // D^T: rows = channels
             }
         __syncthreads();
     }
-    // ---- epilogue: accumulator (i, j, r): tile row wrow+i, column (lane>>4)*4 + r, channel n0 + j*16 + (lane&15)
+    // ---- epilogue.  The operands are swapped (weights as the MFMA "A"), so accumulator (i, j) holds D^T: lane = (pixel lane&15 of tile
+    // row wrow+i, channels n0 + j*16 + (lane>>4)*4 .. +3) -> ONE 16-byte store per lane per tile instead of four 4-byte stores
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 16 + li;
+        const int n = n0 + j * 16 + g4;                       // first of this lane's 4 channels
         if (n >= p.Cout) continue;
-        const float sc = pre_sc[j], sh = pre_sh[j];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int gy = ty0 + wrow + i;
+            const int gy = ty0 + wrow + i, gx = tx0 + li;
+            if (gy < L.H && gx < L.W) {
+                f32x4 v = acc[i][j] * pre_sc4[j] + pre_sh4[j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gx = tx0 + g4 + r;
-                if (gy < L.H && gx < L.W) {
-                    float v = acc[i][j][r] * sc + sh;
-                    if (n < p.relu_cout) v = fmaxf(v, 0.f);
-                    p.out[(size_t)(obase + gy * L.W + gx) * p.out_ld + p.out_coff + n] = v;
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.f);
+                float* o = p.out + (size_t)(obase + gy * L.W + gx) * p.out_ld + p.out_coff + n;
+                if (n + 3 < p.Cout) {
+                    *reinterpret_cast<f32x4*>(o) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.Cout) o[r] = v[r];
                 }
             }
         }
@@ -564,6 +571,7 @@ int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH
 static int patch_launch(const ConvP& c, hipStream_t st) {
     // returns ORE_OK if launched, 1 if the layer is not eligible (caller falls back to the generic kernel)
     if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.Cout16 % 64 != 0 || c.in_mul || c.add || c.colsum) return 1;
+    if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 15) != 0) return 1;      // the epilogue stores 16 bytes per lane
     if (g_patch_mode == 0) return 1;
     int TH = g_patch_mode > 0 ? g_patch_mode : 4;
     if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
