@@ -213,15 +213,44 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 
     // epilogue operands fetched NOW, under the K loop's loads (a dependent global load after the last MFMA costs ~1 us of pure
     // latency on the small layers); per-level scale/shift (ep_stride != 0) keep the late path
-    float pre_sc[TN], pre_sh[TN];
+    // The MFMA operands are swapped (weights as "A"), so accumulator (i, j) holds D^T: this lane = pixel row
+    // m0 + wm*WM + i*16 + (lane&15), channels n0 + wn*WN + j*16 + (lane>>4)*4 .. +3  -> 16-byte stores.
+    // Epilogue operands (scale/shift of the block's BN channels) go to LDS NOW, under the K loop's loads: a dependent global load
+    // after the last MFMA costs ~1 us of pure latency on the small layers.  Per-level scale/shift (ep_stride != 0) keep the late path.
+    __shared__ float sh_sc[BN], sh_sh[BN];
     const bool ep_pre = p.ep_stride == 0;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + (lane & 15);
+    const int cg4 = (lane >> 4) * 4;
+    if (tid < BN) {
+        const int n = n0 + tid;
         const bool okn = ep_pre && n < p.Cout;
-        pre_sc[j] = (okn && p.scale) ? p.scale[n] : 1.0f;
-        pre_sh[j] = (okn && p.shift) ? p.shift[n] : 0.0f;
+        sh_sc[tid] = (okn && p.scale) ? p.scale[n] : 1.0f;
+        sh_sh[tid] = (okn && p.shift) ? p.shift[n] : 0.0f;
     }
+    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+    // finish one accumulator vector: 4 channels of one pixel
+    auto finish = [&](f32x4 a, int m, int n, f32x4& vout) -> bool {
+        if (m >= p.M || n >= p.Cout) return false;
+        f32x4 v;
+        if (ep_pre && !p.add) {
+            v = a * *reinterpret_cast<const f32x4*>(sh_sc + (n - n0)) + *reinterpret_cast<const f32x4*>(sh_sh + (n - n0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.0f);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = n + r < p.Cout ? epilogue_one(p, a[r], m, n + r) : 0.0f;
+        }
+        float* o = p.out + (size_t)m * p.out_ld + p.out_coff + n;
+        if (vec_ok && n + 3 < p.Cout) {
+            *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.Cout) o[r] = v[r];
+        }
+        vout = v;
+        return true;
+    };
 
     const int frow = lane & 15, fk = kg * 16 + (lane >> 4) * 4;
     // one K step: (optionally) issue the loads of step st+PF into ring slot u, MFMA on LDS buffer `cur`, (optionally) park the
@@ -238,11 +267,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                           \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0); /* D^T */         \
         if (DO_STORE)                                                                                                           \
             lstore(cur ^ 1, ra[((u) + 1) % PF], rb[((u) + 1) % PF], rmul[((u) + 1) % PF], radd[((u) + 1) % PF], rok[((u) + 1) % PF]); \
         __syncthreads();                                                                                                        \
     }
+    if (s_begin >= s_end) __syncthreads();                     // publishes sh_sc/sh_sh when the K loop (and its barriers) is empty
     if (s_begin < s_end) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) gload(s_begin + u, ra[u], rb[u], rmul[u], radd[u], rok[u]);   // steps past the end load zeros
@@ -276,30 +306,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
             for (int j = 0; j < TN; ++j)
                 *reinterpret_cast<f32x4*>(lds + ((kg * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4) = acc[i][j];
         __syncthreads();
+        // every 16-byte item (wmn, tile, lane) is finished by exactly one of the 256 threads: 4x the store parallelism of a single wave
+        constexpr int NT = (WGM * WGN) * TM * TN;                       // tiles of the block
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int q0 = 0; q0 < NT * 64; q0 += 256) {
+            const int q = q0 + tid;
+            if (q < NT * 64) {
+                const int tl = q >> 6, ln = q & 63;                     // tile index ((wmn*TM + i)*TN + j), source lane
+                const int j2 = tl % TN, i2 = (tl / TN) % TM, w2 = tl / (TM * TN);
+                const int wm2 = w2 / WGN, wn2 = w2 % WGN;
+                f32x4 a = *reinterpret_cast<const f32x4*>(lds + (0 * NT + tl) * 256 + ln * 4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + (lane & 15);
-#pragma unroll
-                for (int rr = 0; rr < 4 / WGK; ++rr) {
-                    const int r = kg + rr * WGK;
-                    float a = lds[((0 * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4 + r];
-#pragma unroll
-                    for (int g = 1; g < WGK; ++g) a += lds[((g * (WGM * WGN) + wmn) * TM * TN + i * TN + j) * 256 + lane * 4 + r];
-                    const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-                    if (m < p.M && n < p.Cout) {
-                        float v;
-                        if (ep_pre && !p.add) {
-                            v = a * pre_sc[j] + pre_sh[j];
-                            if (n < p.relu_cout) v = fmaxf(v, 0.0f);
-                        } else {
-                            v = epilogue_one(p, a, m, n);
-                        }
-                        p.out[(size_t)m * p.out_ld + p.out_coff + n] = v;
-                    }
-                }
+                for (int g = 1; g < WGK; ++g) a += *reinterpret_cast<const f32x4*>(lds + (g * NT + tl) * 256 + ln * 4);
+                const int m = m0 + wm2 * WM + i2 * 16 + (ln & 15);
+                const int n = n0 + wn2 * WN + j2 * 16 + (ln >> 4) * 4;
+                f32x4 vo;
+                finish(a, m, n, vo);
             }
+        }
         return;
     }
     // Slow path: groups kg>0 park their tiles in LDS, group 0 adds them in group order and carries on alone
@@ -370,58 +394,50 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         return;
     }
 
-    // ---- fused epilogue
-    float csum[TN];
+    // ---- fused epilogue (transposed accumulators: one pixel, 4 consecutive channels per lane and tile)
+    f32x4 csum[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) csum[j] = 0.f;
+    for (int j = 0; j < TN; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-                if (m < p.M && n < p.Cout) {
-                    float v;
-                    if (ep_pre && !p.add) {
-                        v = acc[i][j][r] * pre_sc[j] + pre_sh[j];
-                        if (n < p.relu_cout) v = fmaxf(v, 0.0f);
-                    } else {
-                        v = epilogue_one(p, acc[i][j][r], m, n);
-                    }
-                    p.out[(size_t)m * p.out_ld + p.out_coff + n] = v;
-                    csum[j] += v;
-                }
-            }
+            const int m = m0 + wm * WM + i * 16 + (lane & 15);
+            const int n = n0 + wn * WN + j * 16 + cg4;
+            f32x4 v;
+            if (finish(acc[i][j], m, n, v)) csum[j] += v;
         }
     if (p.colsum) {
-        // column sums of this tile: 4 lane groups hold different rows of the same column -> xor 16 / 32, then across WGM waves
+        // column sums of this tile: the 16 pixel lanes of a channel group -> xor 1, 2, 4, 8; then across the WGM waves
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            csum[j] += __shfl_xor(csum[j], 16);
-            csum[j] += __shfl_xor(csum[j], 32);
-        }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[j][r] += __shfl_xor(csum[j][r], d);
+        const bool owner = (lane & 15) == 0;                         // holds channels j*16 + cg4 .. +3
         if (WGM > 1) {
             __syncthreads();
-            if (lane < 16)
+            if (owner)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) lds[(wm * WGN + wn) * (TN * 16) + j * 16 + lane] = csum[j];
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(lds + (wm * WGN + wn) * (TN * 16) + j * 16 + cg4) = csum[j];
             __syncthreads();
-            if (wm == 0 && lane < 16)
+            if (wm == 0 && owner)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float s = csum[j];
-                    for (int w2 = 1; w2 < WGM; ++w2) s += lds[(w2 * WGN + wn) * (TN * 16) + j * 16 + lane];
-                    csum[j] = s;
+                    f32x4 sacc = csum[j];
+                    for (int w2 = 1; w2 < WGM; ++w2) sacc += *reinterpret_cast<const f32x4*>(lds + (w2 * WGN + wn) * (TN * 16) + j * 16 + cg4);
+                    csum[j] = sacc;
                 }
         }
-        if (wm == 0 && lane < 16)
+        if (wm == 0 && owner)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + lane;
-                if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = csum[j];
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * WN + j * 16 + cg4 + r;
+                    if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = csum[j][r];
+                }
     }
 }
 
