@@ -127,8 +127,9 @@ struct RoiBwdP {
     const int* bidx;
 };
 
+constexpr int ROI_BWD_SPLIT = 4;        // blocks per ROI (the 128 sampled ROIs alone leave half of the CUs idle)
 __global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p) {
-    const int r = blockIdx.x;
+    const int r = blockIdx.x / ROI_BWD_SPLIT, part = blockIdx.x % ROI_BWD_SPLIT;
     const int P = p.pooled, C4 = p.C >> 2;
     const float* src = p.dout + (size_t)r * P * P * p.C;
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p) {
     const float bw = rw / (float)P, bh = rh / (float)P;
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float cnt = (float)max(gh * gw, 1);
-    for (int i = threadIdx.x; i < P * P * C4; i += 256) {
+    for (int i = part * 256 + threadIdx.x; i < P * P * C4; i += 256 * ROI_BWD_SPLIT) {
         const int c = (i % C4) * 4, bin = i / C4;
         const int ph = bin / P, pw = bin - ph * P;
         const f32x4 g = *reinterpret_cast<const f32x4*>(src + (size_t)bin * p.C + c) / cnt;
@@ -368,6 +369,6 @@ extern "C" int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const i
     p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
     p.canonical_size = 224.0f; p.canonical_level = 4;
     p.boxes = boxes; p.n = n; p.dout = dout; p.bidx = box_image;
-    hipLaunchKernelGGL(k_roi_align_bwd, dim3(n), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_roi_align_bwd, dim3(n * ROI_BWD_SPLIT), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_roi_align_bwd");
 }
