@@ -677,3 +677,35 @@ def test_default_trainer_loop_with_synthetic_loader(oh, tmp_path):
     tr2.resume_or_load(resume=True)
     assert torch.equal(tr2.model.conv3.weight.detach(), w_end) and torch.equal(tr2.optimizer.bucket.momentum, mom_end)
     assert tr2.start_iter == 4
+
+
+def test_train_iteration_full_size_vs_oracle(oh):
+    """BASELINE.json's training shape (640x640 query, 24 support crops of 240x240, 17 gt boxes): the five losses and the gradients
+    against the CPU oracle at full size (same conditioning-aware bounds as the small case)."""
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod.train_forward import train_forward
+    shots = 24
+    m, sd, cfg = _train_model(shots)
+    img, gt, sup, sbox = T.synth_train_inputs(4, (640, 640), n_gt=17, shots=shots, support_hw=240)
+    leaf = T.leaf_state(sd)
+    g = torch.Generator().manual_seed(21)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    ref = T.train_iteration(leaf, img, gt, sup, sbox, lambda n: torch.randperm(n, generator=g))
+    sum(ref["losses"].values()).backward()
+    inst = Instances((640, 640))
+    inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+    item = {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+    over = {"boxes": ref["roi_boxes"], "labels": ref["roi_labels"], "gt": ref["roi_gt"]}
+    losses, aux = train_forward(m, [item], return_aux=True, roi_override=over)
+    assert int(aux["pos_count"].item()) == len(ref["pos_inds"]) and torch.equal(aux["pos_inds"][: len(ref["pos_inds"])].cpu(), ref["pos_inds"])
+    for k, v in ref["losses"].items():
+        assert abs(float(losses[k].detach()) - float(v.detach())) <= 5e-4 * max(abs(float(v.detach())), 1e-3), (k, float(losses[k]), float(v))
+    sum(losses.values()).backward()
+    named = dict(m.named_parameters())
+    errs = []
+    for k, t in leaf.items():
+        if t.requires_grad and t.grad is not None:
+            errs.append(float((named[k].grad.cpu() - t.grad).abs().max()) / max(float(t.grad.abs().max()), 1e-8))
+    errs.sort()
+    assert len(errs) == 73 and errs[len(errs) // 2] <= 2e-4 and errs[-1] <= 5e-2, (errs[len(errs) // 2], errs[-3:])
