@@ -582,7 +582,278 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
     }
 }
 
-int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH
+// Double-buffered 8-wave variant: a block of 512 threads owns an 8 x 16 pixel tile x 64 output channels; wave w = tile row w.
+// Two LDS buffers (2 x 72 KB, one block per CU): the slab k+1 written to the other buffer while slab k is multiplied, ONE barrier per
+// slab, the 36 KB weight slab staged once per 128 pixels (half of the 4-wave kernel's weight traffic per pixel).
+__global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
+    constexpr int TH = 8, TW = 16, BN = 64, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDA = 24, NT_ = 512;
+    constexpr int TN = BN / 16;
+    constexpr int A_IT = (NPIX * 4 + NT_ - 1) / NT_;            // 720 float4 -> 2 slots
+    constexpr int B_IT = (9 * BN * 4 + NT_ - 1) / NT_;          // 2304 float4 -> 5 slots (4.5)
+    constexpr int BUF = (NPIX + 9 * BN) * LDA;                  // floats per buffer
+    extern __shared__ __attribute__((aligned(16))) float plds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+        if (l < p.nlev && (int)blockIdx.x >= p.tile0[l]) lvl = l;
+    const Lvl L = p.lv[lvl];
+    const int tl = blockIdx.x - p.tile0[lvl];
+    const int tpi = p.tiles_x[lvl] * p.tiles_y[lvl];
+    const int b = tl / tpi, tr = tl - b * tpi;
+    const int ty0 = (tr / p.tiles_x[lvl]) * TH, tx0 = (tr % p.tiles_x[lvl]) * TW;
+    const int n0 = blockIdx.y * BN;
+    const int ibase = L.irow0 + b * L.H * L.W, obase = L.orow0 + b * L.H * L.W;
+    const float* zero = g_zero16;
+    auto sel = [&](bool ok, const float* ptr) -> const f32x4* {
+        const uintptr_t m = (uintptr_t)0 - (uintptr_t)ok;
+        return reinterpret_cast<const f32x4*>(((uintptr_t)ptr & m) | ((uintptr_t)zero & ~m));
+    };
+    const float* a_ptr[A_IT]; bool a_ok[A_IT]; int a_lds[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int f = tid + i * NT_, pi = f >> 2, q = f & 3;
+        const int py = pi / PW, px = pi - py * PW;
+        const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+        a_ok[i] = pi < NPIX && (unsigned)gy < (unsigned)L.H && (unsigned)gx < (unsigned)L.W;
+        a_ptr[i] = p.in + (ptrdiff_t)(ibase + gy * L.W + gx) * p.in_ld + p.in_coff + q * 4;
+        a_lds[i] = pi < NPIX ? pi * LDA + q * 4 : -1;
+    }
+    const float* b_ptr[B_IT]; bool b_ok[B_IT]; int b_lds[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int f = tid + j * NT_;                           // float4 index over [tap][bn][q]
+        const int tap = f / (BN * 4), rem = f - tap * (BN * 4), bn = rem >> 2, q = rem & 3;
+        b_ok[j] = f < 9 * BN * 4 && n0 + bn < p.Cout16;
+        b_ptr[j] = p.w + (size_t)(b_ok[j] ? n0 + bn : 0) * p.K + (size_t)(tap < 9 ? tap : 0) * p.Cin + q * 4;
+        b_lds[j] = f < 9 * BN * 4 ? NPIX * LDA + (tap * BN + bn) * LDA + q * 4 : -1;
+    }
+    f32x4 ra[A_IT], rb[B_IT];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) ra[i] = *sel(a_ok[i], a_ptr[i] + c0);
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) rb[j] = *sel(b_ok[j], b_ptr[j] + c0);
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (a_lds[i] >= 0) *reinterpret_cast<f32x4*>(buf + a_lds[i]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j)
+            if (b_lds[j] >= 0) *reinterpret_cast<f32x4*>(buf + b_lds[j]) = rb[j];
+    };
+    f32x4 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, g4 = (lane >> 4) * 4;
+    f32x4 pre_sc4[TN], pre_sh4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + j * 16 + g4 + r;
+            pre_sc4[j][r] = (p.scale && n < p.Cout) ? p.scale[lvl * p.ep_stride + n] : 1.0f;
+            pre_sh4[j][r] = (p.shift && n < p.Cout) ? p.shift[lvl * p.ep_stride + n] : 0.0f;
+        }
+    gload(0);
+    lstore(plds);
+    if (16 < p.Cin) gload(16);
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < p.Cin; c0 += 16) {
+        const float* As = plds + cur * BUF;
+        const float* Bs = As + NPIX * LDA;
+        // park the next slab (already in registers) in the other buffer, then fetch the one after it: both overlap the MFMAs below
+        if (c0 + 16 < p.Cin) {
+            lstore(plds + (cur ^ 1) * BUF);
+            if (c0 + 32 < p.Cin) gload(c0 + 32);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                f32x4 bf[TN];
+                const f32x4 af = *reinterpret_cast<const f32x4*>(As + ((wave + dy) * PW + li + dx) * LDA + g4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + ((dy * 3 + dx) * BN + j * 16 + li) * LDA + g4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[t], acc[j], 0, 0, 0);
+            }
+        __syncthreads();            // everyone is done reading `cur` and done writing `cur ^ 1`
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 16 + g4;
+        if (n >= p.Cout) continue;
+        const int gy = ty0 + wave, gx = tx0 + li;
+        if (gy < L.H && gx < L.W) {
+            f32x4 v = acc[j] * pre_sc4[j] + pre_sh4[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.f);
+            float* o = p.out + (size_t)(obase + gy * L.W + gx) * p.out_ld + p.out_coff + n;
+            if (n + 3 < p.Cout) {
+                *reinterpret_cast<f32x4*>(o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.Cout) o[r] = v[r];
+            }
+        }
+    }
+}
+
+// Weight-stationary 3x3 kernel for Cin = 64 layers (stem_2, the 64->64 layers of stage 2: a third of the network's FLOPs).
+// wave w of a block keeps the weights of 16 output channels x 9 taps x 64 input channels in REGISTERS (36 MFMA A-fragments, 144
+// VGPRs) for the whole launch; the block is persistent and walks pixel tiles (TH x 16 px), staging only the (TH+2) x 18 x 64ch halo
+// patch per tile (double-buffered LDS, one barrier per tile, 144*TH MFMAs per wave between barriers).  No weight re-staging, one
+// LDS read per 4 MFMAs, small tiles (TH = 2) balance 3200 tiles over 512 resident blocks.
+template <int TH>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_ws64(PatchP p, int ntiles) {
+    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = 72, NCH = 4;
+    constexpr int A_IT = (NPIX * 16 + 255) / 256;              // float4 slots per thread for one halo patch
+    constexpr int BUF = NPIX * LDC;
+    extern __shared__ __attribute__((aligned(16))) float plds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g4 = (lane >> 4) * 4;
+    const int n0 = blockIdx.y * 64 + wave * 16;               // this wave's 16 output channels
+    // ---- weights -> registers (MFMA A operand: row = channel n0 + li, k = chunk*16 + g4 + t)
+    f32x4 wf[9][NCH];
+    {
+        const bool okw = n0 + li < p.Cout16;
+        const float* wrow = p.w + (size_t)(okw ? n0 + li : 0) * p.K + g4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                wf[tap][c] = *reinterpret_cast<const f32x4*>(wrow + tap * 64 + c * 16);
+                if (!okw) wf[tap][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    const float* zero = g_zero16;
+    auto sel = [&](bool ok, const float* ptr) -> const f32x4* {
+        const uintptr_t m = (uintptr_t)0 - (uintptr_t)ok;
+        return reinterpret_cast<const f32x4*>(((uintptr_t)ptr & m) | ((uintptr_t)zero & ~m));
+    };
+    // tile-independent part of the staging slots
+    int s_py[A_IT], s_px[A_IT], s_q[A_IT], s_lds[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int f = tid + i * 256, pi = f >> 4;
+        s_q[i] = (f & 15) * 4;
+        s_py[i] = pi / PW; s_px[i] = pi - s_py[i] * PW;
+        s_lds[i] = pi < NPIX ? pi * LDC + s_q[i] : -1;
+    }
+    struct TileGeo { int lvl, ty0, tx0, ibase, obase, H, W; };
+    auto decode = [&](int t) -> TileGeo {
+        TileGeo g;
+        g.lvl = 0;
+#pragma unroll
+        for (int l = 1; l < 4; ++l)
+            if (l < p.nlev && t >= p.tile0[l]) g.lvl = l;
+        const Lvl& L = p.lv[g.lvl];
+        const int tl = t - p.tile0[g.lvl];
+        const int tpi = p.tiles_x[g.lvl] * p.tiles_y[g.lvl];
+        const int b = tl / tpi, tr = tl - b * tpi;
+        g.ty0 = (tr / p.tiles_x[g.lvl]) * TH; g.tx0 = (tr % p.tiles_x[g.lvl]) * TW;
+        g.ibase = L.irow0 + b * L.H * L.W; g.obase = L.orow0 + b * L.H * L.W; g.H = L.H; g.W = L.W;
+        return g;
+    };
+    f32x4 ra[A_IT];
+    auto gload = [&](const TileGeo& g) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int gy = g.ty0 - 1 + s_py[i], gx = g.tx0 - 1 + s_px[i];
+            const bool ok = s_lds[i] >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            ra[i] = *sel(ok, p.in + (ptrdiff_t)(g.ibase + gy * g.W + gx) * p.in_ld + p.in_coff + s_q[i]);
+        }
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (s_lds[i] >= 0) *reinterpret_cast<f32x4*>(buf + s_lds[i]) = ra[i];
+    };
+    f32x4 sc4, sh4;
+    int t = blockIdx.x;
+    TileGeo cur_g = decode(t < ntiles ? t : 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                             // epilogue operands (single level in practice; per-level scales re-read below)
+        const int n = n0 + g4 + r;
+        sc4[r] = (p.scale && n < p.Cout) ? p.scale[cur_g.lvl * p.ep_stride + n] : 1.0f;
+        sh4[r] = (p.shift && n < p.Cout) ? p.shift[cur_g.lvl * p.ep_stride + n] : 0.0f;
+    }
+    if (t < ntiles) { gload(cur_g); lstore(plds); }
+    __syncthreads();
+    int cur = 0;
+    for (; t < ntiles; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        const bool has_next = tn < ntiles;
+        TileGeo nxt_g = cur_g;
+        if (has_next) { nxt_g = decode(tn); gload(nxt_g); }       // the next halo patch flies under this tile's MFMAs
+        const float* As = plds + cur * BUF;
+        f32x4 acc[TH];
+#pragma unroll
+        for (int sg = 0; sg < TH; ++sg) acc[sg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    f32x4 af[TH];
+#pragma unroll
+                    for (int sg = 0; sg < TH; ++sg)
+                        af[sg] = *reinterpret_cast<const f32x4*>(As + ((sg + dy) * PW + li + dx) * LDC + c * 16 + g4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int sg = 0; sg < TH; ++sg)
+                            acc[sg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[dy * 3 + dx][c][k], af[sg][k], acc[sg], 0, 0, 0);
+                }
+        if (has_next) lstore(plds + (cur ^ 1) * BUF);
+        // ---- epilogue: lane = pixel (row ty0 + sg, column tx0 + li), channels n0 + g4 .. +3
+        if (p.ep_stride != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + g4 + r;
+                sc4[r] = (p.scale && n < p.Cout) ? p.scale[cur_g.lvl * p.ep_stride + n] : 1.0f;
+                sh4[r] = (p.shift && n < p.Cout) ? p.shift[cur_g.lvl * p.ep_stride + n] : 0.0f;
+            }
+        }
+        const int n = n0 + g4;
+        if (n < p.Cout) {
+#pragma unroll
+            for (int sg = 0; sg < TH; ++sg) {
+                const int gy = cur_g.ty0 + sg, gx = cur_g.tx0 + li;
+                if (gy < cur_g.H && gx < cur_g.W) {
+                    f32x4 v = acc[sg] * sc4 + sh4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.f);
+                    float* o = p.out + (size_t)(cur_g.obase + gy * cur_g.W + gx) * p.out_ld + p.out_coff + n;
+                    if (n + 3 < p.Cout) {
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.Cout) o[r] = v[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();            // `cur` fully read, `cur ^ 1` fully written
+        cur ^= 1;
+        cur_g = nxt_g;
+    }
+}
+
+int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH, 16 = double-buffered 8-wave kernel, 102 / 104 = weight-stationary Cin=64 kernel (TH 2 / 4)
 
 static int patch_launch(const ConvP& c, hipStream_t st) {
     // returns ORE_OK if launched, 1 if the layer is not eligible (caller falls back to the generic kernel)
@@ -590,7 +861,14 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 15) != 0) return 1;      // the epilogue stores 16 bytes per lane
     if (g_patch_mode == 0) return 1;
     int TH = g_patch_mode > 0 ? g_patch_mode : 4;
-    if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
+    const bool db = TH == 16;
+    if (db) TH = 8;
+    bool ws = TH == 102 || TH == 104;
+    if (ws) { TH -= 100; if (c.Cin != 64) return 1; }
+    if (g_patch_mode < 0 && c.M < 6000) return 1;
+    // plan: the weight-stationary kernel wins once a resident block walks >= 4 tiles (stem_2: 3200 tiles, 71 vs 82 us); below that its
+    // 36-fragment weight prologue is not amortised (stage-2 64->64 layers: 800 tiles, 29 vs 26 us)
+    if (g_patch_mode < 0 && c.Cin == 64 && c.nlev == 1 && (long long)c.B * ceil_div(c.lv[0].H, 2) * ceil_div(c.lv[0].W, 16) >= 2048) { ws = true; TH = 2; }        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
     PatchP p{};
     p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = c.nlev;
     int tiles = 0;
@@ -605,7 +883,28 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
     p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
     const dim3 grid(tiles, c.Cout16 / 64);
-    if (TH == 8) {
+    if (ws) {
+        const int resident = 512;                               // 2 blocks per CU (LDS 2 x 41/62 KB, <= 256 VGPRs)
+        const dim3 pgrid(tiles < resident ? tiles : resident, c.Cout16 / 64);   // (a grid of tiles/rounds blocks measured 7 % slower on stem_2)
+        if (TH == 2) {
+            const size_t lds = (size_t)2 * (4 * 18) * 72 * sizeof(float);
+            static bool a2 = false;
+            if (!a2) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws64<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a2 = true; }
+            hipLaunchKernelGGL(k_conv3x3_ws64<2>, pgrid, dim3(256), lds, st, p, tiles);
+        } else {
+            const size_t lds = (size_t)2 * (6 * 18) * 72 * sizeof(float);
+            static bool a4 = false;
+            if (!a4) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a4 = true; }
+            hipLaunchKernelGGL(k_conv3x3_ws64<4>, pgrid, dim3(256), lds, st, p, tiles);
+        }
+        return ore_launch_status("k_conv3x3_ws64");
+    }
+    if (db) {
+        const size_t lds = (size_t)2 * (10 * 18 + 9 * 64) * 24 * sizeof(float);
+        static bool attrdb = false;
+        if (!attrdb) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrdb = true; }
+        hipLaunchKernelGGL(k_conv3x3_patch_db, grid, dim3(512), lds, st, p);
+    } else if (TH == 8) {
         const size_t lds = (size_t)(10 * 18 + 9 * 64) * 24 * sizeof(float);
         static bool attr8 = false;
         if (!attr8) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr8 = true; }
