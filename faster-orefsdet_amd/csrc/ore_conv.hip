@@ -865,10 +865,10 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     if (db) TH = 8;
     bool ws = TH == 102 || TH == 104;
     if (ws) { TH -= 100; if (c.Cin != 64) return 1; }
-    if (g_patch_mode < 0 && c.M < 6000) return 1;
+    if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
     // plan: the weight-stationary kernel wins once a resident block walks >= 4 tiles (stem_2: 3200 tiles, 71 vs 82 us); below that its
     // 36-fragment weight prologue is not amortised (stage-2 64->64 layers: 800 tiles, 29 vs 26 us)
-    if (g_patch_mode < 0 && c.Cin == 64 && c.nlev == 1 && (long long)c.B * ceil_div(c.lv[0].H, 2) * ceil_div(c.lv[0].W, 16) >= 2048) { ws = true; TH = 2; }        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
+    if (g_patch_mode < 0 && c.Cin == 64 && c.nlev == 1 && (long long)c.B * ceil_div(c.lv[0].H, 2) * ceil_div(c.lv[0].W, 16) >= 2048) { ws = true; TH = 2; }
     PatchP p{};
     p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = c.nlev;
     int tiles = 0;
