@@ -709,30 +709,37 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
     }
 }
 
-// Weight-stationary 3x3 kernel for Cin = 64 layers (stem_2, the 64->64 layers of stage 2: a third of the network's FLOPs).
-// wave w of a block keeps the weights of 16 output channels x 9 taps x 64 input channels in REGISTERS (36 MFMA A-fragments, 144
-// VGPRs) for the whole launch; the block is persistent and walks pixel tiles (TH x 16 px), staging only the (TH+2) x 18 x 64ch halo
-// patch per tile (double-buffered LDS, one barrier per tile, 144*TH MFMAs per wave between barriers).  No weight re-staging, one
-// LDS read per 4 MFMAs, small tiles (TH = 2) balance 3200 tiles over 512 resident blocks.
-template <int TH>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_ws64(PatchP p, int ntiles) {
-    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = 72, NCH = 4;
-    constexpr int A_IT = (NPIX * 16 + 255) / 256;              // float4 slots per thread for one halo patch
+// Weight-stationary 3x3 kernels (stem_2 and the Cin = 64 / 128 layers with large M: half of the network's FLOPs).
+// A wave keeps the weights of 16 output channels x 9 taps x 64 input channels in REGISTERS (36 MFMA A-fragments, 144 VGPRs) for the
+// whole launch; the block is persistent and walks pixel tiles (TH x 16 px), staging only the (TH+2) x 18 x CIN halo patch per tile
+// (double-buffered LDS, one barrier per tile, 144*TH MFMAs per wave between barriers).  No weight re-staging, one LDS read per
+// 4 MFMAs, small tiles (TH = 2) balance thousands of tiles over the resident blocks.
+//   CIN = 64,  KS = 1: 4 waves = 4 groups of 16 output channels.
+//   CIN = 128, KS = 2: 8 waves; waves w and w+4 share a channel group and split the input channels (64 each); the upper half
+//                      parks its accumulators in LDS (parity double-buffered) and the lower half adds them before the epilogue.
+template <int TH, int CIN, int KS>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP p, int ntiles) {
+    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = CIN + 8, NCH = 4, NTH = 256 * KS, F4 = CIN / 4;
+    static_assert(CIN == 64 * KS, "one 64-channel weight slice per wave");
+    constexpr int A_IT = (NPIX * F4 + NTH - 1) / NTH;          // float4 slots per thread for one halo patch
     constexpr int BUF = NPIX * LDC;
+    constexpr int PARK = KS > 1 ? 4 * TH * 256 : 0;            // floats per parity buffer of parked accumulators
     extern __shared__ __attribute__((aligned(16))) float plds[];
+    float* park = plds + 2 * BUF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cgp = wave & 3, kh = wave >> 2;                  // channel group, K half
     const int li = lane & 15, g4 = (lane >> 4) * 4;
-    const int n0 = blockIdx.y * 64 + wave * 16;               // this wave's 16 output channels
-    // ---- weights -> registers (MFMA A operand: row = channel n0 + li, k = chunk*16 + g4 + t)
+    const int n0 = blockIdx.y * 64 + cgp * 16;                 // this wave's 16 output channels
+    // ---- weights -> registers (MFMA A operand: row = channel n0 + li, k = kh*64 + chunk*16 + g4 + t)
     f32x4 wf[9][NCH];
     {
         const bool okw = n0 + li < p.Cout16;
-        const float* wrow = p.w + (size_t)(okw ? n0 + li : 0) * p.K + g4;
+        const float* wrow = p.w + (size_t)(okw ? n0 + li : 0) * p.K + kh * 64 + g4;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                wf[tap][c] = *reinterpret_cast<const f32x4*>(wrow + tap * 64 + c * 16);
+                wf[tap][c] = *reinterpret_cast<const f32x4*>(wrow + tap * CIN + c * 16);
                 if (!okw) wf[tap][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
     }
@@ -745,8 +752,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ws64(PatchP p, int ntiles) {
     int s_py[A_IT], s_px[A_IT], s_q[A_IT], s_lds[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int f = tid + i * 256, pi = f >> 4;
-        s_q[i] = (f & 15) * 4;
+        const int f = tid + i * NTH, pi = f / F4;
+        s_q[i] = (f - pi * F4) * 4;
         s_py[i] = pi / PW; s_px[i] = pi - s_py[i] * PW;
         s_lds[i] = pi < NPIX ? pi * LDC + s_q[i] : -1;
     }
@@ -779,24 +786,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ws64(PatchP p, int ntiles) {
         for (int i = 0; i < A_IT; ++i)
             if (s_lds[i] >= 0) *reinterpret_cast<f32x4*>(buf + s_lds[i]) = ra[i];
     };
-    f32x4 sc4, sh4;
     int t = blockIdx.x;
     TileGeo cur_g = decode(t < ntiles ? t : 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                             // epilogue operands (single level in practice; per-level scales re-read below)
-        const int n = n0 + g4 + r;
-        sc4[r] = (p.scale && n < p.Cout) ? p.scale[cur_g.lvl * p.ep_stride + n] : 1.0f;
-        sh4[r] = (p.shift && n < p.Cout) ? p.shift[cur_g.lvl * p.ep_stride + n] : 0.0f;
-    }
     if (t < ntiles) { gload(cur_g); lstore(plds); }
     __syncthreads();
-    int cur = 0;
+    int cur = 0, parity = 0;
     for (; t < ntiles; t += gridDim.x) {
         const int tn = t + gridDim.x;
         const bool has_next = tn < ntiles;
         TileGeo nxt_g = cur_g;
         if (has_next) { nxt_g = decode(tn); gload(nxt_g); }       // the next halo patch flies under this tile's MFMAs
-        const float* As = plds + cur * BUF;
+        const float* As = plds + cur * BUF + kh * 64;
         f32x4 acc[TH];
 #pragma unroll
         for (int sg = 0; sg < TH; ++sg) acc[sg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -816,23 +816,29 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ws64(PatchP p, int ntiles) {
                         for (int sg = 0; sg < TH; ++sg)
                             acc[sg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[dy * 3 + dx][c][k], af[sg][k], acc[sg], 0, 0, 0);
                 }
+        if (KS > 1 && kh == 1) {
+#pragma unroll
+            for (int sg = 0; sg < TH; ++sg)
+                *reinterpret_cast<f32x4*>(park + parity * PARK + ((cgp * TH + sg) * 64 + lane) * 4) = acc[sg];
+        }
         if (has_next) lstore(plds + (cur ^ 1) * BUF);
-        // ---- epilogue: lane = pixel (row ty0 + sg, column tx0 + li), channels n0 + g4 .. +3
-        if (p.ep_stride != 0) {
+        __syncthreads();            // `cur` fully read, `cur ^ 1` fully written, parked accumulators visible
+        // ---- epilogue (lower K half only): lane = pixel (row ty0 + sg, column tx0 + li), channels n0 + g4 .. +3
+        const int n = n0 + g4;
+        if (kh == 0 && n < p.Cout) {
+            f32x4 sc4, sh4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + g4 + r;
-                sc4[r] = (p.scale && n < p.Cout) ? p.scale[cur_g.lvl * p.ep_stride + n] : 1.0f;
-                sh4[r] = (p.shift && n < p.Cout) ? p.shift[cur_g.lvl * p.ep_stride + n] : 0.0f;
+                sc4[r] = (p.scale && n + r < p.Cout) ? p.scale[cur_g.lvl * p.ep_stride + n + r] : 1.0f;
+                sh4[r] = (p.shift && n + r < p.Cout) ? p.shift[cur_g.lvl * p.ep_stride + n + r] : 0.0f;
             }
-        }
-        const int n = n0 + g4;
-        if (n < p.Cout) {
 #pragma unroll
             for (int sg = 0; sg < TH; ++sg) {
+                f32x4 a = acc[sg];
+                if (KS > 1) a += *reinterpret_cast<const f32x4*>(park + parity * PARK + ((cgp * TH + sg) * 64 + lane) * 4);
                 const int gy = cur_g.ty0 + sg, gx = cur_g.tx0 + li;
                 if (gy < cur_g.H && gx < cur_g.W) {
-                    f32x4 v = acc[sg] * sc4 + sh4;
+                    f32x4 v = a * sc4 + sh4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.f);
@@ -847,13 +853,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_ws64(PatchP p, int ntiles) {
                 }
             }
         }
-        __syncthreads();            // `cur` fully read, `cur ^ 1` fully written
         cur ^= 1;
+        parity ^= 1;
         cur_g = nxt_g;
     }
 }
 
-int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH, 16 = double-buffered 8-wave kernel, 102 / 104 = weight-stationary Cin=64 kernel (TH 2 / 4)
+int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH, 16 = double-buffered 8-wave kernel, 102 / 104 = weight-stationary kernels (TH 2 / 4; Cin = 64, and Cin = 128 with TH 2)
 
 static int patch_launch(const ConvP& c, hipStream_t st) {
     // returns ORE_OK if launched, 1 if the layer is not eligible (caller falls back to the generic kernel)
@@ -864,7 +870,7 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     const bool db = TH == 16;
     if (db) TH = 8;
     bool ws = TH == 102 || TH == 104;
-    if (ws) { TH -= 100; if (c.Cin != 64) return 1; }
+    if (ws) { TH -= 100; if (c.Cin != 64 && !(c.Cin == 128 && TH == 2)) return 1; }
     if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
     // plan: the weight-stationary kernel wins once a resident block walks >= 4 tiles (stem_2: 3200 tiles, 71 vs 82 us); below that its
     // 36-fragment weight prologue is not amortised (stage-2 64->64 layers: 800 tiles, 29 vs 26 us)
@@ -884,20 +890,27 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
     const dim3 grid(tiles, c.Cout16 / 64);
     if (ws) {
-        const int resident = 512;                               // 2 blocks per CU (LDS 2 x 41/62 KB, <= 256 VGPRs)
+        // 64-channel layers: 4 waves, 2 blocks per CU; 128-channel layers: 8 waves (K split in wave pairs), 1 block per CU
+        const bool wide = c.Cin == 128;
+        const int resident = wide ? 256 : 512;
         const dim3 pgrid(tiles < resident ? tiles : resident, c.Cout16 / 64);   // (a grid of tiles/rounds blocks measured 7 % slower on stem_2)
-        if (TH == 2) {
+        if (wide) {
+            const size_t lds = ((size_t)2 * (4 * 18) * 136 + 2 * 4 * 2 * 256) * sizeof(float);
+            static bool a128 = false;
+            if (!a128) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<2, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a128 = true; }
+            hipLaunchKernelGGL((k_conv3x3_ws<2, 128, 2>), pgrid, dim3(512), lds, st, p, tiles);
+        } else if (TH == 2) {
             const size_t lds = (size_t)2 * (4 * 18) * 72 * sizeof(float);
             static bool a2 = false;
-            if (!a2) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws64<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a2 = true; }
-            hipLaunchKernelGGL(k_conv3x3_ws64<2>, pgrid, dim3(256), lds, st, p, tiles);
+            if (!a2) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<2, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a2 = true; }
+            hipLaunchKernelGGL((k_conv3x3_ws<2, 64, 1>), pgrid, dim3(256), lds, st, p, tiles);
         } else {
             const size_t lds = (size_t)2 * (6 * 18) * 72 * sizeof(float);
             static bool a4 = false;
-            if (!a4) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a4 = true; }
-            hipLaunchKernelGGL(k_conv3x3_ws64<4>, pgrid, dim3(256), lds, st, p, tiles);
+            if (!a4) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<4, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a4 = true; }
+            hipLaunchKernelGGL((k_conv3x3_ws<4, 64, 1>), pgrid, dim3(256), lds, st, p, tiles);
         }
-        return ore_launch_status("k_conv3x3_ws64");
+        return ore_launch_status("k_conv3x3_ws");
     }
     if (db) {
         const size_t lds = (size_t)2 * (10 * 18 + 9 * 64) * 24 * sizeof(float);
