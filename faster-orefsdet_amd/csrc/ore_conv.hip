@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
     }
 }
 
-int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH, 16 = double-buffered 8-wave kernel, 102 / 104 = weight-stationary kernels (TH 2 / 4; Cin = 64, and Cin = 128 with TH 2)
+int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH, 16 = double-buffered 8-wave kernel, 102 = weight-stationary kernels (2-row tiles; Cin = 64 or 128)
 
 static int patch_launch(const ConvP& c, hipStream_t st) {
     // returns ORE_OK if launched, 1 if the layer is not eligible (caller falls back to the generic kernel)
@@ -869,8 +869,8 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     int TH = g_patch_mode > 0 ? g_patch_mode : 4;
     const bool db = TH == 16;
     if (db) TH = 8;
-    bool ws = TH == 102 || TH == 104;
-    if (ws) { TH -= 100; if (c.Cin != 64 && !(c.Cin == 128 && TH == 2)) return 1; }
+    bool ws = TH == 102;                                     // TH = 4 needs > 256 VGPRs (spills): only the 2-row tile is built
+    if (ws) { TH = 2; if (c.Cin != 64 && c.Cin != 128) return 1; }
     if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
     // plan: the weight-stationary kernel wins once a resident block walks >= 4 tiles (stem_2: 3200 tiles, 71 vs 82 us); below that its
     // 36-fragment weight prologue is not amortised (stage-2 64->64 layers: 800 tiles, 29 vs 26 us)
@@ -899,16 +899,11 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
             static bool a128 = false;
             if (!a128) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<2, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a128 = true; }
             hipLaunchKernelGGL((k_conv3x3_ws<2, 128, 2>), pgrid, dim3(512), lds, st, p, tiles);
-        } else if (TH == 2) {
+        } else {
             const size_t lds = (size_t)2 * (4 * 18) * 72 * sizeof(float);
             static bool a2 = false;
             if (!a2) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<2, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a2 = true; }
             hipLaunchKernelGGL((k_conv3x3_ws<2, 64, 1>), pgrid, dim3(256), lds, st, p, tiles);
-        } else {
-            const size_t lds = (size_t)2 * (6 * 18) * 72 * sizeof(float);
-            static bool a4 = false;
-            if (!a4) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<4, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a4 = true; }
-            hipLaunchKernelGGL((k_conv3x3_ws<4, 64, 1>), pgrid, dim3(256), lds, st, p, tiles);
         }
         return ore_launch_status("k_conv3x3_ws");
     }

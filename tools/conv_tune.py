@@ -71,7 +71,7 @@ def main():
                     pass
         L.ore_conv_set_plan_override(0, 0, 0, 0, 0)
         if k == 3 and stride == 1 and C16 % 64 == 0:          # 3x3 "patch" kernel, tile height 8 / 4
-            for mode in (102, 104, 16, 8, 4):
+            for mode in (102, 16, 8, 4):
                 L.ore_conv_set_plan_override(-1, mode, 0, 0, 0)
                 for _ in range(3):
                     orehip.conv2d(x, w, Cout, k, stride, out=out, splitk=1)
