@@ -75,7 +75,8 @@ int32_t ore_conv_colsum_rows(const ore_conv_desc* d);   /* number of row tiles (
 int ore_conv2d_fwd(const ore_conv_desc* d, void* stream);
 /* Tuning aid (tools/conv_tune.py): force the block tile (BM x BN, waves WGM x WGN x WGK) of subsequent conv calls;
  * BM = 0 restores the automatic plan; BM = -1 sets the 3x3 patch-kernel mode to BN (-1 automatic, 0 off, 4 / 8 forced tile
- * height).  The product path never calls it. */
+ * height, 16 = double-buffered 8-wave variant, 102 = weight-stationary persistent kernel for Cin = 64 / 128).  The product path
+ * never calls it. */
 int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK);
 /* The same 'same'-padded stride-1 conv over several pyramid levels in ONE launch (shared weights; CenterNet head / conv3):
  * rows are level-major [level][b][y][x] in the input and output matrices (d->H, d->W ignored), scale/shift may differ per
