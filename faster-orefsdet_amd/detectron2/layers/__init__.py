@@ -120,7 +120,22 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         _require_gpu(x, "Conv2d")
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            raise NotImplementedError("training through the HIP conv path is not built yet (round 1 covers the eval path)")
+            # training: the autograd bindings (forward + data/weight-gradient kernels); stride-1 'same' convolutions only
+            from orehip import autograd as A
+            k = self.kernel_size[0]
+            if not (self.groups == 1 and self.dilation == (1, 1) and self.stride == (1, 1) and self.padding == (k // 2, k // 2)
+                    and self.kernel_size[1] == k and self.in_channels % 16 == 0):
+                raise NotImplementedError("the HIP backward kernels cover stride-1 'same' convolutions with Cin % 16 == 0 "
+                                          "(every trainable conv of finetune_vovnet.yaml)")
+            relu = self.activation is not None
+            if isinstance(self.norm, FrozenBatchNorm2d):
+                assert self.bias is None, "conv + FrozenBN has no bias in the reference"
+                sc, sh = self.norm.scale_shift()
+                y = A.conv(nhwc_view(x), self.weight, None, sc.contiguous(), sh.contiguous(), relu)
+            else:
+                assert self.norm is None, "only FrozenBN can be folded into the HIP conv epilogue"
+                y = A.conv(nhwc_view(x), self.weight, self.bias, None, None, relu)
+            return y.permute(0, 3, 1, 2)
         return self.forward_nhwc(nhwc_view(x)).permute(0, 3, 1, 2)
 
 

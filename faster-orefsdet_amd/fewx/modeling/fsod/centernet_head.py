@@ -85,9 +85,11 @@ class CenterNetHead(nn.Module):
         """Reference protocol: returns (clss, bbox_reg, agn_hms) per level as NCHW tensors (clss entries are None)."""
         for f in x:
             _require_gpu(f, "CenterNetHead")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and any(f.requires_grad for f in x):
-            raise NotImplementedError("training through the HIP head is not built yet (round 1 covers the eval path)")
-        heads = self.forward_nhwc([nhwc_view(f) for f in x])
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or any(f.requires_grad for f in x)):
+            from .train_forward import head_train            # autograd bindings: conv fwd/dgrad/wgrad, GroupNorm fwd/bwd kernels
+            heads = head_train(self, [nhwc_view(f) for f in x])
+        else:
+            heads = self.forward_nhwc([nhwc_view(f) for f in x])
         regs = [h[..., :4].permute(0, 3, 1, 2) for h in heads]
         hms = [h[..., 4:5].permute(0, 3, 1, 2) for h in heads]
         return [None] * len(heads), regs, hms

@@ -709,3 +709,33 @@ def test_train_iteration_full_size_vs_oracle(oh):
             errs.append(float((named[k].grad.cpu() - t.grad).abs().max()) / max(float(t.grad.abs().max()), 1e-8))
     errs.sort()
     assert len(errs) == 73 and errs[len(errs) // 2] <= 2e-4 and errs[-1] <= 5e-2, (errs[len(errs) // 2], errs[-3:])
+
+
+def test_module_level_training_forwards(oh):
+    """detectron2.layers.Conv2d and CenterNetHead follow the reference call protocol in training mode too (NCHW in/out, autograd)."""
+    import torch.nn.functional as F
+    from detectron2.layers import Conv2d
+    g = torch.Generator().manual_seed(3)
+    c = Conv2d(32, 48, kernel_size=3, padding=1, bias=True).cuda()
+    x = torch.randn(2, 32, 9, 11, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    y = c(xg)
+    ref_x = x.clone().requires_grad_(True)
+    w, b = c.weight.detach().cpu().requires_grad_(True), c.bias.detach().cpu().requires_grad_(True)
+    ref = F.conv2d(ref_x, w, b, padding=1)
+    _close(y, ref)
+    up = torch.randn(ref.shape, generator=g)
+    (y * up.cuda()).sum().backward(); (ref * up).sum().backward()
+    _close(xg.grad, ref_x.grad); _close(c.weight.grad, w.grad); _close(c.bias.grad, b.grad)
+    m, sd, cfg = _train_model(4)
+    head = m.proposal_generator.centernet_head
+    feats = [torch.randn(1, 128, 16 >> l, 24 >> l, generator=g) for l in range(3)]
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("proposal_generator.centernet_head.")}
+    regs_ref, hms_ref = R.centernet_head(feats, {**sd, **leaf})
+    _, regs, hms = head([f.cuda().requires_grad_(True) for f in feats])
+    for l in range(3):
+        _close(regs[l], regs_ref[l]); _close(hms[l], hms_ref[l])
+    (sum((r ** 2).sum() for r in regs) + sum(h.sum() for h in hms)).backward()
+    (sum((r ** 2).sum() for r in regs_ref) + sum(h.sum() for h in hms_ref)).backward()
+    _close(head.bbox_tower[0].weight.grad, leaf["proposal_generator.centernet_head.bbox_tower.0.weight"].grad, tol=1e-4)
+    _close(head.scales[1].scale.grad, leaf["proposal_generator.centernet_head.scales.1.scale"].grad, tol=1e-4)
