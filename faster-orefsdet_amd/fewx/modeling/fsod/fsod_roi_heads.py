@@ -70,17 +70,38 @@ class CustomCascadeROIHeads(nn.Module):
             self._comp = (key, Wp.to(dev), bp.to(dev))
         return self._comp[1], self._comp[2]
 
-    @torch.no_grad()
-    def forward(self, images, features, support_box_features, proposals, targets=None):
+    def forward(self, images, features, support_box_features, proposals, targets=None, perm=None):
+        if self.training:
+            return self._forward_train(features, support_box_features, proposals, targets, perm)
+        with torch.no_grad():
+            return self._forward_eval(images, features, support_box_features, proposals)
+
+    def _forward_train(self, features, support_box_features, proposals, targets, perm=None):
+        """Reference protocol (ref fsod_roi_heads.py:247-262, :404-520): label_and_sample_proposals, then the single cascade stage and
+        its losses.  support_box_features[0] = rcnn_8 features of the support crops, [N,C,8,8] as the reference pools them."""
+        from detectron2.layers import nhwc_view
+        from .train_forward import label_and_sample, roi_stage_losses
+        assert targets is not None and len(proposals) == 1 and len(targets) == 1 and len(self.box_head) == 1
+        props = proposals[0]
+        dev = props.proposal_boxes.tensor.device
+        gt = targets[0].gt_boxes
+        gt = (gt.tensor if hasattr(gt, "tensor") else gt).to(dev).float()
+        if perm is None:
+            perm = lambda n: torch.randperm(n, device=dev)      # noqa: E731
+        _, roi_boxes, roi_labels, roi_gt = label_and_sample(self, props.proposal_boxes.tensor.detach(), gt, perm)
+        qf = [nhwc_view(features[f])[0] for f in self.in_features]
+        s8 = support_box_features[0]
+        sup8 = s8.permute(0, 2, 3, 1).reshape(s8.shape[0], -1)            # [N,C,8,8] -> [N, pos*C + c]
+        losses, _ = roi_stage_losses(self, qf, sup8, roi_boxes, roi_labels, roi_gt, [8, 16, 32][: len(qf)])
+        return proposals, losses
+
+    def _forward_eval(self, images, features, support_box_features, proposals, targets=None):
         """Eval second stage for one image on the HIP kernels: ROIAlign 8x8 over p3..p5 -> pre-composed [8192->128] GEMM + ReLU
         -> cls/box -> softmax, apply_deltas, clip, score filter, NMS, keep[:topk].  (ref fsod_roi_heads.py:374-457; the second
         `_forward_box` definition shadows the first, so MULT_PROPOSAL_SCORE is NOT applied -- SURVEY 8f row 1.)"""
         import orehip
         from detectron2.layers import nhwc_view
         from detectron2.structures import Boxes, Instances
-        if self.training:
-            raise NotImplementedError("in training the second stage runs inside fewx.modeling.fsod.train_forward.train_forward "
-                                      "(sampling, ROIAlign fwd/bwd, DSA mix, losses); call the detector")
         assert len(proposals) == 1 and len(self.box_head) == 1, "one image, one cascade stage (finetune_vovnet.yaml)"
         props = proposals[0]
         boxes = props.proposal_boxes.tensor

@@ -41,8 +41,17 @@ class CenterNet(nn.Module):
 
     def forward(self, images, features_dict, gt_instances=None):
         if self.training:
-            raise NotImplementedError("in training the proposal generator runs inside fewx.modeling.fsod.train_forward.train_forward "
-                                      "(head -> ore_centernet_targets_fwd / ore_centernet_losses_fwd -> proposals); call the detector")
+            # reference protocol (fsod_rpn.py:644-700): (proposals, losses) for ONE query image and its gt instances
+            from .train_forward import head_train, proposal_losses_and_proposals
+            assert gt_instances is not None and len(gt_instances) == 1 and len(images.image_sizes) == 1, "one query image per call"
+            feats = [features_dict[f] for f in self.in_features]
+            for f in feats:
+                _require_gpu(f, "CenterNet")
+            heads = head_train(self.centernet_head, [nhwc_view(f) for f in feats])
+            gt = gt_instances[0].gt_boxes
+            gt = (gt.tensor if hasattr(gt, "tensor") else gt).to(feats[0].device).float()
+            boxes, scores, losses, _ = proposal_losses_and_proposals(self, heads, gt)
+            return [make_proposals(images.image_sizes[0], boxes, scores)], losses
         feats = [features_dict[f] for f in self.in_features]
         for f in feats:
             _require_gpu(f, "CenterNet")

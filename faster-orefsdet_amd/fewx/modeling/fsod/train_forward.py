@@ -122,13 +122,81 @@ def graphed_dense_part(model, xq, xs):
     return g(xq, xs) if g is not None else dense_part(model, xq, xs)
 
 
+def proposal_losses_and_proposals(pg, heads: List[torch.Tensor], gt_boxes: torch.Tensor):
+    """CenterNet.forward, training branch, after the head (ref:fewx/modeling/fsod/fsod_rpn.py:658-700): ground truth, the three
+    losses, and the proposals with the *_TRAIN thresholds.  heads[l] [1,H,W,16] (0..3 ltrb after Scale+ReLU, 4 heatmap logit).
+    Returns (proposal boxes [n,4], scores [n], losses dict, targets dict)."""
+    import orehip
+    from orehip import autograd as A
+    dev = heads[0].device
+    shapes = [tuple(h.shape[1:3]) for h in heads]
+    rows = torch.cat([h.reshape(-1, h.shape[-1]) for h in heads], 0)
+    tg = orehip.centernet_targets([gt_boxes], shapes, pg.strides, pg.sizes_of_interest, pg.hm_min_overlap, pg.min_radius, device=dev)
+    hp = dict(gamma=pg.loss_gamma, beta=pg.hm_focal_beta, sigmoid_clamp=pg.sigmoid_clamp, ignore_high_fp=pg.ignore_high_fp,
+              alpha=pg.hm_focal_alpha, pos_weight=pg.pos_weight, neg_weight=pg.neg_weight, reg_weight=pg.reg_weight)
+    l3 = A.centernet_losses(rows, tg["reg_targets"], tg["hm_targets"], tg["pos_inds"], tg["pos_count"], hp)
+    with torch.no_grad():
+        o = orehip.detect([h[0].detach().contiguous() for h in heads], pg.strides, pg.score_thresh, pg.pre_nms_topk_train,
+                          pg.nms_thresh_train, pg.post_nms_topk_train)
+        n = int(o["counts"][1].item())
+    losses = {"loss_centernet_loc": l3[0], "loss_centernet_agn_pos": l3[1], "loss_centernet_agn_neg": l3[2]}
+    return o["out_boxes"][:n], o["out_scores"][:n], losses, tg
+
+
+@torch.no_grad()
+def label_and_sample(rh, proposals: torch.Tensor, gt_boxes: torch.Tensor, perm: Callable[[int], torch.Tensor]):
+    """label_and_sample_proposals for one image and one foreground class (d2z:modeling/roi_heads/roi_heads.py:181-295):
+    append the gt boxes, IoU matcher (>= IOUS[0] -> foreground), BATCH_SIZE_PER_IMAGE samples with <= POSITIVE_FRACTION
+    foreground.  Returns (sampled indices, roi boxes, labels (0 fg / 1 bg), matched gt boxes)."""
+    dev = proposals.device
+    boxes = torch.cat([proposals, gt_boxes], 0) if rh.proposal_append_gt else proposals
+    if gt_boxes.shape[0]:
+        vals, midx = pairwise_iou(gt_boxes, boxes).max(0)
+        labels = torch.where(vals >= rh.iou_threshold, torch.zeros_like(midx), torch.ones_like(midx))
+    else:
+        midx = torch.zeros(len(boxes), dtype=torch.int64, device=dev)
+        labels = torch.ones(len(boxes), dtype=torch.int64, device=dev)
+    p_idx = torch.nonzero(labels == 0).squeeze(1)
+    n_idx = torch.nonzero(labels == 1).squeeze(1)
+    n_pos = min(p_idx.numel(), int(rh.batch_size_per_image * rh.positive_fraction))
+    n_neg = min(n_idx.numel(), rh.batch_size_per_image - n_pos)
+    sampled = torch.cat([p_idx[perm(p_idx.numel()).to(dev)[:n_pos]], n_idx[perm(n_idx.numel()).to(dev)[:n_neg]]], 0)
+    roi_gt = gt_boxes[midx[sampled]] if gt_boxes.shape[0] else boxes[sampled]
+    return sampled, boxes[sampled].contiguous(), labels[sampled], roi_gt
+
+
+def roi_stage_losses(rh, qf: List[torch.Tensor], sup8: torch.Tensor, roi_boxes, roi_labels, roi_gt, strides):
+    """_run_stage + CustomFastRCNNOutputLayers.losses for the single cascade stage (ref:fewx/modeling/fsod/fsod_roi_heads.py:459-520,
+    custom_fast_rcnn.py:52-81).  qf[l] [H,W,C] query pyramid (NHWC), sup8 [N, P*P*C] pooled support features ordered [pos][c]."""
+    from orehip import autograd as A
+    R = roi_boxes.shape[0]
+    C = qf[0].shape[-1]
+    P = rh.pooler_resolution
+    x = A.roi_align(qf, roi_boxes, strides, P).reshape(R * P * P, C)                    # rows ordered [roi][pos], channels last
+    s = sup8.mean(0, True).reshape(P * P, C)
+    s_exp = s.unsqueeze(0).expand(R, P * P, C).reshape(R * P * P, C)
+    a = A.linear(torch.cat((x, s_exp), 1), rh.conv3.weight.flatten(1), rh.conv3.bias) + \
+        torch.cat((A.linear(x, rh.conv1.weight.flatten(1), rh.conv1.bias),
+                   A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).unsqueeze(0).expand(R, P * P, C // 2).reshape(R * P * P, C // 2)), 1)
+    a = a.reshape(R, P * P, C).permute(0, 2, 1).reshape(R, C * P * P)                   # NCHW flatten order of fc1's weight
+    fc1 = rh.box_head[0].fc1
+    h = A.linear(a.contiguous(), fc1.weight, fc1.bias, True)
+    pr = rh.box_predictor[0]
+    scores = A.linear(h, pr.cls_score.weight, pr.cls_score.bias)
+    deltas = A.linear(h, pr.bbox_pred.weight, pr.bbox_pred.bias)
+    loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
+    fg = torch.nonzero(roi_labels == 0).squeeze(1)
+    tgt = get_deltas(roi_boxes[fg], roi_gt[fg], rh.bbox_reg_weights)
+    loss_box = (deltas[fg] - tgt).abs().sum() / max(roi_labels.numel(), 1)               # smooth_l1, beta = 0
+    return {"loss_cls_stage0": loss_cls, "loss_box_reg_stage0": loss_box}, dict(scores=scores, deltas=deltas, h=h)
+
+
 def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Tensor]] = None, return_aux: bool = False,
                   roi_override: Optional[Dict[str, torch.Tensor]] = None):
     """model: CenterNet2Detector in training mode.  batched_inputs[i]: image [3,H,W] (uint8/float BGR), instances (gt_boxes),
     support_images [N,3,h,w], support_bboxes [N,4].  Returns the 5 losses (mean over the images of the call).
     `perm(n)` replaces torch.randperm in the fg/bg subsampling; `roi_override` = {boxes, labels, gt} replaces the sampled set
     altogether (parity tests pin the second stage on the oracle's sample so a 1-ulp heatmap difference cannot change the batch)."""
-    import orehip
     from orehip import autograd as A
     dev = model.device
     pg, rh = model.proposal_generator, model.roi_heads
@@ -140,7 +208,6 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
     aux = {}
     for item in batched_inputs:
         img = item["image"].to(dev)
-        H, W = img.shape[-2:]
         inst = item["instances"]
         gt_boxes = (inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes).to(dev).float()
         sup = item["support_images"].to(dev)
@@ -150,65 +217,21 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
         xq, xs = _normalise_pad(img[None], mean, std, div), _normalise_pad(sup, mean, std, div)
         outs = graphed_dense_part(model, xq, xs) if getattr(model, "train_graph", False) else dense_part(model, xq, xs)
         qf, sf_levels, heads = list(outs[0:3]), list(outs[3:6]), list(outs[6:9])
-        # ---- CenterNet ground truth, losses
-        shapes = [tuple(h.shape[1:3]) for h in heads]
-        rows = torch.cat([h.reshape(-1, h.shape[-1]) for h in heads], 0)
-        tg = orehip.centernet_targets([gt_boxes], shapes, pg.strides, pg.sizes_of_interest, pg.hm_min_overlap, pg.min_radius, device=dev)
-        hp = dict(gamma=pg.loss_gamma, beta=pg.hm_focal_beta, sigmoid_clamp=pg.sigmoid_clamp, ignore_high_fp=pg.ignore_high_fp,
-                  alpha=pg.hm_focal_alpha, pos_weight=pg.pos_weight, neg_weight=pg.neg_weight, reg_weight=pg.reg_weight)
-        l3 = A.centernet_losses(rows, tg["reg_targets"], tg["hm_targets"], tg["pos_inds"], tg["pos_count"], hp)
-        # ---- proposals with the training thresholds; labels and samples (no gradient)
-        with torch.no_grad():
-            o = orehip.detect([h[0].detach().contiguous() for h in heads], pg.strides, pg.score_thresh, pg.pre_nms_topk_train,
-                              pg.nms_thresh_train, pg.post_nms_topk_train)
-            n = int(o["counts"][1].item())
-            proposals = o["out_boxes"][:n]
-            boxes = torch.cat([proposals, gt_boxes], 0)                                   # proposal_append_gt
-            if gt_boxes.shape[0]:
-                vals, midx = pairwise_iou(gt_boxes, boxes).max(0)
-                labels = torch.where(vals >= rh.iou_threshold, torch.zeros_like(midx), torch.ones_like(midx))
-            else:
-                midx = torch.zeros(len(boxes), dtype=torch.int64, device=dev)
-                labels = torch.ones(len(boxes), dtype=torch.int64, device=dev)
-            p_idx = torch.nonzero(labels == 0).squeeze(1)
-            n_idx = torch.nonzero(labels == 1).squeeze(1)
-            n_pos = min(p_idx.numel(), int(rh.batch_size_per_image * rh.positive_fraction))
-            n_neg = min(n_idx.numel(), rh.batch_size_per_image - n_pos)
-            sampled = torch.cat([p_idx[perm(p_idx.numel()).to(dev)[:n_pos]], n_idx[perm(n_idx.numel()).to(dev)[:n_neg]]], 0)
-            roi_boxes, roi_labels = boxes[sampled].contiguous(), labels[sampled]
-            roi_gt = gt_boxes[midx[sampled]] if gt_boxes.shape[0] else roi_boxes
-            if roi_override is not None:
-                roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
-                roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
-        # ---- second stage
+        # ---- first stage: ground truth, losses, proposals (no gradient through the proposals)
+        proposals, _scores, l_rpn, tg = proposal_losses_and_proposals(pg, heads, gt_boxes)
+        sampled, roi_boxes, roi_labels, roi_gt = label_and_sample(rh, proposals, gt_boxes, perm)
+        if roi_override is not None:
+            roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
+            roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
+        # ---- second stage: support rcnn_8 features (one box per support crop), DSA mix, fc1, predictor, losses
         qf = [f[0] for f in qf]
-        R = roi_boxes.shape[0]
-        C = qf[0].shape[-1]
-        P = rh.pooler_resolution
-        x = A.roi_align(qf, roi_boxes, pg.strides, P).reshape(R * P * P, C)                # rows ordered [roi][pos], channels last
-        sup8 = A.roi_align_batched(sf_levels, sboxes,
-                                   torch.arange(sup.shape[0], dtype=torch.int32, device=dev), pg.strides, P)   # one box per support crop
-        s = sup8.mean(0, True).reshape(P * P, C)
-        s_exp = s.unsqueeze(0).expand(R, P * P, C).reshape(R * P * P, C)
-        a = A.linear(torch.cat((x, s_exp), 1), rh.conv3.weight.flatten(1), rh.conv3.bias) + \
-            torch.cat((A.linear(x, rh.conv1.weight.flatten(1), rh.conv1.bias),
-                       A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).unsqueeze(0).expand(R, P * P, C // 2).reshape(R * P * P, C // 2)), 1)
-        a = a.reshape(R, P * P, C).permute(0, 2, 1).reshape(R, C * P * P)                   # NCHW flatten order of fc1's weight
-        fc1 = rh.box_head[0].fc1
-        h = A.linear(a.contiguous(), fc1.weight, fc1.bias, True)
-        pr = rh.box_predictor[0]
-        scores = A.linear(h, pr.cls_score.weight, pr.cls_score.bias)
-        deltas = A.linear(h, pr.bbox_pred.weight, pr.bbox_pred.bias)
-        loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
-        fg = torch.nonzero(roi_labels == 0).squeeze(1)
-        tgt = get_deltas(roi_boxes[fg], roi_gt[fg], rh.bbox_reg_weights)
-        loss_box = (deltas[fg] - tgt).abs().sum() / max(roi_labels.numel(), 1)               # smooth_l1, beta = 0
-        for k, v in (("loss_cls_stage0", loss_cls), ("loss_box_reg_stage0", loss_box), ("loss_centernet_loc", l3[0]),
-                     ("loss_centernet_agn_pos", l3[1]), ("loss_centernet_agn_neg", l3[2])):
+        sup8 = A.roi_align_batched(sf_levels, sboxes, torch.arange(sup.shape[0], dtype=torch.int32, device=dev), pg.strides,
+                                   rh.pooler_resolution)
+        l_roi, a2 = roi_stage_losses(rh, qf, sup8, roi_boxes, roi_labels, roi_gt, pg.strides)
+        for k, v in {**l_roi, **l_rpn}.items():
             acc.setdefault(k, []).append(v)
         if return_aux:
             aux = dict(proposals=proposals, sampled=sampled, roi_boxes=roi_boxes, roi_labels=roi_labels, pos_inds=tg["pos_inds"],
-                       pos_count=tg["pos_count"], features={k: f.permute(2, 0, 1)[None] for k, f in zip(LEVELS, qf)}, heads=heads,
-                       scores=scores, deltas=deltas, h=h)
+                       pos_count=tg["pos_count"], features={k: f.permute(2, 0, 1)[None] for k, f in zip(LEVELS, qf)}, heads=heads, **a2)
     losses = {k: (v[0] if len(v) == 1 else torch.stack(v).mean()) for k, v in acc.items()}
     return (losses, aux) if return_aux else losses

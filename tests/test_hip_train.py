@@ -739,3 +739,33 @@ def test_module_level_training_forwards(oh):
     (sum((r ** 2).sum() for r in regs_ref) + sum(h.sum() for h in hms_ref)).backward()
     _close(head.bbox_tower[0].weight.grad, leaf["proposal_generator.centernet_head.bbox_tower.0.weight"].grad, tol=1e-4)
     _close(head.scales[1].scale.grad, leaf["proposal_generator.centernet_head.scales.1.scale"].grad, tol=1e-4)
+
+
+def test_training_call_protocol_of_submodules(oh):
+    """proposal_generator(images, features, gt_instances) -> (proposals, 3 losses) and roi_heads(images, features, support_box_features,
+    proposals, targets) -> (proposals, 2 losses) in training mode, as the reference's detector calls them (fsod_cen.py:277-278)."""
+    from detectron2.structures import Boxes, ImageList, Instances
+    from detectron2.layers import nhwc_view
+    from fewx.modeling.fsod.train_forward import head_train, proposal_losses_and_proposals
+    m, sd, cfg = _train_model(4)
+    g = torch.Generator().manual_seed(12)
+    H, W = 128, 160
+    gt = _rand_boxes(g, 5, W, H, lo=2.8, span=1.2)
+    inst = Instances((H, W))
+    inst.gt_boxes, inst.gt_classes = Boxes(gt.cuda()), torch.zeros(5, dtype=torch.int64).cuda()
+    feats = {k: (torch.randn(1, 128, H >> s, W >> s, generator=g) * 0.5).cuda().requires_grad_(True) for k, s in (("p3", 3), ("p4", 4), ("p5", 5))}
+    images = ImageList(torch.zeros(1, 3, H, W).cuda(), [(H, W)])
+    pg, rh = m.proposal_generator, m.roi_heads
+    props, l3 = pg(images, feats, [inst])
+    assert set(l3) == {"loss_centernet_loc", "loss_centernet_agn_pos", "loss_centernet_agn_neg"} and len(props) == 1
+    assert props[0].proposal_boxes.tensor.shape[1] == 4 and len(props[0].objectness_logits) == len(props[0].proposal_boxes.tensor)
+    _, _, want, _ = proposal_losses_and_proposals(pg, head_train(pg.centernet_head, [nhwc_view(feats[k]) for k in ("p3", "p4", "p5")]), gt.cuda())
+    for k in l3:
+        assert abs(float(l3[k]) - float(want[k])) <= 1e-6 * max(abs(float(want[k])), 1e-3)
+    sup8 = (torch.randn(4, 128, 8, 8, generator=g) * 0.3).cuda().requires_grad_(True)
+    g1 = torch.Generator().manual_seed(5)
+    out_props, l2 = rh(images, feats, [sup8, None], props, [inst], perm=lambda n: torch.randperm(n, generator=g1))
+    assert set(l2) == {"loss_cls_stage0", "loss_box_reg_stage0"} and out_props is props
+    (sum(l3.values()) + sum(l2.values())).backward()
+    assert all(torch.isfinite(f.grad).all() and float(f.grad.abs().max()) > 0 for f in feats.values())
+    assert float(sup8.grad.abs().max()) > 0 and float(rh.box_predictor[0].cls_score.weight.grad.abs().max()) > 0
