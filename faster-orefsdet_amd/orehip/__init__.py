@@ -72,7 +72,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
-           "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile"]
+           "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
 
 _lib = None
 
@@ -711,6 +711,13 @@ def sumpool2x2(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, Cc, device=x.device, dtype=torch.float32)
     _chk(lib().ore_sumpool2x2_fwd(C.c_void_p(_ptr(x)), Cc, B, H, W, Cc, C.c_void_p(_ptr(out)), _stream()), "ore_sumpool2x2_fwd")
     return out
+
+
+def event_pair_overhead_us(reps: int = 200) -> float:
+    """Median (event, empty launch, event) time on the current stream (see ore_event_pair_overhead_us)."""
+    v = C.c_double(0.0)
+    _chk(lib().ore_event_pair_overhead_us(_stream(), reps, C.byref(v)), "ore_event_pair_overhead_us")
+    return float(v.value)
 
 
 def compose_roi_head(sd, support_8: torch.Tensor, prefix: str = "roi_heads."):

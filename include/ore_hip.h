@@ -359,6 +359,9 @@ double ore_engine_last_flops(ore_engine* e);
  * the algorithmic FLOPs of those launches and the launch count since the last read, and resets the counters. */
 int ore_engine_set_profiling(ore_engine* e, int32_t enable);
 int ore_engine_read_profile(ore_engine* e, double* conv_ms, double* conv_flops, int32_t* n_launches);
+/* What bracketing ONE launch with hipEvents adds beyond the launch itself: 2*T(1) - T(2), T(n) = median time of (event, n empty
+ * launches, event) on `stream`; subtracting launches x this value makes the event-based kernel time agree with rocprofv3's. */
+int ore_event_pair_overhead_us(void* stream, int32_t reps, double* median_us);
 
 #ifdef __cplusplus
 }
