@@ -58,13 +58,14 @@ __device__ __forceinline__ f32x4 bilinear4(const float* f, int ld, int H, int W,
 }
 
 // one block per ROI; thread = (bin, 4 channels)
+constexpr int ROI_FWD_SPLIT = 4;        // blocks per ROI: 256-320 ROIs alone do not fill 256 CUs with enough loads in flight
 __global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
-    const int r = blockIdx.x;
+    const int r = blockIdx.x / ROI_FWD_SPLIT, part = blockIdx.x % ROI_FWD_SPLIT;
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
     const int P = p.pooled, C4 = p.C >> 2;
     float* dst = p.out + (size_t)r * P * P * p.C;
     if (r >= n) {   // keep the GEMM input finite
-        for (int i = threadIdx.x; i < P * P * C4; i += 256) *reinterpret_cast<f32x4*>(dst + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = part * 256 + threadIdx.x; i < P * P * C4; i += 256 * ROI_FWD_SPLIT) *reinterpret_cast<f32x4*>(dst + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
     const float bw = rw / (float)P, bh = rh / (float)P;
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float cnt = (float)max(gh * gw, 1);
-    for (int i = threadIdx.x; i < P * P * C4; i += 256) {
+    for (int i = part * 256 + threadIdx.x; i < P * P * C4; i += 256 * ROI_FWD_SPLIT) {
         const int c = (i % C4) * 4, bin = i / C4;
         const int ph = bin / P, pw = bin - ph * P;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -300,7 +301,7 @@ static int roi_align_fwd_impl(const float* const* feat, const int32_t* ld, const
     p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
     p.canonical_size = 224.0f; p.canonical_level = 4;      // ROIPooler defaults (poolers.py:96-97)
     p.boxes = boxes; p.n_ptr = n_dev; p.n_host = n_host; p.cap = cap; p.out = out; p.bidx = box_image;
-    hipLaunchKernelGGL(k_roi_align, dim3(cap), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_roi_align, dim3(cap * ROI_FWD_SPLIT), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_roi_align");
 }
 
