@@ -66,16 +66,18 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
         for (int j = 0; j < 7; ++j)
 #pragma unroll
             for (int t = 0; t < MAXNT; ++t)
-                if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bw[t][j], acc[t], 0, 0, 0);
+                if (t < NT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[t][j], a[j], acc[t], 0, 0, 0);   // D^T: rows = channels
+        // weights are the MFMA "A" operand, so acc[t] = 4 consecutive channels (t*16 + g*4 ..) of pixel grp*16 + li: 16-byte stores
+        const int m = grp * 16 + li;
+        if (m < M) {
 #pragma unroll
-        for (int t = 0; t < MAXNT; ++t) {
-            if (t < NT) {
-                const int n = t * 16 + li;
-                const float sc = scale[n], sh = shift[n];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int m = grp * 16 + g * 4 + rr;
-                    if (m < M) out[(size_t)m * out_ld + out_coff + n] = fmaxf(acc[t][rr] * sc + sh, 0.f);
+            for (int t = 0; t < MAXNT; ++t) {
+                if (t < NT) {
+                    const int n = t * 16 + g * 4;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n), sh = *reinterpret_cast<const f32x4*>(shift + n);
+                    f32x4 v = acc[t] * sc + sh;
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    *reinterpret_cast<f32x4*>(out + (size_t)m * out_ld + out_coff + n) = v;
                 }
             }
         }
