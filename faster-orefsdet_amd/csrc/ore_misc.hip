@@ -34,11 +34,19 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
         kmean[j] = kc[j] == 0 ? m0 : (kc[j] == 1 ? m1 : m2);
         kstd[j] = kc[j] == 0 ? s0 : (kc[j] == 1 ? s1 : s2);
     }
+    // weights: one coalesced pass into LDS (rows padded to 28), then each lane picks its 7 x NT values -- the direct per-lane gather
+    // (28 loads with a 108-byte lane stride) was ~18 us of latency in front of every wave's first pixel group
+    __shared__ float sw[NT * 16 * 28];
+    for (int i = threadIdx.x; i < NT * 16 * 28; i += 256) {
+        const int n = i / 28, k = i - n * 28;
+        sw[i] = k < 27 ? w[n * 27 + k] : 0.f;
+    }
+    __syncthreads();
     float bw[MAXNT][7];
 #pragma unroll
     for (int t = 0; t < MAXNT; ++t)
 #pragma unroll
-        for (int j = 0; j < 7; ++j) bw[t][j] = (t < NT && kv[j]) ? w[(t * 16 + li) * 27 + 4 * j + g] : 0.f;
+        for (int j = 0; j < 7; ++j) bw[t][j] = sw[(t * 16 + li) * 28 + 4 * j + g];
     const int M = B * Ho * Wo;
     const int ngroups = (M + 15) >> 4;
     const int gw0 = (blockIdx.x * 4 + wave) * groups_per_wave;
@@ -397,7 +405,7 @@ extern "C" int ore_stem1_fwd(const void* img, int32_t img_is_u8, int32_t B, int3
     hipStream_t st = (hipStream_t)stream;
     // mean/std are host-readable by contract (3 floats each)
     const int ngroups = ceil_div(M, 16);
-    const int gpw = ngroups >= 2048 ? 2 : 1;            // groups of 16 pixels per wave (measured: 1 -> 24.4, 2 -> 22.3, 4 -> 25.1 us at 640x640)
+    const int gpw = ngroups >= 2048 ? 2 : 1;            // groups of 16 pixels per wave (measured at 640x640 with LDS-staged weights: 1 -> 17.6, 2 -> 17.5, 4 -> 20.4, 8 -> 28.0 us)
     const int blocks = ceil_div(ngroups, 4 * gpw);
 #define ORE_STEM1(T, NT)                                                                                              \
     hipLaunchKernelGGL((k_stem1<T, NT>), dim3(blocks), dim3(256), 0, st, (const T*)img, B, H, W, Ho, Wo, mean3[0], mean3[1], \
