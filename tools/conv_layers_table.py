@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""profiles/r01_bench_image_timeline.txt (tools/trace_summary.py on a rocprofv3 --kernel-trace of `bench.py --inflight 1`) ->
+per-conv-launch efficiency table profiles/r01_conv_layers.txt.  Layer order = launch order of the engine at 640x640."""
+import re
+import sys
+
+LAYERS = [("stem2", 320, 320, 64, 64, 3, 1), ("stem3", 320, 320, 64, 128, 3, 2), ("s2l0", 160, 160, 128, 64, 3, 1), ("s2l1", 160, 160, 64, 64, 3, 1),
+          ("s2l2", 160, 160, 64, 64, 3, 1), ("s2cat", 160, 160, 320, 112, 1, 1), ("s3l0", 80, 80, 112, 80, 3, 1), ("s3l1", 80, 80, 80, 80, 3, 1),
+          ("s3l2", 80, 80, 80, 80, 3, 1), ("s3cat", 80, 80, 352, 256, 1, 1), ("s4l0", 40, 40, 256, 96, 3, 1), ("s4l1", 40, 40, 96, 96, 3, 1),
+          ("s4l2", 40, 40, 96, 96, 3, 1), ("s4cat", 40, 40, 544, 384, 1, 1), ("s5l0", 20, 20, 384, 112, 3, 1), ("s5l1", 20, 20, 112, 112, 3, 1),
+          ("s5l2", 20, 20, 112, 112, 3, 1), ("s5cat", 20, 20, 720, 512, 1, 1), ("lat5", 20, 20, 512, 128, 1, 1), ("out5", 20, 20, 128, 128, 3, 1),
+          ("lat4", 40, 40, 384, 128, 1, 1), ("out4", 40, 40, 128, 128, 3, 1), ("lat3", 80, 80, 256, 128, 1, 1), ("out3", 80, 80, 128, 128, 3, 1)]
+EXTRA = [("conv3 (3 levels)", 8400, 256, 128, 1), ("head tower (3 levels)", 8400, 128, 128, 3), ("head reg|hm (3 levels)", 8400, 128, 5, 3),
+         ("roi DSA+fc1 (320 rois)", 320, 8192, 128, 1)]
+PEAK = 157.3
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_bench_image_timeline.txt"
+    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_conv_layers.txt"
+    tl = [l for l in open(src) if l.startswith("k_conv")]
+    assert len(tl) == 28, len(tl)
+    out = ["# per-conv-launch efficiency of ONE image, strictly sequential mode (rocprofv3 --kernel-trace of `bench.py --inflight 1`,",
+           "# %s); algorithmic FLOPs = 2*M*Cout*Cin*k*k; peak = %.1f TFLOP/s (fp32 MFMA, gfx950)" % (src, PEAK),
+           "%-26s %-44s %9s %8s %8s %7s" % ("layer", "kernel / grid", "us", "GFLOP", "TFLOP/s", "% peak")]
+    tu = tg = 0.0
+    for i, l in enumerate(tl):
+        m = re.match(r"(\S+.*?)\s+grid=(\([^)]*\))\s+dur=\s*([\d.]+)", l)
+        kn, grid, us = m.group(1).strip(), m.group(2), float(m.group(3))
+        if i < 24:
+            n, H, W, ci, co, k, s = LAYERS[i]
+            gf = 2.0 * (H // s) * (W // s) * co * ci * k * k / 1e9
+        else:
+            n, M, ci, co, k = EXTRA[i - 24]
+            gf = 2.0 * M * co * ci * k * k / 1e9
+        tu += us
+        tg += gf
+        out.append("%-26s %-44s %9.2f %8.3f %8.1f %7.1f" % (n, (kn + " " + grid)[:44], us, gf, gf / us * 1e3, gf / us * 1e3 / PEAK * 100))
+    out.append("%-26s %-44s %9.2f %8.3f %8.1f %7.1f" % ("all 28 conv launches", "", tu, tg, tg / tu * 1e3, tg / tu * 1e3 / PEAK * 100))
+    open(dst, "w").write("\n".join(out) + "\n")
+    print(out[-1])
+
+
+if __name__ == "__main__":
+    main()
