@@ -1,0 +1,122 @@
+"""Size-independent properties at BASELINE.json's full sizes (no oracle needed): what must hold for ANY input.
+NMS: idempotent, survivors pairwise below the threshold, every suppressed box overlaps an earlier survivor, order by score.
+Top-k / decode: per-level counts, threshold, score monotonicity.  ROIAlign and conv: linearity.  Engine: determinism."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oh():
+    import orehip
+    orehip.lib()
+    return orehip
+
+
+def _iou(a, b):
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    wh = (torch.min(a[:, None, 2:], b[:, 2:]) - torch.max(a[:, None, :2], b[:, :2])).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (area_a[:, None] + area_b - inter)
+
+
+@pytest.mark.parametrize("n,thr", [(6000, 0.9), (2400, 0.6), (700, 0.3)])
+def test_nms_properties_full_size(oh, n, thr):
+    g = torch.Generator().manual_seed(n)
+    ctr = torch.rand(n, 2, generator=g) * 640
+    wh = torch.exp(torch.rand(n, 2, generator=g) * 2.5 + 2.0)
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).cuda()
+    scores = torch.rand(n, generator=g).cuda()
+    m7 = len(scores[1::7])
+    scores[::7][:m7] = scores[1::7]                                        # plenty of exact score ties
+    keep = oh.nms(boxes, scores, thr)
+    kb, ks = boxes[keep], scores[keep]
+    assert torch.all(ks[:-1] >= ks[1:])                                    # emitted in descending score order
+    iou = _iou(kb, kb)
+    iou.fill_diagonal_(0)
+    assert float(iou.max()) <= thr                                         # survivors are pairwise compatible
+    keep2 = oh.nms(kb, ks, thr)
+    assert torch.equal(keep2.cpu(), torch.arange(len(keep)))               # idempotent
+    dropped = torch.ones(n, dtype=torch.bool, device="cuda")
+    dropped[keep] = False
+    di = torch.nonzero(dropped).squeeze(1)
+    if len(di):                                                            # every dropped box is covered by a survivor that outranks it
+        cover = _iou(boxes[di], kb) > thr
+        outranks = (ks[None, :] > scores[di][:, None]) | ((ks[None, :] == scores[di][:, None]) & (keep[None, :] < di[:, None]))
+        assert bool((cover & outranks).any(1).all())
+
+
+def test_detect_properties_full_size(oh):
+    g = torch.Generator().manual_seed(3)
+    heads = []
+    for s in (80, 40, 20):
+        h = torch.zeros(s, s, 8)
+        h[..., :4] = torch.rand(s, s, 4, generator=g) * 6
+        h[..., 4] = torch.randn(s, s, generator=g) * 2.5 - 1.0
+        heads.append(h.cuda())
+    for (pre, thr, post) in ((1000, 0.6, 256), (4000, 0.9, 2000)):
+        o = oh.detect(heads, (8, 16, 32), 1e-5, pre, thr, post)
+        n_pre, n_keep = int(o["counts"][0]), int(o["counts"][1])
+        lv = o["pre_level"][:n_pre].cpu()
+        for l, s in enumerate((80, 40, 20)):
+            sig = torch.sigmoid(heads[l][..., 4]).flatten()
+            want = min(int((sig > 1e-5).sum()), pre)
+            assert int((lv == l).sum()) == want                              # exactly min(#candidates, pre_topk) per level
+        sc = o["pre_scores"][:n_pre]
+        assert float(sc.min()) > (1e-5) ** 0.5 * 0.999                       # score = sqrt(heatmap) of a candidate above the threshold
+        out_s = o["out_scores"][:n_keep]
+        assert torch.all(out_s[:-1] >= out_s[1:])
+        if n_keep > post:                                                   # more than post_topk only through ties at the k-th score
+            assert float(out_s[post - 1]) == float(out_s[-1])
+        b = o["out_boxes"][:n_keep]
+        assert bool((b[:, 2] > b[:, 0]).all() and (b[:, 3] > b[:, 1]).all())
+
+
+def test_roi_align_and_conv_linearity_full_size(oh):
+    g = torch.Generator().manual_seed(8)
+    f1 = [torch.randn(1, 80 >> l, 80 >> l, 128, generator=g).cuda() for l in range(3)]
+    f2 = [torch.randn(1, 80 >> l, 80 >> l, 128, generator=g).cuda() for l in range(3)]
+    ctr = torch.rand(256, 2, generator=g) * 640
+    wh = torch.exp(torch.rand(256, 2, generator=g) * 3 + 2.5)
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).cuda()
+    a, b = 0.75, -1.5
+    r1, r2 = oh.roi_align(f1, boxes, (8, 16, 32)), oh.roi_align(f2, boxes, (8, 16, 32))
+    r12 = oh.roi_align([a * x + b * y for x, y in zip(f1, f2)], boxes, (8, 16, 32))
+    assert float((r12 - (a * r1 + b * r2)).abs().max()) <= 2e-5 * float(r12.abs().max())
+    # stem_2-sized 3x3 conv (weight-stationary kernel) and a stage-5 sized one (K-split tiles): linear in the input, no epilogue
+    for (H, W, Cin, Cout) in ((320, 320, 64, 64), (20, 20, 384, 112)):
+        x1, x2 = torch.randn(1, H, W, Cin, generator=g).cuda(), torch.randn(1, H, W, Cin, generator=g).cuda()
+        w = oh.pack_conv_weight(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+        y1, y2 = oh.conv2d(x1, w, Cout, 3), oh.conv2d(x2, w, Cout, 3)
+        y12 = oh.conv2d(a * x1 + b * x2, w, Cout, 3)
+        assert float((y12 - (a * y1 + b * y2)).abs().max()) <= 3e-5 * float(y12.abs().max())
+        assert torch.equal(oh.conv2d(x1, w, Cout, 3), y1)                   # and bit-reproducible
+
+
+def test_centernet_targets_properties_full_size(oh):
+    """640x640, 128 boxes: every positive index addresses the cell containing its box centre on a level that cares for the box size;
+    a location with a regression target lies inside that box; heat-map in [0, 1] and exactly 1 at positive cells."""
+    g = torch.Generator().manual_seed(6)
+    ctr = torch.rand(128, 2, generator=g) * 600 + 20
+    wh = torch.exp(torch.rand(128, 2, generator=g) * 3.0 + 2.3)
+    gt = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).clamp(0, 640)
+    shapes = [(80, 80), (40, 40), (20, 20)]
+    o = oh.centernet_targets([gt], shapes)
+    n = int(o["pos_count"])
+    pos = o["pos_inds"][:n].cpu()
+    hm, reg = o["hm_targets"].cpu(), o["reg_targets"].cpu()
+    assert float(hm.min()) >= 0 and float(hm.max()) <= 1.0 and n >= 128
+    assert torch.all(hm[pos] == 1.0)                                        # the discretised centre is a peak of the Gaussian
+    has = reg.max(1)[0] >= 0
+    assert bool((reg[has] > 0).all()) and int(has.sum()) > 0                # targets only strictly inside a box
+    row0 = [0, 6400, 8000]
+    cx, cy = (gt[:, 0] + gt[:, 2]) / 2, (gt[:, 1] + gt[:, 3]) / 2
+    cells = set()
+    for l, s in enumerate((8, 16, 32)):
+        W = 640 // s
+        for i in range(128):
+            cells.add(row0[l] + int(cy[i] / s) * W + int(cx[i] / s))
+    assert set(pos.tolist()) <= cells
