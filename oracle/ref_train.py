@@ -3,9 +3,11 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product path never does.
 torch fp32 on the CPU + torch.autograd; every stage cites the reference lines it follows.  Pinning: the backbone/FPN, SM_Block,
 correlation, CenterNet head and the CenterNet targets/losses used here are the functions of oracle/ref_model.py that
-tests/test_oracle_golden.py pins against outputs of the executed reference files.  The second-stage TRAINING pieces
-(label_and_sample_proposals, ROIAlign, losses) depend on torchvision/detectron2 C++ ops that are not available here:
-they follow the published algorithm and are "parity unpinned" exactly like the eval second stage.
+tests/test_oracle_golden.py pins against outputs of the executed reference files.  The second-stage TRAINING helpers
+that are pure Python in the vendored detectron2 -- pairwise_iou, Matcher([0.6],[0,1]), subsample_labels, Box2BoxTransform.get_deltas
+-- are pinned bit-exactly by tests/golden/roi_train_pieces.npz (those files executed by oracle/refrun/gen_golden.py).  ROIAlign
+(torchvision C++) and fvcore's smooth_l1_loss (beta = 0, i.e. L1) are un-vendored: restated from the published algorithm,
+"parity unpinned" exactly like the eval second stage.
 
     ref:fewx/modeling/fsod/fsod_cen.py:151-308   CenterNet2Detector.forward (training branch)
     ref:fewx/modeling/fsod/fsod_rpn.py:644-700   CenterNet.forward (training: losses + proposals with the *_TRAIN thresholds)

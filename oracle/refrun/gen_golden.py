@@ -231,6 +231,33 @@ def main():
          pos_inds=np_(pos_inds), reg_targets=np_(reg_targets), hms=np_(flattened_hms[:, 0]), reg_pred=np_(reg_pred), hm_logit=np_(hm_logit),
          loss_loc=np_(losses["loss_centernet_loc"]), loss_pos=np_(losses["loss_centernet_agn_pos"]),
          loss_neg=np_(losses["loss_centernet_agn_neg"]))
+    # ---- second-stage training pieces that ARE pure Python in the vendored detectron2 (executed from the 7z extract): pairwise_iou,
+    #      Matcher, subsample_labels, Box2BoxTransform.get_deltas  (d2z:structures/boxes.py, modeling/matcher.py, sampling.py, box_regression.py)
+    D2 = shims.d2_root()
+    mt = shims.load("d2real_matcher", D2 + "/modeling/matcher.py")
+    sp = shims.load("d2real_sampling", D2 + "/modeling/sampling.py")
+    br = shims.load("d2real_box_regression", D2 + "/modeling/box_regression.py")
+    n_p, n_g = 300, 9
+    ctr = torch.rand(n_g, 2, generator=g) * 500 + 60
+    wh = torch.rand(n_g, 2, generator=g) * 120 + 30
+    gtb = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    jit = torch.cat([gtb[torch.randint(0, n_g, (120,), generator=g)] + torch.randn(120, 4, generator=g) * 6.0,
+                     torch.cat([torch.rand(n_p - 120, 2, generator=g) * 500, torch.rand(n_p - 120, 2, generator=g) * 500 + 20], 1)], 0)
+    jit[:, 2:] = torch.max(jit[:, 2:], jit[:, :2] + 4.0)
+    allb = torch.cat([jit, gtb], 0)                                        # proposal_append_gt
+    iou = ns.boxes.pairwise_iou(Boxes(gtb), Boxes(allb))
+    matcher = mt.Matcher([0.6], [0, 1], allow_low_quality_matches=False)
+    midx, mlab = matcher(iou)
+    gt_classes = torch.zeros(n_g, dtype=torch.int64)[midx]
+    gt_classes[mlab == 0] = 1                                              # background = num_classes = 1
+    torch.manual_seed(123)
+    fg_i, bg_i = sp.subsample_labels(gt_classes, 128, 0.5, 1)
+    sampled = torch.cat([fg_i, bg_i], 0)
+    b2b = br.Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0))
+    fg_rows = sampled[gt_classes[sampled] == 0]
+    deltas = b2b.get_deltas(allb[fg_rows], gtb[midx[fg_rows]])
+    save("roi_train_pieces", gt=np_(gtb), boxes=np_(allb), iou=np_(iou), matched_idx=np_(midx), labels=np_(gt_classes),
+         sampled=np_(sampled), fg_rows=np_(fg_rows), deltas=np_(deltas), seed=np.array(123))
     print("missing/unexpected:", missing)
 
 

@@ -135,3 +135,26 @@ def test_centernet_train_targets_and_losses(golden):
     ls = R.centernet_losses(torch.from_numpy(g["reg_pred"]), torch.from_numpy(g["hm_logit"]), pos, reg, hm)
     for k, ref in (("loss_centernet_loc", "loss_loc"), ("loss_centernet_agn_pos", "loss_pos"), ("loss_centernet_agn_neg", "loss_neg")):
         assert abs(float(ls[k]) - float(g[ref])) <= 1e-6 * abs(float(g[ref]))
+
+
+def test_roi_train_pieces_match_reference_run(golden):
+    """Second-stage training helpers of the oracle (oracle/ref_train.py) against the vendored detectron2's own pairwise_iou,
+    Matcher([0.6],[0,1]), subsample_labels and Box2BoxTransform.get_deltas, executed by oracle/refrun/gen_golden.py."""
+    import torch
+    from oracle import ref_train as T
+    g = golden("roi_train_pieces")
+    gt, boxes = torch.from_numpy(g["gt"]), torch.from_numpy(g["boxes"])
+    n_g = gt.shape[0]
+    iou = T.pairwise_iou(gt, boxes)
+    np.testing.assert_array_equal(iou.numpy(), g["iou"])
+    allb, matched, labels = T.label_proposals(boxes[:-n_g], gt, 0.6)
+    np.testing.assert_array_equal(allb.numpy(), g["boxes"])
+    np.testing.assert_array_equal(matched.numpy(), g["matched_idx"])
+    np.testing.assert_array_equal(labels.numpy(), g["labels"])
+    torch.manual_seed(int(g["seed"]))
+    sampled = T.sample_labels(labels, 128, 0.5, lambda n: torch.randperm(n))
+    np.testing.assert_array_equal(sampled.numpy(), g["sampled"])
+    fg = sampled[labels[sampled] == 0]
+    np.testing.assert_array_equal(fg.numpy(), g["fg_rows"])
+    d = T.get_deltas(allb[fg], gt[matched[fg]])
+    np.testing.assert_allclose(d.numpy(), g["deltas"], rtol=1e-6, atol=1e-6)

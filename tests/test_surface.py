@@ -92,3 +92,23 @@ def test_samplers_shard_like_the_reference():
     it = iter(TrainingSampler(4, shuffle=True, seed=1))
     first = [next(it) for _ in range(8)]
     assert sorted(first[:4]) == [0, 1, 2, 3] and sorted(first[4:]) == [0, 1, 2, 3]
+
+
+def test_label_and_sample_host_logic_matches_reference_run(golden):
+    """The product's proposal labelling / sampling / box-delta host logic (fewx/modeling/fsod/train_forward.py) on the
+    reference-run fixture (vendored detectron2 Matcher + subsample_labels + Box2BoxTransform): bit-exact indices."""
+    import types
+    import numpy as np
+    from fewx.modeling.fsod import train_forward as TF
+    g = golden("roi_train_pieces")
+    gt, boxes = torch.from_numpy(g["gt"]), torch.from_numpy(g["boxes"])
+    rh = types.SimpleNamespace(proposal_append_gt=True, iou_threshold=0.6, batch_size_per_image=128, positive_fraction=0.5)
+    np.testing.assert_array_equal(TF.pairwise_iou(gt, boxes).numpy(), g["iou"])
+    torch.manual_seed(int(g["seed"]))
+    sampled, roi_boxes, roi_labels, roi_gt = TF.label_and_sample(rh, boxes[:-gt.shape[0]], gt, lambda n: torch.randperm(n))
+    np.testing.assert_array_equal(sampled.numpy(), g["sampled"])
+    np.testing.assert_array_equal(roi_labels.numpy(), g["labels"][g["sampled"]])
+    np.testing.assert_array_equal(roi_gt.numpy(), g["gt"][g["matched_idx"][g["sampled"]]])
+    fg = roi_labels == 0
+    d = TF.get_deltas(roi_boxes[fg], roi_gt[fg], (10.0, 10.0, 5.0, 5.0))
+    np.testing.assert_allclose(d.numpy(), g["deltas"], rtol=1e-6, atol=1e-6)
