@@ -110,7 +110,7 @@ def cpu_baseline(model, img, budget_s=12.0):
                       f"torch {torch.__version__} CPU, {el:.1f} s)"}
 
 
-def train_leg(device, steps=8, warmup=4, size=640, shots=24):
+def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1):
     """SURVEY 8d metric (ii), single GPU: forward + backward + clip/SGD of finetune_vovnet.yaml on one query + 24 support crops
     (tools/bench_train.py is the stand-alone / multi-GPU version).  Reported beside the headline, never as `value`."""
     from detectron2.structures import Boxes, Instances
@@ -125,19 +125,21 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24):
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).to(device) * (p[0].numel() ** -0.5))
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
-    wh = torch.rand(17, 2, generator=g) * 120 + 30
-    ctr = torch.rand(17, 2, generator=g) * (size - wh) + wh / 2
-    inst = Instances((size, size))
-    inst.gt_boxes = Boxes(torch.cat([ctr - wh / 2, ctr + wh / 2], 1).to(device))
-    inst.gt_classes = torch.zeros(17, dtype=torch.int64, device=device)
-    sup = torch.stack([synth_image(100 + i, 240, 240) for i in range(shots)]).to(device)
-    side = torch.rand(shots, 2, generator=g) * 120 + 80
-    c = torch.rand(shots, 2, generator=g) * (240 - side) + side / 2
-    item = {"image": synth_image(7, size, size).to(device), "instances": inst, "support_images": sup,
-            "support_bboxes": torch.cat([c - side / 2, c + side / 2], 1).numpy()}
+    items = []
+    for b in range(batch):
+        wh = torch.rand(17, 2, generator=g) * 120 + 30
+        ctr = torch.rand(17, 2, generator=g) * (size - wh) + wh / 2
+        inst = Instances((size, size))
+        inst.gt_boxes = Boxes(torch.cat([ctr - wh / 2, ctr + wh / 2], 1).to(device))
+        inst.gt_classes = torch.zeros(17, dtype=torch.int64, device=device)
+        sup = torch.stack([synth_image(100 + 50 * b + i, 240, 240) for i in range(shots)]).to(device)
+        side = torch.rand(shots, 2, generator=g) * 120 + 80
+        c = torch.rand(shots, 2, generator=g) * (240 - side) + side / 2
+        items.append({"image": synth_image(7 + b, size, size).to(device), "instances": inst, "support_images": sup,
+                      "support_bboxes": torch.cat([c - side / 2, c + side / 2], 1).numpy()})
 
     def step():
-        losses = model([item])
+        losses = model(items)
         opt.zero_grad()
         sum(losses.values()).backward()
         opt.step()
@@ -152,9 +154,9 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24):
         losses = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return {"images_per_s": round(steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
-            "workload": "finetune_vovnet.yaml train step on 1 GPU: 1 query %dx%d + %d support 240x240, fwd + bwd (HIP backward kernels) + "
-                        "flat-bucket clip/SGD, FREEZE_AT=3" % (size, size, shots),
+    return {"images_per_s": round(batch * steps / el, 2), "batch_per_gpu": batch, "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
+            "workload": "finetune_vovnet.yaml train step on 1 GPU: %d x (1 query %dx%d + %d support 240x240), fwd + bwd (HIP backward kernels) + "
+                        "flat-bucket clip/SGD, FREEZE_AT=3" % (batch, size, size, shots),
             "dense_part_hipgraph": model.__dict__.get("_ore_train_graph_error") is None,
             "exchanged_bytes_per_step_if_dp": 4 * opt.bucket.size, "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
 
@@ -322,6 +324,10 @@ def main():
                 out["train_step"] = train_leg(device)
             except Exception as ex:                         # the headline line must survive a failure of the side measurement
                 out["train_step"] = {"error": repr(ex)[:300]}
+            try:                                            # BASELINE configs[2]: 16 query images (+ 16 x 24 support crops) per GPU per step
+                out["train_step_bs16"] = train_leg(device, steps=4, warmup=3, batch=16)
+            except Exception as ex:
+                out["train_step_bs16"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, imgs[0].cpu())
         print(json.dumps(out), flush=True)

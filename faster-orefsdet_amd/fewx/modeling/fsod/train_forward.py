@@ -1,7 +1,8 @@
 """Training forward of CenterNet2Detector: returns the reference's loss dict with an autograd tape whose
 FLOP-carrying nodes are libore_hip.so kernels (orehip.autograd).
 
-Reference flow restated here (one query image + its support set per call; the reference trains with IMS_PER_BATCH = 1 per GPU):
+Reference flow restated here (the reference trains with IMS_PER_BATCH = 1 per GPU; for B > 1 the two backbone passes, conv3 and the
+head run batched as the reference's do, the per-image stages loop, and the losses are the mean over the images -- SURVEY App. C.1):
     ref:fewx/modeling/fsod/fsod_cen.py:151-308     CenterNet2Detector.forward, training branch
     ref:fewx/modeling/fsod/fsod_rpn.py:644-700     CenterNet.forward: head -> targets -> 3 losses -> proposals (*_TRAIN thresholds)
     d2z:modeling/roi_heads/roi_heads.py:181-295    label_and_sample_proposals (append gt, IoU matcher 0.6, 128 samples, <= 50 % fg)
@@ -60,7 +61,10 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
     outs = []
     for l, x in enumerate(feats_nhwc):
         t = A.conv(x, tower.weight, tower.bias)
-        t = A.group_norm_relu(t, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
+        if t.shape[0] == 1:
+            t = A.group_norm_relu(t, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
+        else:                                                       # GroupNorm statistics are per image
+            t = torch.cat([A.group_norm_relu(t[b:b + 1], gn.weight, gn.bias, gn.num_groups, gn.eps, True) for b in range(t.shape[0])], 0)
         o = A.conv(t, w5, b5)
         reg = F.relu(o[..., :4] * head.scales[l].scale)
         outs.append(torch.cat([reg, o[..., 4:5], torch.zeros(*o.shape[:3], 11, device=o.device)], -1))
@@ -68,9 +72,13 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
 
 
 def dense_part(model, xq: torch.Tensor, xs: torch.Tensor):
-    """The shape-static part of a training iteration: query and support pyramids, support prototypes, correlation, conv3, head.
-    xq [1,3,H,W], xs [N,3,h,w] normalised + padded.  Returns (q3, q4, q5, s3, s4, s5 as NHWC, head3, head4, head5 [1,H,W,16])."""
+    """The shape-static part of a training iteration for B query images at once: query and support pyramids (two batched backbone
+    passes, fsod_cen.py:165,179), per-image support prototypes and correlation (:197-275), conv3 and the head batched over B.
+    xq [B,3,H,W], xs [B*N,3,h,w] normalised + padded, image b owning support rows b*N..(b+1)*N.
+    Returns (q3, q4, q5 [B,..], s3, s4, s5 [B*N,..] as NHWC, head3, head4, head5 [B,H,W,16])."""
     from orehip import autograd as A
+    B = xq.shape[0]
+    N = xs.shape[0] // B
     feats = model.backbone(xq)
     sfeats = model.backbone(xs)
     pos = []
@@ -79,14 +87,15 @@ def dense_part(model, xq: torch.Tensor, xs: torch.Tensor):
         sf = sfeats[k]
         if sf.shape[-2:] != (size, size):
             sf = F.adaptive_avg_pool2d(sf, (size, size))
-        # support prototypes: avg-pool to 32/16/8, SM_Block, the reference's H<->W swapping permute, mean over shots
+        # support prototypes: avg-pool to 32/16/8, SM_Block, the reference's H<->W swapping permute, mean over the image's shots
         v = getattr(model, f"vip_p{3 + i}")(nhwc_view(sf)).permute(0, 3, 2, 1)
-        proto = v.mean(0, True)
-        k11 = F.adaptive_avg_pool2d(proto, (1, 1))[0, :, 0, 0]                  # support kernels (fsod_cen.py:229-231)
-        k13 = F.adaptive_avg_pool2d(proto, (1, 3))[0, :, 0, :]
-        k31 = F.adaptive_avg_pool2d(proto, (3, 1))[0, :, :, 0]
-        cat = A.correlation_cat(nhwc_view(feats[k]), k11, k13, k31)            # [1,H,W,2C] = [attn | q]
-        pos.append(A.conv(cat, model.conv3.weight, model.conv3.bias, None, None, True))
+        proto = v.mean(0, True) if B == 1 else v.reshape(B, N, *v.shape[1:]).mean(1)
+        k11 = F.adaptive_avg_pool2d(proto, (1, 1))[:, :, 0, 0]                  # support kernels (fsod_cen.py:229-231), [B,C]
+        k13 = F.adaptive_avg_pool2d(proto, (1, 3))[:, :, 0, :]                  # [B,C,3]
+        k31 = F.adaptive_avg_pool2d(proto, (3, 1))[:, :, :, 0]
+        q = nhwc_view(feats[k])
+        cats = [A.correlation_cat(q[b:b + 1], k11[b], k13[b], k31[b]) for b in range(B)]   # [1,H,W,2C] = [attn | q] per image
+        pos.append(A.conv(cats[0] if B == 1 else torch.cat(cats, 0), model.conv3.weight, model.conv3.bias, None, None, True))
     heads = head_train(model.proposal_generator.centernet_head, pos)
     return tuple(nhwc_view(feats[k]) for k in LEVELS) + tuple(nhwc_view(sfeats[k]) for k in LEVELS) + tuple(heads)
 
@@ -206,17 +215,27 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
         perm = lambda n: torch.randperm(n, device=dev)          # noqa: E731  (subsample_labels, d2z:modeling/sampling.py:49-50)
     acc: Dict[str, List[torch.Tensor]] = {}
     aux = {}
-    for item in batched_inputs:
-        img = item["image"].to(dev)
+    B = len(batched_inputs)
+    N = model.support_way * model.support_shot
+    assert model.support_way == 1
+    imgs = [item["image"].to(dev).float() for item in batched_inputs]
+    Hm, Wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+    # ImageList.from_tensors semantics (d2z:structures/image_list.py:69-121): normalise each image, zero-pad bottom/right to the batch
+    # maximum rounded up to the size divisibility; the whole batch goes through the backbone at once (fsod_cen.py:156,165)
+    xq = torch.cat([F.pad(_normalise_pad(i[None], mean, std, 1), (0, Wm - i.shape[-1], 0, Hm - i.shape[-2])) for i in imgs], 0)
+    xq = F.pad(xq, (0, (Wm + div - 1) // div * div - Wm, 0, (Hm + div - 1) // div * div - Hm)).contiguous()
+    sups = [item["support_images"].to(dev) for item in batched_inputs]
+    for s_ in sups:
+        assert s_.shape[0] == N, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
+    xs = _normalise_pad(torch.cat(sups, 0) if B > 1 else sups[0], mean, std, div)
+    outs = graphed_dense_part(model, xq, xs) if getattr(model, "train_graph", False) else dense_part(model, xq, xs)
+    for b, item in enumerate(batched_inputs):
         inst = item["instances"]
         gt_boxes = (inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes).to(dev).float()
-        sup = item["support_images"].to(dev)
         sboxes = torch.as_tensor(item["support_bboxes"], dtype=torch.float32, device=dev)
-        assert sup.shape[0] == model.support_way * model.support_shot, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
-        assert model.support_way == 1
-        xq, xs = _normalise_pad(img[None], mean, std, div), _normalise_pad(sup, mean, std, div)
-        outs = graphed_dense_part(model, xq, xs) if getattr(model, "train_graph", False) else dense_part(model, xq, xs)
-        qf, sf_levels, heads = list(outs[0:3]), list(outs[3:6]), list(outs[6:9])
+        qf = [f[b] for f in outs[0:3]]
+        sf_levels = [f[b * N:(b + 1) * N] for f in outs[3:6]]
+        heads = [h[b:b + 1] for h in outs[6:9]]
         # ---- first stage: ground truth, losses, proposals (no gradient through the proposals)
         proposals, _scores, l_rpn, tg = proposal_losses_and_proposals(pg, heads, gt_boxes)
         sampled, roi_boxes, roi_labels, roi_gt = label_and_sample(rh, proposals, gt_boxes, perm)
@@ -224,9 +243,7 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
             roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
             roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
         # ---- second stage: support rcnn_8 features (one box per support crop), DSA mix, fc1, predictor, losses
-        qf = [f[0] for f in qf]
-        sup8 = A.roi_align_batched(sf_levels, sboxes, torch.arange(sup.shape[0], dtype=torch.int32, device=dev), pg.strides,
-                                   rh.pooler_resolution)
+        sup8 = A.roi_align_batched(sf_levels, sboxes, torch.arange(N, dtype=torch.int32, device=dev), pg.strides, rh.pooler_resolution)
         l_roi, a2 = roi_stage_losses(rh, qf, sup8, roi_boxes, roi_labels, roi_gt, pg.strides)
         for k, v in {**l_roi, **l_rpn}.items():
             acc.setdefault(k, []).append(v)

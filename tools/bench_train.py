@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--shots", type=int, default=24)
+    ap.add_argument("--batch", type=int, default=1, help="query images per GPU per step (BASELINE configs[2]: 16)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the shape-static dense part (fwd + bwd) into hipGraphs")
     a = ap.parse_args()
@@ -55,13 +56,15 @@ def main():
     model = FlatDataParallel(m, cfg, overlap=not a.no_overlap) if world > 1 else m
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
-    img, gt, sup, sbox = T.synth_train_inputs(rank, (a.size, a.size), n_gt=17, shots=a.shots, support_hw=240)
-    inst = Instances((a.size, a.size))
-    inst.gt_boxes, inst.gt_classes = Boxes(gt.cuda()), torch.zeros(len(gt), dtype=torch.int64).cuda()
-    item = {"image": img.cuda(), "instances": inst, "support_images": sup.cuda(), "support_bboxes": sbox.numpy()}
+    items = []
+    for b in range(a.batch):
+        img, gt, sup, sbox = T.synth_train_inputs(rank * a.batch + b, (a.size, a.size), n_gt=17, shots=a.shots, support_hw=240)
+        inst = Instances((a.size, a.size))
+        inst.gt_boxes, inst.gt_classes = Boxes(gt.cuda()), torch.zeros(len(gt), dtype=torch.int64).cuda()
+        items.append({"image": img.cuda(), "instances": inst, "support_images": sup.cuda(), "support_bboxes": sbox.numpy()})
 
     def step():
-        losses = model([item])
+        losses = model(items)
         opt.zero_grad()
         sum(losses.values()).backward()
         opt.step()
@@ -85,10 +88,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "train_images_per_second", "value": world * a.steps / el, "unit": "img/s", "n_gpus": world,
+        print(json.dumps({"metric": "train_images_per_second", "value": world * a.batch * a.steps / el, "unit": "img/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
                           "scaling": "weak", "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "finetune_vovnet.yaml train step, 1 query %dx%d + %d support 240x240 per GPU" % (a.size, a.size, a.shots),
+                          "config": {"workload": "finetune_vovnet.yaml train step, %d x (1 query %dx%d + %d support 240x240) per GPU" % (a.batch, a.size, a.size, a.shots),
+                                     "batch_per_gpu": a.batch,
                                      "bucket_bytes": 4 * opt.bucket.size},
                           "train_graph": bool(a.graph), "train_graph_error": m.__dict__.get("_ore_train_graph_error"),
                           "losses": {k: float(v.detach()) for k, v in losses.items()}}))
