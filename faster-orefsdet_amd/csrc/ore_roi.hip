@@ -128,9 +128,43 @@ struct RoiBwdP {
     const int* bidx;
 };
 
-constexpr int ROI_BWD_SPLIT = 4;        // blocks per ROI (the 128 sampled ROIs alone leave half of the CUs idle)
-__global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p) {
-    const int r = blockIdx.x / ROI_BWD_SPLIT, part = blockIdx.x % ROI_BWD_SPLIT;
+constexpr int ROI_BWD_SPLIT = 4;        // blocks per ROI (the 128 sampled ROIs alone leave half of the CUs idle); x2 for small ROI lists
+constexpr int ROI_AX = 8;               // cells one bin's samples can touch along one axis on the separable path (grid <= 7 samples)
+
+// 1-D footprint of the g samples of one bin along one axis of length L: cells base..base+n-1 and, per cell, the SUM of the samples'
+// bilinear weights on it (same sample coordinates, validity and border clamps as bilinear4_gather).  The 2-D weight of a cell is
+// the product of its two axis sums because the sample grid and the bilinear weights are both separable -> (gy+1)(gx+1) atomics per
+// bin and channel instead of 4*gy*gx.  Returns n, 0 when no sample is valid, -1 when the footprint does not fit ROI_AX cells.
+__device__ __forceinline__ int roi_axis_weights(float start, float bin, int g, int L, float* w, int& base) {
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = 0; i < g; ++i) {
+        float v = start + ((float)i + 0.5f) * bin / (float)g;
+        if (v < -1.0f || v > (float)L) continue;
+        if (v <= 0.f) v = 0.f;
+        int l = (int)v, h;
+        if (l >= L - 1) h = l = L - 1; else h = l + 1;
+        lo = min(lo, l); hi = max(hi, h);
+    }
+    if (hi < 0) return 0;
+    if (hi - lo + 1 > ROI_AX) return -1;
+    base = lo;
+#pragma unroll
+    for (int k = 0; k < ROI_AX; ++k) w[k] = 0.f;
+    for (int i = 0; i < g; ++i) {
+        float v = start + ((float)i + 0.5f) * bin / (float)g;
+        if (v < -1.0f || v > (float)L) continue;
+        if (v <= 0.f) v = 0.f;
+        int l = (int)v, h;
+        if (l >= L - 1) { h = l = L - 1; v = (float)l; } else h = l + 1;
+        const float fr = v - (float)l;
+#pragma unroll
+        for (int k = 0; k < ROI_AX; ++k) w[k] += (k == l - lo ? 1.f - fr : 0.f) + (k == h - lo ? fr : 0.f);
+    }
+    return hi - lo + 1;
+}
+
+__global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p, int split) {
+    const int r = blockIdx.x / split, part = blockIdx.x % split;
     const int P = p.pooled, C4 = p.C >> 2;
     const float* src = p.dout + (size_t)r * P * P * p.C;
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
@@ -146,11 +180,32 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p) {
     const float bw = rw / (float)P, bh = rh / (float)P;
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float cnt = (float)max(gh * gw, 1);
-    for (int i = part * 256 + threadIdx.x; i < P * P * C4; i += 256 * ROI_BWD_SPLIT) {
+    for (int i = part * 256 + threadIdx.x; i < P * P * C4; i += 256 * split) {
         const int c = (i % C4) * 4, bin = i / C4;
         const int ph = bin / P, pw = bin - ph * P;
         const f32x4 g = *reinterpret_cast<const f32x4*>(src + (size_t)bin * p.C + c) / cnt;
-        for (int iy = 0; iy < gh; ++iy) {
+        float wy[ROI_AX], wx[ROI_AX];
+        int by = 0, bx = 0;
+        const int ny = roi_axis_weights(y0 + (float)ph * bh, bh, gh, H, wy, by);
+        const int nx = roi_axis_weights(x0 + (float)pw * bw, bw, gw, W, wx, bx);
+        if (ny == 0 || nx == 0) continue;
+        if (ny > 0 && nx > 0) {
+#pragma unroll
+            for (int ky = 0; ky < ROI_AX; ++ky) {
+                if (ky >= ny) break;
+#pragma unroll
+                for (int kx = 0; kx < ROI_AX; ++kx) {
+                    if (kx >= nx) break;
+                    const float wgt = wy[ky] * wx[kx];
+                    if (wgt == 0.f) continue;
+                    float* dst = f + (size_t)((by + ky) * W + bx + kx) * ld + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) atomicAdd(dst + k, wgt * g[k]);
+                }
+            }
+            continue;
+        }
+        for (int iy = 0; iy < gh; ++iy) {                                       // oversized sampling grid: one scatter per sample
             const float y = y0 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
             for (int ix = 0; ix < gw; ++ix) {
                 const float x = x0 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
@@ -370,6 +425,7 @@ extern "C" int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const i
     p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
     p.canonical_size = 224.0f; p.canonical_level = 4;
     p.boxes = boxes; p.n = n; p.dout = dout; p.bidx = box_image;
-    hipLaunchKernelGGL(k_roi_align_bwd, dim3(n * ROI_BWD_SPLIT), dim3(256), 0, (hipStream_t)stream, p);
+    const int split = n < 64 ? 2 * ROI_BWD_SPLIT : ROI_BWD_SPLIT;
+    hipLaunchKernelGGL(k_roi_align_bwd, dim3(n * split), dim3(256), 0, (hipStream_t)stream, p, split);
     return ore_launch_status("k_roi_align_bwd");
 }

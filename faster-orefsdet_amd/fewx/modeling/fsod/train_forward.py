@@ -64,7 +64,7 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
         if t.shape[0] == 1:
             t = A.group_norm_relu(t, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
         else:                                                       # GroupNorm statistics are per image
-            t = torch.cat([A.group_norm_relu(t[b:b + 1], gn.weight, gn.bias, gn.num_groups, gn.eps, True) for b in range(t.shape[0])], 0)
+            t = torch.cat([A.group_norm_relu(tb, gn.weight, gn.bias, gn.num_groups, gn.eps, True) for tb in t.split(1, 0)], 0)
         o = A.conv(t, w5, b5)
         reg = F.relu(o[..., :4] * head.scales[l].scale)
         outs.append(torch.cat([reg, o[..., 4:5], torch.zeros(*o.shape[:3], 11, device=o.device)], -1))
@@ -94,7 +94,8 @@ def dense_part(model, xq: torch.Tensor, xs: torch.Tensor):
         k13 = F.adaptive_avg_pool2d(proto, (1, 3))[:, :, 0, :]                  # [B,C,3]
         k31 = F.adaptive_avg_pool2d(proto, (3, 1))[:, :, :, 0]
         q = nhwc_view(feats[k])
-        cats = [A.correlation_cat(q[b:b + 1], k11[b], k13[b], k31[b]) for b in range(B)]   # [1,H,W,2C] = [attn | q] per image
+        qs, k11s, k13s, k31s = q.split(1, 0), k11.unbind(0), k13.unbind(0), k31.unbind(0)
+        cats = [A.correlation_cat(qs[b], k11s[b], k13s[b], k31s[b]) for b in range(B)]     # [1,H,W,2C] = [attn | q] per image
         pos.append(A.conv(cats[0] if B == 1 else torch.cat(cats, 0), model.conv3.weight, model.conv3.bias, None, None, True))
     heads = head_train(model.proposal_generator.centernet_head, pos)
     return tuple(nhwc_view(feats[k]) for k in LEVELS) + tuple(nhwc_view(sfeats[k]) for k in LEVELS) + tuple(heads)
@@ -131,10 +132,10 @@ def graphed_dense_part(model, xq, xs):
     return g(xq, xs) if g is not None else dense_part(model, xq, xs)
 
 
-def proposal_losses_and_proposals(pg, heads: List[torch.Tensor], gt_boxes: torch.Tensor):
+def first_stage(pg, heads: List[torch.Tensor], gt_boxes: torch.Tensor):
     """CenterNet.forward, training branch, after the head (ref:fewx/modeling/fsod/fsod_rpn.py:658-700): ground truth, the three
-    losses, and the proposals with the *_TRAIN thresholds.  heads[l] [1,H,W,16] (0..3 ltrb after Scale+ReLU, 4 heatmap logit).
-    Returns (proposal boxes [n,4], scores [n], losses dict, targets dict)."""
+    losses, and the proposals with the *_TRAIN thresholds, WITHOUT a host sync.  heads[l] [1,H,W,16] (0..3 ltrb after Scale+ReLU,
+    4 heatmap logit).  Returns (detect outputs with the device-side counts, losses dict, targets dict)."""
     import orehip
     from orehip import autograd as A
     dev = heads[0].device
@@ -147,8 +148,14 @@ def proposal_losses_and_proposals(pg, heads: List[torch.Tensor], gt_boxes: torch
     with torch.no_grad():
         o = orehip.detect([h[0].detach().contiguous() for h in heads], pg.strides, pg.score_thresh, pg.pre_nms_topk_train,
                           pg.nms_thresh_train, pg.post_nms_topk_train)
-        n = int(o["counts"][1].item())
     losses = {"loss_centernet_loc": l3[0], "loss_centernet_agn_pos": l3[1], "loss_centernet_agn_neg": l3[2]}
+    return o, losses, tg
+
+
+def proposal_losses_and_proposals(pg, heads: List[torch.Tensor], gt_boxes: torch.Tensor):
+    """first_stage for one image + the host read of the proposal count.  Returns (proposal boxes [n,4], scores [n], losses, targets)."""
+    o, losses, tg = first_stage(pg, heads, gt_boxes)
+    n = int(o["counts"][1].item())
     return o["out_boxes"][:n], o["out_scores"][:n], losses, tg
 
 
@@ -174,29 +181,46 @@ def label_and_sample(rh, proposals: torch.Tensor, gt_boxes: torch.Tensor, perm: 
     return sampled, boxes[sampled].contiguous(), labels[sampled], roi_gt
 
 
-def roi_stage_losses(rh, qf: List[torch.Tensor], sup8: torch.Tensor, roi_boxes, roi_labels, roi_gt, strides):
+def roi_stage_losses(rh, qf: List[torch.Tensor], sup8: torch.Tensor, roi_boxes, roi_labels, roi_gt, strides,
+                     roi_image: Optional[torch.Tensor] = None, rois_per_image: Optional[List[int]] = None):
     """_run_stage + CustomFastRCNNOutputLayers.losses for the single cascade stage (ref:fewx/modeling/fsod/fsod_roi_heads.py:459-520,
-    custom_fast_rcnn.py:52-81).  qf[l] [H,W,C] query pyramid (NHWC), sup8 [N, P*P*C] pooled support features ordered [pos][c]."""
+    custom_fast_rcnn.py:52-81).  One image: qf[l] [H,W,C] query pyramid (NHWC), sup8 [N, P*P*C] pooled support features ordered
+    [pos][c].  B images in one pass: qf[l] [B,H,W,C], sup8 [B,N,P*P*C], the ROIs of all images concatenated with roi_image [R]
+    (int32 image of each ROI) and rois_per_image (host ints); each image's losses keep their own 1/R_b normaliser and the result is
+    the mean over the images."""
     from orehip import autograd as A
     R = roi_boxes.shape[0]
     C = qf[0].shape[-1]
     P = rh.pooler_resolution
-    x = A.roi_align(qf, roi_boxes, strides, P).reshape(R * P * P, C)                    # rows ordered [roi][pos], channels last
-    s = sup8.mean(0, True).reshape(P * P, C)
-    s_exp = s.unsqueeze(0).expand(R, P * P, C).reshape(R * P * P, C)
+    if roi_image is None:
+        x = A.roi_align(qf, roi_boxes, strides, P).reshape(R * P * P, C)                # rows ordered [roi][pos], channels last
+        s = sup8.mean(0, True).reshape(P * P, C)
+        s_exp = s.unsqueeze(0).expand(R, P * P, C).reshape(R * P * P, C)
+        s2_exp = A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).unsqueeze(0).expand(R, P * P, C // 2).reshape(R * P * P, C // 2)
+    else:
+        B = sup8.shape[0]
+        img = roi_image.long()
+        x = A.roi_align_batched(qf, roi_boxes, roi_image, strides, P).reshape(R * P * P, C)
+        s = sup8.mean(1).reshape(B * P * P, C)                                          # each image's own support prototype
+        s_exp = s.reshape(B, P * P, C)[img].reshape(R * P * P, C)
+        s2_exp = A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).reshape(B, P * P, C // 2)[img].reshape(R * P * P, C // 2)
     a = A.linear(torch.cat((x, s_exp), 1), rh.conv3.weight.flatten(1), rh.conv3.bias) + \
-        torch.cat((A.linear(x, rh.conv1.weight.flatten(1), rh.conv1.bias),
-                   A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).unsqueeze(0).expand(R, P * P, C // 2).reshape(R * P * P, C // 2)), 1)
+        torch.cat((A.linear(x, rh.conv1.weight.flatten(1), rh.conv1.bias), s2_exp), 1)
     a = a.reshape(R, P * P, C).permute(0, 2, 1).reshape(R, C * P * P)                   # NCHW flatten order of fc1's weight
     fc1 = rh.box_head[0].fc1
     h = A.linear(a.contiguous(), fc1.weight, fc1.bias, True)
     pr = rh.box_predictor[0]
     scores = A.linear(h, pr.cls_score.weight, pr.cls_score.bias)
     deltas = A.linear(h, pr.bbox_pred.weight, pr.bbox_pred.bias)
-    loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
     fg = torch.nonzero(roi_labels == 0).squeeze(1)
     tgt = get_deltas(roi_boxes[fg], roi_gt[fg], rh.bbox_reg_weights)
-    loss_box = (deltas[fg] - tgt).abs().sum() / max(roi_labels.numel(), 1)               # smooth_l1, beta = 0
+    if roi_image is None:
+        loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
+        loss_box = (deltas[fg] - tgt).abs().sum() / max(roi_labels.numel(), 1)           # smooth_l1, beta = 0
+    else:
+        w = torch.tensor([1.0 / (max(n, 1) * len(rois_per_image)) for n in rois_per_image], device=scores.device)[img]
+        loss_cls = (F.cross_entropy(scores, roi_labels, reduction="none") * w).sum()
+        loss_box = ((deltas[fg] - tgt).abs().sum(1) * w[fg]).sum()
     return {"loss_cls_stage0": loss_cls, "loss_box_reg_stage0": loss_box}, dict(scores=scores, deltas=deltas, h=h)
 
 
@@ -229,13 +253,13 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
         assert s_.shape[0] == N, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
     xs = _normalise_pad(torch.cat(sups, 0) if B > 1 else sups[0], mean, std, div)
     outs = graphed_dense_part(model, xq, xs) if getattr(model, "train_graph", False) else dense_part(model, xq, xs)
-    for b, item in enumerate(batched_inputs):
+    gts, sbx = [], []
+    for item in batched_inputs:
         inst = item["instances"]
-        gt_boxes = (inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes).to(dev).float()
-        sboxes = torch.as_tensor(item["support_bboxes"], dtype=torch.float32, device=dev)
-        qf = [f[b] for f in outs[0:3]]
-        sf_levels = [f[b * N:(b + 1) * N] for f in outs[3:6]]
-        heads = [h[b:b + 1] for h in outs[6:9]]
+        gts.append((inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes).to(dev).float())
+        sbx.append(torch.as_tensor(item["support_bboxes"], dtype=torch.float32, device=dev))
+    if B == 1:
+        gt_boxes, qf, sf_levels, heads = gts[0], [f[0] for f in outs[0:3]], list(outs[3:6]), list(outs[6:9])
         # ---- first stage: ground truth, losses, proposals (no gradient through the proposals)
         proposals, _scores, l_rpn, tg = proposal_losses_and_proposals(pg, heads, gt_boxes)
         sampled, roi_boxes, roi_labels, roi_gt = label_and_sample(rh, proposals, gt_boxes, perm)
@@ -243,12 +267,35 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
             roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
             roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
         # ---- second stage: support rcnn_8 features (one box per support crop), DSA mix, fc1, predictor, losses
-        sup8 = A.roi_align_batched(sf_levels, sboxes, torch.arange(N, dtype=torch.int32, device=dev), pg.strides, rh.pooler_resolution)
+        sup8 = A.roi_align_batched(sf_levels, sbx[0], torch.arange(N, dtype=torch.int32, device=dev), pg.strides, rh.pooler_resolution)
         l_roi, a2 = roi_stage_losses(rh, qf, sup8, roi_boxes, roi_labels, roi_gt, pg.strides)
-        for k, v in {**l_roi, **l_rpn}.items():
-            acc.setdefault(k, []).append(v)
+        losses = {**l_roi, **l_rpn}
         if return_aux:
             aux = dict(proposals=proposals, sampled=sampled, roi_boxes=roi_boxes, roi_labels=roi_labels, pos_inds=tg["pos_inds"],
                        pos_count=tg["pos_count"], features={k: f.permute(2, 0, 1)[None] for k, f in zip(LEVELS, qf)}, heads=heads, **a2)
-    losses = {k: (v[0] if len(v) == 1 else torch.stack(v).mean()) for k, v in acc.items()}
+        return (losses, aux) if return_aux else losses
+    # ---- B > 1.  Phase 1 (no host sync): per image ground truth, first-stage losses, proposals
+    hd_b = [h.split(1, 0) for h in outs[6:9]]       # one split per level: its backward is ONE cat, not B zero-filled full-size adds
+    stage1 = [first_stage(pg, [h[b] for h in hd_b], gts[b]) for b in range(B)]
+    for _, l_rpn, _ in stage1:
+        for k, v in l_rpn.items():
+            acc.setdefault(k, []).append(v)
+    counts = torch.stack([o["counts"][1] for o, _, _ in stage1]).tolist()             # ONE sync for the B proposal counts
+    # ---- phase 2: label + sample per image (host-shaped, only tiny kernels queued behind its syncs)
+    rb, rl, rg, per_image = [], [], [], []
+    for b in range(B):
+        _, roi_boxes, roi_labels, roi_gt = label_and_sample(rh, stage1[b][0]["out_boxes"][:counts[b]], gts[b], perm)
+        if roi_override is not None:
+            roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
+            roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
+        rb.append(roi_boxes); rl.append(roi_labels); rg.append(roi_gt); per_image.append(int(roi_boxes.shape[0]))
+    roi_image = torch.repeat_interleave(torch.arange(B, dtype=torch.int32), torch.tensor(per_image)).to(dev)
+    # ---- phase 3: the second stage of all B images in one pass (ROIAlign of every support crop's own box, then the ROI head)
+    sup8 = A.roi_align_batched(list(outs[3:6]), torch.cat(sbx, 0), torch.arange(B * N, dtype=torch.int32, device=dev), pg.strides,
+                               rh.pooler_resolution)
+    l_roi, a2 = roi_stage_losses(rh, list(outs[0:3]), sup8.reshape(B, N, -1), torch.cat(rb, 0), torch.cat(rl, 0), torch.cat(rg, 0),
+                                 pg.strides, roi_image, per_image)
+    if return_aux:
+        aux = dict(roi_boxes=rb, roi_labels=rl, rois_per_image=per_image, **a2)
+    losses = {**l_roi, **{k: torch.stack(v).mean() for k, v in acc.items()}}
     return (losses, aux) if return_aux else losses

@@ -355,10 +355,16 @@ def detect(heads: Sequence[torch.Tensor], strides: Sequence[int], score_thresh: 
     L = len(heads)
     dev = heads[0].device
     cap = L * pre_topk
-    o = {"pre_boxes": torch.zeros(cap, 4, device=dev), "pre_scores": torch.zeros(cap, device=dev),
-         "pre_loc": torch.zeros(cap, dtype=torch.int64, device=dev), "pre_level": torch.zeros(cap, dtype=torch.int32, device=dev),
-         "keep_idx": torch.zeros(cap, dtype=torch.int64, device=dev), "counts": torch.zeros(4, dtype=torch.int32, device=dev),
-         "out_boxes": torch.zeros(cap, 4, device=dev), "out_scores": torch.zeros(cap, device=dev)}
+    capa = (cap + 3) // 4 * 4                                   # one zero-filled allocation carved into the 8 outputs (16-byte aligned)
+    spec = (("pre_boxes", torch.float32, 4 * capa, (cap, 4)), ("pre_scores", torch.float32, capa, (cap,)),
+            ("pre_loc", torch.int64, capa, (cap,)), ("pre_level", torch.int32, capa, (cap,)), ("keep_idx", torch.int64, capa, (cap,)),
+            ("counts", torch.int32, 4, (4,)), ("out_boxes", torch.float32, 4 * capa, (cap, 4)), ("out_scores", torch.float32, capa, (cap,)))
+    raw = torch.zeros(sum(n * (8 if dt == torch.int64 else 4) for _, dt, n, _ in spec), dtype=torch.uint8, device=dev)
+    o, off = {}, 0
+    for name, dt, n, shape in spec:
+        nb = n * (8 if dt == torch.int64 else 4)
+        o[name] = raw[off:off + nb].view(dt)[: shape[0] * (4 if len(shape) == 2 else 1)].view(shape)
+        off += nb
     wsb = lib().ore_detect_workspace_bytes(L, pre_topk)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     d = DetectDesc()

@@ -628,6 +628,34 @@ def test_train_forward_batch_and_empty_gt(oh):
             assert abs(float(lab[k]) - 0.5 * (float(la[k]) + float(lb[k]))) <= 1e-5 * max(abs(float(lab[k])), 1e-3), k
     sum(lab.values()).backward()
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+    # the batched pass (two batched backbone passes, ONE second-stage pass over the ROIs of both images) against the two
+    # single-image passes, with a deterministic fg/bg subsample so that all five losses and the gradients are comparable
+    from fewx.modeling.fsod import train_forward as TF
+    c = item(3, 3)
+    det = lambda n: torch.arange(n - 1, -1, -1)                                                 # noqa: E731
+    singles, grads = [], []
+    for it in (a, c):
+        m.zero_grad(set_to_none=True)
+        l1 = TF.train_forward(m, [it], perm=det)
+        sum(l1.values()).backward()
+        singles.append({k: float(v) for k, v in l1.items()})
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    m.zero_grad(set_to_none=True)
+    l2, aux = TF.train_forward(m, [a, c], perm=det, return_aux=True)
+    assert len(aux["rois_per_image"]) == 2 and aux["scores"].shape[0] == sum(aux["rois_per_image"])
+    sum(l2.values()).backward()
+    for k in singles[0]:
+        want = 0.5 * (singles[0][k] + singles[1][k])
+        assert abs(float(l2[k]) - want) <= 2e-4 * max(abs(want), 1e-3), (k, float(l2[k]), want)
+    errs = []
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            assert n not in grads[0]
+            continue
+        want = 0.5 * (grads[0][n] + grads[1][n])
+        errs.append(float((p.grad - want).abs().max() / want.abs().max().clamp_min(1e-12)))
+    errs.sort()
+    assert errs[len(errs) // 2] <= 1e-4 and errs[int(len(errs) * 0.85)] <= 1e-3 and errs[-1] <= 2e-2, errs[-5:]
 
 
 def test_default_trainer_loop_with_synthetic_loader(oh, tmp_path):
