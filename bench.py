@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same table); only used with --conv-operands bf16
 
 
 def synth_image(seed, h=640, w=640):
@@ -110,14 +111,14 @@ def cpu_baseline(model, img, budget_s=12.0):
                       f"torch {torch.__version__} CPU, {el:.1f} s)"}
 
 
-def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1):
+def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True):
     """SURVEY 8d metric (ii), single GPU: forward + backward + clip/SGD of finetune_vovnet.yaml on one query + 24 support crops
     (tools/bench_train.py is the stand-alone / multi-GPU version).  Reported beside the headline, never as `value`."""
     from detectron2.structures import Boxes, Instances
     from fewx.solver import build_lr_scheduler, build_optimizer
     model, cfg = build_model(device)
     model.train()
-    model.train_graph = True        # the shape-static dense part (fwd + bwd) replays as two hipGraphs; falls back to eager if capture fails
+    model.train_graph = graph       # the shape-static dense part (fwd + bwd) replays as two hipGraphs; falls back to eager if capture fails
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():                                   # second-stage weights: small, so the synthetic losses stay finite
         for n, p in model.named_parameters():
@@ -157,7 +158,7 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1):
     return {"images_per_s": round(batch * steps / el, 2), "batch_per_gpu": batch, "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
             "workload": "finetune_vovnet.yaml train step on 1 GPU: %d x (1 query %dx%d + %d support 240x240), fwd + bwd (HIP backward kernels) + "
                         "flat-bucket clip/SGD, FREEZE_AT=3" % (batch, size, size, shots),
-            "dense_part_hipgraph": model.__dict__.get("_ore_train_graph_error") is None,
+            "dense_part_hipgraph": bool(graph) and model.__dict__.get("_ore_train_graph_error") is None,
             "exchanged_bytes_per_step_if_dp": 4 * opt.bucket.size, "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
 
 
@@ -170,6 +171,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the single-GPU train-step measurement printed as \"train_step\"")
     ap.add_argument("--profile-passes", type=int, default=20)
+    ap.add_argument("--conv-operands", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 = the reference's precision (the headline).  bf16 = BASELINE configs[4]: MFMA conv operands rounded to bf16, "
+                         "fp32 storage / accumulation / NMS (include/ore_hip.h ORE_CONV_BF16); reported with dtype \"bf16\", never the default")
     ap.add_argument("--inflight", type=int, default=4,
                     help="images kept in flight per GPU, each a bs=1 forward on its own engine + HIP stream (bs=1 leaves most of "
                          "the 256 CUs idle in the small pyramid layers; independent images fill them).  1 = strictly one image "
@@ -190,6 +194,8 @@ def main():
 
     device = torch.device("cuda", local_rank)
     model, cfg = build_model(device)
+    model.conv_operands = args.conv_operands
+    bf16 = args.conv_operands == "bf16"
     # each rank owns its shard of images (pure data parallel); a handful of distinct images is cycled
     imgs = [synth_image(rank * 1000 + i).to(device) for i in range(4)]
     eng = model.engine()
@@ -288,11 +294,14 @@ def main():
                     traffic = float(json.load(f)["conv_hbm_bytes_per_image"])
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_note": "HBM-side bytes per image over the same conv launches: (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 "
                                 "--pmc passes (tools/pmc_pass.py -> profiles/r01_pmc_traffic.json); ~0.7 TB/s, far below the 8 TB/s roof",
-                "kernel": "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv incl. in-kernel split-K; 28 convs + the ROI fc GEMM)",
+                "kernel": ("k_conv_igemm / k_conv3x3_patch / k_conv3x3_ws with bf16 operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate); 28 convs "
+                           "+ the fp32 ROI fc GEMM" if bf16 else
+                           "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv incl. in-kernel split-K; 28 convs + the ROI fc GEMM)"),
                 "launches_per_image": nl // max(args.profile_passes, 1),
                 "gflop_per_image": round(fl / max(args.profile_passes, 1) / 1e9, 3),
                 "kernel_ms_per_image": round(ms / max(args.profile_passes, 1), 4),
@@ -308,8 +317,9 @@ def main():
             "metric": "images/sec at 640x640 25-shot (eval FPS, bs=1 per GPU)",
             "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]): "
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": ("bf16 MFMA conv operands + fp32 NMS (BASELINE configs[4] precision) on " if bf16 else "") +
+                                   "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]): "
                                    "preprocess+VoVNet-19-slim-eSE+FPN -> correlation -> CenterNet head -> top-k/NMS proposals -> ROIAlign + cascade ROI head -> NMS -> detections",
                        "parallelism": f"dp{world} (images sharded, no data-path collective)", "hipgraph": use_graph,
                        "images_in_flight_per_gpu": len(engines),
@@ -325,7 +335,7 @@ def main():
             except Exception as ex:                         # the headline line must survive a failure of the side measurement
                 out["train_step"] = {"error": repr(ex)[:300]}
             try:                                            # BASELINE configs[2]: 16 query images (+ 16 x 24 support crops) per GPU per step
-                out["train_step_bs16"] = train_leg(device, steps=4, warmup=3, batch=16)
+                out["train_step_bs16"] = train_leg(device, steps=4, warmup=3, batch=16, graph=False)
             except Exception as ex:
                 out["train_step_bs16"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:

@@ -69,7 +69,9 @@ __device__ __forceinline__ float epilogue_one(const ConvP& p, float acc, int m, 
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int WGK, bool AFF>
+// BF: the MFMA operands are rounded to bf16 when they leave LDS (fp32 tensors in HBM and LDS, fp32 accumulation): one
+// v_mfma_f32_16x16x16_bf16 takes the place of four v_mfma_f32_16x16x4_f32 (ore_conv_set_precision).
+template <int BM, int BN, int WGM, int WGN, int WGK, bool AFF, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     constexpr int BK = 16 * WGK, LD = BK + 8;   // +8: ds_read_b128 lane groups mix two k-offsets; BK+8 is conflict-free, BK+4 is 2-way
@@ -264,10 +266,19 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
             af[i] = *reinterpret_cast<const f32x4*>(As + cur * BM * LD + (wm * WM + i * 16 + frow) * LD + fk);                  \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                          \
             bf[j] = *reinterpret_cast<const f32x4*>(Bs + cur * BN * LD + (wn * WN + j * 16 + frow) * LD + fk);                  \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                           \
+        if constexpr (BF) {                                                                                                     \
+            s16x4 ah[TM], bh[TN];                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) ah[i] = to_bf16x4(af[i]);                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bh[j] = to_bf16x4(bf[j]);                                            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0); /* D^T */         \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah[i], acc[i][j], 0, 0, 0);                    \
+        } else {                                                                                                                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                       \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                  \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                              \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0); /* D^T */     \
+        }                                                                                                                       \
         if (DO_STORE)                                                                                                           \
             lstore(cur ^ 1, ra[((u) + 1) % PF], rb[((u) + 1) % PF], rmul[((u) + 1) % PF], radd[((u) + 1) % PF], rok[((u) + 1) % PF]); \
         __syncthreads();                                                                                                        \
@@ -458,7 +469,7 @@ struct PatchP {
     float* out; int out_ld, out_coff;
 };
 
-template <int TH>
+template <int TH, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
     constexpr int TW = 16, BN = 64, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDA = 24;
     constexpr int TM = TH / 4, TN = BN / 16;
@@ -545,13 +556,25 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     bf[j] = *reinterpret_cast<const f32x4*>(Bs + ((dy * 3 + dx) * BN + j * 16 + li) * LDA + g4);
+                if constexpr (BF) {
+                    s16x4 ah[TM], bh[TN];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int i = 0; i < TM; ++i) ah[i] = to_bf16x4(af[i]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bh[j] = to_bf16x4(bf[j]);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);   // D^T: rows = channels
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);   // D^T: rows = channels
+                }
             }
         __syncthreads();
     }
@@ -586,6 +609,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
 // Two LDS buffers (2 x 72 KB, one block per CU): the slab k+1 written to the other buffer while slab k is multiplied, ONE barrier per
 // slab, the 36 KB weight slab staged once per 128 pixels (half of the 4-wave kernel's weight traffic per pixel).
 __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
+    constexpr bool BF = false;                                  // tuner-only kernel: fp32 operands only
     constexpr int TH = 8, TW = 16, BN = 64, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDA = 24, NT_ = 512;
     constexpr int TN = BN / 16;
     constexpr int A_IT = (NPIX * 4 + NT_ - 1) / NT_;            // 720 float4 -> 2 slots
@@ -678,11 +702,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     bf[j] = *reinterpret_cast<const f32x4*>(Bs + ((dy * 3 + dx) * BN + j * 16 + li) * LDA + g4);
+                if constexpr (BF) {
+                    const s16x4 ah = to_bf16x4(af);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(bf[j]), ah, acc[j], 0, 0, 0);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[t], acc[j], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[t], acc[j], 0, 0, 0);
+                }
             }
         __syncthreads();            // everyone is done reading `cur` and done writing `cur ^ 1`
         cur ^= 1;
@@ -717,7 +747,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
 //   CIN = 64,  KS = 1: 4 waves = 4 groups of 16 output channels.
 //   CIN = 128, KS = 2: 8 waves; waves w and w+4 share a channel group and split the input channels (64 each); the upper half
 //                      parks its accumulators in LDS (parity double-buffered) and the lower half adds them before the epilogue.
-template <int TH, int CIN, int KS>
+template <int TH, int CIN, int KS, bool BF = false>
 __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP p, int ntiles) {
     constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = CIN + 8, NCH = 4, NTH = 256 * KS, F4 = CIN / 4;
     static_assert(CIN == 64 * KS, "one 64-channel weight slice per wave");
@@ -810,11 +840,18 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
 #pragma unroll
                     for (int sg = 0; sg < TH; ++sg)
                         af[sg] = *reinterpret_cast<const f32x4*>(As + ((sg + dy) * PW + li + dx) * LDC + c * 16 + g4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    if constexpr (BF) {
+                        const s16x4 wh = to_bf16x4(wf[dy * 3 + dx][c]);
 #pragma unroll
                         for (int sg = 0; sg < TH; ++sg)
-                            acc[sg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[dy * 3 + dx][c][k], af[sg][k], acc[sg], 0, 0, 0);
+                            acc[sg] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, to_bf16x4(af[sg]), acc[sg], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int sg = 0; sg < TH; ++sg)
+                                acc[sg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[dy * 3 + dx][c][k], af[sg][k], acc[sg], 0, 0, 0);
+                    }
                 }
         if (KS > 1 && kh == 1) {
 #pragma unroll
@@ -859,6 +896,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
     }
 }
 
+int g_conv_bf16 = 0;     // ore_conv_set_precision: 1 = bf16 MFMA operands (fp32 storage and accumulation)
 int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH, 16 = double-buffered 8-wave kernel, 102 = weight-stationary kernels (2-row tiles; Cin = 64 or 128)
 
 static int patch_launch(const ConvP& c, hipStream_t st) {
@@ -866,11 +904,12 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.Cout16 % 64 != 0 || c.in_mul || c.add || c.colsum) return 1;
     if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 15) != 0) return 1;      // the epilogue stores 16 bytes per lane
     if (g_patch_mode == 0) return 1;
+    if (g_conv_bf16 && g_patch_mode > 0 && g_patch_mode != 4 && g_patch_mode != 102) return 1;   // bf16 builds: patch<4> and ws<2,64,1> only
     int TH = g_patch_mode > 0 ? g_patch_mode : 4;
     const bool db = TH == 16;
     if (db) TH = 8;
     bool ws = TH == 102;                                     // TH = 4 needs > 256 VGPRs (spills): only the 2-row tile is built
-    if (ws) { TH = 2; if (c.Cin != 64 && c.Cin != 128) return 1; }
+    if (ws) { TH = 2; if (c.Cin != 64 && (c.Cin != 128 || g_conv_bf16)) return 1; }
     if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
     // plan: the weight-stationary kernel wins once a resident block walks >= 4 tiles (stem_2: 3200 tiles, 71 vs 82 us); below that its
     // 36-fragment weight prologue is not amortised (stage-2 64->64 layers: 800 tiles, 29 vs 26 us)
@@ -902,8 +941,13 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
         } else {
             const size_t lds = (size_t)2 * (4 * 18) * 72 * sizeof(float);
             static bool a2 = false;
-            if (!a2) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<2, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); a2 = true; }
-            hipLaunchKernelGGL((k_conv3x3_ws<2, 64, 1>), pgrid, dim3(256), lds, st, p, tiles);
+            if (!a2) {
+                ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<2, 64, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<2, 64, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                a2 = true;
+            }
+            if (g_conv_bf16) hipLaunchKernelGGL((k_conv3x3_ws<2, 64, 1, true>), pgrid, dim3(256), lds, st, p, tiles);
+            else hipLaunchKernelGGL((k_conv3x3_ws<2, 64, 1, false>), pgrid, dim3(256), lds, st, p, tiles);
         }
         return ore_launch_status("k_conv3x3_ws");
     }
@@ -920,40 +964,57 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     } else {
         const size_t lds = (size_t)(6 * 18 + 9 * 64) * 24 * sizeof(float);
         static bool attr4 = false;
-        if (!attr4) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr4 = true; }
-        hipLaunchKernelGGL(k_conv3x3_patch<4>, grid, dim3(256), lds, st, p);
+        if (!attr4) {
+            ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr4 = true;
+        }
+        if (g_conv_bf16) hipLaunchKernelGGL((k_conv3x3_patch<4, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((k_conv3x3_patch<4, false>), grid, dim3(256), lds, st, p);
     }
     return ore_launch_status("k_conv3x3_patch");
 }
 
-template <int BM, int BN, int WGM, int WGN, int WGK>
-void launch_conv(const ConvP& p, dim3 grid, hipStream_t st) {
-    if (p.in_mul) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, false>), grid, dim3(256), 0, st, p);
+template <int BM, int BN, int WGM, int WGN, int WGK, bool HASBF>
+int launch_conv(const ConvP& p, dim3 grid, hipStream_t st) {
+    if (g_conv_bf16) {
+        if constexpr (HASBF) {
+            if (p.in_mul) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, true, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, false, true>), grid, dim3(256), 0, st, p);
+            return ORE_OK;
+        } else {
+            return ORE_EINVAL;                                   // tuner-only tile: no bf16 build
+        }
+    }
+    if (p.in_mul) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, true, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WGM, WGN, WGK, false, false>), grid, dim3(256), 0, st, p);
+    return ORE_OK;
 }
 
 struct TileCfg { int BM, BN, WGM, WGN, WGK; };
 
 int dispatch(const ConvP& p, const TileCfg& t, dim3 grid, hipStream_t st) {
-#define ORE_CASE(bm, bn, wgm, wgn, wgk)                                                              \
-    if (t.BM == bm && t.BN == bn && t.WGM == wgm && t.WGN == wgn && t.WGK == wgk) {                  \
-        launch_conv<bm, bn, wgm, wgn, wgk>(p, grid, st);                                             \
-        return ORE_OK;                                                                               \
-    }
+#define ORE_CASE_(bm, bn, wgm, wgn, wgk, hasbf)                                                      \
+    if (t.BM == bm && t.BN == bn && t.WGM == wgm && t.WGN == wgn && t.WGK == wgk)                    \
+        return launch_conv<bm, bn, wgm, wgn, wgk, hasbf>(p, grid, st);
+#define ORE_CASE(bm, bn, wgm, wgn, wgk) ORE_CASE_(bm, bn, wgm, wgn, wgk, false)
+#define ORE_CASEB(bm, bn, wgm, wgn, wgk) ORE_CASE_(bm, bn, wgm, wgn, wgk, true)     /* tiles of the automatic plan: also built for bf16 operands */
     // large-M tiles: 4 waves along M, whole N in the block
     ORE_CASE(128, 16, 4, 1, 1) ORE_CASE(128, 32, 4, 1, 1) ORE_CASE(128, 48, 4, 1, 1) ORE_CASE(128, 64, 4, 1, 1)
     ORE_CASE(128, 80, 4, 1, 1) ORE_CASE(128, 96, 4, 1, 1) ORE_CASE(128, 112, 4, 1, 1) ORE_CASE(128, 128, 2, 2, 1)
-    ORE_CASE(64, 16, 4, 1, 1) ORE_CASE(64, 32, 4, 1, 1) ORE_CASE(64, 48, 4, 1, 1) ORE_CASE(64, 64, 4, 1, 1)
-    ORE_CASE(64, 80, 4, 1, 1) ORE_CASE(64, 96, 4, 1, 1) ORE_CASE(64, 112, 4, 1, 1) ORE_CASE(64, 128, 2, 2, 1)
+    ORE_CASEB(64, 16, 4, 1, 1) ORE_CASEB(64, 32, 4, 1, 1) ORE_CASEB(64, 48, 4, 1, 1) ORE_CASEB(64, 64, 4, 1, 1)
+    ORE_CASEB(64, 80, 4, 1, 1) ORE_CASEB(64, 96, 4, 1, 1) ORE_CASEB(64, 112, 4, 1, 1) ORE_CASEB(64, 128, 2, 2, 1)
     // mid/small-M tiles: waves split K inside the block
     ORE_CASE(64, 64, 2, 1, 2) ORE_CASE(64, 32, 2, 1, 2) ORE_CASE(64, 16, 2, 1, 2) ORE_CASE(64, 48, 2, 1, 2)
-    ORE_CASE(32, 64, 1, 1, 4) ORE_CASE(32, 48, 1, 1, 4) ORE_CASE(32, 32, 1, 1, 4) ORE_CASE(32, 16, 1, 1, 4)
-    ORE_CASE(16, 64, 1, 1, 4) ORE_CASE(16, 48, 1, 1, 4) ORE_CASE(16, 32, 1, 1, 4) ORE_CASE(16, 16, 1, 1, 4)
+    ORE_CASE(32, 64, 1, 1, 4) ORE_CASE(32, 48, 1, 1, 4) ORE_CASEB(32, 32, 1, 1, 4) ORE_CASE(32, 16, 1, 1, 4)
+    ORE_CASE(16, 64, 1, 1, 4) ORE_CASE(16, 48, 1, 1, 4) ORE_CASEB(16, 32, 1, 1, 4) ORE_CASEB(16, 16, 1, 1, 4)
     ORE_CASE(64, 128, 2, 1, 2) ORE_CASE(64, 96, 2, 1, 2) ORE_CASE(64, 80, 2, 1, 2) ORE_CASE(64, 112, 2, 1, 2)
     ORE_CASE(32, 128, 1, 1, 4) ORE_CASE(32, 96, 1, 1, 4) ORE_CASE(32, 80, 1, 1, 4) ORE_CASE(32, 112, 1, 1, 4)
-    ORE_CASE(32, 128, 2, 1, 2) ORE_CASE(32, 64, 2, 1, 2) ORE_CASE(32, 32, 2, 1, 2)
+    ORE_CASE(32, 128, 2, 1, 2) ORE_CASEB(32, 64, 2, 1, 2) ORE_CASE(32, 32, 2, 1, 2)
     ORE_CASE(128, 64, 2, 1, 2) ORE_CASE(128, 128, 2, 1, 2)
 #undef ORE_CASE
+#undef ORE_CASEB
+#undef ORE_CASE_
     return ORE_EINVAL;
 }
 
@@ -1035,6 +1096,14 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     return ORE_OK;
 }
 
+extern "C" int ore_conv_set_precision(int32_t mode) {
+    ORE_CHECK_ARG(mode == ORE_CONV_FP32 || mode == ORE_CONV_BF16, "ore_conv_set_precision: mode must be ORE_CONV_FP32 or ORE_CONV_BF16");
+    g_conv_bf16 = mode;
+    return ORE_OK;
+}
+
+extern "C" int32_t ore_conv_get_precision(void) { return g_conv_bf16; }
+
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
@@ -1067,7 +1136,7 @@ static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t worksp
     p.ws = workspace ? workspace + ORE_CONV_CNT_INTS : nullptr;
     const int rc = dispatch(p, t, dim3(gx, gy, S), st);
     if (rc != ORE_OK) {
-        ore_set_error("ore_conv2d_fwd: no kernel for tile %dx%d (%d,%d,%d)", t.BM, t.BN, t.WGM, t.WGN, t.WGK);
+        ore_set_error("ore_conv2d_fwd: no %skernel for tile %dx%d (%d,%d,%d)", g_conv_bf16 ? "bf16 " : "", t.BM, t.BN, t.WGM, t.WGN, t.WGK);
         return rc;
     }
     return ore_launch_status("k_conv_igemm");

@@ -33,9 +33,17 @@ struct Geo { int B, H, W, Hp, Wp; int h[6], w[6]; };  // h[1]=Hp/2 (stem), h[2]=
 
 }  // namespace
 
+// conv operand precision (ore_conv_set_precision) for the lifetime of a scope
+struct PrecisionScope {
+    int saved;
+    explicit PrecisionScope(int mode) : saved(ore_conv_get_precision()) { ore_conv_set_precision(mode); }
+    ~PrecisionScope() { ore_conv_set_precision(saved); }
+};
+
 struct ore_engine {
     ore_model_cfg cfg{};
     int device = 0;
+    int conv_precision = ORE_CONV_FP32;                   // mode in force at ore_engine_create; every launch of this engine uses it
     bool finalized = false;
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
@@ -338,7 +346,10 @@ int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
     Conv fc{};
     fc.w = e->roi_W; fc.scale = nullptr; fc.shift = e->roi_b; fc.Cin = K; fc.Cout = e->roi_fc; fc.k = 1; fc.stride = 1; fc.pad = 0;
     fc.relu_cout = e->roi_fc;
-    r.conv(fc, e->roi_feat, K, 0, 1, 1, e->roi_cap, e->roi_h, e->roi_fc, 0);        // pre-composed DSA mix + flatten + fc1, ReLU
+    {
+        PrecisionScope fp32(ORE_CONV_FP32);              // the second-stage GEMM stays fp32 in every mode (include/ore_hip.h)
+        r.conv(fc, e->roi_feat, K, 0, 1, 1, e->roi_cap, e->roi_h, e->roi_fc, 0);    // pre-composed DSA mix + flatten + fc1, ReLU
+    }
     if (r.rc) return r.rc;
     *flops = r.flops;
     return ore_roi_predict_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, e->out_boxes, e->counts + 1, 0,
@@ -396,6 +407,7 @@ extern "C" int ore_engine_create(const ore_model_cfg* cfg, int32_t device, ore_e
     ORE_HIP(hipSetDevice(device));
     ore_engine* e = new ore_engine();
     e->cfg = *cfg; e->device = device;
+    e->conv_precision = ore_conv_get_precision();
     *out = e;
     return ORE_OK;
 }
@@ -588,6 +600,7 @@ extern "C" int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t i
     ORE_CHECK_ARG(img, "null image");
     const Geo g = make_geo(B, H, W);
     e->last = g;
+    PrecisionScope ps(e->conv_precision);
     return run_backbone(e, img, is_u8, g, (hipStream_t)stream, &e->last_flops);
 }
 
@@ -599,6 +612,7 @@ extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8
     hipStream_t st = (hipStream_t)stream;
     const Geo g = make_geo(1, H, W);
     e->last = g;
+    PrecisionScope ps(e->conv_precision);
     const size_t bytes = (size_t)3 * H * W * (is_u8 ? 1 : 4);
     ORE_HIP(hipMemcpyAsync(e->img_in, img, bytes, hipMemcpyDeviceToDevice, st));
     auto body = [&](hipStream_t s, double* fl) -> int {

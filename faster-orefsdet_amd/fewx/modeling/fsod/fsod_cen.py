@@ -124,6 +124,9 @@ class CenterNet2Detector(nn.Module):
             score_thresh=cfg.MODEL.CENTERNET.INFERENCE_TH, pre_topk=cfg.MODEL.CENTERNET.PRE_NMS_TOPK_TEST,
             nms_thresh=cfg.MODEL.CENTERNET.NMS_TH_TEST, post_topk=cfg.MODEL.CENTERNET.POST_NMS_TOPK_TEST)
         self.support_dict = None
+        # "fp32" (the reference's precision) or "bf16": operand precision of the MFMA convs of the EVAL engines this detector
+        # builds (orehip.set_conv_precision / include/ore_hip.h ORE_CONV_BF16 -- BASELINE configs[4]); set it before the first forward
+        self.conv_operands = "fp32"
         self._engine = None
         self._engine_key = None
         self.max_hw = (int(cfg.INPUT.MAX_SIZE_TEST), int(cfg.INPUT.MAX_SIZE_TEST))
@@ -216,11 +219,15 @@ class CenterNet2Detector(nn.Module):
         assert all(b == 1 for b in spec["block_per_stage"]), "the fused engine covers one OSA block per stage (V-19 bodies)"
         dev = self.device
         assert dev.type == "cuda", "CenterNet2Detector inference runs on the MI355X only"
-        e = orehip.Engine(stem=spec["stem"], conv=spec["stage_conv_ch"], out=spec["stage_out_ch"], layers=spec["layer_per_block"],
-                          fpn_ch=c["fpn_ch"], strides=c["strides"], pixel_mean=c["pixel_mean"], pixel_std=c["pixel_std"],
-                          score_thresh=c["score_thresh"], pre_topk=c["pre_topk"], nms_thresh=c["nms_thresh"],
-                          post_topk=c["post_topk"], max_batch=1, max_h=self.max_hw[0], max_w=self.max_hw[1],
-                          device=dev.index or 0)
+        prev = orehip.set_conv_precision(self.conv_operands)      # the engine keeps the mode in force at its creation
+        try:
+            e = orehip.Engine(stem=spec["stem"], conv=spec["stage_conv_ch"], out=spec["stage_out_ch"], layers=spec["layer_per_block"],
+                              fpn_ch=c["fpn_ch"], strides=c["strides"], pixel_mean=c["pixel_mean"], pixel_std=c["pixel_std"],
+                              score_thresh=c["score_thresh"], pre_topk=c["pre_topk"], nms_thresh=c["nms_thresh"],
+                              post_topk=c["post_topk"], max_batch=1, max_h=self.max_hw[0], max_w=self.max_hw[1],
+                              device=dev.index or 0)
+        finally:
+            orehip.set_conv_precision(prev)
         e.load_state_dict(self.state_dict())
         assert self.support_dict is not None, "support prototypes not set (init_model / set_support_dict)"
         cls_id = list(self.support_dict["p3"].keys())[-1]   # the reference keeps only the last class
@@ -233,7 +240,7 @@ class CenterNet2Detector(nn.Module):
         return e
 
     def engine(self):
-        key = (self._state_key(), str(self.device))
+        key = (self._state_key(), str(self.device), self.conv_operands)
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()

@@ -69,7 +69,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
-           "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
+           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
@@ -347,6 +347,18 @@ def groupnorm_affine(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: to
                                         C.c_void_p(_ptr(_f32(gamma))), C.c_void_p(_ptr(_f32(beta))), C.c_void_p(_ptr(mul)),
                                         C.c_void_p(_ptr(add)), C.c_void_p(_ptr(ws)), _stream()), "ore_groupnorm_affine_fwd")
     return mul, add
+
+
+def set_conv_precision(mode: str) -> str:
+    """"fp32" (default) or "bf16": operand precision of the MFMA conv kernels for subsequent launches (include/ore_hip.h,
+    ore_conv_set_precision); engines keep the mode in force when they were created.  Returns the previous mode."""
+    prev = get_conv_precision()
+    _chk(lib().ore_conv_set_precision({"fp32": 0, "bf16": 1}[mode]), "ore_conv_set_precision")
+    return prev
+
+
+def get_conv_precision() -> str:
+    return ("fp32", "bf16")[int(lib().ore_conv_get_precision())]
 
 
 def detect(heads: Sequence[torch.Tensor], strides: Sequence[int], score_thresh: float, pre_topk: int, nms_thresh: float,

@@ -78,6 +78,16 @@ int ore_conv2d_fwd(const ore_conv_desc* d, void* stream);
  * height, 16 = double-buffered 8-wave variant, 102 = weight-stationary persistent kernel for Cin = 64 / 128).  The product path
  * never calls it. */
 int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK);
+/* Operand precision of the MFMA conv kernels for all subsequent ore_conv2d*_fwd launches (BASELINE configs[4], "bf16 MFMA conv
+ * path + fp32 NMS"; the reference itself is fp32 only, ref:configs/fsod/finetune_vovnet.yaml).  ORE_CONV_FP32 (default): fp32
+ * operands, v_mfma_f32_16x16x4_f32.  ORE_CONV_BF16: tensors stay fp32 in HBM and LDS, both operands are rounded to bf16 (nearest
+ * even) as they are fed to v_mfma_f32_16x16x16_bf16, fp32 accumulation and epilogue.  stem_1 (Cin = 3), the depthwise
+ * correlation, GroupNorm, top-k / NMS and the second-stage GEMM of an engine always run in fp32.  An engine keeps the mode that was
+ * in force when it was created. */
+#define ORE_CONV_FP32 0
+#define ORE_CONV_BF16 1
+int ore_conv_set_precision(int32_t mode);
+int32_t ore_conv_get_precision(void);
 /* The same 'same'-padded stride-1 conv over several pyramid levels in ONE launch (shared weights; CenterNet head / conv3):
  * rows are level-major [level][b][y][x] in the input and output matrices (d->H, d->W ignored), scale/shift may differ per
  * level (ep_stride floats apart, 0 = shared), in_mul/in_add are indexed [level*B + b][Cin]. */

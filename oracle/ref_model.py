@@ -40,6 +40,39 @@ VOVNET_SPECS = {
                      layers=5, blocks=(1, 3, 9, 3)),
 }
 
+# Operand precision of the dense convolutions.  "fp32" is the reference.  "bf16" restates include/ore_hip.h's ORE_CONV_BF16 mode
+# (BASELINE configs[4]; the reference has no reduced-precision path, so this mode is pinned by construction only): both operands of
+# every MFMA convolution -- all VoVNet/FPN convs except stem_1, conv3, the CenterNet head convs -- are rounded to bf16 (nearest
+# even) at the point where they enter the convolution; accumulation, FrozenBN, eSE, GroupNorm, the depthwise correlation and
+# everything after the head stay fp32.
+_OPERANDS = "fp32"
+
+
+class operand_precision:
+    """with operand_precision("bf16"): ... -- scoped switch of the dense-conv operand rounding."""
+
+    def __init__(self, mode: str):
+        assert mode in ("fp32", "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        global _OPERANDS
+        self.saved, _OPERANDS = _OPERANDS, self.mode
+
+    def __exit__(self, *exc):
+        global _OPERANDS
+        _OPERANDS = self.saved
+
+
+def _rnd(t: Tensor) -> Tensor:
+    return t.bfloat16().float() if _OPERANDS == "bf16" else t
+
+
+def dense_conv(x: Tensor, w: Tensor, b=None, stride: int = 1, padding: int = 0) -> Tensor:
+    """F.conv2d with the operand rounding of the current mode (bias and accumulation in fp32)."""
+    return F.conv2d(_rnd(x), _rnd(w), b, stride, padding)
+
+
 PIXEL_MEAN = (103.530, 116.280, 123.675)  # d2z:config/defaults.py PIXEL_MEAN (BGR)
 PIXEL_STD = (1.0, 1.0, 1.0)
 
@@ -71,7 +104,10 @@ def frozen_bn(x: Tensor, sd: SD, prefix: str, eps: float = 1e-5) -> Tensor:
 
 def conv_bn_relu(x: Tensor, sd: SD, name: str, stride: int, pad: int) -> Tensor:
     """conv (no bias) -> FrozenBN -> ReLU; d2z:modeling/backbone/vovnet.py:205-235."""
-    x = F.conv2d(x, sd[name + "/conv.weight"], None, stride, pad)
+    if name.endswith("stem.stem_1"):                         # Cin = 3: fp32 in every mode
+        x = F.conv2d(x, sd[name + "/conv.weight"], None, stride, pad)
+    else:
+        x = dense_conv(x, sd[name + "/conv.weight"], None, stride, pad)
     return F.relu(frozen_bn(x, sd, name + "/norm."))
 
 
@@ -129,12 +165,12 @@ def fpn(feats: Mapping[str, Tensor], sd: SD, prefix: str = "backbone.",
     res: Dict[str, Tensor] = {}
     prev = None
     for name, st in reversed(list(zip(in_features, stages))):
-        lat = F.conv2d(feats[name], sd[f"{prefix}fpn_lateral{st}.weight"], sd[f"{prefix}fpn_lateral{st}.bias"])
+        lat = dense_conv(feats[name], sd[f"{prefix}fpn_lateral{st}.weight"], sd[f"{prefix}fpn_lateral{st}.bias"])
         if prev is not None:
             lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
         prev = lat
-        res[f"p{st}"] = F.conv2d(lat, sd[f"{prefix}fpn_output{st}.weight"],
-                                 sd[f"{prefix}fpn_output{st}.bias"], padding=1)
+        res[f"p{st}"] = dense_conv(lat, sd[f"{prefix}fpn_output{st}.weight"],
+                                   sd[f"{prefix}fpn_output{st}.bias"], padding=1)
     return {k: res[k] for k in sorted(res)}
 
 
@@ -200,7 +236,7 @@ def correlation(q: Tensor, s_pool: Tensor, conv3_w: Tensor, conv3_b: Tensor) -> 
     b = F.relu(F.conv2d(q, k13, padding=(0, 1), groups=C))
     b = F.relu(F.conv2d(b, k31, padding=(1, 0), groups=C))
     attn = a + b + q
-    return F.relu(F.conv2d(torch.cat((attn, q), 1), conv3_w, conv3_b))
+    return F.relu(dense_conv(torch.cat((attn, q), 1), conv3_w, conv3_b))
 
 
 # --------------------------------------------------------------------------------------
@@ -211,11 +247,11 @@ def centernet_head(feats: Sequence[Tensor], sd: SD,
                    prefix: str = "proposal_generator.centernet_head.") -> Tuple[List[Tensor], List[Tensor]]:
     regs, hms = [], []
     for l, x in enumerate(feats):
-        t = F.conv2d(x, sd[prefix + "bbox_tower.0.weight"], sd[prefix + "bbox_tower.0.bias"], padding=1)
+        t = dense_conv(x, sd[prefix + "bbox_tower.0.weight"], sd[prefix + "bbox_tower.0.bias"], padding=1)
         t = F.group_norm(t, 32, sd[prefix + "bbox_tower.1.weight"], sd[prefix + "bbox_tower.1.bias"], eps=1e-5)
         t = F.relu(t)
-        hms.append(F.conv2d(t, sd[prefix + "agn_hm.weight"], sd[prefix + "agn_hm.bias"], padding=1))
-        r = F.conv2d(t, sd[prefix + "bbox_pred.weight"], sd[prefix + "bbox_pred.bias"], padding=1)
+        hms.append(dense_conv(t, sd[prefix + "agn_hm.weight"], sd[prefix + "agn_hm.bias"], padding=1))
+        r = dense_conv(t, sd[prefix + "bbox_pred.weight"], sd[prefix + "bbox_pred.bias"], padding=1)
         r = r * sd[prefix + f"scales.{l}.scale"]
         regs.append(F.relu(r))
     return regs, hms
