@@ -469,6 +469,15 @@ struct PatchP {
     float* out; int out_ld, out_coff;
 };
 
+#ifdef ORE_TRACE
+// Phase-timeline build (make trace -> lib/libore_hip_trace.so; tools/conv_phase_trace.py): thread 0 of every block stamps s_memtime
+// at the phase boundaries of k_conv3x3_patch into g_trace[block][64].  Never part of the product library.
+__device__ unsigned long long* g_trace = nullptr;
+#define ORE_TR(i) do { if (g_trace && threadIdx.x == 0 && (i) < 64) g_trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ORE_TR(i) do { } while (0)
+#endif
+
 template <int TH, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
     constexpr int TW = 16, BN = 64, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDA = 24;
@@ -540,10 +549,14 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
             pre_sc4[j][r] = (p.scale && n < p.Cout) ? p.scale[lvl * p.ep_stride + n] : 1.0f;
             pre_sh4[j][r] = (p.shift && n < p.Cout) ? p.shift[lvl * p.ep_stride + n] : 0.0f;
         }
+    ORE_TR(0);
     gload(0);
+    ORE_TR(1);
     for (int c0 = 0; c0 < p.Cin; c0 += 16) {
         lstore();
+        ORE_TR(2 + (c0 >> 4) * 4);
         __syncthreads();
+        ORE_TR(3 + (c0 >> 4) * 4);
         if (c0 + 16 < p.Cin) gload(c0 + 16);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -576,7 +589,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);   // D^T: rows = channels
                 }
             }
+        ORE_TR(4 + (c0 >> 4) * 4);
         __syncthreads();
+        ORE_TR(5 + (c0 >> 4) * 4);
     }
     // ---- epilogue.  The operands are swapped (weights as the MFMA "A"), so accumulator (i, j) holds D^T: lane = (pixel lane&15 of tile
     // row wrow+i, channels n0 + j*16 + (lane>>4)*4 .. +3) -> ONE 16-byte store per lane per tile instead of four 4-byte stores
@@ -603,6 +618,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
             }
         }
     }
+    ORE_TR(62);
 }
 
 // Double-buffered 8-wave variant: a block of 512 threads owns an 8 x 16 pixel tile x 64 output channels; wave w = tile row w.
@@ -1095,6 +1111,13 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     g_override = {BM, BN, WGM, WGN, WGK};
     return ORE_OK;
 }
+
+#ifdef ORE_TRACE
+extern "C" int ore_debug_set_trace(unsigned long long* buf) {
+    ORE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)));
+    return ORE_OK;
+}
+#endif
 
 extern "C" int ore_conv_set_precision(int32_t mode) {
     ORE_CHECK_ARG(mode == ORE_CONV_FP32 || mode == ORE_CONV_BF16, "ore_conv_set_precision: mode must be ORE_CONV_FP32 or ORE_CONV_BF16");
