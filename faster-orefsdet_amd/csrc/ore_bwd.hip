@@ -43,7 +43,11 @@ struct WgradP {
 
 constexpr int WG_T = 64;     // block tile: 64 output channels x 64 input channels of one tap
 constexpr int WG_K = 16;     // rows per step
-constexpr int WG_LD = 80;    // LDS row stride: the 4 k-rows of an MFMA operand land 16 banks apart -> conflict-free ds_read_b32
+constexpr int WG_LD = 80;
+#ifndef ORE_WG_BLOCKS
+#define ORE_WG_BLOCKS 1536
+#endif
+constexpr int WG_BLOCKS = ORE_WG_BLOCKS;   // blocks aimed at per weight-gradient launch (rows are split until the grid has this many)    // LDS row stride: the 4 k-rows of an MFMA operand land 16 banks apart -> conflict-free ds_read_b32
 
 __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     __shared__ float sA[2][WG_K][WG_LD];   // dZ rows x co
@@ -121,6 +125,107 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
                 }
             }
         }
+}
+
+// 3x3 variant: ONE block owns the three dx taps of one kernel row dy.  In flattened pixel order the x rows of the taps (dy, -1..+1)
+// of 16 consecutive output rows are 18 consecutive rows, so a step stages dZ[16][64] and X[18][64] once and issues 48 MFMAs on them
+// (k_wgrad: 16 MFMAs per staged pair) -- 2.8x fewer L2 bytes per FLOP, the limiter of k_wgrad at large M.  Taps that leave the image
+// are masked on the dZ operand (per output row and dx).
+__global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
+    __shared__ float sA[2][WG_K][WG_LD];       // dZ rows x co
+    __shared__ float sB[2][WG_K + 2][WG_LD];   // X rows (m0 + dy*W - 1 ...) x ci
+    __shared__ int sM[2][WG_K];                // bit dx: tap (dy, dx) of this output row reads inside the image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_ci_tiles = (p.Cin + WG_T - 1) / WG_T;
+    const int co0 = blockIdx.x * WG_T;
+    const int ci0 = (blockIdx.y % n_ci_tiles) * WG_T;
+    const int dyi = blockIdx.y / n_ci_tiles;                 // kernel row 0..2
+    const int dy = dyi - 1;
+    const int m_begin = blockIdx.z * p.chunk, m_end = min(p.M, m_begin + p.chunk);
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    f32x4 acc[3][2][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[d][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto xrow = [&](int r, f32x4& v) {                       // X row r of the flattened [M] pixel order, zero outside
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r >= 0 && r < p.M && ci0 + lc < p.Cin) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)r * p.x_ld + p.x_coff + ci0 + lc);
+    };
+    auto load = [&](int m0, f32x4& va, f32x4& vb, f32x4& vb2, int& msk) {
+        va = f32x4{0.f, 0.f, 0.f, 0.f};
+        msk = 0;
+        const int m = m0 + lr;
+        if (m < m_end) {
+            if (co0 + lc < p.Cout) va = *reinterpret_cast<const f32x4*>(p.dz + (size_t)m * p.dz_ld + p.dz_coff + co0 + lc);
+            const int xq = m % p.W, ys = (m / p.W) % p.H + dy;
+            if (ys >= 0 && ys < p.H) msk = (xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.W ? 4 : 0);
+        }
+        xrow(m0 + lr + dy * p.W - 1, vb);                   // staged rows 0..15
+        vb2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lr < 2) xrow(m0 + WG_K + lr + dy * p.W - 1, vb2);   // staged rows 16, 17
+    };
+    f32x4 va, vb, vb2;
+    int msk;
+    load(m_begin, va, vb, vb2, msk);
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+        *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
+        *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
+        if (lr < 2) *reinterpret_cast<f32x4*>(&sB[buf][WG_K + lr][lc]) = vb2;
+        if ((tid & 15) == 0) sM[buf][lr] = msk;
+        __syncthreads();
+        if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb, vb2, msk);
+#pragma unroll
+        for (int kk = 0; kk < WG_K / 4; ++kk) {
+            const int k = kk * 4 + (lane >> 4);
+            const int mk = sM[buf][k];
+            float a[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = sA[buf][k][wm * 32 + t * 16 + (lane & 15)];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) b[t] = sB[buf][k + d][wn * 32 + t * 16 + (lane & 15)];
+                const bool on = (mk >> d) & 1;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const float am = on ? a[tm] : 0.f;
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, b[tn], acc[d][tm][tn], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    float* slab = p.slab + (size_t)blockIdx.z * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int tap = dyi * 3 + d;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int ci = ci0 + wn * 32 + tn * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wm * 32 + tm * 16 + (lane >> 4) * 4 + r;
+                    if (co < p.Cout && ci < p.Cin) {
+                        if (p.dw) {
+                            float* o = p.dw + ((size_t)co * p.Cin + ci) * 9 + tap;
+                            *o = p.beta != 0.0f ? p.beta * *o + acc[d][tm][tn][r] : acc[d][tm][tn][r];
+                        } else {
+                            slab[((size_t)co * 9 + tap) * p.Cin + ci] = acc[d][tm][tn][r];
+                        }
+                    }
+                }
+            }
+    }
 }
 
 // dw_oihw[co][ci][tap] = beta * dw + sum_z slab[z][co][tap][ci]  (z ascending: fixed summation order)
@@ -464,10 +569,15 @@ extern "C" int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32
     return ore_launch_status("k_pack_weight");
 }
 
+// blocks of one split: k_wgrad3 (3x3) owns the three dx taps of a kernel row per block
+static int wgrad_tiles(int Cin, int Cout, int kh, int kw) {
+    return ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T) * (kh == 3 && kw == 3 ? 3 : kh * kw);
+}
+
 extern "C" size_t ore_conv_wgrad_workspace_floats(int32_t rows, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw) {
     const long long per = (long long)Cout * kh * kw * Cin;
-    const int tiles = ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T) * kh * kw;
-    int S = max(1, min(ceil_div(512, tiles), ceil_div(rows, 128)));
+    const int tiles = wgrad_tiles(Cin, Cout, kh, kw);
+    int S = max(1, min(ceil_div(WG_BLOCKS, tiles), ceil_div(rows, 128)));
     return (size_t)(per * S);
 }
 
@@ -482,8 +592,8 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     const long long M = (long long)B * H * W;
     ORE_CHECK_ARG(M < (1ll << 31), "ore_conv2d_wgrad_fwd: too many rows");
     const long long per = (long long)Cout * kh * kw * Cin;
-    const int tiles = ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T) * kh * kw;
-    int S = max(1, min(ceil_div(512, tiles), ceil_div((int)M, 128)));
+    const int tiles = wgrad_tiles(Cin, Cout, kh, kw);
+    int S = max(1, min(ceil_div(WG_BLOCKS, tiles), ceil_div((int)M, 128)));
     { const long long cap = (long long)(workspace_floats / (size_t)per); if (cap < S) S = (int)cap; }
     if (S < 1) { ore_set_error("ore_conv2d_wgrad_fwd: workspace too small (%zu < %lld floats)", workspace_floats, per); return ORE_ENOMEM; }
     WgradP p{};
@@ -494,7 +604,8 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     p.slab = workspace;
     if (S == 1) { p.dw = dw_oihw; p.beta = beta; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
+    if (kh == 3 && kw == 3) hipLaunchKernelGGL(k_wgrad3, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * 3, S), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
     int rc = ore_launch_status("k_wgrad");
     if (rc || S == 1) return rc;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
