@@ -69,6 +69,15 @@ __device__ __forceinline__ float epilogue_one(const ConvP& p, float acc, int m, 
     return v;
 }
 
+#ifdef ORE_TRACE
+// Phase-timeline build (make trace -> lib/libore_hip_trace.so; tools/conv_phase_trace.py): thread 0 of every block stamps s_memtime
+// at the phase boundaries of k_conv3x3_patch / k_conv_igemm into g_trace[block][64].  Never part of the product library.
+__device__ unsigned long long* g_trace = nullptr;
+#define ORE_TR(i) do { if (g_trace && threadIdx.x == 0 && (i) < 64) g_trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ORE_TR(i) do { } while (0)
+#endif
+
 // BF: the MFMA operands are rounded to bf16 when they leave LDS (fp32 tensors in HBM and LDS, fp32 accumulation): one
 // v_mfma_f32_16x16x16_bf16 takes the place of four v_mfma_f32_16x16x4_f32 (ore_conv_set_precision).
 template <int BM, int BN, int WGM, int WGN, int WGK, bool AFF, bool BF = false>
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     {                                                                                                                           \
         const int cur = ((st) - s_begin) & 1;                                                                                   \
         if (DO_LOAD) gload((st) + PF, ra[u], rb[u], rmul[u], radd[u], rok[u]);                                                  \
+        ORE_TR(2 + 4 * ((st) - s_begin));                                                                                       \
         f32x4 af[TM], bf[TN];                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                          \
             af[i] = *reinterpret_cast<const f32x4*>(As + cur * BM * LD + (wm * WM + i * 16 + frow) * LD + fk);                  \
@@ -279,16 +289,21 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                              \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0); /* D^T */     \
         }                                                                                                                       \
+        ORE_TR(3 + 4 * ((st) - s_begin));                                                                                       \
         if (DO_STORE)                                                                                                           \
             lstore(cur ^ 1, ra[((u) + 1) % PF], rb[((u) + 1) % PF], rmul[((u) + 1) % PF], radd[((u) + 1) % PF], rok[((u) + 1) % PF]); \
+        ORE_TR(4 + 4 * ((st) - s_begin));                                                                                       \
         __syncthreads();                                                                                                        \
+        ORE_TR(5 + 4 * ((st) - s_begin));                                                                                       \
     }
     if (s_begin >= s_end) __syncthreads();                     // publishes sh_sc/sh_sh when the K loop (and its barriers) is empty
+    ORE_TR(0);
     if (s_begin < s_end) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) gload(s_begin + u, ra[u], rb[u], rmul[u], radd[u], rok[u]);   // steps past the end load zeros
         lstore(0, ra[0], rb[0], rmul[0], radd[0], rok[0]);
         __syncthreads();
+        ORE_TR(1);
         int s0 = s_begin;
         for (; s0 + 2 * PF <= s_end; s0 += PF) {      // steady state: no branch between a load and its use -> counted vmcnt waits
 #pragma unroll
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         }
     }
 #undef ORE_STEP
+    ORE_TR(61);
 
     // ---- in-block K reduction.
     // Fast path (no cross-block split-K, no fused column sums): every k-group parks its tiles in LDS and then ALL WGK waves share
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 finish(a, m, n, vo);
             }
         }
-        return;
+        { ORE_TR(62); return; }
     }
     // Slow path: groups kg>0 park their tiles in LDS, group 0 adds them in group order and carries on alone
     if (WGK > 1) {
@@ -402,7 +418,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
     if (kg != 0) {
         if (p.colsum && WGM > 1) { __syncthreads(); __syncthreads(); }   // keep barrier counts uniform (see below)
-        return;
+        { ORE_TR(62); return; }
     }
 
     // ---- fused epilogue (transposed accumulators: one pixel, 4 consecutive channels per lane and tile)
@@ -450,6 +466,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                     if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = csum[j][r];
                 }
     }
+    ORE_TR(62);
 }
 
 
@@ -468,15 +485,6 @@ struct PatchP {
     const float* scale; const float* shift; int ep_stride, relu_cout;
     float* out; int out_ld, out_coff;
 };
-
-#ifdef ORE_TRACE
-// Phase-timeline build (make trace -> lib/libore_hip_trace.so; tools/conv_phase_trace.py): thread 0 of every block stamps s_memtime
-// at the phase boundaries of k_conv3x3_patch into g_trace[block][64].  Never part of the product library.
-__device__ unsigned long long* g_trace = nullptr;
-#define ORE_TR(i) do { if (g_trace && threadIdx.x == 0 && (i) < 64) g_trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define ORE_TR(i) do { } while (0)
-#endif
 
 template <int TH, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
