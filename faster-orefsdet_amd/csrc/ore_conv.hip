@@ -106,16 +106,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 
     // ---- per-thread A rows, fixed across the K loop: pointer to the (top-left tap, channel 0) element of the row's
     // receptive field, the row's image width, its segment id and a bitmask of the taps that fall inside the image.
-    const int my_q = tid % QPR, my_ks = my_q >> 2;               // QPR | 256: the same for all float4s of a thread
+    // Wave-private staging (PRIV): with the K dimension split over the block's 4 waves and one wave per K group, wave kg stages exactly
+    // the 16-channel slice of the A and B tiles that it multiplies itself (lane -> row lane>>2 (+16 per slot), float4 lane&3 of the
+    // slice).  Its LDS columns are touched by no other wave, so the K loop needs NO barrier: the four waves drift apart and cover
+    // each other's load / LDS latency instead of meeting at a barrier every 64 channels.
+    constexpr bool PRIV = (WGK == 4 && WGM * WGN == 1);
+    static_assert(!PRIV || (BM % 16 == 0 && BN % 16 == 0 && QPR == 16), "wave-private staging: 16-row slots, 16 float4 per tile row");
+    const int my_q = PRIV ? kg * 4 + (lane & 3) : tid % QPR;     // float4 slot within a tile row: the same for all float4s of a thread
+    const int my_ks = my_q >> 2;
+    auto slot_row = [&](int i) -> int { return PRIV ? i * 16 + (lane >> 2) : (tid + i * 256) / QPR; };
     const float* a_ptr[A_IT];
     int a_sid[A_IT], a_W[A_IT];
     unsigned a_taps[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int f = tid + i * 256, row = f / QPR;
+        const int f = tid + i * 256, row = slot_row(i);
         const int m = m0 + row;
         a_sid[i] = 0; a_W[i] = 0; a_taps[i] = 0u; a_ptr[i] = p.in;
-        if ((A_IT * 256 == BM * QPR || f < BM * QPR) && m < p.M) {
+        if ((PRIV || A_IT * 256 == BM * QPR || f < BM * QPR) && m < p.M) {
             int lvl, b, oy, ox;
             decode_row(p, m, lvl, b, oy, ox);
             const Lvl& L = p.lv[lvl];
@@ -134,8 +142,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     bool b_ok[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int f = tid + i * 256, n = n0 + f / QPR;
-        b_ok[i] = (B_IT * 256 == BN * QPR || f < BN * QPR) && n < p.Cout16;
+        const int f = tid + i * 256, n = n0 + slot_row(i);
+        b_ok[i] = (PRIV || B_IT * 256 == BN * QPR || f < BN * QPR) && n < p.Cout16;
         b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + (my_q & 3) * 4;
     }
 #ifndef ORE_PF
@@ -207,12 +215,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                 if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (!((okm >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (A_FULL || f < BM * QPR) *reinterpret_cast<f32x4*>(As + buf * BM * LD + (f / QPR) * LD + (f % QPR) * 4) = v;
+            if (A_FULL || f < BM * QPR) *reinterpret_cast<f32x4*>(As + buf * BM * LD + slot_row(i) * LD + my_q * 4) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int f = tid + i * 256;
-            if (B_FULL || f < BN * QPR) *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (f / QPR) * LD + (f % QPR) * 4) = rb[i];
+            if (B_FULL || f < BN * QPR) *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + slot_row(i) * LD + my_q * 4) = rb[i];
         }
     };
 
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         if (DO_STORE)                                                                                                           \
             lstore(cur ^ 1, ra[((u) + 1) % PF], rb[((u) + 1) % PF], rmul[((u) + 1) % PF], radd[((u) + 1) % PF], rok[((u) + 1) % PF]); \
         ORE_TR(4 + 4 * ((st) - s_begin));                                                                                       \
-        __syncthreads();                                                                                                        \
+        if constexpr (!PRIV) __syncthreads();                                                                                   \
         ORE_TR(5 + 4 * ((st) - s_begin));                                                                                       \
     }
     if (s_begin >= s_end) __syncthreads();                     // publishes sh_sc/sh_sh when the K loop (and its barriers) is empty
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) gload(s_begin + u, ra[u], rb[u], rmul[u], radd[u], rok[u]);   // steps past the end load zeros
         lstore(0, ra[0], rb[0], rmul[0], radd[0], rok[0]);
-        __syncthreads();
+        __syncthreads();                                       // (also publishes sh_sc / sh_sh)
         ORE_TR(1);
         int s0 = s_begin;
         for (; s0 + 2 * PF <= s_end; s0 += PF) {      // steady state: no branch between a load and its use -> counted vmcnt waits
