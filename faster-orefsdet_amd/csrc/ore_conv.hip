@@ -486,6 +486,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 // The next slab is prefetched into registers while the current one is being multiplied (single LDS buffer, 72 KB -> two blocks
 // per CU overlap each other's staging phase).  wave w owns tile rows [w*TH/4, (w+1)*TH/4): an MFMA A fragment is one tile row of
 // 16 consecutive pixels, so the tap shift (dy, dx) is a plain LDS address offset.
+constexpr int PATCH_LDA = 16;   // floats per LDS row of k_conv3x3_patch (16 channels, swizzled instead of padded)
+
 struct PatchP {
     const float* in; int in_ld, in_coff;
     int B, Cin, nlev; Lvl lv[4]; int tile0[5]; int tiles_x[4], tiles_y[4];
@@ -496,7 +498,11 @@ struct PatchP {
 
 template <int TH, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
-    constexpr int TW = 16, BN = 64, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDA = 24;
+    // LDS rows hold the 16 channels of a slab with NO padding (64 bytes): the four 16-byte slots of row r are stored at slot ^ ((r >> 2) & 3),
+    // which makes the ds_read_b128 of 16 consecutive rows (one per lane, same logical slot) hit 16 disjoint bank groups -- conflict-free
+    // like the padded layout (row stride 96 bytes) at 2/3 of the footprint: 43.8 KB per block, three blocks per CU instead of two.
+    constexpr int TW = 16, BN = 64, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDA = PATCH_LDA;
+    auto swz = [](int row, int slot) -> int { return row * LDA + ((slot ^ ((row >> 2) & 3)) << 2); };
     constexpr int TM = TH / 4, TN = BN / 16;
     constexpr int A_IT = (NPIX * 4 + 255) / 256, B_IT = 9;          // float4 slots per thread (B: tap j = slot j since BN*4 == 256)
     extern __shared__ __attribute__((aligned(16))) float plds[];
@@ -529,12 +535,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
         const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
         a_ok[i] = pi < NPIX && (unsigned)gy < (unsigned)L.H && (unsigned)gx < (unsigned)L.W;
         a_ptr[i] = p.in + (ptrdiff_t)(ibase + gy * L.W + gx) * p.in_ld + p.in_coff + q * 4;
-        a_lds[i] = pi < NPIX ? pi * LDA + q * 4 : -1;
+        a_lds[i] = pi < NPIX ? swz(pi, q) : -1;
     }
     const int bn = tid >> 2, bq = tid & 3;
     const bool b_ok = n0 + bn < p.Cout16;
     const float* b_ptr = p.w + (size_t)(b_ok ? n0 + bn : 0) * p.K + bq * 4;
-    const int b_lds = bn * LDA + bq * 4;
+    const int b_lds = swz(bn, bq);                           // tap j adds j * BN rows: BN % 16 == 0 keeps the swizzle phase
     f32x4 ra[A_IT], rb[B_IT];
     auto gload = [&](int c0) {
 #pragma unroll
@@ -581,10 +587,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
                 f32x4 af[TM], bf[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[i] = *reinterpret_cast<const f32x4*>(As + ((wrow + i + dy) * PW + li + dx) * LDA + g4);
+                    af[i] = *reinterpret_cast<const f32x4*>(As + swz((wrow + i + dy) * PW + li + dx, lane >> 4));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + ((dy * 3 + dx) * BN + j * 16 + li) * LDA + g4);
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + swz((dy * 3 + dx) * BN + j * 16 + li, lane >> 4));
                 if constexpr (BF) {
                     s16x4 ah[TM], bh[TN];
 #pragma unroll
@@ -989,12 +995,12 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
         if (!attrdb) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrdb = true; }
         hipLaunchKernelGGL(k_conv3x3_patch_db, grid, dim3(512), lds, st, p);
     } else if (TH == 8) {
-        const size_t lds = (size_t)(10 * 18 + 9 * 64) * 24 * sizeof(float);
+        const size_t lds = (size_t)(10 * 18 + 9 * 64) * PATCH_LDA * sizeof(float);
         static bool attr8 = false;
         if (!attr8) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr8 = true; }
         hipLaunchKernelGGL(k_conv3x3_patch<8>, grid, dim3(256), lds, st, p);
     } else {
-        const size_t lds = (size_t)(6 * 18 + 9 * 64) * 24 * sizeof(float);
+        const size_t lds = (size_t)(6 * 18 + 9 * 64) * PATCH_LDA * sizeof(float);
         static bool attr4 = false;
         if (!attr4) {
             ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_patch<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
