@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--conv-operands", choices=("fp32", "bf16"), default="fp32",
                     help="fp32 = the reference's precision (the headline).  bf16 = BASELINE configs[4]: MFMA conv operands rounded to bf16, "
                          "fp32 storage / accumulation / NMS (include/ore_hip.h ORE_CONV_BF16); reported with dtype \"bf16\", never the default")
+    ap.add_argument("--fold-streams", type=int, default=4, help="engine passes kept in flight in the folded-serving leg")
+    ap.add_argument("--fold", type=int, default=8,
+                    help="also time the same requests folded F at a time into one engine pass (\"folded_serving\" in the output); 0/1 = skip")
     ap.add_argument("--inflight", type=int, default=4,
                     help="images kept in flight per GPU, each a bs=1 forward on its own engine + HIP stream (bs=1 leaves most of "
                          "the 256 CUs idle in the small pyramid layers; independent images fill them).  1 = strictly one image "
@@ -250,6 +253,39 @@ def main():
                 ref = got
             else:
                 assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref)), "concurrent engines disagree"
+    def comm_max(v):
+        from detectron2.utils import comm as _c
+        return _c.max_over_ranks(v, device)
+
+    # folded serving: the SAME single-image requests, F at a time through ONE engine pass (dense stages batched over the F images,
+    # detection tail and second stage per image).  Reported beside the headline, never as `value`.
+    folded = None
+    if args.fold > 1:
+        S = max(args.fold_streams, 1)
+        efs = [model.make_engine(max_batch=args.fold) for _ in range(S)]
+        fstreams = [torch.cuda.Stream(device) for _ in range(S)]
+        packs = [torch.stack([imgs[(j + i) % len(imgs)] for i in range(args.fold)]).contiguous() for j in range(len(imgs))]
+        nb = max(args.steps // args.fold, S)
+
+        def fstep(j):
+            with torch.cuda.stream(fstreams[j % S]):
+                efs[j % S].eval_forward_batch(packs[j % len(packs)], use_graph=use_graph)
+        for j in range(max(args.warmup // args.fold, 2 * S)):
+            fstep(j)
+        sync_all()
+        tf0 = time.perf_counter()
+        for j in range(nb):
+            fstep(j)
+        sync_all()
+        f_el = comm_max(time.perf_counter() - tf0)
+        folded = {"images_per_s": round(world * nb * args.fold / f_el, 2), "requests_per_pass": args.fold, "passes_in_flight": S,
+                  "ms_per_pass": round(f_el / nb * 1e3, 4),
+                  "note": "the same bs=1 requests, %d folded into one engine pass (ore_engine_eval_batch_fwd), %d passes in flight on "
+                          "separate streams: the dense stages run batched, so a CU fetches each layer's weights once per pass instead "
+                          "of once per image; per-image results are checked against the bs=1 engine in tests/test_hip_parity.py"
+                          % (args.fold, S)}
+        for ef in efs:
+            ef.close()
     from detectron2.utils import comm
     elapsed = comm.max_over_ranks(elapsed, device)          # the slowest rank defines the job time
     seq_elapsed = comm.max_over_ranks(seq_elapsed, device)
@@ -327,6 +363,7 @@ def main():
             "sequential": {"images_per_s": round(total_images / seq_elapsed, 2), "ms_per_image": round(seq_elapsed / args.steps * 1e3, 4),
                            "note": "same K steps, one image at a time on one stream (images_in_flight_per_gpu = 1)"},
             "latency_ms_host_sync": {"p50": round(lat[len(lat) // 2] * 1e3, 4), "min": round(lat[0] * 1e3, 4)},
+            "folded_serving": folded,
             "roofline": roof,
         }
         if not args.no_train_leg and world == 1:

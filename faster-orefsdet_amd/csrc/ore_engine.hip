@@ -81,7 +81,7 @@ struct ore_engine {
     void* roi_ws = nullptr; size_t roi_ws_bytes = 0;
     // graph cache
     hipStream_t cap_stream = nullptr;
-    struct GraphKey { int u8, H, W; hipGraphExec_t exec; };
+    struct GraphKey { int u8, H, W, B; hipGraphExec_t exec; };
     std::vector<GraphKey> graphs;
     Geo last{};
     double last_flops = 0.0;
@@ -315,30 +315,35 @@ int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
     return r.rc;
 }
 
-int run_detect(ore_engine* e, const Geo& g, hipStream_t st) {
+int run_detect(ore_engine* e, const Geo& g, hipStream_t st, int b = 0) {        // image b of the batch
     const ore_model_cfg& c = e->cfg;
+    const size_t cap = (size_t)3 * c.pre_topk;
     ore_detect_desc d{};
     d.n_levels = 3; d.head_ld = 8;
     for (int l = 0; l < 3; ++l) {
-        d.head[l] = e->head.p + (size_t)lvl_row0(g, l) * 8;
+        d.head[l] = e->head.p + ((size_t)lvl_row0(g, l) + (size_t)b * g.h[l + 3] * g.w[l + 3]) * 8;
         d.H[l] = g.h[l + 3]; d.W[l] = g.w[l + 3]; d.stride[l] = c.strides[l];
     }
     d.score_thresh = c.score_thresh; d.pre_topk = c.pre_topk; d.nms_thresh = c.nms_thresh; d.post_topk = c.post_topk;
-    d.pre_boxes = e->pre_boxes; d.pre_scores = e->pre_scores; d.pre_loc = e->pre_loc; d.pre_level = e->pre_level;
-    d.keep_idx = e->keep_idx; d.counts = e->counts; d.out_boxes = e->out_boxes; d.out_scores = e->out_scores;
+    d.pre_boxes = e->pre_boxes + b * cap * 4; d.pre_scores = e->pre_scores + b * cap; d.pre_loc = e->pre_loc + b * cap;
+    d.pre_level = e->pre_level + b * cap; d.keep_idx = e->keep_idx + b * cap; d.counts = e->counts + b * 4;
+    d.out_boxes = e->out_boxes + b * cap * 4; d.out_scores = e->out_scores + b * cap;
     d.workspace = e->det_ws; d.workspace_bytes = e->det_ws_bytes;
     return ore_detect_fwd(&d, st);
 }
 
-int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
+int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops, int b = 0) {   // image b (scratch roi_feat / roi_h / roi_ws is shared: stream order)
     const ore_model_cfg& c = e->cfg;
     const int F = c.fpn_ch;
+    const size_t cap = (size_t)3 * c.pre_topk, rcap = (size_t)e->roi_cap;
+    float* out_boxes = e->out_boxes + b * cap * 4;
+    int32_t* counts = e->counts + b * 4;
     const float* feat[3]; int ld[3], coff[3], H[3], W[3]; float sc[3];
     for (int l = 0; l < 3; ++l) {
-        feat[l] = e->pcat.p + (size_t)lvl_row0(g, l) * 2 * F; ld[l] = 2 * F; coff[l] = F;
+        feat[l] = e->pcat.p + ((size_t)lvl_row0(g, l) + (size_t)b * g.h[l + 3] * g.w[l + 3]) * 2 * F; ld[l] = 2 * F; coff[l] = F;
         H[l] = g.h[l + 3]; W[l] = g.w[l + 3]; sc[l] = 1.0f / (float)c.strides[l];
     }
-    int rc = ore_roi_align_fwd(feat, ld, coff, H, W, sc, 3, 3, F, e->roi_pooled, e->out_boxes, e->counts + 1, 0, e->roi_cap, e->roi_feat, st);
+    int rc = ore_roi_align_fwd(feat, ld, coff, H, W, sc, 3, 3, F, e->roi_pooled, out_boxes, counts + 1, 0, e->roi_cap, e->roi_feat, st);
     if (rc) return rc;
     const int K = e->roi_pooled * e->roi_pooled * F;
     Run r{e, st};
@@ -352,9 +357,10 @@ int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
     }
     if (r.rc) return r.rc;
     *flops = r.flops;
-    return ore_roi_predict_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, e->out_boxes, e->counts + 1, 0,
+    return ore_roi_predict_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, out_boxes, counts + 1, 0,
                                e->roi_cap, e->roi_reg_w, (float)g.H, (float)g.W, e->roi_score_thresh, e->roi_nms_thresh, e->roi_topk,
-                               e->det_boxes, e->det_scores, e->det_src, e->det_count, e->roi_ws, e->roi_ws_bytes, st);
+                               e->det_boxes + b * rcap * 4, e->det_scores + b * rcap, e->det_src + b * rcap, e->det_count + b * 4, e->roi_ws,
+                               e->roi_ws_bytes, st);
 }
 
 }  // namespace
@@ -380,13 +386,14 @@ extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const
         return rc;
     if (!e->roi_set) {
         const size_t cap = (size_t)e->roi_cap;
-        if ((rc = e->dalloc(&e->roi_feat, cap * K)) || (rc = e->dalloc(&e->roi_h, cap * fc_dim)) || (rc = e->dalloc(&e->det_boxes, cap * 4)) ||
-            (rc = e->dalloc(&e->det_scores, cap)) || (rc = e->dalloc(&e->det_src, cap)) || (rc = e->dalloc(&e->det_count, (size_t)4))) return rc;
+        const size_t MB = (size_t)e->cfg.max_batch;
+        if ((rc = e->dalloc(&e->roi_feat, cap * K)) || (rc = e->dalloc(&e->roi_h, cap * fc_dim)) || (rc = e->dalloc(&e->det_boxes, MB * cap * 4)) ||
+            (rc = e->dalloc(&e->det_scores, MB * cap)) || (rc = e->dalloc(&e->det_src, MB * cap)) || (rc = e->dalloc(&e->det_count, MB * 4))) return rc;
         e->roi_ws_bytes = ore_roi_predict_workspace_bytes(e->roi_cap);
         char* w = nullptr;
         if ((rc = e->dalloc(&w, e->roi_ws_bytes))) return rc;
         e->roi_ws = w;
-        ORE_HIP(hipMemset(e->det_count, 0, 4 * sizeof(int32_t)));
+        ORE_HIP(hipMemset(e->det_count, 0, MB * 4 * sizeof(int32_t)));
     }
     e->roi_fc = fc_dim; e->roi_pooled = pooled; e->roi_topk = topk; e->roi_score_thresh = score_thresh; e->roi_nms_thresh = nms_thresh;
     for (int i = 0; i < 4; ++i) e->roi_reg_w[i] = reg_weights4_host[i];
@@ -565,10 +572,11 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
     if ((rc = e->dalloc(&e->colsum, cs_need))) return rc;
     if ((rc = e->dalloc(&e->gn_ws, (rows_all / 64 + 3 * B + 8) * 64 * 2))) return rc;
     const size_t cap = (size_t)3 * c.pre_topk;
-    if ((rc = e->dalloc(&e->pre_boxes, cap * 4)) || (rc = e->dalloc(&e->pre_scores, cap)) || (rc = e->dalloc(&e->pre_loc, cap)) ||
-        (rc = e->dalloc(&e->pre_level, cap)) || (rc = e->dalloc(&e->keep_idx, cap)) || (rc = e->dalloc(&e->counts, (size_t)4)) ||
-        (rc = e->dalloc(&e->out_boxes, cap * 4)) || (rc = e->dalloc(&e->out_scores, cap))) return rc;
-    ORE_HIP(hipMemset(e->counts, 0, 4 * sizeof(int32_t)));
+    const size_t MB = (size_t)c.max_batch;                  // detection outputs: one set per image of a batch, image b at b * stride
+    if ((rc = e->dalloc(&e->pre_boxes, MB * cap * 4)) || (rc = e->dalloc(&e->pre_scores, MB * cap)) || (rc = e->dalloc(&e->pre_loc, MB * cap)) ||
+        (rc = e->dalloc(&e->pre_level, MB * cap)) || (rc = e->dalloc(&e->keep_idx, MB * cap)) || (rc = e->dalloc(&e->counts, MB * 4)) ||
+        (rc = e->dalloc(&e->out_boxes, MB * cap * 4)) || (rc = e->dalloc(&e->out_scores, MB * cap))) return rc;
+    ORE_HIP(hipMemset(e->counts, 0, MB * 4 * sizeof(int32_t)));
     e->det_ws_bytes = ore_detect_workspace_bytes(3, c.pre_topk);
     char* dws = nullptr;
     if ((rc = e->dalloc(&dws, e->det_ws_bytes))) return rc;
@@ -606,28 +614,38 @@ extern "C" int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t i
 
 extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t H, int32_t W, int32_t use_graph,
                                    void* stream) {
-    int rc = check_geo(e, 1, H, W);
+    return ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, use_graph, stream);
+}
+
+extern "C" int ore_engine_eval_batch_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t B, int32_t H, int32_t W,
+                                         int32_t use_graph, void* stream) {
+    int rc = check_geo(e, B, H, W);
     if (rc) return rc;
     ORE_CHECK_ARG(img, "null image");
     hipStream_t st = (hipStream_t)stream;
-    const Geo g = make_geo(1, H, W);
+    const Geo g = make_geo(B, H, W);
     e->last = g;
     PrecisionScope ps(e->conv_precision);
-    const size_t bytes = (size_t)3 * H * W * (is_u8 ? 1 : 4);
+    const size_t bytes = (size_t)B * 3 * H * W * (is_u8 ? 1 : 4);
+    ORE_CHECK_ARG(bytes <= e->img_bytes, "image batch exceeds the engine's input buffer");
     ORE_HIP(hipMemcpyAsync(e->img_in, img, bytes, hipMemcpyDeviceToDevice, st));
     auto body = [&](hipStream_t s, double* fl) -> int {
         double f1 = 0, f2 = 0;
         int r = run_backbone(e, e->img_in, is_u8, g, s, &f1);
         double f3 = 0;
         if (!r) r = run_heads(e, g, s, &f2);
-        if (!r) r = run_detect(e, g, s);
-        if (!r && e->roi_set) r = run_roi(e, g, s, &f3);
+        for (int b = 0; b < B && !r; ++b) {                 // the detection tail and the second stage are per image
+            double fb = 0;
+            r = run_detect(e, g, s, b);
+            if (!r && e->roi_set) r = run_roi(e, g, s, &fb, b);
+            f3 += fb;
+        }
         *fl = f1 + f2 + f3;
         return r;
     };
     if (!use_graph) return body(st, &e->last_flops);
     for (auto& k : e->graphs)
-        if (k.u8 == is_u8 && k.H == H && k.W == W) {
+        if (k.u8 == is_u8 && k.H == H && k.W == W && k.B == B) {
             ORE_HIP(hipGraphLaunch(k.exec, st));
             return ORE_OK;
         }
@@ -644,7 +662,7 @@ extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8
     hipGraphExec_t exec = nullptr;
     ORE_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     hipGraphDestroy(graph);
-    e->graphs.push_back({is_u8, H, W, exec});
+    e->graphs.push_back({is_u8, H, W, B, exec});
     ORE_HIP(hipGraphLaunch(exec, st));
     return ORE_OK;
 }
@@ -733,19 +751,25 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
         if (n == "tower" + k) return set(e->tow.p + r0 * F, rows, F, F, 0);
         if (n == "head" + k) return set(e->head.p + r0 * 8, rows, 5, 8, 0);
     }
-    if (n == "pre_boxes") return set(e->pre_boxes, cap, 4, 4, 0);
-    if (n == "pre_scores") return set(e->pre_scores, cap, 1, 1, 0);
-    if (n == "pre_loc") return set(e->pre_loc, cap, 1, 1, 0);
-    if (n == "pre_level") return set(e->pre_level, cap, 1, 1, 0);
-    if (n == "keep_idx") return set(e->keep_idx, cap, 1, 1, 0);
-    if (n == "counts") return set(e->counts, 4, 1, 1, 0);
-    if (n == "out_boxes") return set(e->out_boxes, cap, 4, 4, 0);
-    if (n == "out_scores") return set(e->out_scores, cap, 1, 1, 0);
+    // per-image detection outputs: "name" = image 0, "name#b" = image b of the last batch
+    size_t ib = 0;
+    std::string base = n;
+    { const size_t h = n.find('#'); if (h != std::string::npos) { base = n.substr(0, h); ib = (size_t)std::atoi(n.c_str() + h + 1); } }
+    if (ib >= (size_t)e->cfg.max_batch) { ore_set_error("ore_engine_buffer: image index in '%s' exceeds max_batch", name); return ORE_EINVAL; }
+    const size_t ucap = (size_t)cap, rcap = (size_t)e->roi_cap;
+    if (base == "pre_boxes") return set(e->pre_boxes + ib * ucap * 4, cap, 4, 4, 0);
+    if (base == "pre_scores") return set(e->pre_scores + ib * ucap, cap, 1, 1, 0);
+    if (base == "pre_loc") return set(e->pre_loc + ib * ucap, cap, 1, 1, 0);
+    if (base == "pre_level") return set(e->pre_level + ib * ucap, cap, 1, 1, 0);
+    if (base == "keep_idx") return set(e->keep_idx + ib * ucap, cap, 1, 1, 0);
+    if (base == "counts") return set(e->counts + ib * 4, 4, 1, 1, 0);
+    if (base == "out_boxes") return set(e->out_boxes + ib * ucap * 4, cap, 4, 4, 0);
+    if (base == "out_scores") return set(e->out_scores + ib * ucap, cap, 1, 1, 0);
     if (e->roi_set) {
-        if (n == "det_boxes") return set(e->det_boxes, e->roi_cap, 4, 4, 0);
-        if (n == "det_scores") return set(e->det_scores, e->roi_cap, 1, 1, 0);
-        if (n == "det_src") return set(e->det_src, e->roi_cap, 1, 1, 0);
-        if (n == "det_count") return set(e->det_count, 4, 1, 1, 0);
+        if (base == "det_boxes") return set(e->det_boxes + ib * rcap * 4, e->roi_cap, 4, 4, 0);
+        if (base == "det_scores") return set(e->det_scores + ib * rcap, e->roi_cap, 1, 1, 0);
+        if (base == "det_src") return set(e->det_src + ib * rcap, e->roi_cap, 1, 1, 0);
+        if (base == "det_count") return set(e->det_count + ib * 4, 4, 1, 1, 0);
         if (n == "roi_h") return set(e->roi_h, e->roi_cap, e->roi_fc, e->roi_fc, 0);
     }
     ore_set_error("ore_engine_buffer: unknown buffer '%s'", name);

@@ -209,9 +209,10 @@ class CenterNet2Detector(nn.Module):
     def _state_key(self):
         return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
 
-    def make_engine(self):
+    def make_engine(self, max_batch: int = 1):
         """A fresh engine (own buffers, own hipGraph) for the current parameters and support set.  `engine()` caches one; a server
-        that keeps several images in flight on separate streams makes one per stream (bench.py --inflight)."""
+        that keeps several images in flight on separate streams makes one per stream (bench.py --inflight), or folds concurrent
+        requests into one pass with max_batch > 1 (Engine.eval_forward_batch)."""
         import orehip
         from detectron2.modeling.backbone.vovnet import _STAGE_SPECS
         c = self._cfg_engine
@@ -224,7 +225,7 @@ class CenterNet2Detector(nn.Module):
             e = orehip.Engine(stem=spec["stem"], conv=spec["stage_conv_ch"], out=spec["stage_out_ch"], layers=spec["layer_per_block"],
                               fpn_ch=c["fpn_ch"], strides=c["strides"], pixel_mean=c["pixel_mean"], pixel_std=c["pixel_std"],
                               score_thresh=c["score_thresh"], pre_topk=c["pre_topk"], nms_thresh=c["nms_thresh"],
-                              post_topk=c["post_topk"], max_batch=1, max_h=self.max_hw[0], max_w=self.max_hw[1],
+                              post_topk=c["post_topk"], max_batch=max_batch, max_h=self.max_hw[0], max_w=self.max_hw[1],
                               device=dev.index or 0)
         finally:
             orehip.set_conv_precision(prev)

@@ -71,7 +71,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
            "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
-           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd",
+           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
 
 _lib = None
@@ -836,10 +836,10 @@ class Engine:
              "ore_engine_set_roi_head")
         self.has_roi = True
 
-    def detections(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """(boxes [k,4], scores [k], source proposal index [k]) of the second stage -- one sync to read the count."""
-        k = int(self.buffer("det_count")[0, 0].item())
-        return self.buffer("det_boxes")[:k], self.buffer("det_scores")[:k, 0], self.buffer("det_src")[:k, 0]
+    def detections(self, b: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(boxes [k,4], scores [k], source proposal index [k]) of the second stage for image b -- one sync to read the count."""
+        k = int(self.buffer(f"det_count#{b}")[0, 0].item())
+        return self.buffer(f"det_boxes#{b}")[:k], self.buffer(f"det_scores#{b}")[:k, 0], self.buffer(f"det_src#{b}")[:k, 0]
 
     def backbone(self, img: torch.Tensor) -> Dict[str, torch.Tensor]:
         """img [B,3,H,W] u8/f32 on device -> {'p3','p4','p5'} as logical NCHW views of engine-owned NHWC buffers."""
@@ -856,6 +856,14 @@ class Engine:
         _, H, W = img.shape
         _chk(lib().ore_engine_eval_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W,
                                        int(use_graph), _stream()), "ore_engine_eval_fwd")
+
+    def eval_forward_batch(self, imgs: torch.Tensor, use_graph: bool = True) -> None:
+        """imgs [B,3,H,W] u8/f32 on device, B <= max_batch: dense stages batched, detection tail + second stage per image
+        (ore_engine_eval_batch_fwd).  Image b's results: .proposals(b) / .detections(b) / .buffer("name#b")."""
+        assert imgs.is_cuda and imgs.is_contiguous() and imgs.dim() == 4
+        B, _, H, W = imgs.shape
+        _chk(lib().ore_engine_eval_batch_fwd(self._h, C.c_void_p(imgs.data_ptr()), int(imgs.dtype == torch.uint8), B, H, W,
+                                             int(use_graph), _stream()), "ore_engine_eval_batch_fwd")
 
     def last_flops(self) -> float:
         return float(lib().ore_engine_last_flops(self._h))
@@ -876,7 +884,7 @@ class Engine:
         _chk(lib().ore_engine_buffer(self._h, name.encode(), C.byref(p), dims), f"ore_engine_buffer({name})")
         rows, ch, ld, coff = (int(x) for x in dims)
         dt = {"pre_loc": torch.int64, "keep_idx": torch.int64, "pre_level": torch.int32, "counts": torch.int32, "det_src": torch.int64,
-              "det_count": torch.int32}.get(name, torch.float32)
+              "det_count": torch.int32}.get(name.split("#")[0], torch.float32)
         flat = _from_ptr(p.value, rows * ld, dt, self.device)
         t = flat.view(rows, ld)[:, coff:coff + ch]
         if bhw is not None:
@@ -886,10 +894,10 @@ class Engine:
             return t.permute(0, 3, 1, 2)
         return t
 
-    def proposals(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """(boxes [n,4], scores [n], keep_idx [n]) -- reads the device-side count (one sync)."""
-        n = int(self.buffer("counts")[1, 0].item())
-        return self.buffer("out_boxes")[:n], self.buffer("out_scores")[:n, 0], self.buffer("keep_idx")[:n, 0]
+    def proposals(self, b: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(boxes [n,4], scores [n], keep_idx [n]) of image b -- reads the device-side count (one sync)."""
+        n = int(self.buffer(f"counts#{b}")[1, 0].item())
+        return self.buffer(f"out_boxes#{b}")[:n], self.buffer(f"out_scores#{b}")[:n, 0], self.buffer(f"keep_idx#{b}")[:n, 0]
 
 
 class _Arr:

@@ -358,6 +358,13 @@ int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t img_is_u8, i
  * for this (H,W)).  Results stay on device; query with ore_engine_buffer(). */
 int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t use_graph,
                         void* stream);
+/* The same for B images of one size in ONE pass (B <= cfg.max_batch; img [B][3][H][W] contiguous): the dense stages -- backbone, FPN,
+ * correlation, conv3, head -- run batched (a CU fetches every layer's weights once for B images instead of once per image, which is
+ * what bounds the bs = 1 kernels), the detection tail and the second stage run per image.  This is how a server folds concurrent
+ * single-image requests (the reference's inference protocol is one image per forward, ref:fewx/modeling/fsod/fsod_cen.py:434-527);
+ * image b's results are the buffers "out_boxes#b", "counts#b", "det_boxes#b", ... ("#0" may be omitted). */
+int ore_engine_eval_batch_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t use_graph,
+                              void* stream);
 /* Named device buffers: "p3","p4","p5" (NHWC, ld=2*fpn_ch, coff=fpn_ch), "pos3".."pos5", "head3".."head5",
  * "pre_boxes","pre_scores","pre_loc","keep_idx","counts","out_boxes","out_scores", "stage2".."stage5", ...
  * Returns device pointer and fills dims[0..3] = {rows(H*W*B), channels, ld, coff}. */
