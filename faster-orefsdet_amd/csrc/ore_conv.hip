@@ -951,7 +951,13 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     if (g_patch_mode < 0 && c.M < 6000) return 1;        // plan: only the large-M layers (profiles/r01_conv_tune.txt); TH=4 wins or ties
     // plan: the weight-stationary kernel wins once a resident block walks >= 4 tiles (stem_2: 3200 tiles, 71 vs 82 us); below that its
     // 36-fragment weight prologue is not amortised (stage-2 64->64 layers: 800 tiles, 29 vs 26 us)
-    if (g_patch_mode < 0 && c.Cin == 64 && c.nlev == 1 && (long long)c.B * ceil_div(c.lv[0].H, 2) * ceil_div(c.lv[0].W, 16) >= 2048) { ws = true; TH = 2; }
+    const long long ws_tiles = (long long)c.B * ceil_div(c.lv[0].H, 2) * ceil_div(c.lv[0].W, 16);
+    if (g_patch_mode < 0 && c.Cin == 64 && c.nlev == 1 && ws_tiles >= 2048) { ws = true; TH = 2; }
+    // Cin = 128 (8 waves, K split in wave pairs, fp32 build only): alone on the GPU it wins from ~1600 tiles (8 x 80x80: 140 vs 154 us,
+    // 8 x 160x160: 263 vs 315 us; one 160x160 image, 800 tiles: 47 vs 45 us -- tools/ws128_exp.py), but its one 512-thread,
+    // 256-VGPR block per CU leaves no room for another stream's kernel: with several passes in flight the folded-serving rate DROPS
+    // 2 %.  Used for training-sized launches only.
+    if (g_patch_mode < 0 && c.Cin == 128 && c.nlev == 1 && !g_conv_bf16 && ws_tiles >= 8192) { ws = true; TH = 2; }
     PatchP p{};
     p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = c.nlev;
     int tiles = 0;
