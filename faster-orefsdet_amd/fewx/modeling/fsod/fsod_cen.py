@@ -310,6 +310,47 @@ class CenterNet2Detector(nn.Module):
             return CenterNet2Detector._postprocess(results, batched_inputs, images.image_sizes)
         return results
 
+    @torch.no_grad()
+    def inference_many(self, requests, do_postprocess=True, max_fold: int = 8):
+        """Serving entry point beside the reference's one-image `inference`: `requests` is a list of single-image inputs (the dicts
+        the reference passes one at a time).  Requests of equal image size and dtype are folded, up to `max_fold` per engine pass
+        (Engine.eval_forward_batch: dense stages batched, detection tail and second stage per image); results come back in request
+        order and equal the one-at-a-time results (tests/test_hip_parity.py)."""
+        from detectron2.structures import Boxes, Instances
+        assert not self.training
+        self.init_model()
+        key = (self._state_key(), str(self.device), self.conv_operands, max_fold)
+        if getattr(self, "_fold_engine_key", None) != key:
+            if getattr(self, "_fold_engine", None) is not None:
+                self._fold_engine.close()
+            self._fold_engine, self._fold_engine_key = self.make_engine(max_batch=max_fold), key
+        e = self._fold_engine
+        assert getattr(e, "has_roi", False), "inference_many needs the second stage inside the engine (support set with rcnn_8 features)"
+        imgs = []
+        for r in requests:
+            img = r["image"].to(self.device)
+            imgs.append((img if img.dtype == torch.uint8 else img.float()).contiguous())
+        groups = {}
+        for i, im in enumerate(imgs):
+            groups.setdefault((tuple(im.shape), im.dtype), []).append(i)
+        results = [None] * len(requests)
+        for idxs in groups.values():
+            for j in range(0, len(idxs), max_fold):
+                part = idxs[j:j + max_fold]
+                e.eval_forward_batch(torch.stack([imgs[i] for i in part]).contiguous(), use_graph=True)
+                for b, i in enumerate(part):
+                    boxes, scores, _ = e.detections(b)
+                    H, W = imgs[i].shape[-2:]
+                    res = Instances((H, W))
+                    res.pred_boxes = Boxes(boxes.clone())
+                    res.scores = scores.clone()
+                    res.pred_classes = torch.zeros(len(scores), dtype=torch.int64, device=scores.device)
+                    results[i] = res
+        if do_postprocess:
+            sizes = [tuple(im.shape[-2:]) for im in imgs]
+            return CenterNet2Detector._postprocess(results, requests, sizes)
+        return results
+
     def preprocess_image(self, batched_inputs):
         """ref fsod_cen.py:540-555 (kept for API parity; the engine fuses this into stem_1)."""
         images = [x["image"].to(self.device) for x in batched_inputs]

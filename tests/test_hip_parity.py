@@ -511,6 +511,26 @@ def test_detector_end_to_end(model, sd):
     np.testing.assert_allclose(res[0].pred_boxes.tensor.cpu().numpy(), eb.cpu().numpy(), rtol=1e-4, atol=1e-2)
 
 
+def test_detector_inference_many_equals_one_at_a_time(model, sd):
+    """CenterNet2Detector.inference_many: single-image requests of two sizes, folded per size into batched engine passes, return
+    the detections of the reference protocol (one image per forward) in request order."""
+    sd2 = R.synth_roi_state(sd)
+    sd2["roi_heads.box_head.0.fc1.weight"] = sd2["roi_heads.box_head.0.fc1.weight"] * 0.01
+    model.load_state_dict({k: v for k, v in sd2.items() if k.startswith("roi_heads.")}, strict=False)
+    g = torch.Generator().manual_seed(9)
+    rc8 = torch.randn(24, 128, 8, 8, generator=g) * 0.1
+    model.set_support_dict({**{k: {0: v} for k, v in R.synth_support(0).items()}, "rcnn_8": {0: rc8}, "rcnn_4": {0: torch.zeros(24, 128, 4, 4)}})
+    reqs = [{"image": R.synth_image(20 + i, *hw)} for i, hw in enumerate([(320, 320), (256, 384), (320, 320), (320, 320), (256, 384)])]
+    many = model.inference_many(reqs, max_fold=3)
+    assert len(many) == len(reqs)
+    for r, got in zip(reqs, many):
+        one = model([r])[0]["instances"]
+        gi = got["instances"]
+        assert gi.image_size == one.image_size and len(gi) == len(one) and len(one) > 0
+        np.testing.assert_allclose(gi.scores.cpu().numpy(), one.scores.cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(gi.pred_boxes.tensor.cpu().numpy(), one.pred_boxes.tensor.cpu().numpy(), rtol=1e-4, atol=0.05)
+
+
 # ------------------------------------------------------------------------------------------ batched-level / fused entry points
 def test_conv_fused_colsum_and_gate(ore):
     """The concat conv's epilogue column sums (eSE average pool) + gate kernel == avgpool -> fc -> hsigmoid."""
