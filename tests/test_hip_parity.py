@@ -748,3 +748,41 @@ def test_engine_batched_eval_matches_single_image_engines(ore, sd):
             assert float((db - d1).abs().max()) < 0.5 and float((ds - s1).abs().max()) < 1e-4     # boxes in pixels (of 640), scores in [0,1]
     eb.close()
     e1.close()
+
+
+def test_engine_batched_eval_non_divisible_size_and_bf16(ore, sd):
+    """Folded pass at a size that needs padding (300x420 -> 320x448) and in the bf16-operand mode: per-image heads equal the bs = 1
+    engine of the same mode (1e-5 in fp32; in bf16 mode the batched tile plan rounds the same operands, so 1e-5 as well), proposals
+    bit-exact against ref_decode.c on the image's own heads."""
+    B = 2
+    imgs = torch.stack([R.synth_image(30 + i, 300, 420) for i in range(B)]).cuda()
+    for mode in ("fp32", "bf16"):
+        prev = ore.set_conv_precision(mode)
+        try:
+            eb, e1 = ore.Engine(max_batch=B, max_h=320, max_w=448), ore.Engine(max_batch=1, max_h=320, max_w=448)
+        finally:
+            ore.set_conv_precision(prev)
+        for e in (eb, e1):
+            e.load_state_dict(sd)
+            e.set_support(R.synth_support(0))
+            e.finalize()
+        eb.eval_forward_batch(imgs, use_graph=True)
+        torch.cuda.synchronize()
+        for b in range(B):
+            e1.eval_forward(imgs[b], use_graph=False)
+            torch.cuda.synchronize()
+            hms, regs = [], []
+            for l in range(3):
+                hh, ww = 320 >> (l + 3), 448 >> (l + 3)
+                got = eb.buffer(f"head{l + 3}", (B, hh, ww))[b].cpu().numpy()
+                want = e1.buffer(f"head{l + 3}", (1, hh, ww))[0].cpu().numpy()
+                assert rel_err(got, want) < (1e-5 if mode == "fp32" else 2e-2), (mode, l, b)
+                hd = eb.buffer(f"head{l + 3}").cpu().numpy().reshape(B, hh, ww, 5)[b]
+                hms.append(np.ascontiguousarray(hd[..., 4]))
+                regs.append(np.ascontiguousarray(hd[..., :4]))
+            want = odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+            boxes, scores, keep = eb.proposals(b)
+            assert np.array_equal(keep.cpu().numpy(), want["keep"]) and len(want["keep"]) > 0
+            assert np.array_equal(boxes.cpu().numpy(), want["boxes"]) and np.array_equal(scores.cpu().numpy(), want["scores"])
+        eb.close()
+        e1.close()
