@@ -161,6 +161,19 @@ def osa_block(x_in, layers: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Ten
     return OSAFn.apply(x_in, *flat)
 
 
+_UNIT = {}
+
+
+def _unit_affine(C: int, device):
+    """(ones[C], zeros[C]) on `device`, created once (GroupNorm statistics are taken with a unit affine)."""
+    key = (C, str(device))
+    if key not in _UNIT:
+        if torch.cuda.is_current_stream_capturing():          # a fill captured into a graph only runs on replay: do not cache it
+            return torch.ones(C, device=device), torch.zeros(C, device=device)
+        _UNIT[key] = (torch.ones(C, device=device), torch.zeros(C, device=device))
+    return _UNIT[key]
+
+
 class GroupNormReluFn(Function):
     """relu?(GroupNorm(x)) for ONE image x [1,H,W,C] (head tower: GN(32,128) + ReLU).  Statistics by the engine's Chan-combine
     kernels (ore_groupnorm_affine_fwd with unit gamma), apply + backward in ore_groupnorm_apply_fwd / ore_groupnorm_bwd."""
@@ -170,7 +183,7 @@ class GroupNormReluFn(Function):
         assert x.shape[0] == 1, "one image per call (statistics are per image)"
         x = x.contiguous()
         C = x.shape[-1]
-        one, zero = torch.ones(C, device=x.device), torch.zeros(C, device=x.device)
+        one, zero = _unit_affine(C, x.device)
         r, a = orehip.groupnorm_affine(x, groups, one, zero, eps)              # [1,C]: rstd, -mean*rstd of the channel's group
         r, a = r.reshape(C).contiguous(), a.reshape(C).contiguous()
         y = orehip.groupnorm_apply(x, r, a, gamma.detach().contiguous(), beta.detach().contiguous(), relu)
