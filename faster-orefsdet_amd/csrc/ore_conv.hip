@@ -1088,12 +1088,36 @@ void plan_conv(int M, int Cout, int nchunks, int req_splitk, TileCfg* t, int* S_
         else if (C16 % 128 == 0) *t = {64, 128, 2, 2, 1};
         else *t = {64, C16 <= 128 ? C16 : 64, 4, 1, 1};
     } else if (M >= 2048) {
-        if (C16 % 64 == 0) *t = {32, 64, 2, 1, 2};
+        if (C16 % 64 == 0) { if (C16 >= 256 && !g_conv_bf16) *t = {64, 64, 2, 1, 2}; else *t = {32, 64, 2, 1, 2}; }
         else if (C16 >= 32) *t = {32, 32, 1, 1, 4};
         else *t = {16, 16, 1, 1, 4};
     } else {
         bn = C16 >= 32 ? 32 : 16;
         *t = {16, bn, 1, 1, 4};
+    }
+    // K-split tiles, second pass (re-tuned after the K loop lost its barriers, profiles/r01_conv_tune.txt): with wave-private staging
+    // the layers of stages 3-4 and the FPN run best at about ONE block per CU -- every CU then pulls each weight row through its
+    // memory path once -- so pick the (BM, BN) of the 1x1x4 family with >= 192 blocks and the fewest staged bytes per FLOP,
+    // (1/BM + 1/BN) x the padding waste of BN.  (The bf16 builds exist for the first-pass tiles only.)
+    // (at M < 2048 only for N < 128: the 128- and 384-channel layers of stage 4 / the FPN -- input affine, fused column sums in the
+    // epilogue -- measured slower with the picked tile inside the engine: s4cat 19.7 -> 22.6 us, lat4 11.0 -> 12.4 us)
+    const bool ksplit_pick = !g_conv_bf16 && C16 >= 32 && ((M >= 2048 && M < 16384 && C16 % 64 != 0) || (M >= 1024 && M < 2048 && C16 < 128));
+    if (ksplit_pick) {
+        static const int bms[2] = {32, 16};
+        static const int bns32[8] = {128, 112, 96, 80, 64, 48, 32, 16}, bns16[4] = {64, 48, 32, 16};
+        float best = 1e30f;
+        for (int a = 0; a < 2; ++a) {
+            const int bm = bms[a];
+            const int* bns = bm == 32 ? bns32 : bns16;
+            for (int b = 0; b < (bm == 32 ? 8 : 4); ++b) {
+                const int bnc = bns[b];
+                if (bnc > C16) continue;
+                const int nt = ceil_div(C16, bnc);
+                if (ceil_div(M, bm) * nt < 192) continue;
+                const float cost = (1.0f / (float)bm + 1.0f / (float)bnc) * (float)(nt * bnc) / (float)C16;
+                if (cost < best) { best = cost; *t = {bm, bnc, 1, 1, 4}; }
+            }
+        }
     }
     const int nsteps = ceil_div(nchunks, t->WGK);
     const int blocks = ceil_div(M, t->BM) * ceil_div(C16, t->BN);
