@@ -343,7 +343,7 @@ def main():
                 "kernel_ms_per_image": round(ms / max(args.profile_passes, 1), 4),
                 "kernel_ms_per_image_calibrated": round(ms_cal / max(args.profile_passes, 1), 4), "event_pair_overhead_us": round(ev_us, 3),
                 "achieved_calibrated": round(fl / (ms_cal * 1e-3) / 1e12, 2),
-                "rocprof_note": "rocprofv3 --kernel-trace of the same launches (fp32): 0.691 ms per image = 49.1 TFLOP/s = 0.312 of peak (profiles/r01_conv_layers.txt)",
+                "rocprof_note": "rocprofv3 --kernel-trace of the same launches (fp32): 0.665 ms per image = 51.1 TFLOP/s = 0.325 of peak (profiles/r01_conv_layers.txt)",
                 "note": "per-kernel figure from isolated (one image at a time) launches; with images in flight the conv FLOP rate "
                         "end to end is value x gflop_per_image"}
         roof["end_to_end_tflops"] = round(total_images / elapsed * roof["gflop_per_image"] / 1e3, 2)
