@@ -261,8 +261,13 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
     const float ai = (a.z - a.x) * (a.w - a.y);
     unsigned long long bits = 0;
     const int jmax = min(64, n - bj * 64);
+    // off-diagonal block (bj > bi): bit c = "row i suppresses row bj*64+c".  Diagonal block: the TRANSPOSED word, bit c (c < t) =
+    // "row i is suppressed by row bi*64+c" (IoU is symmetric and computed from the same operands, so this is exactly the transpose
+    // of the upper triangle): the scan resolves a block with one AND + ballot per fixpoint iteration instead of a scalar loop
+    // over the suppressing rows.
+    const bool dg = bi == bj;
     for (int c = 0; c < jmax; ++c) {
-        if (bj * 64 + c <= i) continue;
+        if (dg && c >= t) continue;
         const float xx1 = fmaxf(a.x, cb[c * 4 + 0]), yy1 = fmaxf(a.y, cb[c * 4 + 1]);
         const float xx2 = fminf(a.z, cb[c * 4 + 2]), yy2 = fminf(a.w, cb[c * 4 + 3]);
         const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
@@ -319,35 +324,17 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_bo
             unsigned long long rem = removed[bi];
             const int nvalid = min(64, n - bi * 64);
             if (nvalid < 64) rem |= ~0ull << nvalid;
-            // Greedy resolution inside the block as a fixpoint: K <- cand & ~OR_{s in K} diag[s].  diag[s] only has bits > s,
-            // so iteration i is exact on the first i rows and the unique fixpoint IS the sequential greedy answer; it is
-            // reached after (longest suppression chain) iterations, typically a handful instead of 64 serial steps.
+            // Greedy resolution inside the block as a fixpoint: K <- cand & ~{ j : diagT[j] & K != 0 } (row j is suppressed by a kept
+            // earlier row of the block).  Iteration i is exact on the first i rows, so the unique fixpoint IS the sequential greedy
+            // answer; it is reached after (longest suppression chain) iterations of one AND + one ballot each.
             const unsigned long long cand = ~rem;
             unsigned long long kept = cand;
-            const unsigned long long nz = __ballot(diag != 0ull);   // rows that suppress anything inside this block (usually few)
-            if (nz != 0ull) {
-                const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-                auto uni = [](unsigned long long v) -> unsigned long long {      // provably wave-uniform copy (SGPR pair)
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
-                    return ((unsigned long long)hi << 32) | lo;
-                };
-                const unsigned long long cand_u = uni(cand), nz_u = uni(nz);
-                unsigned long long k_u = cand_u;
+            if (__ballot(diag != 0ull) != 0ull) {
                 for (int it = 0; it < 64; ++it) {
-                    unsigned long long sup = 0ull, m = k_u & nz_u;   // scalar loop over the active suppressors only
-                    while (m) {
-                        const int t = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-                        m &= m - 1;
-                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(dlo, t);   // readlane returns a signed int:
-                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane(dhi, t);   // go through unsigned, no sign extension
-                        sup |= ((unsigned long long)hi << 32) | lo;
-                    }
-                    const unsigned long long kn = cand_u & ~sup;
-                    if (kn == k_u) break;
-                    k_u = kn;
+                    const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
+                    if (kn == kept) break;
+                    kept = kn;
                 }
-                kept = k_u;
             }
             if (lane == 0) sh_kept = kept;
             if ((kept >> lane) & 1ull) {               // emit survivors of this block in order
