@@ -372,7 +372,7 @@ def main():
             except Exception as ex:                         # the headline line must survive a failure of the side measurement
                 out["train_step"] = {"error": repr(ex)[:300]}
             try:                                            # BASELINE configs[2]: 16 query images (+ 16 x 24 support crops) per GPU per step
-                out["train_step_bs16"] = train_leg(device, steps=4, warmup=3, batch=16, graph=False)
+                out["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False)
             except Exception as ex:
                 out["train_step_bs16"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:
