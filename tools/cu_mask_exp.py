@@ -48,6 +48,13 @@ def run(streams, label):
 
 run([torch.cuda.Stream(dev) for _ in range(4)], "4 plain streams")
 allb = list(range(256))
+if len(sys.argv) > 1 and sys.argv[1] == "fine":
+    run([masked_stream(set(b for b in allb if b % 8 == i)) for i in range(8)], "8 eighths (bit mod 8), 8 streams")
+    run([masked_stream(set(b for b in allb if b % 8 == i // 2 * 1 + 0 * i)) for i in range(8)], "8 streams on 4 eighths pairs")
+    run([masked_stream(set(b for b in allb if b % 4 == i % 4)) for i in range(8)], "4 quarters (bit mod 4), 2 streams each")
+    run([masked_stream(set(b for b in allb if b % 16 == i)) for i in range(16)], "16 sixteenths (bit mod 16), 16 streams")
+    run([masked_stream(set(b for b in allb if b % 6 == i)) for i in range(6)], "6 sixths (bit mod 6), 6 streams")
+    sys.exit(0)
 run([masked_stream(set(allb[i * 128:(i + 1) * 128])) for i in range(2)] * 2, "2 halves (bit ranges), 2 streams each")
 run([masked_stream(set(b for b in allb if b % 2 == i)) for i in range(2)] * 2, "2 halves (even/odd bits), 2 streams each")
 run([masked_stream(set(allb[i * 64:(i + 1) * 64])) for i in range(4)], "4 quarters (bit ranges)")
