@@ -296,6 +296,6 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
     l_roi, a2 = roi_stage_losses(rh, list(outs[0:3]), sup8.reshape(B, N, -1), torch.cat(rb, 0), torch.cat(rl, 0), torch.cat(rg, 0),
                                  pg.strides, roi_image, per_image)
     if return_aux:
-        aux = dict(roi_boxes=rb, roi_labels=rl, rois_per_image=per_image, **a2)
+        aux = dict(roi_boxes=rb, roi_labels=rl, roi_gt=rg, rois_per_image=per_image, **a2)
     losses = {**l_roi, **{k: torch.stack(v).mean() for k, v in acc.items()}}
     return (losses, aux) if return_aux else losses

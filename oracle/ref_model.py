@@ -382,8 +382,8 @@ def roi_align(feat: Tensor, boxes: Tensor, scale: float, pooled: int) -> Tensor:
     """torchvision.ops.roi_align(aligned=True, sampling_ratio=0) restated from its published algorithm (torchvision 0.8.2 is an
     un-vendored dependency of the reference: d2z:layers/roi_align.py:49-65).  feat [C,H,W], boxes [R,4] -> [R,C,pooled,pooled]."""
     C, H, W = feat.shape
-    out = torch.zeros(len(boxes), C, pooled, pooled, dtype=torch.float32)
-    f32 = torch.float32
+    f32 = feat.dtype                 # fp32 in every parity use; fp64 only for the conditioning runs of oracle/refrun/gen_golden.py
+    out = torch.zeros(len(boxes), C, pooled, pooled, dtype=f32)
     for r in range(len(boxes)):
         b = boxes[r].to(f32) * scale - 0.5
         x0, y0, x1, y1 = b[0], b[1], b[2], b[3]

@@ -87,10 +87,29 @@ def preprocess_batch(imgs: Tensor, div: int = 32) -> Tensor:
     return F.pad(x, (0, (W + div - 1) // div * div - W, 0, (H + div - 1) // div * div - H))
 
 
+def second_stage_losses(feats: Sequence[Tensor], roi_boxes: Tensor, roi_labels: Tensor, roi_gt: Tensor, sup8: Tensor,
+                        sd: Dict[str, Tensor], prefix: str = "roi_heads.") -> Dict[str, Tensor]:
+    """Second stage in training mode for one image, on already sampled ROIs (fsod_roi_heads.py:404-520 `_forward_box`/`_run_stage`,
+    the live second definition; custom_fast_rcnn.py:52-81,131-157 `losses`; d2z fast_rcnn.py:490-530 `box_reg_loss`): ROIAlign 8x8 of
+    the query pyramid, DSA mix with the mean support feature, fc1, predictor, softmax cross-entropy (mean over the ROIs) and
+    smooth-L1 with beta 0 (= L1) over the foreground rows, normalised by the number of ROIs.  `_ScaleGradient` is the identity
+    for one cascade stage.  Pinned by tests/golden/roi_stage_train.npz (the reference classes executed)."""
+    box_feat = R.roi_pool_levels(feats, roi_boxes, 8)
+    h = R.roi_head_features(box_feat, sup8, sd, prefix)
+    p = prefix + "box_predictor.0."
+    scores = F.linear(h, sd[p + "cls_score.weight"], sd[p + "cls_score.bias"])
+    deltas = F.linear(h, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"])
+    loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
+    fg = torch.nonzero(roi_labels == 0).squeeze(1)
+    tgt = get_deltas(roi_boxes[fg], roi_gt[fg])
+    loss_box = (deltas[fg] - tgt).abs().sum() / max(roi_labels.numel(), 1)
+    return {"box_features": box_feat, "h": h, "scores": scores, "deltas": deltas, "loss_cls": loss_cls, "loss_box_reg": loss_box}
+
+
 def train_iteration(sd: Dict[str, Tensor], image: Tensor, gt_boxes: Tensor, support_images: Tensor, support_boxes: Tensor,
                     perm: Callable[[int], Tensor], num_gpus: int = 1, batch_per_image: int = 128,
                     positive_fraction: float = 0.5, iou_thresh: float = 0.6, pre_topk: int = 4000, nms_thresh: float = 0.9,
-                    post_topk: int = 2000, score_thresh: float = 1e-5) -> Dict[str, object]:
+                    post_topk: int = 2000, score_thresh: float = 1e-5, roi_override: Optional[Dict[str, Tensor]] = None) -> Dict[str, object]:
     """One query image [3,H,W] + its support set ([N,3,h,w], [N,4]); batch size 1 per process as the reference trains.
     `sd` holds leaf tensors (requires_grad where trainable); returns the 5 losses (graph attached) and the intermediates the
     parity tests compare (proposals, sampled indices, targets)."""
@@ -118,20 +137,14 @@ def train_iteration(sd: Dict[str, Tensor], image: Tensor, gt_boxes: Tensor, supp
         boxes, matched, labels = label_proposals(proposals, gt_boxes, iou_thresh)
         sampled = sample_labels(labels, batch_per_image, positive_fraction, perm)
         roi_boxes, roi_labels, roi_gt = boxes[sampled], labels[sampled], gt_boxes[matched[sampled]] if len(gt_boxes) else boxes[sampled]
-    # --- second stage (fsod_roi_heads.py:459-520): ROIAlign 8x8 of the query pyramid, support rcnn_8 = ROIAlign of each support
-    #     image's own box, DSA mix, fc1, predictor
+        if roi_override is not None:      # conditioning runs: the sampled ROIs of another run (fp64 vs fp32 decide NMS ties differently)
+            roi_boxes, roi_labels, roi_gt = (roi_override[k] for k in ("boxes", "labels", "gt"))
+    # --- second stage
     flist = [feats[k] for k in levels]
-    box_feat = R.roi_pool_levels(flist, roi_boxes, 8)
     sup8 = torch.cat([R.roi_pool_levels([sfeats[k][n:n + 1] for k in levels], support_boxes[n:n + 1], 8)
                       for n in range(support_images.shape[0])], 0)
-    h = R.roi_head_features(box_feat, sup8, sd)
-    p = "roi_heads.box_predictor.0."
-    scores = F.linear(h, sd[p + "cls_score.weight"], sd[p + "cls_score.bias"])
-    deltas = F.linear(h, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"])
-    loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
-    fg = torch.nonzero(roi_labels == 0).squeeze(1)
-    tgt = get_deltas(roi_boxes[fg], roi_gt[fg])
-    loss_box = (deltas[fg] - tgt).abs().sum() / max(roi_labels.numel(), 1)          # smooth_l1 with beta = 0 is L1
+    st = second_stage_losses(flist, roi_boxes, roi_labels, roi_gt, sup8, sd)
+    box_feat, h, scores, deltas, loss_cls, loss_box = (st[k] for k in ("box_features", "h", "scores", "deltas", "loss_cls", "loss_box_reg"))
     losses = {"loss_cls_stage0": loss_cls, "loss_box_reg_stage0": loss_box,
               "loss_centernet_loc": cn["loss_centernet_loc"], "loss_centernet_agn_pos": cn["loss_centernet_agn_pos"],
               "loss_centernet_agn_neg": cn["loss_centernet_agn_neg"]}

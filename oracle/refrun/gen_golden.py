@@ -32,7 +32,8 @@ def save(name, **arrays):
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
-    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in arrays.items()))
+    desc = ", ".join(f"{k}{tuple(v.shape)}" for k, v in arrays.items() if not k.startswith(("gs/", "gn/", "gc/")))
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  {desc}")
 
 
 def sub_sd(sd, prefix):
@@ -259,6 +260,210 @@ def main():
     save("roi_train_pieces", gt=np_(gtb), boxes=np_(allb), iou=np_(iou), matched_idx=np_(midx), labels=np_(gt_classes),
          sampled=np_(sampled), fg_rows=np_(fg_rows), deltas=np_(deltas), seed=np.array(123))
     print("missing/unexpected:", missing)
+
+    gen_roi_stage(ns, sd)
+    gen_train_iteration(sd)
+    gen_state_dict_layout()
+    gen_demo_images()
+
+
+def reference_detector(sd, shots, device_cfg="cpu"):
+    """The reference's complete CenterNet2Detector built by ITS OWN __init__ / from_config chain from ITS OWN logged resolved config
+    (ref:fewx/modeling/fsod/fsod_cen.py:45-78), with the builders it imports pointed at the reference's real classes."""
+    ns = shims.load_roi_heads()
+    cen = shims.load_fsod_cen()
+    cfg = shims.logged_cfg()
+    cfg.INPUT.FS.SUPPORT_SHOT = shots
+    cfg.MODEL.DEVICE = device_cfg
+    SS = ns.layers.ShapeSpec
+    cen.build_backbone = lambda c: ns.vovnet.build_fcos_vovnet_fpn_backbone(c, SS(channels=len(c.MODEL.PIXEL_MEAN)))
+    cen.build_proposal_generator = lambda c, shape: ns.fsod_rpn.CenterNet(c, shape)
+    cen.build_roi_heads = ns.roi_heads.build_roi_heads
+    det = cen.CenterNet2Detector(cfg)
+    missing = det.load_state_dict(sd, strict=True)
+    return det, cfg, ns
+
+
+def gen_roi_stage(ns, sd0):
+    """f1: CustomCascadeROIHeads (ref:fewx/modeling/fsod/fsod_roi_heads.py:380-520), CustomFastRCNNOutputLayers
+    (ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:51-170), FastRCNNOutputLayers.box_reg_loss / predict_boxes and
+    fast_rcnn_inference (d2z:modeling/roi_heads/fast_rcnn.py:118-171,490-620), ROIPooler (d2z:modeling/poolers.py), executed."""
+    ns = shims.load_roi_heads()
+    cfg = shims.logged_cfg()
+    SS = ns.layers.ShapeSpec
+    Boxes, Instances = ns.boxes.Boxes, ns.instances.Instances
+    shape = {k: SS(channels=128, stride=st) for k, st in (("p3", 8), ("p4", 16), ("p5", 32))}
+    rh = ns.roi_heads.CustomCascadeROIHeads(cfg, shape)
+    sd = R.synth_roi_state(sd0, SEED)
+    rh.load_state_dict(sub_sd(sd, "roi_heads."), strict=True)
+    g = torch.Generator().manual_seed(77)
+    H, W = 160, 192
+    feats = {f"p{l}": torch.randn(1, 128, H >> l, W >> l, generator=g) for l in (3, 4, 5)}
+    sup8 = torch.randn(3, 128, 8, 8, generator=g) * 0.5
+    sup4 = torch.randn(3, 128, 4, 4, generator=g) * 0.5
+    n = 72                                                          # sizes 6..600 px: all three pyramid levels, many outside the image
+    wh = torch.exp(torch.rand(n, 1, generator=g) * 4.6 + 1.8) * torch.exp(torch.randn(n, 2, generator=g) * 0.25)
+    ctr = torch.rand(n, 2, generator=g) * torch.tensor([W + 20.0, H + 20.0]) - 10.0
+    pb = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    pb[:8] = pb[8:16] + torch.randn(8, 4, generator=g) * 1.5        # near-duplicates: the 0.9 NMS has something to suppress
+    ps = torch.rand(n, generator=g)
+    cap = {}
+    rh.box_pooler.register_forward_hook(lambda m, i, o: cap.__setitem__("box_features", o.detach().clone()))
+    rh.box_head[0].register_forward_hook(lambda m, i, o: cap.__setitem__("h", o.detach().clone()))
+    rh.box_predictor[0].register_forward_hook(lambda m, i, o: cap.__setitem__("pred", (o[0].detach().clone(), o[1].detach().clone())))
+    # ---- eval
+    rh.eval()
+    prop = Instances((H, W))
+    prop.proposal_boxes, prop.objectness_logits = Boxes(pb.clone()), ps.clone()
+    prop.scores, prop.pred_classes = ps.clone(), torch.zeros(n, dtype=torch.int64)       # as CenterNet.inference leaves them
+    with torch.no_grad():
+        pred, _ = rh(None, feats, [sup8, sup4], [prop])
+    pi = pred[0]
+    sub = torch.tensor([0, 5, 17, 33, 41, 58, 71])                  # a few pooled ROIs in full (all levels), the rest through h
+    save("roi_stage_eval", seed=np.int64(SEED), **{k: np_(v) for k, v in feats.items()}, sup8=np_(sup8), sup4=np_(sup4),
+         proposals=np_(pb), proposal_scores=np_(ps), image_hw=np.array([H, W]), sub=np_(sub), box_features_sub=np_(cap["box_features"][sub]),
+         h=np_(cap["h"]), cls_logits=np_(cap["pred"][0]), deltas=np_(cap["pred"][1]),
+         pred_boxes=np_(pi.pred_boxes.tensor), scores=np_(pi.scores), pred_classes=np_(pi.pred_classes))
+    # ---- train: label_and_sample_proposals (d2z:modeling/roi_heads/roi_heads.py:181-295) + the two second-stage losses
+    rh.train()
+    n_g = 7
+    gwh = torch.rand(n_g, 2, generator=g) * 60 + 20
+    gctr = torch.rand(n_g, 2, generator=g) * (torch.tensor([float(W), float(H)]) - gwh) + gwh / 2
+    gtb = torch.cat([gctr - gwh / 2, gctr + gwh / 2], 1)
+    tp = torch.cat([gtb[torch.randint(0, n_g, (150,), generator=g)] + torch.randn(150, 4, generator=g) * 3.0, pb], 0)
+    tp[:, 2:] = torch.max(tp[:, 2:], tp[:, :2] + 2.0)
+    prop = Instances((H, W))
+    prop.proposal_boxes, prop.objectness_logits = Boxes(tp.clone()), torch.rand(len(tp), generator=g)
+    tgt = Instances((H, W))
+    tgt.gt_boxes, tgt.gt_classes = Boxes(gtb.clone()), torch.zeros(n_g, dtype=torch.int64)
+    for pth in rh.parameters():
+        pth.grad = None
+    fl = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    torch.manual_seed(31)                                            # seeds subsample_labels' two randperm calls
+    sampled, losses = rh(None, fl, [sup8, sup4], [prop], [tgt])
+    (losses["loss_cls_stage0"] + losses["loss_box_reg_stage0"]).backward()
+    sp = sampled[0]
+    named = dict(rh.named_parameters())
+    save("roi_stage_train", seed=np.int64(SEED), randperm_seed=np.int64(31), proposals=np_(tp), gt=np_(gtb),
+         roi_boxes=np_(sp.proposal_boxes.tensor), roi_labels=np_(sp.gt_classes), roi_gt=np_(sp.gt_boxes.tensor),
+         loss_cls=np_(losses["loss_cls_stage0"]), loss_box_reg=np_(losses["loss_box_reg_stage0"]),
+         cls_logits=np_(cap["pred"][0]), deltas=np_(cap["pred"][1]),
+         g_cls_w=np_(named["box_predictor.0.cls_score.weight"].grad), g_box_w=np_(named["box_predictor.0.bbox_pred.weight"].grad),
+         g_fc1_b=np_(named["box_head.0.fc1.bias"].grad), g_conv3_w=np_(named["conv3.weight"].grad),
+         g_conv1_b=np_(named["conv1.bias"].grad), **{f"g_{k}_sum": np_(v.grad.sum((0, 2, 3))) for k, v in fl.items() if v.grad is not None},
+         dead=np.array([k for k, v in named.items() if v.grad is None]))
+
+
+def grad_sample(t):
+    """Fixed strided sample (<= 1024 values) of a gradient + its (l2, max|.|): what the fixtures keep of a large tensor."""
+    f = t.detach().reshape(-1)
+    return f[:: max(1, f.numel() // 1024)][:1024].clone(), torch.stack([f.double().norm().float(), f.abs().max()])
+
+
+def gen_train_iteration(sd0):
+    """The reference's COMPLETE training forward (ref:fewx/modeling/fsod/fsod_cen.py:151-308: two backbone passes, support pooling,
+    SM blocks, correlation, CenterNet losses + train-mode proposals, label/sample, second stage) + backward, executed on the seeded
+    synthetic sample of oracle.ref_train.synth_train_inputs.  Dropout(0.1) of SM_Block.reweighting is set to p = 0 (the one knob
+    turned: it is stochastic); subsample_labels' randperm is seeded by a forward-pre-hook on roi_heads."""
+    from oracle import ref_train as T
+    for tag, shots, hw, n_gt, shw, in_seed, rp_seed in (("small", 4, (320, 384), 9, 112, 0, 11), ("full", 24, (640, 640), 17, 240, 4, 21)):
+        sd = R.synth_roi_state(sd0, SEED)
+        sd["roi_heads.box_head.0.fc1.weight"] = sd["roi_heads.box_head.0.fc1.weight"] * 0.02
+        sd["proposal_generator.centernet_head.agn_hm.bias"] = torch.full((1,), -2.0)
+        det, cfg, ns = reference_detector(sd, shots)
+        Boxes, Instances = ns.boxes.Boxes, ns.instances.Instances
+        det.train()
+        for m in det.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        img, gt, sup, sbox = T.synth_train_inputs(in_seed, hw, n_gt=n_gt, shots=shots, support_hw=shw)
+        inst = Instances(hw)
+        inst.gt_boxes, inst.gt_classes = Boxes(gt.clone()), torch.zeros(len(gt), dtype=torch.int64)
+        cap = {}
+        det.roi_heads.register_forward_pre_hook(lambda m, a: (torch.manual_seed(rp_seed), cap.__setitem__("proposals", a[3][0]))[0] and None)
+        orig = det.roi_heads.label_and_sample_proposals
+
+        def spy(proposals, targets):
+            out = orig(proposals, targets)
+            cap["sampled"] = out[0]
+            return out
+        det.roi_heads.label_and_sample_proposals = spy
+        cap_t = {}
+        og = det.proposal_generator._get_ground_truth
+
+        def spy_gt(*a, **k):
+            out = og(*a, **k)
+            cap_t["pos_inds"] = out[0].clone()
+            return out
+        det.proposal_generator._get_ground_truth = spy_gt
+        torch.set_num_threads(8)
+        losses = det([{"image": img.float(), "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}])
+        sum(losses.values()).backward()
+        out = {f"loss/{k}": np_(v) for k, v in losses.items()}
+        dead = []
+        for k, p_ in det.named_parameters():
+            if not T.is_trainable(k):
+                continue
+            if p_.grad is None:
+                dead.append(k)
+                continue
+            smp, nrm = grad_sample(p_.grad)
+            out["gs/" + k], out["gn/" + k] = np_(smp), np_(nrm)
+        sp = cap["sampled"]
+        pr = cap["proposals"]
+        # conditioning of this sample: the SAME reference code in fp64 on the same sampled ROIs; gc/<name> = max|g32 - g64| / max|g64|
+        # over the stored sample.  Hard decisions (ReLU masks, min/max picks, the 1e-4 heat-map cut) flip between precisions, so this is
+        # the spread any two correct fp32 implementations may show on that parameter; the GPU tests bound each parameter with it.
+        det64, _, _ = reference_detector(sd, shots)
+        det64.train().double()
+        for m in det64.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        sp64 = Instances(hw)
+        sp64.proposal_boxes, sp64.gt_boxes = Boxes(sp.proposal_boxes.tensor.double()), Boxes(sp.gt_boxes.tensor.double())
+        sp64.gt_classes, sp64.objectness_logits = sp.gt_classes.clone(), sp.objectness_logits.double()
+        det64.roi_heads.label_and_sample_proposals = lambda proposals, targets: [sp64]
+        inst64 = Instances(hw)
+        inst64.gt_boxes, inst64.gt_classes = Boxes(gt.double()), torch.zeros(len(gt), dtype=torch.int64)
+        l64 = det64([{"image": img.double(), "instances": inst64, "support_images": sup.double(), "support_bboxes": sbox.double().numpy()}])
+        sum(l64.values()).backward()
+        for k, p_ in det64.named_parameters():
+            if "gs/" + k in out:
+                s64, n64 = grad_sample(p_.grad)
+                out["gc/" + k] = np.float32(np.abs(out["gs/" + k].astype(np.float64) - np_(s64)).max() / max(float(n64[1]), 1e-30))
+        out.update({f"loss64/{k}": np_(v) for k, v in l64.items()})
+        save(f"train_iter_ref_{tag}", seed=np.int64(SEED), input_seed=np.int64(in_seed), randperm_seed=np.int64(rp_seed), shots=np.int64(shots),
+             hw=np.array(hw), n_gt=np.int64(n_gt), support_hw=np.int64(shw), proposals=np_(pr.proposal_boxes.tensor),
+             proposal_scores=np_(pr.objectness_logits), pos_inds=np_(cap_t["pos_inds"]), roi_boxes=np_(sp.proposal_boxes.tensor),
+             roi_labels=np_(sp.gt_classes), roi_gt=np_(sp.gt_boxes.tensor), dead=np.array(dead), **out)
+
+
+def gen_state_dict_layout():
+    """Key -> shape of the reference detector's state_dict, from the executed reference modules."""
+    det, cfg, ns = reference_detector(R.synth_roi_state(R.synth_state_dict(SEED), SEED), 24)
+    keys = list(det.state_dict().keys())
+    shapes = [",".join(str(int(d)) for d in v.shape) for v in det.state_dict().values()]
+    params = {k for k, _ in det.named_parameters()}
+    save("state_dict_layout", keys=np.array(keys), shapes=np.array(shapes), is_param=np.array([k in params for k in keys]),
+         n_params=np.int64(sum(p.numel() for p in det.parameters())))
+
+
+def gen_demo_images():
+    """BASELINE configs[0]'s inputs: ref:directory/0000{0,1}.png (the reference's only shipped images; 300x300 RGB), decoded and
+    resized as the reference's predictor does (ref:predictor.py: read BGR, ResizeShortestEdge(MIN_SIZE_TEST = 320) = PIL bilinear,
+    `log:805`), stored as uint8 BGR CHW.  Data only; the R-50-C4 model of that config is out of scope, the VoVNet path
+    runs on these inputs instead."""
+    from PIL import Image
+    out = []
+    for n in ("00000", "00001"):
+        rgb = np.asarray(Image.open(os.path.join(shims.REF, "directory", n + ".png")).convert("RGB"))
+        bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+        h, w = bgr.shape[:2]
+        scale = 320.0 / min(h, w)
+        nh, nw = int(h * scale + 0.5), int(w * scale + 0.5)
+        res = np.asarray(Image.fromarray(bgr).resize((nw, nh), Image.BILINEAR))
+        out.append(np.ascontiguousarray(res.transpose(2, 0, 1)))
+    save("demo_images_320", images=np.stack(out), orig_hw=np.array([300, 300]))
 
 
 if __name__ == "__main__":

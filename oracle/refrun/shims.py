@@ -83,11 +83,35 @@ class _Registry(dict):
         return self[name]
 
 
+def _is_cfg(x):
+    return hasattr(x, "MODEL") and not isinstance(x, torch.nn.Module)
+
+
 def _configurable(init_func=None, *, from_config=None):
-    # explicit-kwargs pass-through: we never construct the reference modules from a cfg
-    if init_func is not None:
-        return init_func
-    return lambda f: f
+    """Our own stand-in for detectron2.config.configurable (d2z:config/config.py needs fvcore/yacs): an ``__init__`` called
+    with a cfg as first argument (or ``cfg=``) gets its explicit arguments from the class's ``from_config``; explicit keyword
+    arguments override; a call with explicit arguments passes straight through."""
+    import functools
+
+    if init_func is None:
+        return lambda f: f
+
+    @functools.wraps(init_func)
+    def wrapped(self, *args, **kwargs):
+        if (args and _is_cfg(args[0])) or _is_cfg(kwargs.get("cfg")):
+            import inspect
+            fc = type(self).from_config
+            params = inspect.signature(fc).parameters
+            if any(p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD) for p in params.values()):
+                explicit = fc(*args, **kwargs)
+            else:                                   # keyword arguments from_config does not know override its result
+                extra = {k: kwargs.pop(k) for k in list(kwargs) if k not in params}
+                explicit = fc(*args, **kwargs)
+                explicit.update(extra)
+            init_func(self, **explicit)
+        else:
+            init_func(self, *args, **kwargs)
+    return wrapped
 
 
 _LOADED = {}
@@ -240,3 +264,103 @@ def vovnet_cfg(body="V-19-slim-eSE", fpn_ch=128):
         BACKBONE=NS(FREEZE_AT=3),
         FPN=NS(IN_FEATURES=["stage3", "stage4", "stage5"], OUT_CHANNELS=fpn_ch, NORM="", FUSE_TYPE="sum"),
         FCOS=NS(TOP_LEVELS=0)))
+
+
+class AttrDict(dict):
+    """yaml mapping with attribute access (stands in for a CfgNode holding the reference's logged, resolved config)."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def logged_cfg():
+    """The reference's own resolved config (`ref:log/fsod_finetune_stone_vovnet_25_test_log.txt:117-544`, kept as data under
+    tests/golden/) as an attribute tree, so reference classes are built by their own ``from_config``."""
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+    def wrap(x):
+        if isinstance(x, dict):
+            return AttrDict({k: wrap(v) for k, v in x.items()})
+        if isinstance(x, list):
+            return [wrap(v) for v in x]
+        return x
+    with open(os.path.join(root, "tests", "golden", "vovnet_25shot_full_config.yaml")) as f:
+        return wrap(yaml.safe_load(f))
+
+
+class _Storage:
+    """EventStorage stand-in: the second-stage code logs scalars while computing the losses."""
+    def put_scalar(self, *a, **k):
+        pass
+
+    def name_scope(self, name):
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def load_roi_heads():
+    """Load the second stage unmodified: d2z:modeling/{poolers,matcher,sampling,box_regression}.py,
+    d2z:modeling/proposal_generator/proposal_utils.py, d2z:modeling/roi_heads/{box_head,fast_rcnn,roi_heads,cascade_rcnn}.py,
+    d2z:layers/roi_align.py, ref:CenterNet2/centernet/modeling/roi_heads/{fed_loss,custom_fast_rcnn}.py and
+    ref:fewx/modeling/fsod/{fsod_fast_rcnn,fsod_roi_heads}.py.  Non-reference arithmetic in the chain (un-vendored third
+    parties): torchvision.ops.roi_align and batched_nms (restated: oracle.ref_model.roi_align, oracle.decode.nms) and
+    fvcore.nn.smooth_l1_loss (restated below from its published definition)."""
+    ns = setup()
+    if "roi_heads" in _LOADED:
+        return types.SimpleNamespace(**_LOADED)
+    from oracle import ref_model as R
+    D2 = d2_root()
+
+    def smooth_l1_loss(input, target, beta, reduction="none"):
+        # fvcore.nn.smooth_l1_loss: beta < 1e-5 -> plain L1; else 0.5 n^2 / beta below beta, n - 0.5 beta above
+        n = torch.abs(input - target)
+        loss = n if beta < 1e-5 else torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+        return loss.mean() if reduction == "mean" else loss.sum() if reduction == "sum" else loss
+
+    sys.modules["fvcore.nn"].smooth_l1_loss = smooth_l1_loss
+
+    def roi_align(input, rois, output_size, spatial_scale, sampling_ratio, aligned):
+        assert aligned and sampling_ratio == 0
+        ps = output_size[0] if isinstance(output_size, (tuple, list)) else output_size
+        out = input.new_zeros(len(rois), input.shape[1], ps, ps)
+        for n in range(input.shape[0]):
+            idx = torch.nonzero(rois[:, 0] == n).squeeze(1)
+            if len(idx):
+                out[idx] = R.roi_align(input[n], rois[idx, 1:], spatial_scale, ps)
+        return out
+
+    mod("torchvision", __version__="0.8.2")
+    mod("torchvision.ops", RoIPool=None, roi_align=roi_align)
+    sys.modules["torchvision"].ops = sys.modules["torchvision.ops"]
+    mod("turtle", shape=None)
+    L = sys.modules["detectron2.layers"]
+    ra = load("detectron2.layers.roi_align", D2 + "/layers/roi_align.py")
+    L.ROIAlign, L.ROIAlignRotated = ra.ROIAlign, None
+    sys.modules["detectron2.utils.events"].get_event_storage = lambda: _Storage()
+    M = D2 + "/modeling/"
+    br = load("detectron2.modeling.box_regression", M + "box_regression.py")
+    mt = load("detectron2.modeling.matcher", M + "matcher.py")
+    sp = load("detectron2.modeling.sampling", M + "sampling.py")
+    pl = load("detectron2.modeling.poolers", M + "poolers.py")
+    pu = load("detectron2.modeling.proposal_generator.proposal_utils", M + "proposal_generator/proposal_utils.py")
+    res = sys.modules["detectron2.modeling.backbone.resnet"]
+    res.BottleneckBlock = res.ResNet = res.make_stage = None
+    pkg("detectron2.modeling.roi_heads", M + "roi_heads")
+    mod("detectron2.modeling.roi_heads.keypoint_head", build_keypoint_head=None)
+    mod("detectron2.modeling.roi_heads.mask_head", build_mask_head=None)
+    bh = load("detectron2.modeling.roi_heads.box_head", M + "roi_heads/box_head.py")
+    fr = load("detectron2.modeling.roi_heads.fast_rcnn", M + "roi_heads/fast_rcnn.py")
+    rh = load("detectron2.modeling.roi_heads.roi_heads", M + "roi_heads/roi_heads.py")
+    cr = load("detectron2.modeling.roi_heads.cascade_rcnn", M + "roi_heads/cascade_rcnn.py")
+    C2 = REF + "/CenterNet2/centernet/modeling/roi_heads"
+    pkg("CenterNet2.centernet.modeling.roi_heads", C2)
+    load("CenterNet2.centernet.modeling.roi_heads.fed_loss", C2 + "/fed_loss.py")
+    cf = load("CenterNet2.centernet.modeling.roi_heads.custom_fast_rcnn", C2 + "/custom_fast_rcnn.py")
+    load("fewx.modeling.fsod.fsod_fast_rcnn", REF + "/fewx/modeling/fsod/fsod_fast_rcnn.py")
+    fro = load("fewx.modeling.fsod.fsod_roi_heads", REF + "/fewx/modeling/fsod/fsod_roi_heads.py")
+    _LOADED.update(roi_heads=fro, d2_roi_heads=rh, cascade_rcnn=cr, fast_rcnn=fr, custom_fast_rcnn=cf, box_head=bh, poolers=pl,
+                   matcher=mt, sampling=sp, box_regression=br, proposal_utils=pu)
+    return types.SimpleNamespace(**_LOADED)

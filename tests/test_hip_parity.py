@@ -343,6 +343,39 @@ def test_engine_eval_640_vs_oracle(engine, sd, use_graph):
     assert len(want["keep"]) > 0
 
 
+def test_engine_on_reference_demo_images(ore, sd, golden):
+    """BASELINE configs[0]'s inputs (ref:directory/0000{0,1}.png resized to 320x320 as the reference's predictor does; the R-50-C4
+    model of that config is out of scope per SURVEY 2, so the VoVNet path stands in): the whole first stage on real ore images
+    against the oracle at 1e-4, the detection tail bit-exact on the engine's own head outputs."""
+    g = golden("demo_images_320")
+    e = ore.Engine(max_batch=1, max_h=320, max_w=320)
+    e.load_state_dict(sd)
+    e.set_support(R.synth_support(0))
+    e.finalize()
+    for i in range(2):
+        img = torch.from_numpy(g["images"][i])
+        assert img.dtype == torch.uint8 and tuple(img.shape) == (3, 320, 320)
+        ref = R.eval_dense(img, sd, R.synth_support(0))
+        e.eval_forward(img.cuda(), use_graph=bool(i))
+        e.eval_forward(img.cuda(), use_graph=bool(i))
+        torch.cuda.synchronize()
+        hms, regs = [], []
+        for l, k in enumerate(("p3", "p4", "p5")):
+            s = 320 >> (l + 3)
+            assert rel_err(e.buffer(k, (1, s, s)).cpu().numpy(), ref["features"][k].numpy()) < TOL, k
+            hd = e.buffer(f"head{l + 3}", (1, s, s)).cpu()
+            assert rel_err(hd[:, :4].numpy(), ref["reg"][l].numpy()) < TOL
+            assert rel_err(hd[:, 4:5].numpy(), ref["hm"][l].numpy()) < TOL
+            raw = e.buffer(f"head{l + 3}").cpu().numpy().reshape(s, s, 5)
+            hms.append(np.ascontiguousarray(raw[..., 4]))
+            regs.append(np.ascontiguousarray(raw[..., :4]))
+        want = odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+        boxes, scores, keep = e.proposals()
+        assert np.array_equal(keep.cpu().numpy(), want["keep"]) and np.array_equal(boxes.cpu().numpy(), want["boxes"])
+        assert np.array_equal(scores.cpu().numpy(), want["scores"])
+    e.close()
+
+
 def test_engine_eval_non_divisible_size(engine, sd):
     img = R.synth_image(1, 300, 420)  # padded to 320x448 inside stem_1
     ref = R.eval_dense(img, sd, R.synth_support(0))
@@ -468,6 +501,52 @@ def test_roi_stage_vs_oracle(ore):
     assert np.array_equal(det["src"][:k].cpu().numpy(), want["src"])
     # and close to the all-oracle result (its h differs by float rounding)
     np.testing.assert_allclose(det["scores"][:k].cpu().numpy(), ref["scores"], rtol=1e-3, atol=1e-5)
+
+
+def test_roi_stage_vs_reference_run(ore, golden):
+    """f1 pinned by the EXECUTED reference (tests/golden/roi_stage_eval.npz: CustomCascadeROIHeads._forward_box/_run_stage,
+    CustomFastRCNNOutputLayers.predict_probs, FastRCNNOutputLayers.predict_boxes, fast_rcnn_inference): pooled features, fc1
+    output, final detections.  MULT_PROPOSAL_SCORE is not applied (the shadowed `_forward_box`)."""
+    g = golden("roi_stage_eval")
+    sd = R.synth_roi_state(R.synth_state_dict(0), 0)
+    feats = [torch.from_numpy(g[k]) for k in ("p3", "p4", "p5")]
+    props, sup = torch.from_numpy(g["proposals"]), torch.from_numpy(g["sup8"])
+    hw = tuple(int(v) for v in g["image_hw"])
+    x = ore.roi_align([nhwc(f) for f in feats], props.cuda(), (8, 16, 32), 8)
+    got = x.view(len(props), 64, 128).permute(0, 2, 1).reshape(len(props), 128, 8, 8).cpu()
+    assert rel_err(got[g["sub"]].numpy(), g["box_features_sub"]) < 1e-5
+    Wp, bp = ore.compose_roi_head(sd, sup)
+    h = ore.conv2d(x.view(1, 1, *x.shape), Wp.cuda(), 128, 1, shift=bp.cuda(), relu_cout=128).view(len(props), 128)
+    assert rel_err(h.cpu().numpy(), g["h"]) < TOL
+    p = "roi_heads.box_predictor.0."
+    det = ore.roi_predict(h, dev(sd[p + "cls_score.weight"]), dev(sd[p + "cls_score.bias"]), dev(sd[p + "bbox_pred.weight"]),
+                          dev(sd[p + "bbox_pred.bias"]), props.cuda(), (10.0, 10.0, 5.0, 5.0), hw, 0.0, 0.9, 100)
+    k = int(det["count"].item())
+    assert k == len(g["scores"])
+    np.testing.assert_allclose(det["scores"][:k].cpu().numpy(), g["scores"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(det["boxes"][:k].cpu().numpy(), g["pred_boxes"], rtol=1e-4, atol=2e-2)
+
+
+def test_roi_heads_module_vs_reference_run(model, golden):
+    """The same fixture through the product's registered module, called with the reference's protocol
+    `roi_heads(images, features, [rcnn_8, rcnn_4], proposals, targets)` (fsod_roi_heads.py:368-402)."""
+    from detectron2.structures import Boxes, ImageList, Instances
+    g = golden("roi_stage_eval")
+    sd = R.synth_roi_state(R.synth_state_dict(0), 0)
+    model.load_state_dict({k: v for k, v in sd.items() if k.startswith("roi_heads.")}, strict=False)
+    model.eval()
+    hw = tuple(int(v) for v in g["image_hw"])
+    prop = Instances(hw)
+    prop.proposal_boxes = Boxes(torch.from_numpy(g["proposals"]).cuda())
+    prop.objectness_logits = torch.from_numpy(g["proposal_scores"]).cuda()
+    feats = {k: torch.from_numpy(g[k]).cuda() for k in ("p3", "p4", "p5")}
+    res, _ = model.roi_heads(ImageList(torch.empty(0), [hw]), feats, [torch.from_numpy(g["sup8"]).cuda(), torch.from_numpy(g["sup4"]).cuda()],
+                             [prop], None)
+    r = res[0]
+    assert len(r) == len(g["scores"]) and r.image_size == hw
+    np.testing.assert_allclose(r.scores.cpu().numpy(), g["scores"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(r.pred_boxes.tensor.cpu().numpy(), g["pred_boxes"], rtol=1e-4, atol=2e-2)
+    assert r.pred_classes.dtype == torch.int64 and int(r.pred_classes.abs().sum()) == 0
 
 
 def test_detector_end_to_end(model, sd):

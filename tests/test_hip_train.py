@@ -744,6 +744,96 @@ def test_train_iteration_full_size_vs_oracle(oh):
     assert len(errs) == 73 and errs[len(errs) // 2] <= 2e-4 and errs[-1] <= 5e-2, (errs[len(errs) // 2], errs[-3:])
 
 
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_train_iteration_vs_reference_run(oh, golden, tag):
+    """The product's training forward + backward against the EXECUTED reference (tests/golden/train_iter_ref_*.npz =
+    ref:fewx/modeling/fsod/fsod_cen.py:151-308 run end to end, built by the reference's own __init__ from its logged config):
+    `small` = the 5-shot configuration (SUPPORT_SHOT 4) on a 320x384 query, `full` = BASELINE configs[2]'s per-image shape
+    (640x640, 24 support crops of 240x240).  Five losses, positive indices, train-mode proposals, and every parameter gradient with
+    a PER-PARAMETER bound: gc/<name> in the fixture is the spread of the reference's own gradient between its fp32 and fp64 runs
+    on this sample (hard decisions flip between precisions), i.e. what two correct fp32 implementations may differ by."""
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod.train_forward import train_forward
+    from oracle import ref_train as T
+    g = golden(f"train_iter_ref_{tag}")
+    shots, hw = int(g["shots"]), tuple(int(v) for v in g["hw"])
+    m, sd, cfg = _train_model(shots)
+    img, gt, sup, sbox = T.synth_train_inputs(int(g["input_seed"]), hw, n_gt=int(g["n_gt"]), shots=shots, support_hw=int(g["support_hw"]))
+    inst = Instances(hw)
+    inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+    item = {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+    over = {"boxes": torch.from_numpy(g["roi_boxes"]), "labels": torch.from_numpy(g["roi_labels"]), "gt": torch.from_numpy(g["roi_gt"])}
+    losses, aux = train_forward(m, [item], return_aux=True, roi_override=over)
+    n = len(g["pos_inds"])
+    assert int(aux["pos_count"].item()) == n and np.array_equal(aux["pos_inds"][:n].cpu().numpy(), g["pos_inds"])
+    pb, rb = aux["proposals"].cpu(), torch.from_numpy(g["proposals"])
+    assert abs(len(pb) - len(rb)) <= 2, (len(pb), len(rb))
+    d = (pb[:, None, :] - rb[None, :, :]).abs().amax(2).min(1)[0]       # order may swap on 1-ulp score ties: compare as sets
+    assert float((d < 1e-2).float().mean()) >= 0.99, float((d < 1e-2).float().mean())
+    for k in ("loss_cls_stage0", "loss_box_reg_stage0", "loss_centernet_loc", "loss_centernet_agn_pos", "loss_centernet_agn_neg"):
+        want = float(g["loss/" + k])
+        assert abs(float(losses[k].detach()) - want) <= 1e-4 * max(abs(want), 1e-3), (k, float(losses[k]), want)
+    sum(losses.values()).backward()
+    named = dict(m.named_parameters())
+    report, n_checked = [], 0
+    for key in g:
+        if not key.startswith("gs/"):
+            continue
+        k = key[3:]
+        f = named[k].grad.reshape(-1)
+        smp = f[:: max(1, f.numel() // 1024)][:1024].cpu().numpy()
+        err = float(np.abs(smp - g[key]).max()) / max(float(g["gn/" + k][1]), 1e-30)
+        bound = max(1e-4, 8.0 * float(g["gc/" + k]))
+        report.append((err / bound, err, bound, k))
+        n_checked += 1
+    report.sort()
+    print("gradient error / bound (worst):", [(round(a, 3), f"{b:.2e}", f"{c:.2e}", d) for a, b, c, d in report[-6:]])
+    assert n_checked == 73
+    assert report[-1][0] <= 1.0, report[-4:]
+    assert sorted(e[1] for e in report)[n_checked // 2] <= 2e-5
+    for k in g["dead"]:
+        p = named[str(k)]
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+
+
+def test_train_forward_bs16_full_size(oh):
+    """BASELINE configs[2] at its stated batch: 16 query images of 640x640 with 24 support crops each through ONE train_forward call.
+    The five losses equal the mean of the 16 single-image calls (the documented bs > 1 semantics), every gradient
+    is finite, and the flat gradient bucket has the size DESIGN 5 states (4,086,478 parameters with a gradient -> 16,365,568 bytes
+    in 256-float chunks)."""
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod.train_forward import train_forward
+    from fewx.solver.build import get_bucket
+    from oracle import ref_train as T
+    shots, B = 24, 16
+    m, sd, cfg = _train_model(shots)
+    items = []
+    for b in range(B):
+        img, gt, sup, sbox = T.synth_train_inputs(40 + b, (640, 640), n_gt=15 + b % 6, shots=shots, support_hw=240)
+        inst = Instances((640, 640))
+        inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+        items.append({"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()})
+    torch.manual_seed(5)
+    losses, aux = train_forward(m, items, return_aux=True)
+    singles = []
+    for b in range(B):                                                   # each image alone, on the ROIs the batched call sampled for it
+        over = {"boxes": aux["roi_boxes"][b], "labels": aux["roi_labels"][b], "gt": aux["roi_gt"][b]}
+        l1, _ = train_forward(m, [items[b]], return_aux=True, roi_override=over)
+        singles.append({k: float(v.detach()) for k, v in l1.items()})
+    for k, v in losses.items():
+        want = sum(s[k] for s in singles) / B
+        assert abs(float(v.detach()) - want) <= 2e-4 * max(abs(want), 1e-3), (k, float(v), want)
+    sum(losses.values()).backward()
+    n_grad = 0
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert bool(torch.isfinite(p.grad).all()), k
+            n_grad += p.numel()
+    assert n_grad == 4086478
+    bucket = get_bucket(m, cfg)
+    assert bucket.grads.numel() * 4 == 16365568, bucket.grads.numel() * 4
+
+
 def test_module_level_training_forwards(oh):
     """detectron2.layers.Conv2d and CenterNetHead follow the reference call protocol in training mode too (NCHW in/out, autograd)."""
     import torch.nn.functional as F

@@ -158,3 +158,132 @@ def test_roi_train_pieces_match_reference_run(golden):
     np.testing.assert_array_equal(fg.numpy(), g["fg_rows"])
     d = T.get_deltas(allb[fg], gt[matched[fg]])
     np.testing.assert_allclose(d.numpy(), g["deltas"], rtol=1e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# f1  second stage: the reference's CustomCascadeROIHeads / CustomFastRCNNOutputLayers / fast_rcnn_inference EXECUTED
+#     (oracle/refrun/gen_golden.py::gen_roi_stage; roi_align / batched_nms / smooth_l1 = the restated un-vendored third parties)
+# ----------------------------------------------------------------------------------------------------------------------------
+def _roi_sd():
+    return R.synth_roi_state(R.synth_state_dict(0), 0)
+
+
+def test_roi_stage_eval_matches_reference_run(golden):
+    """ROIPooler level assignment + ROIAlign, the DSA mix + fc1 (`_run_stage`, fsod_roi_heads.py:459-520), predictor, softmax,
+    apply_deltas, clip, score > 0, NMS 0.9, top-100 (`_forward_box` :404-457, custom_fast_rcnn.py:159-170, d2z fast_rcnn.py:118-171)."""
+    g = golden("roi_stage_eval")
+    sd = _roi_sd()
+    feats = [T(g[k]) for k in ("p3", "p4", "p5")]
+    props = T(g["proposals"])
+    x = R.roi_pool_levels(feats, props, 8)
+    sub = g["sub"]
+    assert rel_err(x[sub].numpy(), g["box_features_sub"]) < 1e-6
+    h = R.roi_head_features(x, T(g["sup8"]), sd)
+    assert rel_err(h.numpy(), g["h"]) < 1e-5
+    p = "roi_heads.box_predictor.0."
+    logits = torch.nn.functional.linear(h, sd[p + "cls_score.weight"], sd[p + "cls_score.bias"])
+    deltas = torch.nn.functional.linear(h, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"])
+    assert rel_err(logits.numpy(), g["cls_logits"]) < 1e-5 and rel_err(deltas.numpy(), g["deltas"]) < 1e-5
+    det = R.roi_head_eval(feats, props, T(g["sup8"]), sd, tuple(int(v) for v in g["image_hw"]))
+    # MULT_PROPOSAL_SCORE is True in the config and still NOT applied: the second `_forward_box` shadows the first (SURVEY 8f.1)
+    assert len(det["scores"]) == len(g["scores"])
+    np.testing.assert_allclose(det["scores"], g["scores"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(det["boxes"], g["pred_boxes"], rtol=1e-5, atol=2e-3)
+    assert (g["pred_classes"] == 0).all()
+    assert np.all(np.diff(det["scores"]) <= 0)
+
+
+def test_roi_stage_train_matches_reference_run(golden):
+    """label_and_sample_proposals (d2z roi_heads.py:181-295) + the two second-stage losses and their gradients."""
+    from oracle import ref_train as RT
+    g = golden("roi_stage_train")
+    sd = {k: (v.clone().requires_grad_(True) if k.startswith("roi_heads.") else v) for k, v in _roi_sd().items()}
+    ge = golden("roi_stage_eval")
+    feats = [T(ge[k]).clone().requires_grad_(True) for k in ("p3", "p4", "p5")]
+    gt = T(g["gt"])
+    boxes, matched, labels = RT.label_proposals(T(g["proposals"]), gt, 0.6)
+    torch.manual_seed(int(g["randperm_seed"]))
+    sampled = RT.sample_labels(labels, 128, 0.5, lambda n: torch.randperm(n))
+    np.testing.assert_array_equal(boxes[sampled].numpy(), g["roi_boxes"])
+    np.testing.assert_array_equal(labels[sampled].numpy(), g["roi_labels"])
+    fg = labels[sampled] == 0
+    np.testing.assert_array_equal(gt[matched[sampled]][fg].numpy(), g["roi_gt"][fg.numpy()])
+    st = RT.second_stage_losses(feats, boxes[sampled], labels[sampled], gt[matched[sampled]], T(ge["sup8"]), sd)
+    assert rel_err(st["scores"].detach().numpy(), g["cls_logits"]) < 1e-5 and rel_err(st["deltas"].detach().numpy(), g["deltas"]) < 1e-5
+    assert abs(float(st["loss_cls"].detach()) - float(g["loss_cls"])) <= 2e-6 * float(g["loss_cls"])
+    assert abs(float(st["loss_box_reg"].detach()) - float(g["loss_box_reg"])) <= 2e-6 * float(g["loss_box_reg"])
+    (st["loss_cls"] + st["loss_box_reg"]).backward()
+    p = "roi_heads."
+    for key, name in (("g_cls_w", "box_predictor.0.cls_score.weight"), ("g_box_w", "box_predictor.0.bbox_pred.weight"),
+                      ("g_fc1_b", "box_head.0.fc1.bias"), ("g_conv3_w", "conv3.weight"), ("g_conv1_b", "conv1.bias")):
+        assert rel_err(sd[p + name].grad.numpy(), g[key]) < 2e-5, name
+    for l, k in enumerate(("p3", "p4", "p5")):
+        assert rel_err(feats[l].grad.sum((0, 2, 3)).numpy(), g[f"g_{k}_sum"]) < 2e-5, k
+    assert sorted(g["dead"]) == sorted(k[len(p):] for k, v in sd.items() if k.startswith(p) and v.grad is None)
+
+
+def _ref_train_setup(g):
+    from oracle import ref_train as RT
+    sd = _roi_sd()
+    sd["roi_heads.box_head.0.fc1.weight"] = sd["roi_heads.box_head.0.fc1.weight"] * 0.02
+    sd["proposal_generator.centernet_head.agn_hm.bias"] = torch.full((1,), -2.0)
+    inputs = RT.synth_train_inputs(int(g["input_seed"]), tuple(int(v) for v in g["hw"]), n_gt=int(g["n_gt"]), shots=int(g["shots"]),
+                                   support_hw=int(g["support_hw"]))
+    return sd, inputs
+
+
+def test_train_iteration_matches_reference_run(golden):
+    """The COMPOSITION: oracle.ref_train.train_iteration against the reference's complete CenterNet2Detector.forward (training
+    branch, fsod_cen.py:151-308) + backward, executed at the 5-shot (SUPPORT_SHOT 4) configuration on a 320x384 query.
+    Five losses, positive indices, train-mode proposals, the sampled ROIs and every parameter gradient."""
+    from oracle import ref_train as RT
+    g = golden("train_iter_ref_small")
+    sd, (img, gt, sup, sbox) = _ref_train_setup(g)
+    leaf = RT.leaf_state(sd)
+    gen = torch.Generator().manual_seed(int(g["randperm_seed"]))
+    ref = RT.train_iteration(leaf, img, gt, sup, sbox, lambda n: torch.randperm(n, generator=gen))
+    sum(ref["losses"].values()).backward()
+    for k, v in ref["losses"].items():
+        want = float(g["loss/" + k])
+        assert abs(float(v.detach()) - want) <= 5e-6 * abs(want), (k, float(v.detach()), want)
+    np.testing.assert_array_equal(ref["pos_inds"].numpy(), g["pos_inds"])
+    a, b = ref["proposals"], T(g["proposals"])
+    assert a.shape == b.shape
+    d = (a[:, None, :] - b[None, :, :]).abs().amax(2).min(1)[0]          # 1-ulp score ties may swap the order: compare as sets
+    assert float((d < 1e-3).float().mean()) >= 0.995
+    np.testing.assert_array_equal(ref["roi_labels"].numpy(), g["roi_labels"])
+    np.testing.assert_allclose(ref["roi_boxes"].numpy(), g["roi_boxes"], atol=1e-3)
+    dead = set()
+    for k, t in leaf.items():
+        if not t.requires_grad:
+            continue
+        if t.grad is None:
+            dead.add(k)
+            continue
+        f = t.grad.reshape(-1)
+        smp = f[:: max(1, f.numel() // 1024)][:1024].numpy()
+        err = float(np.abs(smp - g["gs/" + k]).max()) / max(float(g["gn/" + k][1]), 1e-30)
+        assert err <= 5e-5, (k, err)                                     # measured <= 6e-6
+        assert abs(float(f.double().norm()) - float(g["gn/" + k][0])) <= 1e-4 * float(g["gn/" + k][0]), k
+    assert dead == set(g["dead"])
+
+
+def test_product_state_dict_layout_matches_reference(golden):
+    """key -> shape of the product's CenterNet2Detector.state_dict() equals the executed reference detector's
+    (built by its own __init__ from its own logged config), so a reference .pth loads; parameter count 5,058,174."""
+    import os
+    from conftest import PKG
+    from fewx.config import get_cfg
+    from detectron2.modeling import build_model
+    g = golden("state_dict_layout")
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(PKG, "configs", "fsod", "finetune_vovnet.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
+    m = build_model(cfg)
+    want = dict(zip((str(k) for k in g["keys"]), (tuple(int(d) for d in str(s).split(",") if d) for s in g["shapes"])))
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == want, (sorted(set(got) ^ set(want))[:10], [(k, got[k], want[k]) for k in got if k in want and got[k] != want[k]][:10])
+    assert list(got) == [str(k) for k in g["keys"]]                       # same order too
+    params = {k for k, _ in m.named_parameters()}
+    assert params == {str(k) for k, p in zip(g["keys"], g["is_param"]) if p}
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 5058174
