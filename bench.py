@@ -4,21 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload at N=1 = BASELINE.json configs[1]: finetune_vovnet.yaml, 25-shot eval-only, bs=1, 640x640 synthetic image,
-cached support prototypes, random-init weights (no dataset / checkpoint exists offline).  One "step" = one complete eval
-forward of the detector (fused preprocess + VoVNet-19-slim-eSE + FPN -> query<->support correlation ->
-CenterNet head -> sigmoid/top-k/decode/NMS proposals, then 8f row 1: ROIAlign -> support-guided mix + fc1 -> cls/box -> NMS ->
-top-100 detections) over one image that is already resident in HBM, replayed as ONE hipGraph.  By default 4 such bs=1 forwards
-are kept in flight per GPU (one engine + HIP stream each: bs=1 leaves most CUs idle in the small pyramid layers); the strictly
-one-image-at-a-time rate is measured in the same run and printed as "sequential".
-N>1: pure data parallel, every rank runs the same per-GPU work on its own images, no data-path collective (weak scaling);
-RCCL (backend "nccl") is used only for the barrier and the max-over-ranks of the elapsed time.
+`value` follows the reference's own FPS protocol (d2z:evaluation/evaluator.py:138-161, SURVEY 8d metric (i)): one step =
+`outputs = model([{"image": img, "height": 640, "width": 640}])` followed by `torch.cuda.synchronize()`, one image at a time,
+>= 5 warm-up calls, finetune_vovnet.yaml, 25-shot cached support, bs = 1 (BASELINE configs[1]).  The call is the registered
+meta-architecture's forward: support-cache check, the whole detector (fused preprocess + VoVNet-19-slim-eSE + FPN -> correlation ->
+CenterNet head -> top-k/decode/NMS -> ROIAlign + cascade ROI head -> NMS -> top-100) as one replayed hipGraph, the count read-back,
+`Instances`, `detector_postprocess`.  The image tensor is resident in HBM when the timed region starts (the tier rule for `value`);
+the same protocol fed a host uint8 image (H2D copy inside the step, what a dataloader hands over) is reported as
+"protocol_host_image".  The K steps are repeated until the timed region is >= --min-time seconds (default 1 s) so a small --steps
+still gives a stable figure; `value` = images of all repeats / their time.
+Beside it, never as `value`: "engine_sequential" (the C-ABI engine call alone, no per-image sync), "in_flight" (4 bs=1 forwards in
+flight on 4 streams), "folded_serving", "train_step" / "train_step_bs16".
+N>1: pure data parallel.  Eval: every rank runs the protocol on its own images, no data-path collective (weak scaling); RCCL
+(backend "nccl") carries the barrier and the max-over-ranks.  Training (BASELINE configs[3]): 16 query images per GPU per step under
+FlatDataParallel, the gradient bucket all-reduced over RCCL from backward hooks -- "train_step" then carries the global rate, the
+exchange time alone and the fraction of it hidden behind backward.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     dominant kernel = the fp32 MFMA implicit-GEMM conv (k_conv_igemm): algorithmic FLOPs of all its launches in
-               one image / their summed duration, measured live with HIP events on the launch stream (eager passes after
-               the timed region), against the 157.3 TFLOP/s fp32 matrix peak of gfx950.
-  cpu_baseline the CPU oracle (oracle/: plain-PyTorch fp32 + C decode/NMS restatement of the reference) timed on this
+  roofline     dominant kernels = the fp32 MFMA conv launches: algorithmic FLOPs of all conv launches of one image / their summed
+               duration, measured live with HIP events on the launch stream (eager passes after the timed region), against the
+               157.3 TFLOP/s fp32 matrix peak of gfx950.
+  cpu_baseline the CPU oracle (oracle/: plain-PyTorch fp32 + C decode/NMS restatement of the reference, both stages) timed on this
                box's host cores on a bounded sample of the same workload (kind "port").
 """
 import argparse
@@ -89,13 +95,18 @@ def cpu_baseline(model, img, budget_s=12.0):
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     support = {k: model.support_dict[k][0].cpu() for k in ("p3", "p4", "p5")}
+    rcnn_8 = model.support_dict["rcnn_8"][0].cpu()
+    H, W = img.shape[-2:]
 
     def one():
         with torch.no_grad():
             o = R.eval_dense(img, sd, support)
-        hms = [h[0, 0].numpy() for h in o["hm"]]
-        regs = [r[0].permute(1, 2, 0).contiguous().numpy() for r in o["reg"]]
-        return odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+            hms = [h[0, 0].numpy() for h in o["hm"]]
+            regs = [r[0].permute(1, 2, 0).contiguous().numpy() for r in o["reg"]]
+            d = odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+            # second stage too (ROIAlign + DSA mix + fc1 + predictor + NMS 0.9 + top-100): the GPU step includes it
+            feats = [o["features"][k] for k in ("p3", "p4", "p5")]
+            return R.roi_head_eval(feats, torch.from_numpy(d["boxes"]), rcnn_8, sd, (H, W), 0.0, 0.9, 100)
 
     for _ in range(2):
         one()
@@ -107,15 +118,19 @@ def cpu_baseline(model, img, budget_s=12.0):
         if el >= budget_s or n >= 200:
             break
     return {"value": round(n / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} images of the same 640x640 bs=1 eval workload (oracle/ref_model.py + oracle/ref_decode.c, "
+            "sample": f"{n} images of the same 640x640 bs=1 eval workload, both stages (oracle/ref_model.py + oracle/ref_decode.c, "
                       f"torch {torch.__version__} CPU, {el:.1f} s)"}
 
 
-def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True):
-    """SURVEY 8d metric (ii), single GPU: forward + backward + clip/SGD of finetune_vovnet.yaml on one query + 24 support crops
-    (tools/bench_train.py is the stand-alone / multi-GPU version).  Reported beside the headline, never as `value`."""
+def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True, world=1, rank=0, min_time=0.0):
+    """SURVEY 8d metric (ii): forward + backward (+ gradient exchange) + clip/SGD of finetune_vovnet.yaml, `batch` query images with 24
+    support crops each per GPU per step.  world > 1 (BASELINE configs[3]): the detector is wrapped in FlatDataParallel, every rank runs
+    the same per-GPU batch on its own images and the flat gradient bucket is all-reduced over RCCL from the backward hooks; reported:
+    the global rate, the exchange alone, and how much of it backward hides.  Reported beside the headline, never as `value`."""
+    import torch.distributed as dist
     from detectron2.structures import Boxes, Instances
-    from fewx.solver import build_lr_scheduler, build_optimizer
+    from detectron2.utils import comm
+    from fewx.solver import FlatDataParallel, build_lr_scheduler, build_optimizer
     model, cfg = build_model(device)
     model.train()
     model.train_graph = graph       # the shape-static dense part (fwd + bwd) replays as two hipGraphs; falls back to eager if capture fails
@@ -124,8 +139,11 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
         for n, p in model.named_parameters():
             if n.startswith("roi_heads.") and p.dim() > 1:
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1).to(device) * (p[0].numel() ** -0.5))
-    opt = build_optimizer(cfg, model)
+    dp = FlatDataParallel(model, cfg) if world > 1 else None
+    net = dp if dp is not None else model
+    opt = build_optimizer(cfg, net)
     sched = build_lr_scheduler(cfg, opt)
+    g = torch.Generator().manual_seed(1 + 7919 * rank)       # every rank trains on its own images
     items = []
     for b in range(batch):
         wh = torch.rand(17, 2, generator=g) * 120 + 30
@@ -133,43 +151,90 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
         inst = Instances((size, size))
         inst.gt_boxes = Boxes(torch.cat([ctr - wh / 2, ctr + wh / 2], 1).to(device))
         inst.gt_classes = torch.zeros(17, dtype=torch.int64, device=device)
-        sup = torch.stack([synth_image(100 + 50 * b + i, 240, 240) for i in range(shots)]).to(device)
+        sup = torch.stack([synth_image(100 + 50 * b + i + 5000 * rank, 240, 240) for i in range(shots)]).to(device)
         side = torch.rand(shots, 2, generator=g) * 120 + 80
         c = torch.rand(shots, 2, generator=g) * (240 - side) + side / 2
-        items.append({"image": synth_image(7 + b, size, size).to(device), "instances": inst, "support_images": sup,
+        items.append({"image": synth_image(7 + b + 5000 * rank, size, size).to(device), "instances": inst, "support_images": sup,
                       "support_bboxes": torch.cat([c - side / 2, c + side / 2], 1).numpy()})
 
     def step():
-        losses = model(items)
+        losses = net(items)
         opt.zero_grad()
         sum(losses.values()).backward()
         opt.step()
         sched.step()
         return losses
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(n):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            last = step()
+        sync_all()
+        return comm.max_over_ranks(time.perf_counter() - t0, device), last
+
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        losses = step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    return {"images_per_s": round(batch * steps / el, 2), "batch_per_gpu": batch, "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
-            "workload": "finetune_vovnet.yaml train step on 1 GPU: %d x (1 query %dx%d + %d support 240x240), fwd + bwd (HIP backward kernels) + "
-                        "flat-bucket clip/SGD, FREEZE_AT=3" % (batch, size, size, shots),
-            "dense_part_hipgraph": bool(graph) and model.__dict__.get("_ore_train_graph_error") is None,
-            "exchanged_bytes_per_step_if_dp": 4 * opt.bucket.size, "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
+    el, losses = timed(steps)
+    n_steps = steps
+    while el < min_time and n_steps < 64 * steps:             # every rank sees the same max-over-ranks time: same decision
+        e2, losses = timed(steps)
+        el, n_steps = el + e2, n_steps + steps
+    out = {"images_per_s": round(world * batch * n_steps / el, 2), "n_gpus": world, "batch_per_gpu": batch, "global_batch": world * batch,
+           "ms_per_step": round(el / n_steps * 1e3, 3), "steps": n_steps, "warmup": warmup, "dtype": "f32",
+           "workload": "finetune_vovnet.yaml train step: %d x (1 query %dx%d + %d support 240x240) per GPU, fwd + bwd (HIP backward kernels) + "
+                       "%sflat-bucket clip/SGD, FREEZE_AT=3" % (batch, size, size, shots, "RCCL all-reduce of the gradient bucket + " if world > 1 else ""),
+           "dense_part_hipgraph": bool(graph) and model.__dict__.get("_ore_train_graph_error") is None,
+           "exchanged_bytes_per_step": 4 * opt.bucket.size if world > 1 else 0, "bucket_bytes": 4 * opt.bucket.size,
+           "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
+    if world > 1:
+        # the exchange alone: the same slices, same order, nothing else running
+        bk = opt.bucket
+        def exchange():
+            ws = [dist.all_reduce(bk.grads[b_:e_], op=dist.ReduceOp.SUM, async_op=True) for b_, e_, _, _ in bk.slices]
+            for w in ws:
+                w.wait()
+        for _ in range(3):
+            exchange()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            exchange()
+        sync_all()
+        ar_ms = comm.max_over_ranks(time.perf_counter() - t0, device) / 20 * 1e3
+        bk.zero_grad()
+        # the same step with the exchange switched off (hooks see world = 1): what backward + SGD cost without it
+        dp.world, saved_scale = 1, getattr(bk, "grad_scale", 1.0)
+        for _ in range(2):
+            step()
+        el0, _ = timed(steps)
+        dp.world, bk.grad_scale = world, saved_scale
+        step_ms, base_ms = el / n_steps * 1e3, el0 / steps * 1e3
+        exposed = max(step_ms - base_ms, 0.0)
+        out.update({"allreduce_ms": round(ar_ms, 3), "allreduce_slices": len(bk.slices),
+                    "allreduce_algbw_GBps": round(4 * bk.size / (ar_ms * 1e-3) / 1e9, 2),
+                    "ms_per_step_without_exchange": round(base_ms, 3), "exposed_exchange_ms": round(exposed, 3),
+                    "overlap_frac": round(min(max(1.0 - exposed / ar_ms, 0.0), 1.0), 3) if ar_ms > 0 else None,
+                    "rccl_ranks_seen": int(comm.sum_over_ranks(1, device)), "backend": dist.get_backend()})
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K timed steps until the timed region is at least this long (s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-train-leg", action="store_true", help="skip the single-GPU train-step measurement printed as \"train_step\"")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the train-step measurements printed as \"train_step\"")
+    ap.add_argument("--no-extras", action="store_true", help="skip engine_sequential / in_flight / folded_serving / latency legs")
     ap.add_argument("--profile-passes", type=int, default=20)
     ap.add_argument("--conv-operands", choices=("fp32", "bf16"), default="fp32",
                     help="fp32 = the reference's precision (the headline).  bf16 = BASELINE configs[4]: MFMA conv operands rounded to bf16, "
@@ -178,9 +243,7 @@ def main():
     ap.add_argument("--fold", type=int, default=8,
                     help="also time the same requests folded F at a time into one engine pass (\"folded_serving\" in the output); 0/1 = skip")
     ap.add_argument("--inflight", type=int, default=4,
-                    help="images kept in flight per GPU, each a bs=1 forward on its own engine + HIP stream (bs=1 leaves most of "
-                         "the 256 CUs idle in the small pyramid layers; independent images fill them).  1 = strictly one image "
-                         "at a time; that rate is always reported too (\"sequential\").")
+                    help="\"in_flight\" leg: images kept in flight per GPU, each a bs=1 forward on its own engine + HIP stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,30 +257,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    from detectron2.utils import comm
 
     device = torch.device("cuda", local_rank)
     model, cfg = build_model(device)
     model.conv_operands = args.conv_operands
     bf16 = args.conv_operands == "bf16"
     # each rank owns its shard of images (pure data parallel); a handful of distinct images is cycled
-    imgs = [synth_image(rank * 1000 + i).to(device) for i in range(4)]
-    eng = model.engine()
+    host_imgs = [synth_image(rank * 1000 + i) for i in range(4)]
+    imgs = [t.to(device) for t in host_imgs]
     use_graph = not args.no_graph
-    engines = [eng] + [model.make_engine() for _ in range(max(args.inflight, 1) - 1)]
-    prio = os.environ.get("ORE_BENCH_STREAM_PRIO")          # experiment knob: comma list of stream priorities (e.g. "0,-1")
-    if len(engines) > 1:
-        pl = [int(v) for v in prio.split(",")] if prio else [0]
-        streams = [torch.cuda.Stream(device, priority=pl[i % len(pl)]) for i in range(len(engines))]
-    else:
-        streams = [None]
-
-    def run_step(i):
-        e, s = engines[i % len(engines)], streams[i % len(engines)]
-        if s is None:
-            e.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
-        else:
-            with torch.cuda.stream(s):
-                e.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
+    K, W = max(args.steps, 1), max(args.warmup, 5)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -225,83 +275,117 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(max(args.warmup, len(engines))):
-        run_step(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(i)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    # the same K steps strictly one image at a time on one stream (what --inflight 1 measures)
-    seq_elapsed = elapsed
-    if len(engines) > 1:
-        sync_all()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
-        sync_all()
-        seq_elapsed = time.perf_counter() - t1
-        # every concurrent engine must reproduce engine 0 bit for bit on the same image
-        ref = None
-        for e, st in zip(engines, streams):
-            with torch.cuda.stream(st):
-                e.eval_forward(imgs[1], use_graph=use_graph)
+    def timed_region(step_fn, k, min_time):
+        """K steps between two barrier + synchronize brackets, repeated until >= min_time in total.  Returns (steps, seconds)."""
+        n, el = 0, 0.0
+        while True:
+            sync_all()
+            t0 = time.perf_counter()
+            for i in range(k):
+                step_fn(n + i)
+            sync_all()
+            el += comm.max_over_ranks(time.perf_counter() - t0, device)     # the slowest rank defines the job time
+            n += k
+            if el >= min_time or n >= 1000 * k:
+                return n, el
+
+    # ---- headline: the reference's FPS protocol -- model(batched_inputs) + device sync, one image at a time
+    requests = [[{"image": t, "height": 640, "width": 640}] for t in imgs]
+    out_last = [None]
+
+    def proto_step(i):
+        out_last[0] = model(requests[i % len(requests)])
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        proto_step(i)
+    n_steps, elapsed = timed_region(proto_step, K, args.min_time)
+    total_images = world * n_steps
+    n_det_proto = len(out_last[0][0]["instances"])
+    eng = model.engine()
+
+    extras = {}
+    if not args.no_extras:
+        # the same protocol fed HOST images (uint8 CHW, as a dataloader hands them over): H2D copy inside the step
+        host_requests = [[{"image": t, "height": 640, "width": 640}] for t in host_imgs]
+
+        def host_step(i):
+            model(host_requests[i % len(host_requests)])
             torch.cuda.synchronize()
-            got = [t.clone() for t in e.proposals()] + ([t.clone() for t in e.detections()] if getattr(e, "has_roi", False) else [])
-            if ref is None:
-                ref = got
-            else:
-                assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref)), "concurrent engines disagree"
-    def comm_max(v):
-        from detectron2.utils import comm as _c
-        return _c.max_over_ranks(v, device)
+        for i in range(5):
+            host_step(i)
+        n_h, el_h = timed_region(host_step, K, min(args.min_time, 0.5))
+        extras["protocol_host_image"] = {"images_per_s": round(world * n_h / el_h, 2), "ms_per_image": round(el_h / n_h * 1e3, 4),
+                                         "note": "same protocol, image handed over as a host uint8 tensor (PCIe copy inside the step)"}
+        # the C-ABI engine call alone: one image at a time on one stream, no per-image host sync, no Instances / postprocess
+        def eng_step(i):
+            eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
+        for i in range(5):
+            eng_step(i)
+        n_e, el_e = timed_region(eng_step, K, min(args.min_time, 0.5))
+        extras["engine_sequential"] = {"images_per_s": round(world * n_e / el_e, 2), "ms_per_image": round(el_e / n_e * 1e3, 4),
+                                       "note": "ore_engine_eval_fwd (one hipGraph replay per image) back to back on one stream, no per-image sync"}
+        # per-image latency of the engine call with a host sync after every image
+        lat = []
+        for i in range(50):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - a)
+        lat.sort()
+        extras["engine_latency_ms_host_sync"] = {"p50": round(lat[len(lat) // 2] * 1e3, 4), "min": round(lat[0] * 1e3, 4)}
+        extras["protocol_overhead_us"] = round((elapsed / n_steps - lat[len(lat) // 2]) * 1e6, 1)
+        # several bs=1 forwards in flight per GPU, each on its own engine + HIP stream
+        if args.inflight > 1:
+            engines = [eng] + [model.make_engine() for _ in range(args.inflight - 1)]
+            streams = [torch.cuda.Stream(device) for _ in engines]
 
-    # folded serving: the SAME single-image requests, F at a time through ONE engine pass (dense stages batched over the F images,
-    # detection tail and second stage per image).  Reported beside the headline, never as `value`.
-    folded = None
-    if args.fold > 1:
-        S = max(args.fold_streams, 1)
-        efs = [model.make_engine(max_batch=args.fold) for _ in range(S)]
-        fstreams = [torch.cuda.Stream(device) for _ in range(S)]
-        packs = [torch.stack([imgs[(j + i) % len(imgs)] for i in range(args.fold)]).contiguous() for j in range(len(imgs))]
-        nb = max(args.steps // args.fold, S)
+            def fl_step(i):
+                with torch.cuda.stream(streams[i % len(engines)]):
+                    engines[i % len(engines)].eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
+            for i in range(2 * len(engines)):
+                fl_step(i)
+            n_f, el_f = timed_region(fl_step, K, min(args.min_time, 0.5))
+            ref = None                                       # every concurrent engine must reproduce engine 0 bit for bit
+            for e, st in zip(engines, streams):
+                with torch.cuda.stream(st):
+                    e.eval_forward(imgs[1], use_graph=use_graph)
+                torch.cuda.synchronize()
+                got = [t.clone() for t in e.proposals()] + ([t.clone() for t in e.detections()] if getattr(e, "has_roi", False) else [])
+                if ref is None:
+                    ref = got
+                else:
+                    assert len(got) == len(ref) and all(torch.equal(a_, b_) for a_, b_ in zip(got, ref)), "concurrent engines disagree"
+            for e in engines[1:]:
+                e.close()
+            extras["in_flight"] = {"images_per_s": round(world * n_f / el_f, 2), "images_in_flight_per_gpu": len(engines),
+                                   "ms_per_image": round(el_f / n_f * 1e3, 4),
+                                   "note": "bs=1 forwards of independent images on %d engines / HIP streams; results bit-identical to "
+                                           "the sequential engine (asserted here)" % len(engines)}
+        # folded serving: the SAME single-image requests, F at a time through ONE engine pass
+        if args.fold > 1:
+            S = max(args.fold_streams, 1)
+            efs = [model.make_engine(max_batch=args.fold) for _ in range(S)]
+            fstreams = [torch.cuda.Stream(device) for _ in range(S)]
+            packs = [torch.stack([imgs[(j + i) % len(imgs)] for i in range(args.fold)]).contiguous() for j in range(len(imgs))]
 
-        def fstep(j):
-            with torch.cuda.stream(fstreams[j % S]):
-                efs[j % S].eval_forward_batch(packs[j % len(packs)], use_graph=use_graph)
-        for j in range(max(args.warmup // args.fold, 2 * S)):
-            fstep(j)
-        sync_all()
-        tf0 = time.perf_counter()
-        for j in range(nb):
-            fstep(j)
-        sync_all()
-        f_el = comm_max(time.perf_counter() - tf0)
-        folded = {"images_per_s": round(world * nb * args.fold / f_el, 2), "requests_per_pass": args.fold, "passes_in_flight": S,
-                  "ms_per_pass": round(f_el / nb * 1e3, 4),
-                  "note": "the same bs=1 requests, %d folded into one engine pass (ore_engine_eval_batch_fwd), %d passes in flight on "
-                          "separate streams: the dense stages run batched, so a CU fetches each layer's weights once per pass instead "
-                          "of once per image; per-image results are checked against the bs=1 engine in tests/test_hip_parity.py"
-                          % (args.fold, S)}
-        for ef in efs:
-            ef.close()
-    from detectron2.utils import comm
-    elapsed = comm.max_over_ranks(elapsed, device)          # the slowest rank defines the job time
-    seq_elapsed = comm.max_over_ranks(seq_elapsed, device)
-    total_images = int(comm.sum_over_ranks(args.steps, device))
+            def fstep(j):
+                with torch.cuda.stream(fstreams[j % S]):
+                    efs[j % S].eval_forward_batch(packs[j % len(packs)], use_graph=use_graph)
+            for j in range(2 * S):
+                fstep(j)
+            nb, f_el = timed_region(fstep, max(K // args.fold, S), min(args.min_time, 0.5))
+            extras["folded_serving"] = {"images_per_s": round(world * nb * args.fold / f_el, 2), "requests_per_pass": args.fold,
+                                        "passes_in_flight": S, "ms_per_pass": round(f_el / nb * 1e3, 4),
+                                        "note": "the same bs=1 requests, %d folded into one engine pass (ore_engine_eval_batch_fwd), %d passes "
+                                                "in flight; per-image results are checked against the bs=1 engine in tests/test_hip_parity.py"
+                                                % (args.fold, S)}
+            for ef in efs:
+                ef.close()
+
     n_prop = int(eng.buffer("counts")[1, 0].item())
     n_det = int(eng.buffer("det_count")[0, 0].item()) if getattr(eng, "has_roi", False) else None
-
-    # per-image latency with a host sync after every image (the reference's inference_on_dataset protocol)
-    lat = []
-    for i in range(min(args.steps, 50)):
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        eng.eval_forward(imgs[i % len(imgs)], use_graph=use_graph)
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - a)
-    lat.sort()
 
     roof = None
     if rank == 0:
@@ -314,69 +398,71 @@ def main():
             eng.eval_forward(imgs[i % len(imgs)], use_graph=False)
         ms_raw, fl, nl = eng.read_profile()
         eng.set_profiling(False)
+        import glob
         import orehip
         # `achieved` uses the RAW event time (conservative: each bracket also contains the dispatch latency of its launch, ~10 % over
-        # the durations rocprofv3 reports for the same kernels, profiles/r01_conv_layers.txt).  The calibrated figure subtracts what
-        # an event pair adds around an empty launch beyond back-to-back issue (2*T(1) - T(2)) and is printed beside it.
+        # the durations rocprofv3 reports for the same kernels).  The calibrated figure subtracts what an event pair adds around an
+        # empty launch beyond back-to-back issue (2*T(1) - T(2)) and is printed beside it.
         ev_us = orehip.event_pair_overhead_us(300)
         ms = ms_raw
         ms_cal = max(ms_raw - nl * ev_us * 1e-3, 1e-6)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None                                  # HBM bytes of the conv launches of one image, from the committed PMC passes
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tf):
+        traffic, traffic_src = None, None               # HBM bytes of the conv launches of one image, from the committed PMC passes
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             try:
                 with open(tf) as f:
                     traffic = float(json.load(f)["conv_hbm_bytes_per_image"])
+                traffic_src = os.path.basename(tf)
+                break
             except Exception:
                 traffic = None
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        npp = max(args.profile_passes, 1)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_note": "HBM-side bytes per image over the same conv launches: (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 "
-                                "--pmc passes (tools/pmc_pass.py -> profiles/r01_pmc_traffic.json); ~0.7 TB/s, far below the 8 TB/s roof",
-                "kernel": ("k_conv_igemm / k_conv3x3_patch / k_conv3x3_ws with bf16 operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate); 28 convs "
-                           "+ the fp32 ROI fc GEMM" if bf16 else
-                           "k_conv_igemm (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv incl. in-kernel split-K; 28 convs + the ROI fc GEMM)"),
-                "launches_per_image": nl // max(args.profile_passes, 1),
-                "gflop_per_image": round(fl / max(args.profile_passes, 1) / 1e9, 3),
-                "kernel_ms_per_image": round(ms / max(args.profile_passes, 1), 4),
-                "kernel_ms_per_image_calibrated": round(ms_cal / max(args.profile_passes, 1), 4), "event_pair_overhead_us": round(ev_us, 3),
-                "achieved_calibrated": round(fl / (ms_cal * 1e-3) / 1e12, 2),
-                "rocprof_note": "rocprofv3 --kernel-trace of the same launches (fp32): 0.665 ms per image = 51.1 TFLOP/s = 0.325 of peak (profiles/r01_conv_layers.txt)",
-                "note": "per-kernel figure from isolated (one image at a time) launches; with images in flight the conv FLOP rate "
-                        "end to end is value x gflop_per_image"}
+                                "--pmc passes (tools/pmc_pass.py -> profiles/%s)" % traffic_src,
+                "kernel": ("the MFMA conv kernels with bf16 operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) + the fp32 ROI fc GEMM" if bf16 else
+                           "the fp32 MFMA conv kernels (v_mfma_f32_16x16x4_f32 implicit GEMM: k_conv_igemm, k_conv3x3_patch, k_conv3x3_ws, "
+                           "incl. in-kernel split-K) + the ROI fc GEMM"),
+                "launches_per_image": nl // npp, "gflop_per_image": round(fl / npp / 1e9, 3),
+                "kernel_ms_per_image": round(ms / npp, 4), "kernel_ms_per_image_calibrated": round(ms_cal / npp, 4),
+                "event_pair_overhead_us": round(ev_us, 3), "achieved_calibrated": round(fl / (ms_cal * 1e-3) / 1e12, 2),
+                "note": "FLOP-weighted over all conv launches of one image (different shapes), isolated one-image-at-a-time launches; "
+                        "profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command"}
         roof["end_to_end_tflops"] = round(total_images / elapsed * roof["gflop_per_image"] / 1e3, 2)
+
+    train = {}
+    if not args.no_train_leg:
+        try:
+            if world == 1:
+                train["train_step"] = train_leg(device, min_time=0.3)
+                train["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, min_time=0.8)   # BASELINE configs[2]
+            else:                                           # BASELINE configs[3]: 16 per GPU, gradients over RCCL
+                train["train_step"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, world=world, rank=rank, min_time=0.8)
+        except Exception as ex:                             # the headline line must survive a failure of the side measurement
+            train["train_step_error"] = repr(ex)[:300]
+            if world > 1:
+                raise
 
     if rank == 0:
         out = {
-            "metric": "images/sec at 640x640 25-shot (eval FPS, bs=1 per GPU)",
+            "metric": "images/sec at 640x640 25-shot (eval FPS: model(inputs) + device sync per image, bs=1 per GPU)",
             "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": W, "ms_per_step": round(elapsed / n_steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": ("bf16 MFMA conv operands + fp32 NMS (BASELINE configs[4] precision) on " if bf16 else "") +
-                                   "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]): "
-                                   "preprocess+VoVNet-19-slim-eSE+FPN -> correlation -> CenterNet head -> top-k/NMS proposals -> ROIAlign + cascade ROI head -> NMS -> detections",
+                                   "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]), the reference's FPS protocol: "
+                                   "model([{image,height,width}]) + torch.cuda.synchronize() per image; preprocess+VoVNet-19-slim-eSE+FPN -> "
+                                   "correlation -> CenterNet head -> top-k/NMS proposals -> ROIAlign + cascade ROI head -> NMS -> detections",
                        "parallelism": f"dp{world} (images sharded, no data-path collective)", "hipgraph": use_graph,
-                       "images_in_flight_per_gpu": len(engines),
-                       "proposals_last_image": n_prop, "detections_last_image": n_det},
-            "sequential": {"images_per_s": round(total_images / seq_elapsed, 2), "ms_per_image": round(seq_elapsed / args.steps * 1e3, 4),
-                           "note": "same K steps, one image at a time on one stream (images_in_flight_per_gpu = 1)"},
-            "latency_ms_host_sync": {"p50": round(lat[len(lat) // 2] * 1e3, 4), "min": round(lat[0] * 1e3, 4)},
-            "folded_serving": folded,
-            "roofline": roof,
+                       "images_in_flight_per_gpu": 1, "timed_steps": n_steps, "timed_region_s": round(elapsed, 3),
+                       "input": "uint8 BGR CHW image resident in HBM", "proposals_last_image": n_prop, "detections_last_image": n_det,
+                       "detections_returned": n_det_proto},
+            **extras, "roofline": roof, **train,
         }
-        if not args.no_train_leg and world == 1:
-            try:
-                out["train_step"] = train_leg(device)
-            except Exception as ex:                         # the headline line must survive a failure of the side measurement
-                out["train_step"] = {"error": repr(ex)[:300]}
-            try:                                            # BASELINE configs[2]: 16 query images (+ 16 x 24 support crops) per GPU per step
-                out["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False)
-            except Exception as ex:
-                out["train_step_bs16"] = {"error": repr(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, imgs[0].cpu())
+            out["cpu_baseline"] = cpu_baseline(model, host_imgs[0])
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

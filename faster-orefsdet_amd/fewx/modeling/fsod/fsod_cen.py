@@ -207,7 +207,13 @@ class CenterNet2Detector(nn.Module):
 
     # ---- engine -------------------------------------------------------------------------------------------------
     def _state_key(self):
-        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        """Changes whenever any parameter or buffer is written through torch (optimizer steps -- FlatSGD bumps the version counters
+        for its raw-pointer kernel --, load_state_dict, in-place edits).  Version counters only grow, so their sum is a valid key;
+        the tensor list is collected once (the module tree is fixed after construction)."""
+        ts = self.__dict__.get("_key_tensors")
+        if ts is None:
+            ts = self.__dict__["_key_tensors"] = list(self.parameters()) + list(self.buffers())
+        return sum([t._version for t in ts])
 
     def make_engine(self, max_batch: int = 1):
         """A fresh engine (own buffers, own hipGraph) for the current parameters and support set.  `engine()` caches one; a server

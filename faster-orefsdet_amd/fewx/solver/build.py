@@ -66,6 +66,7 @@ class FlatBucket:
                 if e[0].startswith(pre):
                     return i
             return len(_READY_ORDER)
+        self.definition_order = [e[0] for e in entries]      # the order torch.optim would number them in
         entries = sorted(entries, key=order)          # stable: keeps definition order inside a group
         assert entries, "no parameter to optimise"
         dev = entries[0][1].device
@@ -127,8 +128,10 @@ def get_bucket(model, cfg=None, entries=None) -> FlatBucket:
         if entries is None:
             entries = param_groups_like_reference(cfg, model)
         dead = tuple(getattr(model, "gradless_parameter_prefixes", lambda: ())())
+        every = [e[0] for e in entries]               # torch.optim numbers ALL of them, the gradient-less ones included
         entries = [e for e in entries if not any(e[0].startswith(d) for d in dead)]
         b = FlatBucket(entries)
+        b.definition_order = every
         object.__setattr__(model, "_ore_flat_bucket", b)
     return b
 
@@ -172,6 +175,11 @@ class FlatDataParallel(torch.nn.Module):
         s = self.bucket.param_slice[i]
 
         def hook(_p):
+            if self._issued[s] and self.world > 1:
+                # this slice was already all-reduced for the current step: a second backward() before optimizer.step() would add
+                # un-exchanged local gradients to it and the ranks would diverge silently (DDP's no_sync() case; not built)
+                raise RuntimeError("FlatDataParallel: backward() ran twice before optimizer.step(); gradient accumulation is not "
+                                   "supported (one backward per step, as d2z:engine/train_loop.py:258-294 runs it)")
             self._pending[s] -= 1
             if self._pending[s] == 0 and self.overlap:
                 self._issue(s)
@@ -238,15 +246,39 @@ class FlatSGD:
         from orehip import autograd as A
         orehip.sgd_step(b.params, b.grads, b.momentum, b.chunk_lr, b.chunk_wd, lr_scale=self.lr_factor, momentum=self.momentum,
                         clip_value=self.clip_value, grad_scale=scale)
-        A.weights_changed()                         # packed weight layouts are rebuilt lazily by the next forward
+        # The kernel rewrote the parameters through raw pointers: tell torch (every cache in the package -- engines, hipGraphs,
+        # packed / composed weights -- keys on the parameters' version counters) and drop the packed copies.
+        torch.autograd.graph.increment_version(b.tensors)
+        A.weights_changed()
 
     def state_dict(self) -> Dict:
         return {"momentum": self.bucket.momentum.detach().cpu(), "names": list(self.bucket.names), "lr_factor": self.lr_factor}
 
     def load_state_dict(self, sd: Dict):
-        assert list(sd["names"]) == list(self.bucket.names), "optimizer state belongs to a different parameter set"
-        self.bucket.momentum.copy_(sd["momentum"])
-        self.set_lr_factor(sd.get("lr_factor", 1.0))
+        """Accepts this class's own layout and torch.optim.SGD's ({"state": {i: {"momentum_buffer"}}, "param_groups": [...]}, what a
+        reference run's checkpoint holds): there the i-th state entry belongs to the i-th parameter in param-group order, which for the
+        reference is model.named_parameters() order minus the parameters without a gradient (ref:fewx/solver/build.py:110-139)."""
+        if "names" in sd and "momentum" in sd:
+            if list(sd["names"]) != list(self.bucket.names):
+                raise ValueError("optimizer state belongs to a different parameter set")
+            self.bucket.momentum.copy_(sd["momentum"])
+            self.set_lr_factor(sd.get("lr_factor", 1.0))
+            return
+        if "state" in sd and "param_groups" in sd:
+            ids = [i for g in sd["param_groups"] for i in g["params"]]
+            order = getattr(self.bucket, "definition_order", None)
+            if order is None or len(ids) != len(order):
+                raise ValueError(f"torch.optim state with {len(ids)} parameters does not match this model's {len(self.bucket.names)} "
+                                 "optimised parameters; resume from a checkpoint written by this trainer or drop the optimizer state")
+            by_name = dict(zip(self.bucket.names, zip(self.bucket.offsets, self.bucket.numels)))
+            for pid, name in zip(ids, order):
+                st = sd["state"].get(pid, {})
+                if "momentum_buffer" in st and st["momentum_buffer"] is not None and name in by_name:
+                    o, n = by_name[name]
+                    self.bucket.momentum[o:o + n].copy_(st["momentum_buffer"].reshape(-1))
+            return
+        raise ValueError("unrecognised optimizer state: expected {'momentum','names'} (this trainer) or torch.optim.SGD's "
+                         "{'state','param_groups'}")
 
 
 def build_optimizer(cfg, model) -> FlatSGD:

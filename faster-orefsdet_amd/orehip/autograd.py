@@ -20,24 +20,38 @@ from torch.autograd import Function
 import orehip
 
 _EPOCH = [0]
-_PACK = {}
 
 
 def weights_changed() -> None:
-    """Called by the optimizer after it rewrote the flat parameter bucket: packed copies are stale."""
+    """Invalidate every packed copy (called where weights are rewritten behind torch's back, and inside a captured training graph so
+    that each replay repacks the current parameters)."""
     _EPOCH[0] += 1
 
 
+def weights_epoch() -> int:
+    return _EPOCH[0]
+
+
+def _base_param(w: torch.Tensor):
+    b = w._base if w._base is not None else w
+    return b if isinstance(b, torch.nn.Parameter) else None
+
+
 def packed(w: torch.Tensor, dgrad: bool) -> torch.Tensor:
-    key = (id(w), bool(dgrad))
-    tag = (_EPOCH[0], w.data_ptr(), w._version, tuple(w.shape))
-    e = _PACK.get(key)
-    if e is None and len(_PACK) > 512:               # temporaries (e.g. the concatenated head weight) come and go: bound the cache
-        _PACK.clear()
+    """MFMA-packed copy of a conv / linear weight.  Only parameters and views of parameters are cached, and the cache lives ON the
+    parameter object (it dies with the model; an address- or id-keyed table can hand a new model the packed weights of a freed one):
+    key = the view's geometry, tag = the weight epoch, the parameter's version counter (views share it) and its storage address.
+    A temporary built from parameters (e.g. the concatenated (reg|hm) head weight) is packed afresh on every call."""
+    base = _base_param(w)
+    if base is None:
+        return orehip.pack_conv_weight_dev(w.detach().contiguous(), dgrad)
+    cache = base.__dict__.setdefault("_ore_packed", {})
+    key = (tuple(w.shape), tuple(w.stride()), w.storage_offset(), bool(dgrad))
+    tag = (_EPOCH[0], base._version, base.data_ptr())
+    e = cache.get(key)
     if e is None or e[0] != tag:
-        buf = e[1] if e is not None and e[0][3] == tag[3] else None
-        _PACK[key] = (tag, orehip.pack_conv_weight_dev(w.detach().contiguous(), dgrad, out=buf))
-    return _PACK[key][1]
+        cache[key] = e = (tag, orehip.pack_conv_weight_dev(w.detach().contiguous(), dgrad, out=e[1] if e is not None else None))
+    return e[1]
 
 
 def _c16(n: int) -> int:
