@@ -79,6 +79,11 @@ struct ore_engine {
     float* roi_feat = nullptr; float* roi_h = nullptr;
     float* det_boxes = nullptr; float* det_scores = nullptr; int64_t* det_src = nullptr; int32_t* det_count = nullptr;
     void* roi_ws = nullptr; size_t roi_ws_bytes = 0;
+    // detector_postprocess inside the graph (ore_engine_detect_fwd): device {sx, sy, out_w, out_h} per image slot, the postprocessed
+    // detections, and a pinned host word the count is copied into behind the graph
+    float* post = nullptr; float post_host[4] = {1.f, 1.f, 0.f, 0.f};
+    float* fin_boxes = nullptr; float* fin_scores = nullptr; int32_t* fin_count = nullptr;
+    int32_t* pin_count = nullptr; float* pin_post = nullptr;
     // graph cache
     hipStream_t cap_stream = nullptr;
     struct GraphKey { int u8, H, W, B; hipGraphExec_t exec; };
@@ -357,10 +362,11 @@ int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops, int b = 
     }
     if (r.rc) return r.rc;
     *flops = r.flops;
-    return ore_roi_predict_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, out_boxes, counts + 1, 0,
-                               e->roi_cap, e->roi_reg_w, (float)g.H, (float)g.W, e->roi_score_thresh, e->roi_nms_thresh, e->roi_topk,
-                               e->det_boxes + b * rcap * 4, e->det_scores + b * rcap, e->det_src + b * rcap, e->det_count + b * 4, e->roi_ws,
-                               e->roi_ws_bytes, st);
+    return ore_roi_predict_post_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, out_boxes, counts + 1, 0,
+                                    e->roi_cap, e->roi_reg_w, (float)g.H, (float)g.W, e->roi_score_thresh, e->roi_nms_thresh, e->roi_topk,
+                                    e->det_boxes + b * rcap * 4, e->det_scores + b * rcap, e->det_src + b * rcap, e->det_count + b * 4,
+                                    e->post, e->fin_boxes + b * rcap * 4, e->fin_scores + b * rcap, e->fin_count + b * 4, e->roi_ws,
+                                    e->roi_ws_bytes, st);
 }
 
 }  // namespace
@@ -394,6 +400,13 @@ extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const
         if ((rc = e->dalloc(&w, e->roi_ws_bytes))) return rc;
         e->roi_ws = w;
         ORE_HIP(hipMemset(e->det_count, 0, MB * 4 * sizeof(int32_t)));
+        if ((rc = e->dalloc(&e->post, 8)) || (rc = e->dalloc(&e->fin_boxes, MB * cap * 4)) || (rc = e->dalloc(&e->fin_scores, MB * cap)) ||
+            (rc = e->dalloc(&e->fin_count, MB * 4))) return rc;
+        ORE_HIP(hipMemset(e->fin_count, 0, MB * 4 * sizeof(int32_t)));
+        ORE_HIP(hipHostMalloc((void**)&e->pin_count, 64, hipHostMallocDefault));
+        ORE_HIP(hipHostMalloc((void**)&e->pin_post, 64, hipHostMallocDefault));
+        e->post_host[0] = e->post_host[1] = 1.f; e->post_host[2] = e->post_host[3] = 3.0e38f;   // identity until a size is requested
+        ORE_HIP(hipMemcpy(e->post, e->post_host, 4 * sizeof(float), hipMemcpyHostToDevice));
     }
     e->roi_fc = fc_dim; e->roi_pooled = pooled; e->roi_topk = topk; e->roi_score_thresh = score_thresh; e->roi_nms_thresh = nms_thresh;
     for (int i = 0; i < 4; ++i) e->roi_reg_w[i] = reg_weights4_host[i];
@@ -426,6 +439,8 @@ extern "C" void ore_engine_destroy(ore_engine* e) {
     if (e->cap_stream) hipStreamDestroy(e->cap_stream);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
+    if (e->pin_count) hipHostFree(e->pin_count);
+    if (e->pin_post) hipHostFree(e->pin_post);
     delete e;
 }
 
@@ -617,6 +632,27 @@ extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8
     return ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, use_graph, stream);
 }
 
+extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                                     void* stream, int32_t* n_det) {
+    ORE_CHECK_ARG(e && e->roi_set && n_det && out_h >= 1 && out_w >= 1, "ore_engine_detect_fwd: needs the second stage (ore_engine_set_roi_head)");
+    hipStream_t st = (hipStream_t)stream;
+    // detector_postprocess parameters: sx = out_w / W, sy = out_h / H evaluated like the reference's Python floats, rounded once to
+    // fp32 (what `boxes *= scale` does to a float32 tensor); uploaded only when the requested size changes
+    const float pp[4] = {(float)((double)out_w / (double)W), (float)((double)out_h / (double)H), (float)out_w, (float)out_h};
+    if (memcmp(pp, e->post_host, sizeof(pp)) != 0) {
+        ORE_HIP(hipStreamSynchronize(st));                   // the pinned staging word may still be in flight from the previous change
+        memcpy(e->pin_post, pp, sizeof(pp));
+        ORE_HIP(hipMemcpyAsync(e->post, e->pin_post, sizeof(pp), hipMemcpyHostToDevice, st));
+        memcpy(e->post_host, pp, sizeof(pp));
+    }
+    int rc = ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, 1, stream);
+    if (rc) return rc;
+    ORE_HIP(hipMemcpyAsync(e->pin_count, e->fin_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ORE_HIP(hipStreamSynchronize(st));
+    *n_det = e->pin_count[0];
+    return ORE_OK;
+}
+
 extern "C" int ore_engine_eval_batch_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t B, int32_t H, int32_t W,
                                          int32_t use_graph, void* stream) {
     int rc = check_geo(e, B, H, W);
@@ -628,7 +664,7 @@ extern "C" int ore_engine_eval_batch_fwd(ore_engine* e, const void* img, int32_t
     PrecisionScope ps(e->conv_precision);
     const size_t bytes = (size_t)B * 3 * H * W * (is_u8 ? 1 : 4);
     ORE_CHECK_ARG(bytes <= e->img_bytes, "image batch exceeds the engine's input buffer");
-    ORE_HIP(hipMemcpyAsync(e->img_in, img, bytes, hipMemcpyDeviceToDevice, st));
+    if (img != e->img_in) ORE_HIP(hipMemcpyAsync(e->img_in, img, bytes, hipMemcpyDefault, st));   // device or (pinned / pageable) host source
     auto body = [&](hipStream_t s, double* fl) -> int {
         double f1 = 0, f2 = 0;
         int r = run_backbone(e, e->img_in, is_u8, g, s, &f1);
@@ -770,6 +806,9 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
         if (base == "det_scores") return set(e->det_scores + ib * rcap, e->roi_cap, 1, 1, 0);
         if (base == "det_src") return set(e->det_src + ib * rcap, e->roi_cap, 1, 1, 0);
         if (base == "det_count") return set(e->det_count + ib * 4, 4, 1, 1, 0);
+        if (base == "final_boxes") return set(e->fin_boxes + ib * rcap * 4, e->roi_cap, 4, 4, 0);
+        if (base == "final_scores") return set(e->fin_scores + ib * rcap, e->roi_cap, 1, 1, 0);
+        if (base == "final_count") return set(e->fin_count + ib * 4, 4, 1, 1, 0);
         if (n == "roi_h") return set(e->roi_h, e->roi_cap, e->roi_fc, e->roi_fc, 0);
     }
     ore_set_error("ore_engine_buffer: unknown buffer '%s'", name);

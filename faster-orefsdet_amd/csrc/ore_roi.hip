@@ -319,6 +319,250 @@ __global__ __launch_bounds__(256) void k_roi_finalize(const long long* __restric
     if (threadIdx.x == 0) *det_count = n;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fused tail for cap <= ROI_FUSED_CAP (the eval second stage: <= 320 proposals).  Two launches instead of five:
+//   k_roi_predict_mb   64 ROIs per block: the six dot products of a ROI run on three waves (two outputs each), every one the same
+//                      sequential fma chain over the channels as k_roi_predict and the CPU twin (bit-exact); wave 0 finishes
+//                      softmax / apply_deltas / clip and writes the raw box, score and the filter flag.
+//   k_roi_tail         ONE block: ordered compaction of the filtered ROIs, stable rank sort by score, the IoU bit matrix in
+//                      LDS (same float ops as k_nms_mask), greedy resolution per 64-row block as the same fixpoint as
+//                      k_nms_scan, keep[:topk] -> detections, and detector_postprocess (d2z:modeling/postprocessing.py:10-75:
+//                      scale to the requested output size, clip, drop empty boxes) -> final_*.
+constexpr int ROI_FUSED_CAP = 512;
+
+__global__ __launch_bounds__(256) void k_roi_predict_mb(PredP p, int* __restrict__ ok_out) {
+    extern __shared__ float hs[];                 // [64][C+1] rows, then cls_w [2][C], box_w [4][C], then dots [6][64]
+    const int C = p.C, LDH = C + 1;
+    float* wl = hs + 64 * LDH;
+    float* dots = wl + 6 * C;
+    const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 64;
+    if (r0 >= n) {                                // rows beyond the count: flag them out (the tail reads ok[0..cap))
+        if (tid < 64 && r0 + tid < p.cap) ok_out[r0 + tid] = 0;
+        return;
+    }
+    const int rows = min(64, n - r0);
+    for (int i = tid; i < 2 * C; i += 256) wl[i] = p.cls_w[i];
+    for (int i = tid; i < 4 * C; i += 256) wl[2 * C + i] = p.box_w[i];
+    for (int i = tid; i < rows * C; i += 256) hs[(i / C) * LDH + (i % C)] = p.h[(size_t)r0 * C + i];
+    __syncthreads();
+    if (wave < 3 && lane < rows) {
+        const float* h = hs + lane * LDH;
+        const float* w0 = wl + (2 * wave) * C;
+        const float* w1 = w0 + C;
+        float a0 = wave == 0 ? p.cls_b[0] : p.box_b[2 * wave - 2];
+        float a1 = wave == 0 ? p.cls_b[1] : p.box_b[2 * wave - 1];
+        for (int c = 0; c < C; ++c) {
+            const float v = h[c];
+            a0 = fmaf(w0[c], v, a0);
+            a1 = fmaf(w1[c], v, a1);
+        }
+        dots[(2 * wave) * 64 + lane] = a0;
+        dots[(2 * wave + 1) * 64 + lane] = a1;
+    }
+    __syncthreads();
+    if (wave == 0 && r0 + lane < p.cap) {
+        const int r = r0 + lane;
+        int ok = 0;
+        if (lane < rows) {
+            const float l0 = dots[lane], l1 = dots[64 + lane];
+            const float d0 = dots[128 + lane], d1 = dots[192 + lane], d2 = dots[256 + lane], d3 = dots[320 + lane];
+            const float m = fmaxf(l0, l1);
+            const float e0 = ore_expf(l0 - m), e1 = ore_expf(l1 - m);
+            const float score = e0 / (e0 + e1);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
+            const float w = b.z - b.x, hgt = b.w - b.y;
+            const float cx = b.x + 0.5f * w, cy = b.y + 0.5f * hgt;
+            const float dx = d0 / p.wx, dy = d1 / p.wy;
+            const float dw = fminf(d2 / p.ww, p.scale_clamp), dh = fminf(d3 / p.wh, p.scale_clamp);
+            const float pcx = dx * w + cx, pcy = dy * hgt + cy;
+            const float pw = ore_expf(dw) * w, phh = ore_expf(dh) * hgt;
+            f32x4 ob = f32x4{pcx - 0.5f * pw, pcy - 0.5f * phh, pcx + 0.5f * pw, pcy + 0.5f * phh};
+            const bool finite = isfinite(ob.x) && isfinite(ob.y) && isfinite(ob.z) && isfinite(ob.w) && isfinite(score);
+            ob.x = fminf(fmaxf(ob.x, 0.f), p.img_w); ob.y = fminf(fmaxf(ob.y, 0.f), p.img_h);
+            ob.z = fminf(fmaxf(ob.z, 0.f), p.img_w); ob.w = fminf(fmaxf(ob.w, 0.f), p.img_h);
+            *reinterpret_cast<f32x4*>(p.raw_boxes + (size_t)r * 4) = ob;
+            p.raw_scores[r] = score;
+            ok = (finite && score > p.score_thresh) ? 1 : 0;
+        }
+        ok_out[r] = ok;
+    }
+}
+
+struct TailP {
+    const float* raw_boxes; const float* raw_scores; const int* ok; const int* n_ptr; int n_host; int cap;
+    float nms_thresh; int topk;
+    float* det_boxes; float* det_scores; long long* det_src; int* det_count;
+    const float* post;                            // device {sx, sy, out_w, out_h} or null
+    float* fin_boxes; float* fin_scores; int* fin_count;
+};
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, d), hi = __shfl_xor((unsigned)(v >> 32), d);
+        v |= ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
+    // LDS: compacted + sorted boxes / scores / source rows, then the suppression words
+    __shared__ __attribute__((aligned(16))) float cb[ROI_FUSED_CAP * 4];    // compacted (filter order)
+    __shared__ float cs[ROI_FUSED_CAP];
+    __shared__ int csrc[ROI_FUSED_CAP];
+    __shared__ __attribute__((aligned(16))) float sb[ROI_FUSED_CAP * 4];    // sorted by score (desc, stable)
+    __shared__ float sa[ROI_FUSED_CAP];                                     // areas, sorted order
+    __shared__ int sord[ROI_FUSED_CAP];                                     // sorted position -> compacted index
+    __shared__ unsigned long long diagT[ROI_FUSED_CAP];                     // bit c: row is suppressed by row (blk*64+c), c < own lane
+    __shared__ unsigned long long up[ROI_FUSED_CAP * (ROI_FUSED_CAP / 64)]; // [row][word]: bit c: row suppresses row word*64+c (word > blk)
+    __shared__ int wsum[T / 64];
+    __shared__ int keep_pos[ROI_FUSED_CAP];
+    __shared__ int sh_keep;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
+    // ---- ordered compaction of the rows that pass the filter
+    int base = 0;
+    for (int r0 = 0; r0 < n; r0 += T) {
+        const int r = r0 + tid;
+        const int ok = (r < n) ? p.ok[r] : 0;
+        int inc = ok;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int pre = base, tot = 0;
+        for (int w2 = 0; w2 < T / 64; ++w2) { const int s2 = wsum[w2]; if (w2 < wave) pre += s2; tot += s2; }
+        if (ok) {
+            const int pos = pre + inc - 1;
+            *reinterpret_cast<f32x4*>(cb + pos * 4) = *reinterpret_cast<const f32x4*>(p.raw_boxes + (size_t)r * 4);
+            cs[pos] = p.raw_scores[r];
+            csrc[pos] = r;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    const int m = base;
+    const int words = (m + 63) >> 6;
+    // ---- stable descending rank by counting (score desc, compacted index asc), scatter into sorted order
+    for (int e = tid; e < m; e += T) {
+        const float se = cs[e];
+        int c = 0;
+        for (int f = 0; f < m; ++f) {
+            const float sf = cs[f];
+            c += (sf > se || (sf == se && f < e)) ? 1 : 0;
+        }
+        const f32x4 b = *reinterpret_cast<const f32x4*>(cb + e * 4);
+        *reinterpret_cast<f32x4*>(sb + c * 4) = b;
+        sa[c] = (b.z - b.x) * (b.w - b.y);
+        sord[c] = e;
+    }
+    __syncthreads();
+    // ---- suppression bits: task = (row i, word w >= i/64); the same float ops as k_nms_mask
+    for (int task = tid; task < m * words; task += T) {
+        const int i = task / words, w = task - i * words, bi = i >> 6;
+        if (w < bi) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sb + i * 4);
+        const float ai = sa[i];
+        const int j0 = w * 64, jmax = min(64, m - j0);
+        const bool dg = w == bi;
+        const int t = i & 63;
+        unsigned long long bits = 0;
+        for (int c = 0; c < jmax; ++c) {
+            if (dg && c >= t) break;
+            const f32x4 q = *reinterpret_cast<const f32x4*>(sb + (j0 + c) * 4);
+            const float xx1 = fmaxf(a.x, q.x), yy1 = fmaxf(a.y, q.y);
+            const float xx2 = fminf(a.z, q.z), yy2 = fminf(a.w, q.w);
+            const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+            const float inter = ww * hh;
+            const float ovr = inter / (ai + sa[j0 + c] - inter);
+            if (ovr > p.nms_thresh) bits |= 1ull << c;
+        }
+        if (dg) diagT[i] = bits; else up[i * (ROI_FUSED_CAP / 64) + w] = bits;
+    }
+    __syncthreads();
+    // ---- greedy resolution, wave 0: lane = row of the current 64-row block; removed words live in lane w of `rem`
+    if (wave == 0) {
+        unsigned long long rem = 0ull;            // lane w (< words) holds removed[w]
+        int n_keep = 0;
+        for (int bi = 0; bi < words; ++bi) {
+            const int row = bi * 64 + lane;
+            const unsigned long long diag = row < m ? diagT[row] : 0ull;
+            const unsigned rlo = __shfl((unsigned)rem, bi), rhi = __shfl((unsigned)(rem >> 32), bi);
+            unsigned long long rm = ((unsigned long long)rhi << 32) | rlo;       // removed[bi], wave-uniform
+            const int nvalid = min(64, m - bi * 64);
+            if (nvalid < 64) rm |= ~0ull << nvalid;
+            const unsigned long long cand = ~rm;
+            unsigned long long kept = cand;
+            if (__ballot(diag != 0ull) != 0ull) {
+                for (int it = 0; it < 64; ++it) {
+                    const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
+                    if (kn == kept) break;
+                    kept = kn;
+                }
+            }
+            if ((kept >> lane) & 1ull) keep_pos[n_keep + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+            n_keep += __popcll(kept);
+            // OR the kept rows' words into removed[bi+1 ..]: lane = row, one wave-wide OR per later word
+            for (int w = bi + 1; w < words; ++w) {
+                const unsigned long long v = (((kept >> lane) & 1ull) && row < m) ? up[row * (ROI_FUSED_CAP / 64) + w] : 0ull;
+                const unsigned long long o = wave_or64(v);
+                if (lane == w) rem |= o;
+            }
+        }
+        if (lane == 0) sh_keep = n_keep;
+    }
+    __syncthreads();
+    int nk = sh_keep;
+    if (p.topk >= 0 && nk > p.topk) nk = p.topk;
+    // ---- detections (score order) + detector_postprocess
+    for (int i = tid; i < nk; i += T) {
+        const int row = keep_pos[i];
+        const int e = sord[row];
+        *reinterpret_cast<f32x4*>(p.det_boxes + (size_t)i * 4) = *reinterpret_cast<const f32x4*>(sb + row * 4);
+        p.det_scores[i] = cs[e];
+        p.det_src[i] = (long long)csrc[e];
+    }
+    if (tid == 0) *p.det_count = nk;
+    if (p.post != nullptr) {
+        const float sx = p.post[0], sy = p.post[1], ow = p.post[2], oh = p.post[3];
+        int fbase = 0;
+        for (int i0 = 0; i0 < nk; i0 += T) {
+            const int i = i0 + tid;
+            int ok = 0;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            float sc = 0.f;
+            if (i < nk) {
+                const int row = keep_pos[i];
+                b = *reinterpret_cast<const f32x4*>(sb + row * 4);
+                sc = cs[sord[row]];
+                b.x = b.x * sx; b.z = b.z * sx; b.y = b.y * sy; b.w = b.w * sy;
+                b.x = fminf(fmaxf(b.x, 0.f), ow); b.z = fminf(fmaxf(b.z, 0.f), ow);
+                b.y = fminf(fmaxf(b.y, 0.f), oh); b.w = fminf(fmaxf(b.w, 0.f), oh);
+                ok = ((b.z - b.x) > 0.f && (b.w - b.y) > 0.f) ? 1 : 0;
+            }
+            int inc = ok;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+            __syncthreads();
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            int pre = fbase, tot = 0;
+            for (int w2 = 0; w2 < T / 64; ++w2) { const int s2 = wsum[w2]; if (w2 < wave) pre += s2; tot += s2; }
+            if (ok) {
+                const int pos = pre + inc - 1;
+                *reinterpret_cast<f32x4*>(p.fin_boxes + (size_t)pos * 4) = b;
+                p.fin_scores[pos] = sc;
+            }
+            fbase += tot;
+        }
+        if (tid == 0) *p.fin_count = fbase;
+    }
+}
+
 }  // namespace
 
 extern "C" int ore_nms_device_n_fwd(const float* boxes, const float* scores, const int32_t* n_dev, int32_t cap, float thr,
@@ -370,9 +614,22 @@ extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w
                                    const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
                                    int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return ore_roi_predict_post_fwd(h, C, cls_w, cls_b, box_w, box_b, boxes, n_dev, n_host, cap, reg_weights4_host, img_h, img_w,
+                                    score_thresh, nms_thresh, topk, det_boxes, det_scores, det_src, det_count, nullptr, nullptr, nullptr,
+                                    nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
+                                        const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
+                                        const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
+                                        int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
+                                        const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
     ORE_CHECK_ARG(h && cls_w && cls_b && box_w && box_b && boxes && reg_weights4_host && det_boxes && det_scores && det_src && det_count &&
                       workspace, "ore_roi_predict_fwd: null pointer");
     ORE_CHECK_ARG(cap >= 1 && C >= 1, "ore_roi_predict_fwd: bad args");
+    ORE_CHECK_ARG(!post_dev || (fin_boxes && fin_scores && fin_count), "ore_roi_predict_post_fwd: post without outputs");
+    ORE_CHECK_ARG(!post_dev || cap <= ROI_FUSED_CAP, "ore_roi_predict_post_fwd: the fused postprocess covers cap <= %d", ROI_FUSED_CAP);
     if (workspace_bytes < ore_roi_predict_workspace_bytes(cap)) {
         ore_set_error("ore_roi_predict_fwd: workspace %zu < %zu", workspace_bytes, ore_roi_predict_workspace_bytes(cap));
         return ORE_ENOMEM;
@@ -386,7 +643,7 @@ extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w
     float* raw_scores = (float*)(ws + o); o += c * 4;
     float* c_scores = (float*)(ws + o); o += c * 4;
     int* c_src = (int*)(ws + o); o += c * 4;
-    o += c * 4;
+    int* ok = (int*)(ws + o); o += c * 4;
     long long* keep = (long long*)(ws + o); o += c * 8;
     o = (o + 255) & ~(size_t)255;
     void* nms_ws = ws + o;
@@ -398,6 +655,19 @@ extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w
     p.img_h = img_h; p.img_w = img_w; p.score_thresh = score_thresh;
     p.raw_boxes = raw_boxes; p.raw_scores = raw_scores; p.c_boxes = c_boxes; p.c_scores = c_scores; p.c_src = c_src; p.c_count = c_count;
     hipStream_t st = (hipStream_t)stream;
+    if (cap <= ROI_FUSED_CAP && (size_t)C * 4 * 71 + 6 * 64 * 4 <= 60 * 1024) {
+        const size_t lds = ((size_t)64 * (C + 1) + 6 * (size_t)C + 6 * 64) * sizeof(float);
+        hipLaunchKernelGGL(k_roi_predict_mb, dim3(ceil_div(cap, 64)), dim3(256), lds, st, p, ok);
+        int rc = ore_launch_status("k_roi_predict_mb");
+        if (rc) return rc;
+        TailP t{};
+        t.raw_boxes = raw_boxes; t.raw_scores = raw_scores; t.ok = ok; t.n_ptr = n_dev; t.n_host = n_host; t.cap = cap;
+        t.nms_thresh = nms_thresh; t.topk = topk;
+        t.det_boxes = det_boxes; t.det_scores = det_scores; t.det_src = (long long*)det_src; t.det_count = det_count;
+        t.post = post_dev; t.fin_boxes = fin_boxes; t.fin_scores = fin_scores; t.fin_count = fin_count;
+        hipLaunchKernelGGL(k_roi_tail<256>, dim3(1), dim3(256), 0, st, t);
+        return ore_launch_status("k_roi_tail");
+    }
     const size_t lds = ((size_t)256 * (C + 1) + 6 * (size_t)C) * sizeof(float);
     ORE_CHECK_ARG(lds <= 150 * 1024, "ore_roi_predict_fwd: fc width %d too large", C);
     if (lds > 48 * 1024) ORE_HIP(hipFuncSetAttribute((const void*)k_roi_predict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -290,10 +290,27 @@ class CenterNet2Detector(nn.Module):
         assert not self.training
         self.init_model()
         assert len(batched_inputs) == 1, "only 1 query image in test (ref fsod_cen.py:438-439)"
-        img = batched_inputs[0]["image"].to(self.device)
+        inp = batched_inputs[0]
+        img = inp["image"]
+        e = self.engine()
+        if do_postprocess and getattr(e, "has_roi", False):
+            # the whole call -- both stages AND detector_postprocess (fsod_cen.py:557-571) -- is one hipGraph replay behind one C-ABI
+            # call; the image may still be on the host (the engine copies it in).  The only host sync is the detection count.
+            from detectron2.structures import Boxes, Instances
+            if img.dtype != torch.uint8 and img.dtype != torch.float32:
+                img = img.float()
+            img = img.contiguous()
+            H, W = img.shape[-2:]
+            oh, ow = int(inp.get("height", H)), int(inp.get("width", W))
+            boxes, scores = e.detect(img, oh, ow)
+            res = Instances((oh, ow))
+            res.pred_boxes = Boxes(boxes.clone())
+            res.scores = scores.clone()
+            res.pred_classes = torch.zeros(len(scores), dtype=torch.int64, device=scores.device)
+            return [{"instances": res}]
+        img = img.to(self.device)
         img = (img if img.dtype == torch.uint8 else img.float()).contiguous()
         H, W = img.shape[-2:]
-        e = self.engine()
         images = ImageList(torch.empty(0), [(H, W)])
         if getattr(e, "has_roi", False):
             # both stages in ONE hipGraph replay; the only host sync is reading the detection count

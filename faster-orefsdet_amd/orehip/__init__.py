@@ -71,7 +71,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
            "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
-           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd",
+           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_roi_predict_post_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
 
 _lib = None
@@ -856,6 +856,20 @@ class Engine:
         _, H, W = img.shape
         _chk(lib().ore_engine_eval_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W,
                                        int(use_graph), _stream()), "ore_engine_eval_fwd")
+
+    def detect(self, img: torch.Tensor, out_h: int, out_w: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The reference's eval call for one image, end to end, in ONE C-ABI call (ore_engine_detect_fwd): image [3,H,W] u8/f32 on
+        the device or on the host -> both stages + detector_postprocess as one hipGraph replay, the count read back through pinned
+        memory, one stream sync.  Returns (boxes [n,4], scores [n]): views of engine buffers, valid until the next forward."""
+        assert img.is_contiguous() and img.dim() == 3
+        _, H, W = img.shape
+        n = C.c_int32(0)
+        _chk(lib().ore_engine_detect_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W, int(out_h), int(out_w),
+                                         _stream(), C.byref(n)), "ore_engine_detect_fwd")
+        v = self.__dict__.get("_final_views")
+        if v is None:
+            v = self.__dict__["_final_views"] = (self.buffer("final_boxes"), self.buffer("final_scores")[:, 0])
+        return v[0][:n.value], v[1][:n.value]
 
     def eval_forward_batch(self, imgs: torch.Tensor, use_graph: bool = True) -> None:
         """imgs [B,3,H,W] u8/f32 on device, B <= max_batch: dense stages batched, detection tail + second stage per image

@@ -219,6 +219,16 @@ int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const flo
                         const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
                         int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same, plus detector_postprocess (d2z:modeling/postprocessing.py:10-75, reached from
+ * ref:fewx/modeling/fsod/fsod_cen.py:557-571) in the same launch when post_dev != NULL: post_dev = device {sx, sy, out_w, out_h}
+ * (sx = out_w / img_w, sy = out_h / img_h as float); the detections are scaled, clipped to the output size and the empty ones
+ * dropped (order kept) into fin_boxes [cap][4] / fin_scores [cap] / fin_count [1].  cap <= 512 with post_dev. */
+int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
+                             const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
+                             const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
+                             int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
+                             const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ training targets / losses - */
 /* CenterNet2 proposal-generator ground truth for only_proposal=True (class-agnostic), on device.
@@ -358,6 +368,13 @@ int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t img_is_u8, i
  * for this (H,W)).  Results stay on device; query with ore_engine_buffer(). */
 int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t use_graph,
                         void* stream);
+/* The reference's eval call for ONE image, end to end (ref:fewx/modeling/fsod/fsod_cen.py:417-452 `inference` + :557-571
+ * `_postprocess` -> d2z:modeling/postprocessing.py:10-75): copies the image in (device OR host pointer), replays the graph of both
+ * stages with detector_postprocess as its last kernel (scale to out_h x out_w, clip, drop empty boxes), copies the detection count to
+ * pinned host memory and waits for the stream.  *n_det detections are then in the buffers "final_boxes" [n,4] / "final_scores" [n]
+ * (ore_engine_buffer), valid until the next forward of this engine.  Needs ore_engine_set_roi_head. */
+int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                          void* stream, int32_t* n_det);
 /* The same for B images of one size in ONE pass (B <= cfg.max_batch; img [B][3][H][W] contiguous): the dense stages -- backbone, FPN,
  * correlation, conv3, head -- run batched (a CU fetches every layer's weights once for B images instead of once per image, which is
  * what bounds the bs = 1 kernels), the detection tail and the second stage run per image.  This is how a server folds concurrent

@@ -590,6 +590,33 @@ def test_detector_end_to_end(model, sd):
     np.testing.assert_allclose(res[0].pred_boxes.tensor.cpu().numpy(), eb.cpu().numpy(), rtol=1e-4, atol=1e-2)
 
 
+def test_engine_detect_call_equals_python_postprocess(model, sd):
+    """ore_engine_detect_fwd (both stages + detector_postprocess as the last kernel of the graph, count through pinned memory)
+    returns exactly what d2z:modeling/postprocessing.py computes from the engine's raw detections: anisotropic output size, device and
+    host images, uint8 and float32."""
+    from detectron2.modeling.postprocessing import detector_postprocess
+    from detectron2.structures import Boxes, Instances
+    sd2 = R.synth_roi_state(sd)
+    sd2["roi_heads.box_head.0.fc1.weight"] = sd2["roi_heads.box_head.0.fc1.weight"] * 0.01
+    model.load_state_dict({k: v for k, v in sd2.items() if k.startswith("roi_heads.")}, strict=False)
+    g = torch.Generator().manual_seed(9)
+    sup = R.synth_support(0)
+    rc8 = torch.randn(24, 128, 8, 8, generator=g) * 0.1
+    model.set_support_dict({**{k: {0: v} for k, v in sup.items()}, "rcnn_8": {0: rc8}, "rcnn_4": {0: torch.zeros(24, 128, 4, 4)}})
+    img = R.synth_image(6, 320, 352)
+    for image, (oh, ow) in ((img, (480, 800)), (img.cuda(), (320, 352)), (img.float(), (200, 111)), (img.cuda(), (480, 800))):
+        out = model([{"image": image, "height": oh, "width": ow}])[0]["instances"]
+        e = model._engine
+        b, s_, _ = e.detections()                                        # raw second-stage output of the same forward
+        raw = Instances((320, 352))
+        raw.pred_boxes, raw.scores = Boxes(b.clone()), s_.clone()
+        raw.pred_classes = torch.zeros(len(s_), dtype=torch.int64, device=s_.device)
+        want = detector_postprocess(raw, oh, ow)
+        assert out.image_size == (oh, ow) and len(out) == len(want) and len(out) > 0
+        assert torch.equal(out.pred_boxes.tensor, want.pred_boxes.tensor) and torch.equal(out.scores, want.scores)
+        assert out.pred_boxes.tensor.is_cuda and out.pred_classes.dtype == torch.int64
+
+
 def test_detector_inference_many_equals_one_at_a_time(model, sd):
     """CenterNet2Detector.inference_many: single-image requests of two sizes, folded per size into batched engine passes, return
     the detections of the reference protocol (one image per forward) in request order."""
