@@ -21,25 +21,10 @@
 //
 // Replaces F.conv2d + FrozenBatchNorm2d + ReLU / bias / Scale of the reference (see include/ore_hip.h).
 #include "ore_common.h"
+#include "ore_conv_internal.h"
 
 namespace {
-
-struct Lvl { int orow0, irow0, H, W, Ho, Wo; };
-
-struct ConvP {
-    const float* in; int in_ld, in_coff;
-    int B, Cin;
-    int nlev; Lvl lv[4];
-    const float* w;
-    int Cout, Cout16, kh, kw, stride, pad, M, K;
-    const float* scale; const float* shift; int ep_stride; int relu_cout;
-    const float* in_mul; const float* in_add; int in_relu;
-    const float* add; int add_ld, add_coff, add_H, add_W;
-    float* out; int out_ld, out_coff;
-    float* colsum;                       // [gridDim.x][Cout16] or null
-    int splitk, steps_per_split, nchunks;
-    float* ws; int* tile_cnt;
-};
+using namespace oreconv;
 
 // 16 bytes of zeros: the source of every out-of-image / out-of-range staging load, so that the loads themselves are
 // unconditional (no branch around a load => the compiler keeps them in flight behind counted vmcnt waits).

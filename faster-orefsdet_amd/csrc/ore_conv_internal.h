@@ -1,0 +1,29 @@
+// Shared by the conv translation units of libore_hip.so (ore_conv.hip, ore_conv_kw.hip): the kernel parameter block.
+#pragma once
+#include "ore_common.h"
+
+namespace oreconv {
+
+struct Lvl { int orow0, irow0, H, W, Ho, Wo; };
+
+struct ConvP {
+    const float* in; int in_ld, in_coff;
+    int B, Cin;
+    int nlev; Lvl lv[4];
+    const float* w;
+    int Cout, Cout16, kh, kw, stride, pad, M, K;
+    const float* scale; const float* shift; int ep_stride; int relu_cout;
+    const float* in_mul; const float* in_add; int in_relu;
+    const float* add; int add_ld, add_coff, add_H, add_W;
+    float* out; int out_ld, out_coff;
+    float* colsum;                       // [gridDim.x][Cout16] or null
+    int splitk, steps_per_split, nchunks;
+    float* ws; int* tile_cnt;
+};
+
+// ore_conv_kw.hip: wave-private K-split kernel fed by LDS-DMA.  Returns 1 when the layer is not covered (the caller falls back).
+int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st);
+// tile of the kw plan for (M, Cout): used by ore_conv_colsum_rows so the eSE reduction knows how many partial rows to expect
+int conv_kw_tile_rows(const ConvP& p);
+
+}  // namespace oreconv

@@ -82,8 +82,10 @@ struct ore_engine {
     // detector_postprocess inside the graph (ore_engine_detect_fwd): device {sx, sy, out_w, out_h} per image slot, the postprocessed
     // detections, and a pinned host word the count is copied into behind the graph
     float* post = nullptr; float post_host[4] = {1.f, 1.f, 0.f, 0.f};
-    float* fin_boxes = nullptr; float* fin_scores = nullptr; int32_t* fin_count = nullptr;
-    int32_t* pin_count = nullptr; float* pin_post = nullptr;
+    char* fin_pack = nullptr; int32_t* fin_count = nullptr;
+    float* fin_boxes_of(size_t b) const { return (float*)(fin_pack + b * (size_t)roi_cap * 28); }
+    float* fin_scores_of(size_t b) const { return fin_boxes_of(b) + (size_t)roi_cap * 4; }
+    int32_t* pin_count = nullptr; int32_t* pin_count_dev = nullptr; float* pin_post = nullptr;
     // graph cache
     hipStream_t cap_stream = nullptr;
     struct GraphKey { int u8, H, W, B; hipGraphExec_t exec; };
@@ -365,8 +367,8 @@ int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops, int b = 
     return ore_roi_predict_post_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, out_boxes, counts + 1, 0,
                                     e->roi_cap, e->roi_reg_w, (float)g.H, (float)g.W, e->roi_score_thresh, e->roi_nms_thresh, e->roi_topk,
                                     e->det_boxes + b * rcap * 4, e->det_scores + b * rcap, e->det_src + b * rcap, e->det_count + b * 4,
-                                    e->post, e->fin_boxes + b * rcap * 4, e->fin_scores + b * rcap, e->fin_count + b * 4, e->roi_ws,
-                                    e->roi_ws_bytes, st);
+                                    e->post, e->fin_boxes_of(b), e->fin_scores_of(b), e->fin_count + b * 4,
+                                    b == 0 ? e->pin_count_dev : nullptr, e->roi_ws, e->roi_ws_bytes, st);
 }
 
 }  // namespace
@@ -400,10 +402,16 @@ extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const
         if ((rc = e->dalloc(&w, e->roi_ws_bytes))) return rc;
         e->roi_ws = w;
         ORE_HIP(hipMemset(e->det_count, 0, MB * 4 * sizeof(int32_t)));
-        if ((rc = e->dalloc(&e->post, 8)) || (rc = e->dalloc(&e->fin_boxes, MB * cap * 4)) || (rc = e->dalloc(&e->fin_scores, MB * cap)) ||
-            (rc = e->dalloc(&e->fin_count, MB * 4))) return rc;
+        // packed result record per image: [cap][4] boxes | [cap] scores | [cap] int64 classes (always 0: one foreground class), so that
+        // ore_engine_detect_fwd hands the caller everything with ONE device-to-device copy
+        char* pack = nullptr;
+        if ((rc = e->dalloc(&e->post, 8)) || (rc = e->dalloc(&pack, MB * cap * 28)) || (rc = e->dalloc(&e->fin_count, MB * 4))) return rc;
+        ORE_HIP(hipMemset(pack, 0, MB * cap * 28));
+        e->fin_pack = pack;
         ORE_HIP(hipMemset(e->fin_count, 0, MB * 4 * sizeof(int32_t)));
-        ORE_HIP(hipHostMalloc((void**)&e->pin_count, 64, hipHostMallocDefault));
+        ORE_HIP(hipHostMalloc((void**)&e->pin_count, 64, hipHostMallocMapped));
+        ORE_HIP(hipHostGetDevicePointer((void**)&e->pin_count_dev, e->pin_count, 0));
+        e->pin_count[0] = 0;
         ORE_HIP(hipHostMalloc((void**)&e->pin_post, 64, hipHostMallocDefault));
         e->post_host[0] = e->post_host[1] = 1.f; e->post_host[2] = e->post_host[3] = 3.0e38f;   // identity until a size is requested
         ORE_HIP(hipMemcpy(e->post, e->post_host, 4 * sizeof(float), hipMemcpyHostToDevice));
@@ -633,7 +641,7 @@ extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8
 }
 
 extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
-                                     void* stream, int32_t* n_det) {
+                                     void* out_record, void* stream, int32_t* n_det) {
     ORE_CHECK_ARG(e && e->roi_set && n_det && out_h >= 1 && out_w >= 1, "ore_engine_detect_fwd: needs the second stage (ore_engine_set_roi_head)");
     hipStream_t st = (hipStream_t)stream;
     // detector_postprocess parameters: sx = out_w / W, sy = out_h / H evaluated like the reference's Python floats, rounded once to
@@ -647,9 +655,10 @@ extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_
     }
     int rc = ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, 1, stream);
     if (rc) return rc;
-    ORE_HIP(hipMemcpyAsync(e->pin_count, e->fin_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (out_record)         // the caller's freshly allocated result record is filled behind the graph, before the one host sync
+        ORE_HIP(hipMemcpyAsync(out_record, e->fin_pack, (size_t)e->roi_cap * 28, hipMemcpyDeviceToDevice, st));
     ORE_HIP(hipStreamSynchronize(st));
-    *n_det = e->pin_count[0];
+    *n_det = e->pin_count[0];                                // written by the last kernel of the graph through the device-mapped pointer
     return ORE_OK;
 }
 
@@ -806,8 +815,8 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
         if (base == "det_scores") return set(e->det_scores + ib * rcap, e->roi_cap, 1, 1, 0);
         if (base == "det_src") return set(e->det_src + ib * rcap, e->roi_cap, 1, 1, 0);
         if (base == "det_count") return set(e->det_count + ib * 4, 4, 1, 1, 0);
-        if (base == "final_boxes") return set(e->fin_boxes + ib * rcap * 4, e->roi_cap, 4, 4, 0);
-        if (base == "final_scores") return set(e->fin_scores + ib * rcap, e->roi_cap, 1, 1, 0);
+        if (base == "final_boxes") return set(e->fin_boxes_of(ib), e->roi_cap, 4, 4, 0);
+        if (base == "final_scores") return set(e->fin_scores_of(ib), e->roi_cap, 1, 1, 0);
         if (base == "final_count") return set(e->fin_count + ib * 4, 4, 1, 1, 0);
         if (n == "roi_h") return set(e->roi_h, e->roi_cap, e->roi_fc, e->roi_fc, 0);
     }

@@ -332,28 +332,28 @@ __global__ __launch_bounds__(256) void k_roi_finalize(const long long* __restric
 constexpr int ROI_FUSED_CAP = 512;
 
 __global__ __launch_bounds__(256) void k_roi_predict_mb(PredP p, int* __restrict__ ok_out) {
-    extern __shared__ float hs[];                 // [64][C+1] rows, then cls_w [2][C], box_w [4][C], then dots [6][64]
+    extern __shared__ float hs[];                 // [64][C+1] rows, then dots [6][64]
     const int C = p.C, LDH = C + 1;
-    float* wl = hs + 64 * LDH;
-    float* dots = wl + 6 * C;
+    float* dots = hs + 64 * LDH;
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = blockIdx.x * 64;
     if (r0 >= n) {                                // rows beyond the count: flag them out (the tail reads ok[0..cap))
         if (tid < 64 && r0 + tid < p.cap) ok_out[r0 + tid] = 0;
         return;
     }
     const int rows = min(64, n - r0);
-    for (int i = tid; i < 2 * C; i += 256) wl[i] = p.cls_w[i];
-    for (int i = tid; i < 4 * C; i += 256) wl[2 * C + i] = p.box_w[i];
     for (int i = tid; i < rows * C; i += 256) hs[(i / C) * LDH + (i % C)] = p.h[(size_t)r0 * C + i];
     __syncthreads();
     if (wave < 3 && lane < rows) {
+        // the weight index is wave-uniform: the compiler fetches the rows through the scalar cache (s_load), the LDS port only
+        // carries this lane's fc1 row (stride C+1: conflict-free)
         const float* h = hs + lane * LDH;
-        const float* w0 = wl + (2 * wave) * C;
-        const float* w1 = w0 + C;
+        const float* __restrict__ w0 = wave == 0 ? p.cls_w : p.box_w + (size_t)(2 * wave - 2) * C;
+        const float* __restrict__ w1 = w0 + C;
         float a0 = wave == 0 ? p.cls_b[0] : p.box_b[2 * wave - 2];
         float a1 = wave == 0 ? p.cls_b[1] : p.box_b[2 * wave - 1];
+#pragma unroll 8
         for (int c = 0; c < C; ++c) {
             const float v = h[c];
             a0 = fmaf(w0[c], v, a0);
@@ -396,7 +396,7 @@ struct TailP {
     float nms_thresh; int topk;
     float* det_boxes; float* det_scores; long long* det_src; int* det_count;
     const float* post;                            // device {sx, sy, out_w, out_h} or null
-    float* fin_boxes; float* fin_scores; int* fin_count;
+    float* fin_boxes; float* fin_scores; int* fin_count; int* host_count;
 };
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
@@ -422,6 +422,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
     __shared__ int wsum[T / 64];
     __shared__ int keep_pos[ROI_FUSED_CAP];
     __shared__ int sh_keep;
+    constexpr int NW = T / 64, WPR = ROI_FUSED_CAP / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
     // ---- ordered compaction of the rows that pass the filter
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         int pre = base, tot = 0;
-        for (int w2 = 0; w2 < T / 64; ++w2) { const int s2 = wsum[w2]; if (w2 < wave) pre += s2; tot += s2; }
+        for (int w2 = 0; w2 < NW; ++w2) { const int s2 = wsum[w2]; if (w2 < wave) pre += s2; tot += s2; }
         if (ok) {
             const int pos = pre + inc - 1;
             *reinterpret_cast<f32x4*>(cb + pos * 4) = *reinterpret_cast<const f32x4*>(p.raw_boxes + (size_t)r * 4);
@@ -447,41 +448,58 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
     }
     const int m = base;
     const int words = (m + 63) >> 6;
-    // ---- stable descending rank by counting (score desc, compacted index asc), scatter into sorted order
-    for (int e = tid; e < m; e += T) {
-        const float se = cs[e];
+    // ---- stable descending rank by counting (score desc, compacted index asc): 4 lanes per element, scatter into sorted order
+    for (int e0 = 0; e0 < m; e0 += T / 4) {
+        const int e = e0 + (tid >> 2), sub = tid & 3;
+        const bool valid = e < m;
+        const float se = valid ? cs[e] : 0.f;
         int c = 0;
-        for (int f = 0; f < m; ++f) {
-            const float sf = cs[f];
-            c += (sf > se || (sf == se && f < e)) ? 1 : 0;
+        if (valid)
+            for (int f = sub; f < m; f += 4) {
+                const float sf = cs[f];
+                c += (sf > se || (sf == se && f < e)) ? 1 : 0;
+            }
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        if (valid && sub == 0) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cb + e * 4);
+            *reinterpret_cast<f32x4*>(sb + c * 4) = b;
+            sa[c] = (b.z - b.x) * (b.w - b.y);
+            sord[c] = e;
         }
-        const f32x4 b = *reinterpret_cast<const f32x4*>(cb + e * 4);
-        *reinterpret_cast<f32x4*>(sb + c * 4) = b;
-        sa[c] = (b.z - b.x) * (b.w - b.y);
-        sord[c] = e;
     }
     __syncthreads();
-    // ---- suppression bits: task = (row i, word w >= i/64); the same float ops as k_nms_mask
-    for (int task = tid; task < m * words; task += T) {
-        const int i = task / words, w = task - i * words, bi = i >> 6;
-        if (w < bi) continue;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sb + i * 4);
-        const float ai = sa[i];
-        const int j0 = w * 64, jmax = min(64, m - j0);
-        const bool dg = w == bi;
-        const int t = i & 63;
-        unsigned long long bits = 0;
-        for (int c = 0; c < jmax; ++c) {
-            if (dg && c >= t) break;
-            const f32x4 q = *reinterpret_cast<const f32x4*>(sb + (j0 + c) * 4);
-            const float xx1 = fmaxf(a.x, q.x), yy1 = fmaxf(a.y, q.y);
-            const float xx2 = fminf(a.z, q.z), yy2 = fminf(a.w, q.w);
-            const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
-            const float inter = ww * hh;
-            const float ovr = inter / (ai + sa[j0 + c] - inter);
-            if (ovr > p.nms_thresh) bits |= 1ull << c;
+    // ---- suppression bits.  Unit of work = 16 rows of one 64x64 tile (bi <= w); lane = COLUMN of the tile, the row box is a
+    // broadcast LDS read, one ballot per row gives its 64-bit word.  Same float ops as k_nms_mask (row box = `a`, column box = `q`).
+    {
+        const int ntile = words * (words + 1) / 2;
+        for (int u = wave; u < ntile * 4; u += NW) {
+            int t = u >> 2, bi = 0;
+            while (t >= words - bi) { t -= words - bi; ++bi; }     // tile t of row-block bi: w = bi + t
+            const int w = bi + t, rq = (u & 3) * 16;
+            const int col = w * 64 + lane;
+            const bool cvalid = col < m;
+            const f32x4 q = cvalid ? *reinterpret_cast<const f32x4*>(sb + col * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float aq = cvalid ? sa[col] : 0.f;
+            const bool dg = w == bi;
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = bi * 64 + rq + rr;
+                if (row >= m) break;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sb + row * 4);
+                const float ai = sa[row];
+                const float xx1 = fmaxf(a.x, q.x), yy1 = fmaxf(a.y, q.y);
+                const float xx2 = fminf(a.z, q.z), yy2 = fminf(a.w, q.w);
+                const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+                const float inter = ww * hh;
+                const float ovr = inter / (ai + aq - inter);
+                const unsigned long long bits = __ballot(cvalid && ovr > p.nms_thresh);
+                if (lane == 0) {
+                    if (dg) diagT[row] = bits & ((1ull << (rq + rr)) - 1ull);   // earlier rows of the block that suppress this row
+                    else up[row * WPR + w] = bits;
+                }
+            }
         }
-        if (dg) diagT[i] = bits; else up[i * (ROI_FUSED_CAP / 64) + w] = bits;
     }
     __syncthreads();
     // ---- greedy resolution, wave 0: lane = row of the current 64-row block; removed words live in lane w of `rem`
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
             n_keep += __popcll(kept);
             // OR the kept rows' words into removed[bi+1 ..]: lane = row, one wave-wide OR per later word
             for (int w = bi + 1; w < words; ++w) {
-                const unsigned long long v = (((kept >> lane) & 1ull) && row < m) ? up[row * (ROI_FUSED_CAP / 64) + w] : 0ull;
+                const unsigned long long v = (((kept >> lane) & 1ull) && row < m) ? up[row * WPR + w] : 0ull;
                 const unsigned long long o = wave_or64(v);
                 if (lane == w) rem |= o;
             }
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
             if (lane == 63) wsum[wave] = inc;
             __syncthreads();
             int pre = fbase, tot = 0;
-            for (int w2 = 0; w2 < T / 64; ++w2) { const int s2 = wsum[w2]; if (w2 < wave) pre += s2; tot += s2; }
+            for (int w2 = 0; w2 < NW; ++w2) { const int s2 = wsum[w2]; if (w2 < wave) pre += s2; tot += s2; }
             if (ok) {
                 const int pos = pre + inc - 1;
                 *reinterpret_cast<f32x4*>(p.fin_boxes + (size_t)pos * 4) = b;
@@ -559,7 +577,10 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
             }
             fbase += tot;
         }
-        if (tid == 0) *p.fin_count = fbase;
+        if (tid == 0) {
+            *p.fin_count = fbase;
+            if (p.host_count) *p.host_count = fbase;      // pinned, device-mapped host word: the caller reads it after the stream sync
+        }
     }
 }
 
@@ -616,7 +637,7 @@ extern "C" int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w
                                    void* workspace, size_t workspace_bytes, void* stream) {
     return ore_roi_predict_post_fwd(h, C, cls_w, cls_b, box_w, box_b, boxes, n_dev, n_host, cap, reg_weights4_host, img_h, img_w,
                                     score_thresh, nms_thresh, topk, det_boxes, det_scores, det_src, det_count, nullptr, nullptr, nullptr,
-                                    nullptr, workspace, workspace_bytes, stream);
+                                    nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
@@ -624,7 +645,7 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
                                         const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
                                         int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
                                         const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
+                                        int32_t* host_count, void* workspace, size_t workspace_bytes, void* stream) {
     ORE_CHECK_ARG(h && cls_w && cls_b && box_w && box_b && boxes && reg_weights4_host && det_boxes && det_scores && det_src && det_count &&
                       workspace, "ore_roi_predict_fwd: null pointer");
     ORE_CHECK_ARG(cap >= 1 && C >= 1, "ore_roi_predict_fwd: bad args");
@@ -656,7 +677,7 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
     p.raw_boxes = raw_boxes; p.raw_scores = raw_scores; p.c_boxes = c_boxes; p.c_scores = c_scores; p.c_src = c_src; p.c_count = c_count;
     hipStream_t st = (hipStream_t)stream;
     if (cap <= ROI_FUSED_CAP && (size_t)C * 4 * 71 + 6 * 64 * 4 <= 60 * 1024) {
-        const size_t lds = ((size_t)64 * (C + 1) + 6 * (size_t)C + 6 * 64) * sizeof(float);
+        const size_t lds = ((size_t)64 * (C + 1) + 6 * 64) * sizeof(float);
         hipLaunchKernelGGL(k_roi_predict_mb, dim3(ceil_div(cap, 64)), dim3(256), lds, st, p, ok);
         int rc = ore_launch_status("k_roi_predict_mb");
         if (rc) return rc;
@@ -665,7 +686,8 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
         t.nms_thresh = nms_thresh; t.topk = topk;
         t.det_boxes = det_boxes; t.det_scores = det_scores; t.det_src = (long long*)det_src; t.det_count = det_count;
         t.post = post_dev; t.fin_boxes = fin_boxes; t.fin_scores = fin_scores; t.fin_count = fin_count;
-        hipLaunchKernelGGL(k_roi_tail<256>, dim3(1), dim3(256), 0, st, t);
+        t.host_count = host_count;
+        hipLaunchKernelGGL(k_roi_tail<1024>, dim3(1), dim3(1024), 0, st, t);
         return ore_launch_status("k_roi_tail");
     }
     const size_t lds = ((size_t)256 * (C + 1) + 6 * (size_t)C) * sizeof(float);

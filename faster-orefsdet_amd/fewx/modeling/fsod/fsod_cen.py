@@ -302,11 +302,11 @@ class CenterNet2Detector(nn.Module):
             img = img.contiguous()
             H, W = img.shape[-2:]
             oh, ow = int(inp.get("height", H)), int(inp.get("width", W))
-            boxes, scores = e.detect(img, oh, ow)
+            boxes, scores, classes = e.detect(img, oh, ow)        # fresh tensors, filled behind the graph
             res = Instances((oh, ow))
-            res.pred_boxes = Boxes(boxes.clone())
-            res.scores = scores.clone()
-            res.pred_classes = torch.zeros(len(scores), dtype=torch.int64, device=scores.device)
+            res.pred_boxes = Boxes(boxes)
+            res.scores = scores
+            res.pred_classes = classes
             return [{"instances": res}]
         img = img.to(self.device)
         img = (img if img.dtype == torch.uint8 else img.float()).contiguous()

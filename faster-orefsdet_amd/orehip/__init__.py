@@ -835,6 +835,7 @@ class Engine:
                                            C.c_void_p(bb.data_ptr()), rw, C.c_float(score_thresh), C.c_float(nms_thresh), topk),
              "ore_engine_set_roi_head")
         self.has_roi = True
+        self._det_cap = min(max(int(topk), 1), 320)        # rows of the result tensors ore_engine_detect_fwd fills
 
     def detections(self, b: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """(boxes [k,4], scores [k], source proposal index [k]) of the second stage for image b -- one sync to read the count."""
@@ -857,19 +858,23 @@ class Engine:
         _chk(lib().ore_engine_eval_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W,
                                        int(use_graph), _stream()), "ore_engine_eval_fwd")
 
-    def detect(self, img: torch.Tensor, out_h: int, out_w: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def detect(self, img: torch.Tensor, out_h: int, out_w: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """The reference's eval call for one image, end to end, in ONE C-ABI call (ore_engine_detect_fwd): image [3,H,W] u8/f32 on
-        the device or on the host -> both stages + detector_postprocess as one hipGraph replay, the count read back through pinned
-        memory, one stream sync.  Returns (boxes [n,4], scores [n]): views of engine buffers, valid until the next forward."""
+        the device or on the host -> both stages + detector_postprocess as one hipGraph replay, the results copied into freshly
+        allocated tensors behind the graph, the count through a device-mapped pinned word, one stream sync.
+        Returns (boxes [n,4], scores [n], classes [n] int64) -- the caller's own tensors, nothing of the engine aliases them."""
         assert img.is_contiguous() and img.dim() == 3
         _, H, W = img.shape
+        R = 320                                                        # ORE_DET_RECORD_ROWS
+        rec = torch.empty(R * 28, dtype=torch.uint8, device=self.device)  # [R][4] f32 | [R] f32 | [R] i64, filled by one copy
         n = C.c_int32(0)
         _chk(lib().ore_engine_detect_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W, int(out_h), int(out_w),
-                                         _stream(), C.byref(n)), "ore_engine_detect_fwd")
-        v = self.__dict__.get("_final_views")
-        if v is None:
-            v = self.__dict__["_final_views"] = (self.buffer("final_boxes"), self.buffer("final_scores")[:, 0])
-        return v[0][:n.value], v[1][:n.value]
+                                         C.c_void_p(rec.data_ptr()), _stream(), C.byref(n)), "ore_engine_detect_fwd")
+        boxes = rec[: R * 16].view(torch.float32).view(R, 4)
+        scores = rec[R * 16: R * 20].view(torch.float32)
+        classes = rec[R * 20:].view(torch.int64)
+        k = n.value
+        return boxes[:k], scores[:k], classes[:k]
 
     def eval_forward_batch(self, imgs: torch.Tensor, use_graph: bool = True) -> None:
         """imgs [B,3,H,W] u8/f32 on device, B <= max_batch: dense stages batched, detection tail + second stage per image

@@ -222,13 +222,14 @@ int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const flo
 /* The same, plus detector_postprocess (d2z:modeling/postprocessing.py:10-75, reached from
  * ref:fewx/modeling/fsod/fsod_cen.py:557-571) in the same launch when post_dev != NULL: post_dev = device {sx, sy, out_w, out_h}
  * (sx = out_w / img_w, sy = out_h / img_h as float); the detections are scaled, clipped to the output size and the empty ones
- * dropped (order kept) into fin_boxes [cap][4] / fin_scores [cap] / fin_count [1].  cap <= 512 with post_dev. */
+ * dropped (order kept) into fin_boxes [cap][4] / fin_scores [cap] / fin_count [1]; host_count (may be NULL) is a device-mapped
+ * pinned host word that receives the same count, so the caller needs no device-to-host copy.  cap <= 512 with post_dev. */
 int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
                              const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
                              const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
                              int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
                              const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             int32_t* host_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ training targets / losses - */
 /* CenterNet2 proposal-generator ground truth for only_proposal=True (class-agnostic), on device.
@@ -370,11 +371,15 @@ int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32
                         void* stream);
 /* The reference's eval call for ONE image, end to end (ref:fewx/modeling/fsod/fsod_cen.py:417-452 `inference` + :557-571
  * `_postprocess` -> d2z:modeling/postprocessing.py:10-75): copies the image in (device OR host pointer), replays the graph of both
- * stages with detector_postprocess as its last kernel (scale to out_h x out_w, clip, drop empty boxes), copies the detection count to
- * pinned host memory and waits for the stream.  *n_det detections are then in the buffers "final_boxes" [n,4] / "final_scores" [n]
- * (ore_engine_buffer), valid until the next forward of this engine.  Needs ore_engine_set_roi_head. */
+ * stages with detector_postprocess in its last kernel (scale to out_h x out_w, clip, drop empty boxes), which also writes the
+ * detection count to a device-mapped pinned host word, and waits for the stream: ONE host sync per image.  *n_det detections are then
+ * in the engine buffers "final_boxes" [n,4] / "final_scores" [n] (valid until the next forward of this engine) and, when out_record
+ * != NULL, in the caller's own device memory: out_record = ORE_DET_RECORD_BYTES bytes laid out [320][4] f32 boxes | [320] f32 scores
+ * | [320] int64 classes (all 0: one foreground class), filled by ONE copy queued behind the graph.  Needs ore_engine_set_roi_head. */
+#define ORE_DET_RECORD_ROWS 320
+#define ORE_DET_RECORD_BYTES (ORE_DET_RECORD_ROWS * 28)
 int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
-                          void* stream, int32_t* n_det);
+                          void* out_record, void* stream, int32_t* n_det);
 /* The same for B images of one size in ONE pass (B <= cfg.max_batch; img [B][3][H][W] contiguous): the dense stages -- backbone, FPN,
  * correlation, conv3, head -- run batched (a CU fetches every layer's weights once for B images instead of once per image, which is
  * what bounds the bs = 1 kernels), the detection tail and the second stage run per image.  This is how a server folds concurrent
