@@ -1050,6 +1050,7 @@ int dispatch(const ConvP& p, const TileCfg& t, dim3 grid, hipStream_t st) {
 // Tile / split plan.  Goal: >= ~768 waves' worth of blocks (256 CUs x 3) when the layer allows it, slabs small enough
 // for the in-kernel last-arriver reduction (splitk * BM*BN*4 bytes per tile stays in the tens of KB).
 TileCfg g_override = {0, 0, 0, 0, 0};   // tuning aid (ore_conv_set_plan_override); BM == 0 -> automatic
+int g_kw_mode = 1;                      // 0: k_conv_kw off, 1: automatic (after the 3x3 patch kernels), 2: wherever it applies
 
 void plan_conv(int M, int Cout, int nchunks, int req_splitk, TileCfg* t, int* S_out, int* sps_out) {
     const int C16 = round_up(Cout, 16);
@@ -1145,6 +1146,8 @@ extern "C" size_t ore_conv_workspace_floats(void) { return ORE_CONV_WS_FLOATS; }
 // automatic plan.  Not used by the product path.
 extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK) {
     if (BM == -1) { g_patch_mode = BN; g_override = {0, 0, 0, 0, 0}; return ORE_OK; }   // BM = -1: BN selects the 3x3 patch kernel mode
+    if (BM == -2) { g_kw_mode = BN; g_override = {0, 0, 0, 0, 0}; return ORE_OK; }
+    if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
     g_override = {BM, BN, WGM, WGN, WGK};
     return ORE_OK;
 }
@@ -1167,6 +1170,12 @@ extern "C" int32_t ore_conv_get_precision(void) { return g_conv_bf16; }
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !g_conv_bf16 && !d->in_mul && d->B * Ho * Wo < 16384 && d->Cin % 16 == 0) {
+        ConvP q{};
+        q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (d->Cin / 16);
+        const int bm = conv_kw_tile_rows(q);
+        if (bm > 0) return ceil_div(q.M, bm);                 // the layer runs on k_conv_kw (same test as conv_launch)
+    }
     TileCfg t; int S, sps;
     plan_conv(d->B * Ho * Wo, d->Cout, d->kh * d->kw * (d->Cin / 16), d->splitk, &t, &S, &sps);
     return ceil_div(d->B * Ho * Wo, t.BM);
@@ -1174,8 +1183,19 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
 
 static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (g_override.BM == 0 && req_splitk <= 1) {
-        const int prc = patch_launch(p, st);
+        // several pyramid levels in one launch (the head tower): the 16-pixel-wide patch tiles waste 17-37 % on the 40- and 20-wide
+        // levels, k_conv_kw takes it (47 -> 39 us, profiles/r02_kw_sweep.txt)
+        const bool kw_first = g_kw_mode == 2 || (g_kw_mode == 1 && !g_conv_bf16 && p.nlev > 1);
+        const int prc = kw_first ? 1 : patch_launch(p, st);
         if (prc != 1) return prc;
+        if (g_kw_mode && !g_conv_bf16) {                      // small / medium M: the wave-private K-split LDS-DMA kernel (ore_conv_kw.hip)
+            const int krc = conv_kw_launch(p, workspace, workspace_floats, st);
+            if (krc != 1) return krc;
+            if (kw_first && g_kw_mode != 2) {                 // not covered after all: the patch kernels get their turn
+                const int prc2 = patch_launch(p, st);
+                if (prc2 != 1) return prc2;
+            }
+        }
     }
     TileCfg t; int S, sps;
     plan_conv(p.M, p.Cout, p.nchunks, req_splitk, &t, &S, &sps);

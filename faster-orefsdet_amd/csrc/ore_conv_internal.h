@@ -25,5 +25,7 @@ struct ConvP {
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st);
 // tile of the kw plan for (M, Cout): used by ore_conv_colsum_rows so the eSE reduction knows how many partial rows to expect
 int conv_kw_tile_rows(const ConvP& p);
+// tuning aid (ore_conv_set_plan_override(-3, bm, bn, ns, splitk)): force tile / ring depth / split of k_conv_kw; bm = 0 -> automatic
+void conv_kw_force(int bm, int bn, int ns, int splitk);
 
 }  // namespace oreconv

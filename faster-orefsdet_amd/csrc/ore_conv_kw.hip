@@ -1,0 +1,461 @@
+// k_conv_kw -- implicit-GEMM NHWC convolution for the SMALL / MEDIUM-M layers of the path (stages 3-5, the FPN, conv3, the second-stage
+// GEMM: M = 320 .. 8400 rows at batch 1), fp32 MFMA (v_mfma_f32_16x16x4_f32), fed by LDS-DMA.
+//
+// Why a second kernel.  k_conv_igemm stages every K step through registers (global_load -> VGPR -> ds_write -> ds_read -> MFMA)
+// with the address arithmetic, the LDS writes, the fragment reads and the MFMAs of one step issued back to back by the same wave:
+// a step of the 16x32 tile costs ~2400 clocks for 256 clocks of MFMA issue (profiles/r01_igemm_phase_trace.txt).  Here
+//   * every wave of the block owns a K SLICE (chunk c of 16 input channels goes to wave c % 4) and a private LDS ring, so the K loop
+//     has NO barrier: a wave waits only for its own DMA (counted s_waitcnt vmcnt) and the four waves drift apart;
+//   * the tiles travel global -> LDS by `global_load_lds_dwordx4` (1 KiB per wave-instruction = 16 rows x 64 B, no VGPR staging, no
+//     ds_write), NS stages deep, so a stage has (NS-1) MFMA phases to land;
+//   * the LDS image of a 16-row group is lane-linear (the DMA's only form); the bank conflicts of its 64-byte rows are removed by an
+//     XOR swizzle applied to the SOURCE address of each lane and, identically, to the fragment read (cdna guide rule 21);
+//   * per step and wave: (BM/16 + BN/16) DMA instructions, as many ds_read_b128, 4 x (BM/16) x (BN/16) MFMAs, ~10 VALU of addressing.
+// The four partial tiles are summed through LDS in wave order; cross-block split-K (grid.z) uses the same slab + agent-scope
+// release/acquire ticket as k_conv_igemm (last arriver sums the slabs in slice order: bitwise deterministic).
+// Epilogue = k_conv_igemm's: y = acc*scale[n] + shift[n] (+ nearest-2x top-down add) (+ ReLU on n < relu_cout), per-tile column sums
+// (eSE average pool), channel-slice output.  Optional per-(image, channel) input multiplier (the eSE gate folded into the FPN
+// laterals) applied to the A fragments.  Not covered (the caller falls back to k_conv_igemm): input affine with add / ReLU (the
+// GroupNorm fold of the head's last conv), bf16 operand mode, Cin % 16 != 0.
+//
+// Replaces F.conv2d + FrozenBatchNorm2d + ReLU / bias of d2z:modeling/backbone/vovnet.py:205-219,310-332, fpn.py:113-154,
+// ref:fewx/modeling/fsod/fsod_cen.py:470 (conv3), fsod_roi_heads.py:500-520 (composed DSA + fc1).
+#include "ore_conv_internal.h"
+
+namespace {
+using namespace oreconv;
+
+// 256 bytes of zeros: the DMA source of every out-of-image tap / out-of-range row.  The kernels take its ADDRESS as an argument
+// (a reference to the symbol inside the K loop makes hipcc re-fetch the address through the GOT, with a scalar-memory wait, per DMA).
+__device__ __attribute__((aligned(256))) float g_zero_kw[64] = {};
+
+
+__device__ __forceinline__ void decode_row(const ConvP& p, int m, int& lvl, int& b, int& oy, int& ox) {
+    lvl = 0;
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+        if (l < p.nlev && m >= p.lv[l].orow0) lvl = l;
+    const Lvl& L = p.lv[lvl];
+    const int r = m - L.orow0, hw = L.Ho * L.Wo;
+    b = r / hw;
+    const int q = r - b * hw;
+    oy = q / L.Wo;
+    ox = q - oy * L.Wo;
+}
+
+__device__ __forceinline__ float epilogue_one(const ConvP& p, float acc, int m, int n) {
+    float v = acc;
+    int lvl = 0, b = 0, oy = 0, ox = 0;
+    if (p.ep_stride || p.add) decode_row(p, m, lvl, b, oy, ox);
+    if (p.scale) v = v * p.scale[lvl * p.ep_stride + n];
+    if (p.shift) v = v + p.shift[lvl * p.ep_stride + n];
+    if (p.add) v += p.add[(size_t)((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + n];
+    if (n < p.relu_cout) v = fmaxf(v, 0.0f);
+    return v;
+}
+
+// finish one accumulator vector (4 consecutive channels of one pixel): epilogue + store
+__device__ __forceinline__ bool finish4(const ConvP& p, f32x4 a, int m, int n, bool vec_ok, f32x4& vout) {
+    if (m >= p.M || n >= p.Cout) return false;
+    f32x4 v;
+    if (p.ep_stride == 0 && !p.add && n + 3 < p.Cout && p.scale && p.shift) {       // the common form: two 16-byte operand loads
+        v = a * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.0f);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = n + r < p.Cout ? epilogue_one(p, a[r], m, n + r) : 0.0f;
+    }
+    float* o = p.out + (size_t)m * p.out_ld + p.out_coff + n;
+    if (vec_ok && n + 3 < p.Cout) {
+        *reinterpret_cast<f32x4*>(o) = v;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < p.Cout) o[r] = v[r];
+    }
+    vout = v;
+    return true;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// XOR swizzle of the four 16-byte quads of a 64-byte row inside a 16-row group: with q' = q ^ SW[(r >> 2) & 3] every ds_read_b128
+// lane group (rows {0-3, 12-15} of quad q with rows 4-11 of quad q+1, and its mirror) touches 16 distinct 4-bank groups.
+__device__ __forceinline__ int swz(int r16) { return (0x1320 >> (((r16 >> 2) & 3) * 4)) & 3; }   // {0, 2, 3, 1}
+
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restrict__ zero_page) {
+    constexpr int GA = BM / 16, GB = BN / 16, G = GA + GB;        // DMA instructions (= 16-row groups) per stage
+    constexpr int STAGE_F = (BM + BN) * 16;                       // floats per stage
+    constexpr int RING_F = 4 * NS * STAGE_F;
+    constexpr int RED_F = 4 * GA * GB * 256;                      // the four partial tiles, [wave][tile][lane][4]
+    constexpr int CS_F = GA * GB * 16;                            // per-tile column sums (fused eSE average pool)
+    constexpr int LDS_F = RING_F > RED_F + CS_F ? RING_F : RED_F + CS_F;
+    static_assert(BM % 16 == 0 && BN % 16 == 0 && NS >= 2 && (NS - 1) * G <= 63, "tile");
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // LDS_F + 8 floats; ONE LDS object (a second one de-pipelines the DMA waits)
+    int* sh_flag = reinterpret_cast<int*>(lds + LDS_F);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int cpt = p.Cin >> 4;                                   // 16-channel chunks per tap
+    // chunk range of this block (cross-block split-K), then this wave's chunks: c_begin + wave, + 4, ...
+    const int c_begin = blockIdx.z * p.steps_per_split * 4;
+    const int c_end = min(c_begin + p.steps_per_split * 4, p.nchunks);
+    const int nst = p.steps_per_split;                            // same trip count for every wave (short waves multiply zeros)
+
+    // ---- per-lane DMA sources: lane L of a group's instruction fills LDS slot L = (row L>>2, physical quad L&3)
+    const int r16 = lane >> 2, lq = (lane & 3) ^ swz(r16);        // logical k-quad this lane fetches
+    const float* a_base[GA];
+    int a_rs[GA];
+    unsigned a_taps[GA];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int m = m0 + i * 16 + r16;
+        a_base[i] = zero_page; a_rs[i] = 0; a_taps[i] = 0u;
+        if (m < p.M) {
+            int lvl, b, oy, ox;
+            decode_row(p, m, lvl, b, oy, ox);
+            const Lvl& L = p.lv[lvl];
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            a_rs[i] = L.W * p.in_ld;
+            a_base[i] = p.in + ((ptrdiff_t)(L.irow0 + b * L.H * L.W) + (ptrdiff_t)iy0 * L.W + ix0) * p.in_ld + p.in_coff + lq * 4;
+            unsigned mask = 0u;
+            for (int dy = 0; dy < p.kh; ++dy)
+                for (int dx = 0; dx < p.kw; ++dx)
+                    if ((unsigned)(iy0 + dy) < (unsigned)L.H && (unsigned)(ix0 + dx) < (unsigned)L.W) mask |= 1u << (dy * p.kw + dx);
+            a_taps[i] = mask;
+        }
+    }
+    const float* b_base[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int n = n0 + j * 16 + r16;
+        b_base[j] = n < p.Cout16 ? p.w + (size_t)n * p.K + lq * 4 : nullptr;
+    }
+    // (dy, dx, cc) of this wave's next chunk to ISSUE, advanced by 4 chunks per step without divisions (wave-uniform)
+    int i_c = c_begin + wave, i_dy, i_dx, i_cc;
+    {
+        const int tap = i_c / cpt;
+        i_cc = i_c - tap * cpt;
+        i_dy = tap / p.kw; i_dx = tap - i_dy * p.kw;
+    }
+    float* ring = lds + wave * (NS * STAGE_F);
+    auto issue = [&](int slot) {
+        float* dst = ring + slot * STAGE_F;
+        const bool live = i_c < c_end;
+        const unsigned tapbit = live ? (1u << (i_dy * p.kw + i_dx)) : 0u;
+        const int uoff = i_dx * p.in_ld + (i_cc << 4);
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const float* src = (a_taps[i] & tapbit) ? a_base[i] + (i_dy * a_rs[i] + uoff) : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            const float* src = (live && b_base[j]) ? b_base[j] + ((size_t)i_c << 4) : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + (GA + j) * 256), 16, 0, 0);
+        }
+        // advance by 4 chunks
+        i_c += 4;
+        i_cc += 4;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const bool wrap = i_cc >= cpt;
+            i_cc -= wrap ? cpt : 0;
+            i_dx += wrap ? 1 : 0;
+            const bool wy = i_dx == p.kw;
+            i_dx = wy ? 0 : i_dx;
+            i_dy += wy ? 1 : 0;
+        }
+    };
+
+    f32x4 acc[GA][GB];
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+#pragma unroll
+        for (int j = 0; j < GB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (floats) inside a 16-row group: row = lane & 15, logical quad = lane >> 4
+    const int frow = lane & 15;
+    const int foff = frow * 16 + (((lane >> 4) ^ swz(frow)) << 2);
+    // ---- prologue: NS-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    int slot = 0;
+    for (int t = 0; t < nst; ++t) {
+        int nslot = slot + NS - 1;
+        nslot -= nslot >= NS ? NS : 0;
+        asm volatile("" ::: "memory");
+        issue(nslot);                                             // the slot read at step t-1: its fragment reads have retired (own wave)
+        wait_vmcnt<(NS - 1) * G>();                               // stage t has landed (all but the NS-1 youngest stages)
+        const float* st = ring + slot * STAGE_F;
+        f32x4 af[GA], bf[GB];
+#pragma unroll
+        for (int i = 0; i < GA; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + i * 256 + foff);
+#pragma unroll
+        for (int j = 0; j < GB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + (GA + j) * 256 + foff);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < GA; ++i)
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);   // D^T: lane = pixel
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this step's fragment reads are done before the slot is refilled
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    wait_vmcnt<0>();                                              // drain the zero-page tail loads before the ring is reused
+    __syncthreads();
+
+    // ---- sum the four K slices in wave order through LDS; all 256 threads share the epilogue (one 16-byte item each)
+    constexpr int NT = GA * GB;
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+#pragma unroll
+        for (int j = 0; j < GB; ++j)
+            *reinterpret_cast<f32x4*>(lds + ((wave * NT) + i * GB + j) * 256 + lane * 4) = acc[i][j];
+    __syncthreads();
+    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+    const int ntile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.splitk <= 1) {
+        float* cs = lds + RED_F;
+#pragma unroll
+        for (int q0 = 0; q0 < NT * 64; q0 += 256) {
+            const int q = q0 + tid;                               // a wave's 64 items are one 16x16 tile: lane = accumulator lane
+            if (q < NT * 64) {
+                const int tl = q >> 6, ln = q & 63;
+                const int j2 = tl % GB, i2 = tl / GB;
+                f32x4 a = *reinterpret_cast<const f32x4*>(lds + (0 * NT + tl) * 256 + ln * 4);
+#pragma unroll
+                for (int g = 1; g < 4; ++g) a += *reinterpret_cast<const f32x4*>(lds + (g * NT + tl) * 256 + ln * 4);
+                f32x4 vo = {0.f, 0.f, 0.f, 0.f};
+                if (!finish4(p, a, m0 + i2 * 16 + (ln & 15), n0 + j2 * 16 + (ln >> 4) * 4, vec_ok, vo)) vo = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.colsum) {                                   // column sums of the tile: the 16 pixel lanes of a channel quad
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vo[r] += __shfl_xor(vo[r], d);
+                    if ((ln & 15) == 0) *reinterpret_cast<f32x4*>(cs + tl * 16 + (ln >> 4) * 4) = vo;
+                }
+            }
+        }
+        if (p.colsum) {
+            __syncthreads();
+            if (tid < GB * 16) {                                  // sum the block's GA row tiles in order -> one partial row per block
+                const int j2 = tid >> 4, ch = tid & 15;
+                float sacc = cs[j2 * 16 + ch];
+#pragma unroll
+                for (int i2 = 1; i2 < GA; ++i2) sacc += cs[(i2 * GB + j2) * 16 + ch];
+                const int n = n0 + j2 * 16 + ch;
+                if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = sacc;
+            }
+        }
+        return;
+    }
+    // ---- split-K and/or fused column sums: wave 0 carries the block's tile
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+#pragma unroll
+            for (int j = 0; j < GB; ++j) {
+                f32x4 a = acc[i][j];
+#pragma unroll
+                for (int g = 1; g < 4; ++g) a += *reinterpret_cast<const f32x4*>(lds + (g * NT + i * GB + j) * 256 + lane * 4);
+                acc[i][j] = a;
+            }
+    }
+    if (p.splitk > 1) {
+        float* slab = p.ws + ((size_t)ntile * p.splitk + blockIdx.z) * (BM * BN);
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < GA; ++i)
+#pragma unroll
+                for (int j = 0; j < GB; ++j) *reinterpret_cast<f32x4*>(slab + (i * GB + j) * 256 + lane * 4) = acc[i][j];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(p.tile_cnt + ntile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.splitk - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.tile_cnt + ntile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-reset
+            }
+            *sh_flag = last;
+        }
+        __syncthreads();
+        if (!*sh_flag) return;
+        if (wave == 0) {
+            const float* base = p.ws + (size_t)ntile * p.splitk * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < GA; ++i)
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                    for (int z = 0; z < p.splitk; ++z)
+                        s += *reinterpret_cast<const f32x4*>(base + (size_t)z * (BM * BN) + (i * GB + j) * 256 + lane * 4);
+                    acc[i][j] = s;
+                }
+        }
+    }
+    if (wave != 0) return;
+    f32x4 csum[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int cg4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            f32x4 v;
+            if (finish4(p, acc[i][j], m0 + i * 16 + (lane & 15), n0 + j * 16 + cg4, vec_ok, v)) csum[j] += v;
+        }
+    if (p.colsum) {
+#pragma unroll
+        for (int j = 0; j < GB; ++j)
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[j][r] += __shfl_xor(csum[j][r], d);
+        if ((lane & 15) == 0)
+#pragma unroll
+            for (int j = 0; j < GB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + j * 16 + cg4 + r;
+                    if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = csum[j][r];
+                }
+    }
+}
+
+struct KwTile { int BM, BN, S; };      // S = cross-block split-K (0: decide from the block count), BM = 0: layer left to k_conv_igemm / patch
+
+// Tile plan, from tools/conv_kw_sweep.py on MI355X (profiles/r02_kw_sweep.txt).  What the sweep says: the minimal ring (NS = 2) wins
+// almost everywhere -- more resident blocks per CU hide the DMA latency better than a deeper ring --, cross-block split-K pays only
+// for K >= 2048 with < 128 tiles, and the 256-channel 1x1 concat at M = 6400 and the 128 -> 128 3x3 at M = 6400 stay on their round-1
+// kernels.  Shapes outside the table get the tile with the most FLOP per staged byte among those that give >= 384 blocks.
+KwTile kw_tile(int M, int C16, int nchunks) {
+    const int steps = ceil_div(nchunks, 4);
+    if (M >= 4096) {
+        if (C16 >= 256) return {0, 0, 0};
+        if (C16 <= 80) return {32, 16, 1};
+        if (C16 == 128) return {16, 32, 1};
+    } else if (M >= 1024) {
+        if (C16 == 96) return {16, 48, 1};
+        if (C16 == 128) return {16, 32, 1};
+        if (C16 >= 256) return {16, 80, 1};
+    } else {
+        if (C16 <= 128 && steps >= 96) return {16, 48, 4};           // the second-stage GEMM: 320 x 8192 -> 128
+        if (C16 <= 128 && steps >= 32) return {16, 32, 4};           // stage-5 layer 0
+        if (C16 <= 128) return {16, 16, 1};
+        return {16, 32, 1};
+    }
+    static const int bns[5] = {80, 64, 48, 32, 16};
+    KwTile best = {16, 16, 0};
+    float bs = -1.0f;
+    int most = 0;
+    for (int bm = 32; bm >= 16; bm -= 16)
+        for (int b = 0; b < 5; ++b) {
+            const int bn = bns[b];
+            if (bn > C16) continue;
+            const int nt = ceil_div(C16, bn), blocks = ceil_div(M, bm) * nt;
+            const float ai = (float)(bm * bn) / (float)(bm + bn) * (float)C16 / (float)(nt * bn);
+            if (blocks >= 384) { if (ai > bs) { bs = ai; best = {bm, bn, 0}; } }
+            else if (bs < 0.0f && blocks > most) { most = blocks; best = {bm, bn, 0}; }
+        }
+    return best;
+}
+
+template <int BM, int BN, int NS>
+int launch_kw_ns(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
+    constexpr int G = (BM + BN) / 16;
+    if constexpr ((NS - 1) * G > 63) {
+        return ORE_EINVAL;
+    } else {
+        constexpr int RING_F = 4 * NS * (BM + BN) * 16, RED_F = 4 * (BM / 16) * (BN / 16) * 256 + (BM / 16) * (BN / 16) * 16;
+        constexpr size_t lds = ((size_t)(RING_F > RED_F ? RING_F : RED_F) + 8) * sizeof(float);
+        if constexpr (lds > 160 * 1024) {
+            return ORE_EINVAL;
+        } else {
+            static bool attr = false;
+            if (!attr) {
+                ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kw<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr = true;
+            }
+            hipLaunchKernelGGL((k_conv_kw<BM, BN, NS>), grid, dim3(256), lds, st, p, zero);
+            return ORE_OK;
+        }
+    }
+}
+
+int g_kw_force[4] = {0, 0, 0, 0};       // tuning aid: {BM, BN, NS, split-K}; BM = 0 -> automatic
+
+template <int BM, int BN>
+int launch_kw(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
+    int ns = 2;                          // (see kw_tile: the minimal ring wins)
+    if (g_kw_force[0] > 0 && g_kw_force[2] > 0) ns = g_kw_force[2];
+    if (ns == 2) return launch_kw_ns<BM, BN, 2>(p, zero, grid, st);
+    if (ns == 3) return launch_kw_ns<BM, BN, 3>(p, zero, grid, st);
+    if (ns == 4) return launch_kw_ns<BM, BN, 4>(p, zero, grid, st);
+    if (ns == 6) return launch_kw_ns<BM, BN, 6>(p, zero, grid, st);
+    return ORE_EINVAL;
+}
+
+}  // namespace
+
+namespace oreconv {
+
+int conv_kw_tile_rows(const ConvP& p) { return g_kw_force[0] > 0 ? g_kw_force[0] : kw_tile(p.M, p.Cout16, p.nchunks).BM; }
+
+void conv_kw_force(int bm, int bn, int ns, int splitk) { g_kw_force[0] = bm; g_kw_force[1] = bn; g_kw_force[2] = ns; g_kw_force[3] = splitk; }
+
+int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
+    if (p.in_mul || p.M >= 16384 || p.Cin % 16 != 0) return 1;            // large-M layers keep their kernels; input affine not built here
+    KwTile t = kw_tile(p.M, p.Cout16, p.nchunks);
+    if (g_kw_force[0] > 0) t = {g_kw_force[0], g_kw_force[1] < p.Cout16 ? g_kw_force[1] : p.Cout16, g_kw_force[3]};
+    if (t.BM == 0) return 1;
+    const int gx = ceil_div(p.M, t.BM), gy = ceil_div(p.Cout16, t.BN);
+    const int blocks = gx * gy;
+    const int steps = ceil_div(p.nchunks, 4);                             // steps per wave without a cross-block split
+    int S = t.S;
+    if (S <= 0) S = (blocks < 128 && steps >= 32) ? 4 : 1;
+    if (S > steps) S = steps;
+    int sps = ceil_div(steps, S);
+    S = ceil_div(steps, sps);
+    if (S > 1) {
+        const size_t need = ORE_CONV_CNT_INTS + (size_t)blocks * S * t.BM * t.BN;
+        if (!workspace || workspace_floats < need || blocks > ORE_CONV_CNT_INTS) { S = 1; sps = steps; }
+    }
+    p.splitk = S; p.steps_per_split = sps;
+    p.tile_cnt = reinterpret_cast<int*>(workspace);
+    p.ws = workspace ? workspace + ORE_CONV_CNT_INTS : nullptr;
+    const dim3 grid(gx, gy, S);
+    static const float* zero_dev[16] = {};
+    int dev = 0;
+    ORE_HIP(hipGetDevice(&dev));
+    ORE_CHECK_ARG(dev >= 0 && dev < 16, "conv_kw_launch: device index %d", dev);
+    if (!zero_dev[dev]) {
+        void* zp = nullptr;
+        ORE_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_kw)));      // a query, legal during stream capture
+        zero_dev[dev] = (const float*)zp;
+    }
+    const float* zero = zero_dev[dev];
+#define KW_CASE(bm, bn) if (t.BM == bm && t.BN == bn) { const int rc = launch_kw<bm, bn>(p, zero, grid, st); return rc ? rc : ore_launch_status("k_conv_kw"); }
+    KW_CASE(16, 16) KW_CASE(16, 32) KW_CASE(16, 48) KW_CASE(16, 64) KW_CASE(16, 80)
+    KW_CASE(32, 16) KW_CASE(32, 32) KW_CASE(32, 48) KW_CASE(32, 64) KW_CASE(32, 80)
+#undef KW_CASE
+    return 1;
+}
+
+}  // namespace oreconv

@@ -109,6 +109,83 @@ def test_conv_slices_inmul_add_partial_relu(ore):
     assert (o[:, :16] == -7.0).all() and (o[:, 48:] == -7.0).all()  # neighbours of the slice untouched
 
 
+@pytest.fixture
+def kw_forced(ore):
+    """Force the wave-private K-split LDS-DMA kernel (k_conv_kw, csrc/ore_conv_kw.hip) wherever it applies, then restore the plan."""
+    ore.lib().ore_conv_set_plan_override(-2, 2, 0, 0, 0)
+    yield
+    ore.lib().ore_conv_set_plan_override(-2, 1, 0, 0, 0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride", [
+    (1, 20, 20, 384, 112, 3, 1),    # stage-5 layer 0: deep K, cross-block split-K
+    (1, 20, 20, 112, 112, 3, 1),    # stage-5 layers 1/2
+    (1, 20, 20, 720, 512, 1, 1),    # stage-5 concat
+    (1, 40, 40, 256, 96, 3, 1),     # stage-4 layer 0
+    (1, 40, 40, 544, 384, 1, 1),    # stage-4 concat
+    (1, 80, 80, 112, 80, 3, 1),     # stage-3 layer 0 (BN = 80)
+    (1, 80, 80, 352, 256, 1, 1),    # stage-3 concat
+    (1, 40, 40, 128, 128, 3, 1),    # FPN output 4
+    (2, 17, 23, 352, 256, 1, 1),    # odd spatial size, 2 images, rows not a multiple of the tile
+    (1, 9, 7, 16, 5, 3, 1),         # tiny: one chunk per tap, Cout = 5 (padded to 16), most waves idle
+    (3, 33, 31, 64, 80, 3, 2),      # stride 2, odd size
+    (1, 1, 320, 8192, 128, 1, 1),   # the second-stage GEMM (320 ROIs x 8192 -> 128)
+    (1, 13, 11, 48, 48, 3, 1),      # Cin = 48: three chunks per tap, wraps inside one 4-chunk advance
+])
+def test_conv_kw_kernel_vs_oracle(ore, kw_forced, B, H, W, Cin, Cout, k, stride):
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc = torch.rand(Cout, generator=g) + 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, None, stride, k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    y = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+    y2 = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    assert torch.equal(y, y2)                       # split-K slabs are summed in slice order: bit-reproducible
+
+
+def test_conv_kw_slices_add_colsum_levels(ore, kw_forced):
+    """k_conv_kw with everything the engine asks of it: channel-slice input and output inside wider buffers (OSA concat), the FPN
+    nearest-2x top-down add, partial ReLU, fused per-tile column sums (eSE average pool), several pyramid levels in one launch with
+    per-level epilogue parameters."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 1, 20, 24
+    buf = torch.randn(B, 160, H, W, generator=g)                                  # read channels 32..143 (112)
+    w = torch.randn(80, 112, 3, 3, generator=g) * 0.03
+    top = torch.randn(B, 80, (H + 1) // 2, (W + 1) // 2, generator=g)
+    bias = torch.randn(80, generator=g)
+    ref = F.conv2d(buf[:, 32:144], w, bias, 1, 1) + F.interpolate(top, scale_factor=2.0, mode="nearest")[:, :, :H, :W]
+    ref[:, :50] = F.relu(ref[:, :50])
+    out = torch.full((B, H, W, 128), -7.0).cuda()
+    ore.conv2d(nhwc(buf), ore.pack_conv_weight(w).cuda(), 80, 3, 1, in_coff=32, Cin=112, shift=dev(bias), relu_cout=50, add=nhwc(top),
+               out=out, out_coff=16)
+    o = nchw(out)
+    assert rel_err(o[:, 16:96].numpy(), ref.numpy()) < TOL
+    assert (o[:, :16] == -7.0).all() and (o[:, 96:] == -7.0).all()
+    # fused column sums: sum over the tile partials == column sums of the output
+    x = torch.relu(torch.randn(1, 544, 40, 40, generator=g))
+    wc = torch.randn(384, 544, 1, 1, generator=g) / 544 ** 0.5
+    sc, sh = torch.rand(384, generator=g) + 0.5, torch.randn(384, generator=g) * 0.1
+    y, parts = ore.conv2d(nhwc(x), ore.pack_conv_weight(wc).cuda(), 384, 1, 1, scale=dev(sc), shift=dev(sh), relu_cout=384, want_colsum=True)
+    refc = F.relu(F.conv2d(x, wc) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert rel_err(nchw(y).numpy(), refc.numpy()) < TOL
+    assert rel_err(parts.sum(0)[:384].cpu().numpy(), refc.sum((0, 2, 3)).numpy()) < TOL
+    # three pyramid levels in one launch, per-level scale / shift (the head's tower / conv3 form)
+    HW = [(20, 24), (10, 12), (5, 6)]
+    xs = [torch.randn(1, 128, h, w_, generator=g) for h, w_ in HW]
+    wl = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    scl, shl = torch.rand(3, 128, generator=g) + 0.5, torch.randn(3, 128, generator=g) * 0.1
+    rows = torch.cat([nhwc(t).reshape(-1, 128) for t in xs], 0)
+    yl = ore.conv2d_levels(rows, HW, 1, ore.pack_conv_weight(wl).cuda(), 128, 3, scale=dev(scl), shift=dev(shl), ep_stride=128)
+    r0 = 0
+    for l, (h, w_) in enumerate(HW):
+        refl = F.conv2d(xs[l], wl, None, 1, 1) * scl[l].view(1, -1, 1, 1) + shl[l].view(1, -1, 1, 1)
+        got = yl[r0:r0 + h * w_].reshape(1, h, w_, 128).permute(0, 3, 1, 2).cpu()
+        assert rel_err(got.numpy(), refl.numpy()) < TOL, l
+        r0 += h * w_
+
+
 def test_conv_rejects_bad_shapes(ore):
     x = torch.zeros(1, 4, 4, 24).cuda()
     with pytest.raises(ore.OreError):
