@@ -1147,7 +1147,8 @@ extern "C" size_t ore_conv_workspace_floats(void) { return ORE_CONV_WS_FLOATS; }
 extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK) {
     if (BM == -1) { g_patch_mode = BN; g_override = {0, 0, 0, 0, 0}; return ORE_OK; }   // BM = -1: BN selects the 3x3 patch kernel mode
     if (BM == -2) { g_kw_mode = BN; g_override = {0, 0, 0, 0, 0}; return ORE_OK; }
-    if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
+    if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
+    if (BM == -4) { conv_gs_force(BN, WGM); return ORE_OK; }                           // BM = -4: tile of k_conv_gs                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
     g_override = {BM, BN, WGM, WGN, WGK};
     return ORE_OK;
 }
@@ -1170,9 +1171,9 @@ extern "C" int32_t ore_conv_get_precision(void) { return g_conv_bf16; }
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
-    if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !g_conv_bf16 && !d->in_mul && d->B * Ho * Wo < 16384 && d->Cin % 16 == 0) {
+    if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !g_conv_bf16 && !d->in_mul && d->Cin % 16 == 0) {
         ConvP q{};
-        q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (d->Cin / 16);
+        q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (d->Cin / 16); q.kh = d->kh;
         const int bm = conv_kw_tile_rows(q);
         if (bm > 0) return ceil_div(q.M, bm);                 // the layer runs on k_conv_kw (same test as conv_launch)
     }

@@ -339,6 +339,172 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_conv_gs -- the same LDS-DMA feeding for the LARGE-M layers (stem_3, the stage-2 / stage-3 concats, conv3: M >= 6400 rows with
+// enough tiles for the 256 CUs): the four waves tile the block's BM x BN output (WGM x WGN) and SHARE every stage, so a staged
+// byte feeds four times the MFMAs of k_conv_kw.  One raw s_barrier per 16-channel step: a wave waits for its own DMA of stage t
+// (counted vmcnt, stage t+1 stays in flight), the barrier publishes everybody's, the DMA of stage t+2 is issued right behind it
+// (its slot was read at step t-1, which every wave has left), then fragments + MFMAs.  Same swizzle, same epilogue.
+template <int BM, int BN, int WGM, int WGN, int NS>
+__global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restrict__ zero_page) {
+    constexpr int GA = BM / 16, GB = BN / 16, G = GA + GB;
+    constexpr int NI = (G + 3) / 4;                                // DMA instructions per wave and stage (short waves issue dummies)
+    constexpr int TM = GA / WGM, TN = GB / WGN;
+    constexpr int STAGE_F = (BM + BN) * 16;
+    constexpr int DUMMY_F = 4 * 256;                               // where the dummy DMAs land (one KB per wave)
+    constexpr int CS_F = WGM * BN;                                 // column-sum exchange between the WGM row waves
+    constexpr int LDS_F = NS * STAGE_F + DUMMY_F + CS_F;
+    static_assert(WGM * WGN == 4 && GA % WGM == 0 && GB % WGN == 0 && NS == 3 && NI * (NS - 2) <= 63, "tile");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int cpt = p.Cin >> 4;
+    const int nst = p.nchunks;
+
+    const int r16 = lane >> 2, lq = (lane & 3) ^ swz(r16);
+    // this wave's DMA slots: group g = wave + 4 i; g < GA -> A rows, g < G -> B rows, else a dummy from the zero page
+    const float* src[NI];
+    int rs[NI];
+    unsigned taps[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g = wave + 4 * i;
+        src[i] = zero_page; rs[i] = 0; taps[i] = 0u;
+        if (g < GA) {
+            const int m = m0 + g * 16 + r16;
+            if (m < p.M) {
+                int lvl, b, oy, ox;
+                decode_row(p, m, lvl, b, oy, ox);
+                const Lvl& L = p.lv[lvl];
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                rs[i] = L.W * p.in_ld;
+                src[i] = p.in + ((ptrdiff_t)(L.irow0 + b * L.H * L.W) + (ptrdiff_t)iy0 * L.W + ix0) * p.in_ld + p.in_coff + lq * 4;
+                unsigned mask = 0u;
+                for (int dy = 0; dy < p.kh; ++dy)
+                    for (int dx = 0; dx < p.kw; ++dx)
+                        if ((unsigned)(iy0 + dy) < (unsigned)L.H && (unsigned)(ix0 + dx) < (unsigned)L.W) mask |= 1u << (dy * p.kw + dx);
+                taps[i] = mask;
+            }
+        } else if (g < G) {
+            const int n = n0 + (g - GA) * 16 + r16;
+            if (n < p.Cout16) { src[i] = p.w + (size_t)n * p.K + lq * 4; taps[i] = 0xffffffffu; }
+        }
+    }
+    int i_c = 0, i_dy = 0, i_dx = 0, i_cc = 0;                     // chunk to issue next (wave-uniform)
+    auto issue = [&](int slot) {
+        float* dst = lds + slot * STAGE_F;
+        const bool live = i_c < nst;
+        const unsigned tapbit = live ? (1u << (i_dy * p.kw + i_dx)) : 0u;
+        const int uoffA = i_dx * p.in_ld + (i_cc << 4), uoffB = i_c << 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int g = wave + 4 * i;
+            const bool isA = g < GA;
+            const bool ok = isA ? (taps[i] & tapbit) != 0u : (live && taps[i] != 0u);
+            const float* s_ = ok ? src[i] + (isA ? i_dy * rs[i] + uoffA : uoffB) : zero_page;
+            float* d_ = g < G ? dst + g * 256 : lds + NS * STAGE_F + wave * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
+                                             (__attribute__((address_space(3))) void*)d_, 16, 0, 0);
+        }
+        i_c += 1;
+        i_cc += 1;
+        const bool wrap = i_cc >= cpt;
+        i_cc = wrap ? 0 : i_cc;
+        i_dx += wrap ? 1 : 0;
+        const bool wy = i_dx == p.kw;
+        i_dx = wy ? 0 : i_dx;
+        i_dy += wy ? 1 : 0;
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int foff = frow * 16 + (((lane >> 4) ^ swz(frow)) << 2);
+
+    issue(0);
+    issue(1);
+    int slot = 0;
+    for (int t = 0; t < nst; ++t) {
+        wait_vmcnt<NI*(NS - 2)>();                                 // this wave's DMAs of stage t have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and its fragment reads of stage t-1 have retired
+        __builtin_amdgcn_s_barrier();
+        int nslot = slot + 2;
+        nslot -= nslot >= NS ? NS : 0;
+        issue(nslot);
+        const float* st = lds + slot * STAGE_F;
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + (wm * TM + i) * 256 + foff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + (GA + wn * TN + j) * 256 + foff);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    wait_vmcnt<0>();
+
+    // ---- epilogue straight from the accumulators: this lane = pixel row (lane & 15), channels (lane >> 4) * 4 .. + 3 of each tile
+    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+    const int cg4 = (lane >> 4) * 4;
+    f32x4 csum[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v;
+            if (finish4(p, acc[i][j], m0 + (wm * TM + i) * 16 + (lane & 15), n0 + (wn * TN + j) * 16 + cg4, vec_ok, v)) csum[j] += v;
+        }
+    if (p.colsum) {
+        float* cs = lds + NS * STAGE_F + DUMMY_F;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[j][r] += __shfl_xor(csum[j][r], d);
+        __syncthreads();
+        if ((lane & 15) == 0)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(cs + wm * BN + (wn * TN + j) * 16 + cg4) = csum[j];
+        __syncthreads();
+        if (tid < BN) {
+            float sacc = cs[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < WGM; ++w2) sacc += cs[w2 * BN + tid];
+            const int n = n0 + tid;
+            if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = sacc;
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_gs(const ConvP& p, const float* zero, hipStream_t st) {
+    constexpr int NS = 3;
+    constexpr size_t lds = ((size_t)NS * (BM + BN) * 16 + 4 * 256 + WGM * BN) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        ORE_HIP(hipFuncSetAttribute((const void*)k_conv_gs<BM, BN, WGM, WGN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const dim3 grid(ceil_div(p.M, BM), ceil_div(p.Cout16, BN), 1);
+    hipLaunchKernelGGL((k_conv_gs<BM, BN, WGM, WGN, NS>), grid, dim3(256), lds, st, p, zero);
+    return ore_launch_status("k_conv_gs");
+}
+
+int g_gs_force[2] = {0, 0};             // tuning aid: {BM, BN}; 0 -> automatic
+
 struct KwTile { int BM, BN, S; };      // S = cross-block split-K (0: decide from the block count), BM = 0: layer left to k_conv_igemm / patch
 
 // Tile plan, from tools/conv_kw_sweep.py on MI355X (profiles/r02_kw_sweep.txt).  What the sweep says: the minimal ring (NS = 2) wins
@@ -416,12 +582,59 @@ int launch_kw(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
 
 namespace oreconv {
 
-int conv_kw_tile_rows(const ConvP& p) { return g_kw_force[0] > 0 ? g_kw_force[0] : kw_tile(p.M, p.Cout16, p.nchunks).BM; }
+int conv_kw_tile_rows(const ConvP& p) {         // rows per block of the kernel conv_kw_launch will pick (0: not covered) -- keep in step with it
+    if (g_gs_force[0] > 0) return g_gs_force[0];
+    if (p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256)) {
+        if (p.M < 6400 || p.kh != 1) return 0;
+        return (p.Cout16 == 112 || p.Cout16 % 128 == 0 || p.Cout16 == 64) ? 64 : 0;
+    }
+    return g_kw_force[0] > 0 ? g_kw_force[0] : kw_tile(p.M, p.Cout16, p.nchunks).BM;
+}
 
 void conv_kw_force(int bm, int bn, int ns, int splitk) { g_kw_force[0] = bm; g_kw_force[1] = bn; g_kw_force[2] = ns; g_kw_force[3] = splitk; }
 
+static int zero_page_of(const float** out) {
+    static const float* zero_dev[16] = {};
+    int dev = 0;
+    ORE_HIP(hipGetDevice(&dev));
+    ORE_CHECK_ARG(dev >= 0 && dev < 16, "conv_kw_launch: device index %d", dev);
+    if (!zero_dev[dev]) {
+        void* zp = nullptr;
+        ORE_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_kw)));      // a query, legal during stream capture
+        zero_dev[dev] = (const float*)zp;
+    }
+    *out = zero_dev[dev];
+    return ORE_OK;
+}
+
+// shared-stage kernel for the large-M layers; returns 1 when the shape has no tile here
+static int conv_gs_launch(ConvP& p, hipStream_t st) {
+    int bm = g_gs_force[0], bn = g_gs_force[1];
+    if (bm == 0) {
+        // measured (profiles/r02_kw_ab.txt): 2-5 % ahead of k_conv_igemm on the 1x1 concats, 3 % behind on stem_3 (3x3 stride 2) --
+        // the staging mechanism is not what bounds these layers -- so only the 1x1 layers come here automatically
+        if (p.M < 6400 || p.kh != 1) return 1;
+        if (p.Cout16 == 112) { bm = 64; bn = 112; }
+        else if (p.Cout16 % 128 == 0) { bm = 64; bn = 128; }
+        else if (p.Cout16 == 64) { bm = 64; bn = 64; }
+        else return 1;
+    }
+    const float* zero = nullptr;
+    const int zrc = zero_page_of(&zero);
+    if (zrc) return zrc;
+    p.splitk = 1; p.steps_per_split = p.nchunks;
+#define GS_CASE(a, b, wgm, wgn) if (bm == a && bn == b) return launch_gs<a, b, wgm, wgn>(p, zero, st);
+    GS_CASE(64, 112, 4, 1) GS_CASE(64, 128, 2, 2) GS_CASE(64, 64, 2, 2) GS_CASE(128, 64, 4, 1) GS_CASE(128, 128, 2, 2) GS_CASE(32, 128, 1, 4)
+    GS_CASE(128, 112, 4, 1) GS_CASE(64, 80, 4, 1) GS_CASE(32, 64, 2, 2)
+#undef GS_CASE
+    return 1;
+}
+
+void conv_gs_force(int bm, int bn) { g_gs_force[0] = bm; g_gs_force[1] = bn; }
+
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
-    if (p.in_mul || p.M >= 16384 || p.Cin % 16 != 0) return 1;            // large-M layers keep their kernels; input affine not built here
+    if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
+    if (g_gs_force[0] > 0 || p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256)) return conv_gs_launch(p, st);
     KwTile t = kw_tile(p.M, p.Cout16, p.nchunks);
     if (g_kw_force[0] > 0) t = {g_kw_force[0], g_kw_force[1] < p.Cout16 ? g_kw_force[1] : p.Cout16, g_kw_force[3]};
     if (t.BM == 0) return 1;
@@ -441,16 +654,8 @@ int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStrea
     p.tile_cnt = reinterpret_cast<int*>(workspace);
     p.ws = workspace ? workspace + ORE_CONV_CNT_INTS : nullptr;
     const dim3 grid(gx, gy, S);
-    static const float* zero_dev[16] = {};
-    int dev = 0;
-    ORE_HIP(hipGetDevice(&dev));
-    ORE_CHECK_ARG(dev >= 0 && dev < 16, "conv_kw_launch: device index %d", dev);
-    if (!zero_dev[dev]) {
-        void* zp = nullptr;
-        ORE_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_kw)));      // a query, legal during stream capture
-        zero_dev[dev] = (const float*)zp;
-    }
-    const float* zero = zero_dev[dev];
+    const float* zero = nullptr;
+    { const int zrc = zero_page_of(&zero); if (zrc) return zrc; }
 #define KW_CASE(bm, bn) if (t.BM == bm && t.BN == bn) { const int rc = launch_kw<bm, bn>(p, zero, grid, st); return rc ? rc : ore_launch_status("k_conv_kw"); }
     KW_CASE(16, 16) KW_CASE(16, 32) KW_CASE(16, 48) KW_CASE(16, 64) KW_CASE(16, 80)
     KW_CASE(32, 16) KW_CASE(32, 32) KW_CASE(32, 48) KW_CASE(32, 64) KW_CASE(32, 80)

@@ -10,6 +10,8 @@ import torch  # noqa: E402
 import orehip  # noqa: E402
 
 LAYERS = [  # name, H, W, Cin, Cout, k, stride, colsum
+    ("stem3", 320, 320, 64, 128, 3, 2, 0), ("s2l0", 160, 160, 128, 64, 3, 1, 0), ("s2l1", 160, 160, 64, 64, 3, 1, 0),
+    ("s2cat", 160, 160, 320, 112, 1, 1, 1),
     ("s3l0", 80, 80, 112, 80, 3, 1, 0), ("s3l1", 80, 80, 80, 80, 3, 1, 0), ("s3cat", 80, 80, 352, 256, 1, 1, 1),
     ("s4l0", 40, 40, 256, 96, 3, 1, 0), ("s4l1", 40, 40, 96, 96, 3, 1, 0), ("s4cat", 40, 40, 544, 384, 1, 1, 1),
     ("s5l0", 20, 20, 384, 112, 3, 1, 0), ("s5l1", 20, 20, 112, 112, 3, 1, 0), ("s5cat", 20, 20, 720, 512, 1, 1, 1),
