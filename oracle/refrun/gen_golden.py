@@ -265,6 +265,7 @@ def main():
     gen_train_iteration(sd)
     gen_state_dict_layout()
     gen_demo_images()
+    gen_generate_support()
 
 
 def reference_detector(sd, shots, device_cfg="cpu"):
@@ -477,6 +478,50 @@ def gen_demo_images():
         res = np.asarray(Image.fromarray(bgr).resize((nw, nh), Image.BILINEAR))
         out.append(np.ascontiguousarray(res.transpose(2, 0, 1)))
     save("demo_images_320", images=np.stack(out), orig_hw=np.array([300, 300]))
+
+
+def synth_support_df(seed=7, n_img=30, per_img=3):
+    """A stand-in for datasets/coco/*_shot_support_df.pkl (the ore dataset is not shipped): the columns generate_support reads."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    rows, aid = [], 1000
+    for img in range(n_img):
+        for k in range(per_img):
+            x0, y0 = rng.uniform(10, 90, 2)
+            rows.append({"id": aid, "image_id": 500 + img, "category_id": 1 + (img % 3),
+                         "file_path": f"support/{aid}.jpg", "support_box": [float(x0), float(y0), float(x0 + rng.uniform(40, 120)), float(y0 + rng.uniform(40, 120))]})
+            aid += 1
+    return pd.DataFrame(rows)
+
+
+def synth_crop(path):
+    """Deterministic 240x240x3 uint8 'support crop' for a file path (what utils.read_image would decode)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(path.encode()))
+    return rng.integers(0, 256, (240, 240, 3), dtype=np.uint8)
+
+
+def gen_generate_support():
+    """f3: DatasetMapperWithSupport.generate_support (ref:fewx/data/dataset_mapper.py:198-269) executed on a synthetic support
+    dataframe: which support annotations are drawn (pandas .sample(random_state=annotation id), exclusion of the query image and of
+    already used ids), their order, boxes and class flags, for 1-way and 2-way."""
+    dm = shims.load_dataset_mapper(lambda path, format=None: synth_crop(path))
+    df = synth_support_df()
+    out = {}
+    for tag, way, shot, q in (("w1", 1, 9, 4), ("w2", 2, 4, 17)):
+        M = dm.DatasetMapperWithSupport
+        mp = M.__new__(M)
+        mp.support_way, mp.support_shot, mp.img_format, mp.support_df = way, shot, "BGR", df
+        row = df.iloc[q]
+        dd = {"annotations": [{"id": int(a)} for a in df.loc[df["image_id"] == row["image_id"], "id"].tolist()[:2]]}
+        dd["annotations"][0]["id"] = int(row["id"])
+        data, boxes, cls = mp.generate_support(dd)
+        out[f"{tag}_query_ids"] = np.array([a["id"] for a in dd["annotations"]], np.int64)
+        out[f"{tag}_boxes"] = boxes
+        out[f"{tag}_cls"] = np.array(cls, np.int64)
+        out[f"{tag}_pix"] = data[:, :, ::60, ::60].copy()                 # a 4x4 sample of every crop identifies it
+        out[f"{tag}_way_shot"] = np.array([way, shot], np.int64)
+    save("generate_support", seed=np.int64(7), **out)
 
 
 if __name__ == "__main__":

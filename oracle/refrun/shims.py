@@ -364,3 +364,25 @@ def load_roi_heads():
     _LOADED.update(roi_heads=fro, d2_roi_heads=rh, cascade_rcnn=cr, fast_rcnn=fr, custom_fast_rcnn=cf, box_head=bh, poolers=pl,
                    matcher=mt, sampling=sp, box_regression=br, proposal_utils=pu)
     return types.SimpleNamespace(**_LOADED)
+
+
+def load_dataset_mapper(read_image):
+    """ref:fewx/data/dataset_mapper.py loaded unmodified; `utils.read_image` (detectron2.data.detection_utils, needs cv2/PIL paths of
+    the ore dataset) is the caller's synthetic reader."""
+    setup()
+    if "dataset_mapper" in _LOADED:
+        sys.modules["detectron2.data.detection_utils"].read_image = read_image
+        return _LOADED["dataset_mapper"]
+    mod("fvcore.common", file_io=None)
+    mod("fvcore.common.file_io", PathManager=None)
+    sys.modules["fvcore"].common = sys.modules["fvcore.common"]
+    sys.modules["fvcore.common"].file_io = sys.modules["fvcore.common.file_io"]
+    du = mod("detectron2.data.detection_utils", read_image=read_image, convert_image_to_rgb=None)
+    tr = mod("detectron2.data.transforms")
+    cat = mod("detectron2.data.catalog", MetadataCatalog=types.SimpleNamespace(get=lambda name: None))
+    d = mod("detectron2.data", detection_utils=du, transforms=tr, catalog=cat)
+    sys.modules["detectron2"].data = d
+    pkg("fewx.data", REF + "/fewx/data")
+    m = load("fewx.data.dataset_mapper", REF + "/fewx/data/dataset_mapper.py")
+    _LOADED["dataset_mapper"] = m
+    return m

@@ -2,6 +2,7 @@
 faster-orefsdet_amd/, and the thin host-side pieces behave like the originals.  No GPU needed."""
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -112,3 +113,74 @@ def test_label_and_sample_host_logic_matches_reference_run(golden):
     fg = roi_labels == 0
     d = TF.get_deltas(roi_boxes[fg], roi_gt[fg], (10.0, 10.0, 5.0, 5.0))
     np.testing.assert_allclose(d.numpy(), g["deltas"], rtol=1e-6, atol=1e-6)
+
+
+def _synth_support_df(seed=7, n_img=30, per_img=3):
+    """Same stand-in dataframe as oracle/refrun/gen_golden.py::synth_support_df (the fixture's inputs are regenerated from the seed)."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    rows, aid = [], 1000
+    for img in range(n_img):
+        for k in range(per_img):
+            x0, y0 = rng.uniform(10, 90, 2)
+            rows.append({"id": aid, "image_id": 500 + img, "category_id": 1 + (img % 3), "file_path": f"support/{aid}.jpg",
+                         "support_box": [float(x0), float(y0), float(x0 + rng.uniform(40, 120)), float(y0 + rng.uniform(40, 120))]})
+            aid += 1
+    return pd.DataFrame(rows)
+
+
+def _synth_crop(path, format=None):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(path.encode()))            # the full path, as the reference passes it to read_image
+    return rng.integers(0, 256, (240, 240, 3), dtype=np.uint8)
+
+
+def test_generate_support_matches_reference_run(golden):
+    """f3: DatasetMapperWithSupport.generate_support against the reference's own method (ref:fewx/data/dataset_mapper.py:198-269)
+    executed on the same synthetic support dataframe: the drawn support annotations, their order, boxes, class flags, 1- and 2-way."""
+    from fewx.config import get_cfg
+    from fewx.data.dataset_mapper import DatasetMapperWithSupport
+    g = golden("generate_support")
+    df = _synth_support_df(int(g["seed"]))
+    for tag in ("w1", "w2"):
+        way, shot = (int(v) for v in g[f"{tag}_way_shot"])
+        cfg = get_cfg()
+        cfg.merge_from_list(["INPUT.FS.SUPPORT_WAY", way, "INPUT.FS.SUPPORT_SHOT", shot])
+        mp = DatasetMapperWithSupport(cfg, is_train=True, support_df=df, read_image=_synth_crop)
+        data, boxes, cls = mp.generate_support({"annotations": [{"id": int(i)} for i in g[f"{tag}_query_ids"]]})
+        assert data.shape == (way * shot, 3, 240, 240) and data.dtype == np.float32
+        np.testing.assert_array_equal(boxes, g[f"{tag}_boxes"])
+        assert list(cls) == list(g[f"{tag}_cls"])
+        np.testing.assert_array_equal(data[:, :, ::60, ::60], g[f"{tag}_pix"])
+
+
+def test_dataset_mapper_call_produces_the_model_input_dict(tmp_path):
+    """__call__ end to end on a synthetic image file: resize / flip, box transform, Instances, support tensors in the layout
+    train_forward consumes; a missing support dataframe raises instead of inventing data."""
+    from PIL import Image
+    from fewx.config import get_cfg
+    from fewx.data.dataset_mapper import DatasetMapperWithSupport
+    cfg = get_cfg()
+    cfg.merge_from_list(["INPUT.FS.SUPPORT_WAY", 1, "INPUT.FS.SUPPORT_SHOT", 4, "INPUT.MIN_SIZE_TRAIN", (320,), "INPUT.MAX_SIZE_TRAIN", 640])
+    with pytest.raises(FileNotFoundError):
+        DatasetMapperWithSupport(cfg, is_train=True)
+    img = np.random.default_rng(0).integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    f = str(tmp_path / "q.png")
+    Image.fromarray(img).save(f)
+    df = _synth_support_df()
+    q = df.iloc[4]
+
+    def reader(path, format=None):
+        if path == f:
+            return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+        return _synth_crop(path)
+    mp = DatasetMapperWithSupport(cfg, is_train=True, support_df=df, read_image=reader)
+    d = mp({"file_name": f, "height": 200, "width": 300, "image_id": int(q["image_id"]),
+            "annotations": [{"id": int(q["id"]), "bbox": [30.0, 40.0, 100.0, 80.0], "bbox_mode": 1, "category_id": 0},
+                            {"id": int(q["id"]) + 1, "bbox": [295.0, 10.0, 0.0, 50.0], "bbox_mode": 1, "category_id": 0}]})
+    assert tuple(d["image"].shape) == (3, 320, 480) and d["image"].dtype == torch.uint8
+    assert tuple(d["support_images"].shape) == (4, 3, 240, 240) and d["support_bboxes"].shape == (4, 4)
+    inst = d["instances"]
+    assert len(inst) == 1 and inst.image_size == (320, 480)                  # the zero-width box is dropped (filter_empty_instances)
+    b = inst.gt_boxes.tensor[0]
+    assert abs(float(b[2] - b[0]) - 160.0) < 1e-3 and abs(float(b[3] - b[1]) - 128.0) < 1e-3   # 100 x 80 box scaled by 1.6
