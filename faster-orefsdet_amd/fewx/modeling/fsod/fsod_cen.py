@@ -6,6 +6,8 @@ conv3 -> CenterNet head -> sigmoid/top-k/decode/NMS.  The support prototypes are
 support_feature.pkl on every forward) and the engine is rebuilt only when parameters change."""
 import logging
 import os
+
+import numpy as np
 import pickle
 
 import torch
@@ -141,18 +143,45 @@ class CenterNet2Detector(nn.Module):
         self.support_dict = {k: {c: f.to(self.device) for c, f in v.items()} for k, v in support_dict.items()}
         self._engine_key = None
 
-    def init_model(self, support_file="./support_dir/support_feature.pkl"):
+    def init_model(self, support_file="./support_dir/support_feature.pkl", support_df=None, read_image=None,
+                   support_df_path="./datasets/coco/10_shot_support_df.pkl", image_root="./datasets/coco"):
         """ref fsod_cen.py:313-415, minus its two defects: the pickle is read once (not per forward) and tensors go to
-        self.device (not a hard-coded .cuda()).  Reading the support dataframe + images needs the ore dataset (SURVEY 8f row
-        3); the compute it feeds is compute_support_dict()."""
+        self.device (not a hard-coded .cuda()).  With no support_feature.pkl the reference walks the support dataframe (per class:
+        the first SUPPORT_SHOT rows, image + support_box), computes the features, writes the pickle and exits; here the walk
+        (`build_support_from_dataframe`) installs the features and writes the same pickle -- and carries on.  `support_df` /
+        `read_image` are injectable because the ore dataset is not shipped; left unset they are the reference's paths."""
         if self.support_dict is not None:
             return
-        if not os.path.exists(support_file):
-            raise FileNotFoundError(f"{support_file} not found: generating support features needs the few-shot support set "
-                                    "(datasets/coco/*_shot_support_df.pkl, SURVEY 8f row 3): call compute_support_dict(images, boxes) "
-                                    "+ save_support_file(), or set_support_dict()")
-        with open(support_file, "rb") as f:
-            self.set_support_dict(pickle.load(f, encoding="latin1"))
+        if os.path.exists(support_file):
+            with open(support_file, "rb") as f:
+                self.set_support_dict(pickle.load(f, encoding="latin1"))
+            return
+        if support_df is None:
+            if not os.path.exists(support_df_path):
+                raise FileNotFoundError(f"neither {support_file} nor {support_df_path} found: generating support features needs the "
+                                        "few-shot support set (SURVEY 8f row 3): pass support_df / read_image, call "
+                                        "compute_support_dict(images, boxes) + save_support_file(), or set_support_dict()")
+            import pandas as pd
+            support_df = pd.read_pickle(support_df_path)
+        self.build_support_from_dataframe(support_df, read_image=read_image, image_root=image_root)
+        self.save_support_file(support_file)
+
+    def build_support_from_dataframe(self, support_df, read_image=None, image_root="./datasets/coco"):
+        """The dataframe walk of the reference's init_model (ref fsod_cen.py:331-346): for every category the first SUPPORT_SHOT
+        rows (reset_index order) give the support crops and their boxes; the compute is compute_support_dict (HIP kernels)."""
+        if read_image is None:
+            from fewx.data.dataset_mapper import _pil_read_image as read_image
+        for cls in support_df["category_id"].unique():
+            rows = support_df.loc[support_df["category_id"] == cls, :].reset_index()
+            imgs, boxes = [], []
+            for index, r in rows.iterrows():
+                if index >= self.support_shot:
+                    break
+                data = read_image(os.path.join(image_root, r["file_path"]), format="BGR")
+                imgs.append(torch.as_tensor(np.ascontiguousarray(data.transpose(2, 0, 1))))
+                boxes.append(torch.as_tensor(r["support_box"], dtype=torch.float32))
+            self.compute_support_dict(imgs, torch.stack(boxes), cls_id=cls, merge=True)
+        return self.support_dict
 
     @torch.no_grad()
     def compute_support_dict(self, support_images, support_boxes, cls_id=0, merge=True):

@@ -887,6 +887,47 @@ def test_compute_support_dict_vs_oracle(model, sd, tmp_path):
         model.set_support_dict({k: {c: t.cpu() for c, t in v.items()} for k, v in old.items()})
 
 
+def test_init_model_walks_the_support_dataframe(model, tmp_path):
+    """init_model without a support_feature.pkl (ref fsod_cen.py:321-408): per category the first SUPPORT_SHOT rows of the support
+    dataframe (reset_index order) -> crops + boxes -> compute_support_dict; the pickle is written in the reference's layout and a
+    second model start reads it back.  Dataframe and image reader are synthetic (the ore dataset is not shipped)."""
+    import pandas as pd
+    import pickle
+    from oracle import ref_train as T
+    old = model.support_dict
+    shot = model.support_shot
+    try:
+        rows, crops = [], {}
+        for cls in (3, 9):
+            _, _, sup, sbox = T.synth_train_inputs(20 + cls, (64, 64), n_gt=1, shots=shot + 2, support_hw=144)
+            for i in range(shot + 2):
+                path = f"support/{cls}_{i}.png"
+                crops["./x/" + path] = sup[i].permute(1, 2, 0).to(torch.uint8).numpy()
+                rows.append({"id": 100 * cls + i, "image_id": 50 + i, "category_id": cls, "file_path": path, "support_box": sbox[i].tolist()})
+        df = pd.DataFrame(rows).sample(frac=1.0, random_state=1)                     # shuffled: the walk keeps dataframe order per class
+        want = {}
+        for cls in (3, 9):
+            sel = df.loc[df["category_id"] == cls].iloc[:shot]
+            imgs = [torch.as_tensor(crops["./x/" + p].transpose(2, 0, 1).copy()) for p in sel["file_path"]]
+            want[cls] = model.compute_support_dict(imgs, torch.tensor(sel["support_box"].tolist()), cls_id=cls, merge=False)
+        model.support_dict = None
+        f = str(tmp_path / "support_dir" / "support_feature.pkl")
+        model.init_model(support_file=f, support_df=df, read_image=lambda p, format=None: crops[p], image_root="./x")
+        assert set(model.support_dict) == {"p3", "p4", "p5", "rcnn_8", "rcnn_4"} and set(model.support_dict["p3"]) == {3, 9}
+        for cls in (3, 9):
+            for k in ("p3", "p4", "p5", "rcnn_8", "rcnn_4"):
+                assert torch.equal(model.support_dict[k][cls].cpu(), want[cls][k][cls]), (cls, k)
+        assert tuple(model.support_dict["rcnn_8"][3].shape) == (shot, 128, 8, 8)
+        with open(f, "rb") as fh:
+            back = pickle.load(fh)
+        assert torch.equal(back["p5"][9], want[9]["p5"][9])
+        model.support_dict = None
+        model.init_model(support_file=f)                                             # second start: the pickle is simply read
+        assert torch.equal(model.support_dict["p4"][3].cpu(), want[3]["p4"][3])
+    finally:
+        model.set_support_dict({k: {c: t.cpu() for c, t in v.items()} for k, v in old.items()})
+
+
 def test_engine_batched_eval_matches_single_image_engines(ore, sd):
     """ore_engine_eval_batch_fwd: B independent images in one pass (dense stages batched, detection tail + second stage per image)
     against the bs = 1 path on each image: feature maps to 1e-5 (another tile plan = another summation order, never another result),

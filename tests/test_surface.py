@@ -184,3 +184,29 @@ def test_dataset_mapper_call_produces_the_model_input_dict(tmp_path):
     assert len(inst) == 1 and inst.image_size == (320, 480)                  # the zero-width box is dropped (filter_empty_instances)
     b = inst.gt_boxes.tensor[0]
     assert abs(float(b[2] - b[0]) - 160.0) < 1e-3 and abs(float(b[3] - b[1]) - 128.0) < 1e-3   # 100 x 80 box scaled by 1.6
+
+
+def test_coco_json_registration_and_loader(tmp_path):
+    """ref:fewx/data/datasets/builtin.py + register_coco.py: the reference's split names are registered lazily; a COCO json loads into
+    the dataset-dict layout the mapper consumes (annotation ids kept: generate_support keys on them)."""
+    import json
+    import fewx.data  # noqa: F401
+    from detectron2.data import DatasetCatalog, MetadataCatalog
+    from fewx.data.datasets import register_coco_instances
+    for k in ("coco_2017_train_stone", "coco_2017_val_stone", "coco_2017_train_nonvoc", "coco_2017_train_voc_10_shot"):
+        assert k in DatasetCatalog
+    with pytest.raises(FileNotFoundError):
+        DatasetCatalog.get("coco_2017_val_stone")                      # registered lazily; the dataset itself is not shipped
+    js = {"images": [{"id": 7, "file_name": "a.png", "height": 300, "width": 300}, {"id": 3, "file_name": "b.png", "height": 10, "width": 20}],
+          "categories": [{"id": 5, "name": "ore"}],
+          "annotations": [{"id": 11, "image_id": 7, "category_id": 5, "bbox": [1, 2, 30, 40], "iscrowd": 0, "area": 1200},
+                          {"id": 12, "image_id": 7, "category_id": 5, "bbox": [5, 5, 10, 10], "iscrowd": 1, "area": 100}]}
+    f = tmp_path / "inst.json"
+    f.write_text(json.dumps(js))
+    register_coco_instances("ore_test_split", {}, str(f), str(tmp_path / "img"))
+    d = DatasetCatalog.get("ore_test_split")
+    assert [r["image_id"] for r in d] == [3, 7] and d[0]["annotations"] == []
+    a = d[1]["annotations"]
+    assert d[1]["file_name"].endswith("img/a.png") and [x["id"] for x in a] == [11, 12] and a[0]["category_id"] == 0 and a[0]["bbox_mode"] == 1
+    assert MetadataCatalog.get("ore_test_split").thing_classes == ["ore"] and MetadataCatalog.get("ore_test_split").evaluator_type == "coco"
+    DatasetCatalog.remove("ore_test_split")
