@@ -16,11 +16,11 @@ PEAK = 157.3
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_bench_image_timeline.txt"
-    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_conv_layers.txt"
+    src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02_bench_image_timeline.txt"
+    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_conv_layers.txt"
     tl = [l for l in open(src) if l.startswith("k_conv")]
     assert len(tl) == 28, len(tl)
-    out = ["# per-conv-launch efficiency of ONE image, strictly sequential mode (rocprofv3 --kernel-trace of `bench.py --inflight 1`,",
+    out = ["# per-conv-launch efficiency of ONE image, strictly sequential mode (rocprofv3 --kernel-trace of the headline protocol, tools/protocol_loop.py,",
            "# %s); algorithmic FLOPs = 2*M*Cout*Cin*k*k; peak = %.1f TFLOP/s (fp32 MFMA, gfx950)" % (src, PEAK),
            "%-26s %-44s %9s %8s %8s %7s" % ("layer", "kernel / grid", "us", "GFLOP", "TFLOP/s", "% peak")]
     tu = tg = 0.0
