@@ -27,6 +27,6 @@ int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStrea
 int conv_kw_tile_rows(const ConvP& p);
 // tuning aid (ore_conv_set_plan_override(-3, bm, bn, ns, splitk)): force tile / ring depth / split of k_conv_kw; bm = 0 -> automatic
 void conv_kw_force(int bm, int bn, int ns, int splitk);
-void conv_gs_force(int bm, int bn);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic
+void conv_gs_force(int bm, int bn, int ns);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic
 
 }  // namespace oreconv

@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
     constexpr int DUMMY_F = 4 * 256;                               // where the dummy DMAs land (one KB per wave)
     constexpr int CS_F = WGM * BN;                                 // column-sum exchange between the WGM row waves
     constexpr int LDS_F = NS * STAGE_F + DUMMY_F + CS_F;
-    static_assert(WGM * WGN == 4 && GA % WGM == 0 && GB % WGN == 0 && NS == 3 && NI * (NS - 2) <= 63, "tile");
+    static_assert(WGM * WGN == 4 && GA % WGM == 0 && GB % WGN == 0 && NS >= 3 && NI * (NS - 1) <= 63, "tile");
+    constexpr int MPER = (4 * TM * TN) / (NI + TM + TN) > 0 ? (4 * TM * TN) / (NI + TM + TN) : 1;   // MFMAs in front of every interleaved op
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,22 +427,33 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
     const int frow = lane & 15;
     const int foff = frow * 16 + (((lane >> 4) ^ swz(frow)) << 2);
 
-    issue(0);
-    issue(1);
+    // Software pipeline: the fragments of step t+1 are read (into a second register set) and the DMA of stage t+3 is issued BETWEEN
+    // the MFMAs of step t (sched_group_barrier pins the interleave), so DMA issue and LDS latency run in the shadow of the matrix pipe
+    // instead of in front of it.  Slots: stage t+1 is being read, t+2 is landing, t+3 goes into the slot of stage t, whose fragments
+    // every wave took in the previous iteration (the barrier says so).
+#pragma unroll
+    for (int s0 = 0; s0 < NS; ++s0) issue(s0);
+    wait_vmcnt<NI * (NS - 1)>();                                   // stage 0 (own pieces)
+    __builtin_amdgcn_s_barrier();
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(lds + (wm * TM + i) * 256 + foff);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(lds + (GA + wn * TN + j) * 256 + foff);
     int slot = 0;
     for (int t = 0; t < nst; ++t) {
-        wait_vmcnt<NI*(NS - 2)>();                                 // this wave's DMAs of stage t have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and its fragment reads of stage t-1 have retired
-        __builtin_amdgcn_s_barrier();
-        int nslot = slot + 2;
-        nslot -= nslot >= NS ? NS : 0;
-        issue(nslot);
-        const float* st = lds + slot * STAGE_F;
-        f32x4 af[TM], bf[TN];
+        wait_vmcnt<NI * (NS - 2)>();                               // stage t+1 has landed (own pieces); the younger ones may still fly
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // everybody's stage t+1 landed; everybody holds the fragments of step t
+        int s1 = slot + 1;
+        s1 -= s1 >= NS ? NS : 0;
+        issue(slot);                                               // stage t+3 -> the slot of stage t
+        const float* st = lds + s1 * STAGE_F;
+        f32x4 an[TM], bn[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + (wm * TM + i) * 256 + foff);
+        for (int i = 0; i < TM; ++i) an[i] = *reinterpret_cast<const f32x4*>(st + (wm * TM + i) * 256 + foff);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + (GA + wn * TN + j) * 256 + foff);
+        for (int j = 0; j < TN; ++j) bn[j] = *reinterpret_cast<const f32x4*>(st + (GA + wn * TN + j) * 256 + foff);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -449,7 +461,22 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);
-        slot = slot + 1 == NS ? 0 : slot + 1;
+        // interleave: one DMA piece or one fragment read behind every second MFMA
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MPER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < TM + TN; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MPER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = an[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = bn[j];
+        slot = s1;
     }
     wait_vmcnt<0>();
 
@@ -489,9 +516,22 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
     }
 }
 
+int g_gs_ns = 3;                        // tuning aid: ring depth of k_conv_gs (3 / 4 / 6)
+
+template <int BM, int BN, int WGM, int WGN, int NS>
+int launch_gs_ns(const ConvP& p, const float* zero, hipStream_t st);
+
 template <int BM, int BN, int WGM, int WGN>
 int launch_gs(const ConvP& p, const float* zero, hipStream_t st) {
-    constexpr int NS = 3;
+    if (g_gs_ns == 4) return launch_gs_ns<BM, BN, WGM, WGN, 4>(p, zero, st);
+    if (g_gs_ns == 6) return launch_gs_ns<BM, BN, WGM, WGN, 6>(p, zero, st);
+    return launch_gs_ns<BM, BN, WGM, WGN, 3>(p, zero, st);
+}
+
+template <int BM, int BN, int WGM, int WGN, int NS>
+int launch_gs_ns(const ConvP& p, const float* zero, hipStream_t st) {
+    if constexpr (((BM + BN) / 16 + 3) / 4 * (NS - 1) > 63 || (size_t)NS * (BM + BN) * 64 > 150 * 1024) return 1;
+    else {
     constexpr size_t lds = ((size_t)NS * (BM + BN) * 16 + 4 * 256 + WGM * BN) * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -501,6 +541,7 @@ int launch_gs(const ConvP& p, const float* zero, hipStream_t st) {
     const dim3 grid(ceil_div(p.M, BM), ceil_div(p.Cout16, BN), 1);
     hipLaunchKernelGGL((k_conv_gs<BM, BN, WGM, WGN, NS>), grid, dim3(256), lds, st, p, zero);
     return ore_launch_status("k_conv_gs");
+    }
 }
 
 int g_gs_force[2] = {0, 0};             // tuning aid: {BM, BN}; 0 -> automatic
@@ -615,7 +656,7 @@ static int conv_gs_launch(ConvP& p, hipStream_t st) {
         // the staging mechanism is not what bounds these layers -- so only the 1x1 layers come here automatically
         if (p.M < 6400 || p.kh != 1) return 1;
         if (p.Cout16 == 112) { bm = 64; bn = 112; }
-        else if (p.Cout16 % 128 == 0) { bm = 64; bn = 128; }
+        else if (p.Cout16 % 128 == 0) { bm = 64; bn = p.M < 16384 ? 64 : 128; }      // s3cat: 64x64 21.8 us, 64x128 24.0 (400 vs 200 blocks)
         else if (p.Cout16 == 64) { bm = 64; bn = 64; }
         else return 1;
     }
@@ -630,7 +671,7 @@ static int conv_gs_launch(ConvP& p, hipStream_t st) {
     return 1;
 }
 
-void conv_gs_force(int bm, int bn) { g_gs_force[0] = bm; g_gs_force[1] = bn; }
+void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] = bn; if (ns > 0) g_gs_ns = ns; }
 
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
