@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
         const int n = n0 + j * 16 + r16;
         b_base[j] = n < p.Cout16 ? p.w + (size_t)n * p.K + lq * 4 : nullptr;
     }
-    // (dy, dx, cc) of this wave's next chunk to ISSUE, advanced by 4 chunks per step without divisions (wave-uniform)
+    // (dy, dx, cc) of this wave's next chunk to ISSUE (wave-uniform).  The DMA source pointers are carried incrementally: inside a tap
+    // the next chunk of this wave is 4 chunks = 64 floats further; only when the walk crosses into another tap (every Cin/64 steps)
+    // are the per-lane pointers rebuilt (tap validity, zero page for out-of-image taps).  ~2 VALU per piece and step instead of ~10.
     int i_c = c_begin + wave, i_dy, i_dx, i_cc;
     {
         const int tap = i_c / cpt;
@@ -146,34 +148,57 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
         i_dy = tap / p.kw; i_dx = tap - i_dy * p.kw;
     }
     float* ring = lds + wave * (NS * STAGE_F);
+    const float* a_cur[GA];
+    const float* b_cur[GB];
+    int a_inc[GA], b_inc[GB];
+    bool fresh = true;                                            // pointers must be (re)built before the next issue
     auto issue = [&](int slot) {
         float* dst = ring + slot * STAGE_F;
-        const bool live = i_c < c_end;
-        const unsigned tapbit = live ? (1u << (i_dy * p.kw + i_dx)) : 0u;
-        const int uoff = i_dx * p.in_ld + (i_cc << 4);
+        if (fresh) {
+            const bool live = i_c < c_end;
+            const unsigned tapbit = live ? (1u << (i_dy * p.kw + i_dx)) : 0u;
+            const int uoff = i_dx * p.in_ld + (i_cc << 4);
+#pragma unroll
+            for (int i = 0; i < GA; ++i) {
+                const bool ok = (a_taps[i] & tapbit) != 0u;
+                a_cur[i] = ok ? a_base[i] + (i_dy * a_rs[i] + uoff) : zero_page;
+                a_inc[i] = ok ? 64 : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < GB; ++j) {
+                const bool ok = live && b_base[j] != nullptr;
+                b_cur[j] = ok ? b_base[j] + ((size_t)i_c << 4) : zero_page;
+                b_inc[j] = ok ? 64 : 0;
+            }
+            fresh = false;
+        }
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-            const float* src = (a_taps[i] & tapbit) ? a_base[i] + (i_dy * a_rs[i] + uoff) : zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[i],
                                              (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+            a_cur[i] += a_inc[i];
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
-            const float* src = (live && b_base[j]) ? b_base[j] + ((size_t)i_c << 4) : zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_cur[j],
                                              (__attribute__((address_space(3))) void*)(dst + (GA + j) * 256), 16, 0, 0);
+            b_cur[j] += b_inc[j];
         }
-        // advance by 4 chunks
+        // advance by 4 chunks; crossing a tap boundary (or the end of this block's K range) asks for fresh pointers
+        const bool was_live = i_c < c_end;
         i_c += 4;
         i_cc += 4;
+        if (i_cc >= cpt || (was_live && i_c >= c_end)) {
+            fresh = true;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const bool wrap = i_cc >= cpt;
-            i_cc -= wrap ? cpt : 0;
-            i_dx += wrap ? 1 : 0;
-            const bool wy = i_dx == p.kw;
-            i_dx = wy ? 0 : i_dx;
-            i_dy += wy ? 1 : 0;
+            for (int w = 0; w < 4; ++w) {
+                const bool wrap = i_cc >= cpt;
+                i_cc -= wrap ? cpt : 0;
+                i_dx += wrap ? 1 : 0;
+                const bool wy = i_dx == p.kw;
+                i_dx = wy ? 0 : i_dx;
+                i_dy += wy ? 1 : 0;
+            }
         }
     };
 
@@ -394,29 +419,43 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
         }
     }
     int i_c = 0, i_dy = 0, i_dx = 0, i_cc = 0;                     // chunk to issue next (wave-uniform)
+    const float* cur[NI];                                          // incremental DMA sources: +16 floats per chunk inside a tap, rebuilt per tap
+    int inc[NI];
+    bool fresh = true;
     auto issue = [&](int slot) {
         float* dst = lds + slot * STAGE_F;
-        const bool live = i_c < nst;
-        const unsigned tapbit = live ? (1u << (i_dy * p.kw + i_dx)) : 0u;
-        const int uoffA = i_dx * p.in_ld + (i_cc << 4), uoffB = i_c << 4;
+        if (fresh) {
+            const bool live = i_c < nst;
+            const unsigned tapbit = live ? (1u << (i_dy * p.kw + i_dx)) : 0u;
+            const int uoffA = i_dx * p.in_ld + (i_cc << 4), uoffB = i_c << 4;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const bool isA = wave + 4 * i < GA;
+                const bool ok = isA ? (taps[i] & tapbit) != 0u : (live && taps[i] != 0u);
+                cur[i] = ok ? src[i] + (isA ? i_dy * rs[i] + uoffA : uoffB) : zero_page;
+                inc[i] = ok ? 16 : 0;
+            }
+            fresh = false;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int g = wave + 4 * i;
-            const bool isA = g < GA;
-            const bool ok = isA ? (taps[i] & tapbit) != 0u : (live && taps[i] != 0u);
-            const float* s_ = ok ? src[i] + (isA ? i_dy * rs[i] + uoffA : uoffB) : zero_page;
             float* d_ = g < G ? dst + g * 256 : lds + NS * STAGE_F + wave * 256;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)cur[i],
                                              (__attribute__((address_space(3))) void*)d_, 16, 0, 0);
+            cur[i] += inc[i];
         }
         i_c += 1;
         i_cc += 1;
-        const bool wrap = i_cc >= cpt;
-        i_cc = wrap ? 0 : i_cc;
-        i_dx += wrap ? 1 : 0;
-        const bool wy = i_dx == p.kw;
-        i_dx = wy ? 0 : i_dx;
-        i_dy += wy ? 1 : 0;
+        if (i_cc >= cpt || i_c == nst) {
+            fresh = true;
+            const bool wrap = i_cc >= cpt;
+            i_cc = wrap ? 0 : i_cc;
+            i_dx += wrap ? 1 : 0;
+            const bool wy = i_dx == p.kw;
+            i_dx = wy ? 0 : i_dx;
+            i_dy += wy ? 1 : 0;
+        }
     };
 
     f32x4 acc[TM][TN];
