@@ -663,6 +663,7 @@ int launch_kw(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
 namespace oreconv {
 
 int conv_kw_tile_rows(const ConvP& p) {         // rows per block of the kernel conv_kw_launch will pick (0: not covered) -- keep in step with it
+    if (g_kw_force[0] > 0) return g_kw_force[0];
     if (g_gs_force[0] > 0) return g_gs_force[0];
     if (p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256)) {
         if (p.M < 6400 || p.kh != 1) return 0;
@@ -714,7 +715,7 @@ void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] =
 
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
-    if (g_gs_force[0] > 0 || p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256)) return conv_gs_launch(p, st);
+    if (g_kw_force[0] == 0 && (g_gs_force[0] > 0 || p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256))) return conv_gs_launch(p, st);
     KwTile t = kw_tile(p.M, p.Cout16, p.nchunks);
     if (g_kw_force[0] > 0) t = {g_kw_force[0], g_kw_force[1] < p.Cout16 ? g_kw_force[1] : p.Cout16, g_kw_force[3]};
     if (t.BM == 0) return 1;
