@@ -21,6 +21,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -178,3 +180,28 @@ def leaf_state(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
             t.requires_grad_(True)
         out[k] = t
     return out
+
+
+# ---- inputs of tests/golden/eval_end_to_end.npz (regenerated from the seed by the generator and by the tests) ----------------
+def eval_support_df(shots, extra=2, seed=23):
+    """One-category support dataframe for the end-to-end eval fixture (shots + `extra` rows: init_model keeps the first `shots`)."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    rows = []
+    for k in range(shots + extra):
+        x0, y0 = rng.uniform(10, 60, 2)
+        rows.append({"id": 7000 + k, "image_id": 300 + k, "category_id": 1, "file_path": f"support/{7000 + k}.jpg",
+                     "support_box": [float(x0), float(y0), float(x0 + rng.uniform(90, 160)), float(y0 + rng.uniform(90, 160))]})
+    return pd.DataFrame(rows)
+
+
+def eval_support_crop(path, format=None):
+    """Deterministic smooth 240x240x3 uint8 BGR 'support crop' for a path (low-frequency pattern + noise, so features are not flat)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(os.path.basename(path).encode()))
+    yy, xx = np.mgrid[0:240, 0:240].astype(np.float32)
+    img = np.zeros((240, 240, 3), np.float32)
+    for c in range(3):
+        fx, fy, ph = rng.uniform(0.01, 0.08, 3)
+        img[:, :, c] = 120 + 70 * np.sin(fx * xx + fy * yy + ph * 40) + rng.normal(0, 12, (240, 240))
+    return np.clip(img, 0, 255).astype(np.uint8)

@@ -266,6 +266,7 @@ def main():
     gen_state_dict_layout()
     gen_demo_images()
     gen_generate_support()
+    gen_eval_end_to_end(sd)
 
 
 def reference_detector(sd, shots, device_cfg="cpu"):
@@ -524,5 +525,60 @@ def gen_generate_support():
     save("generate_support", seed=np.int64(7), **out)
 
 
+def gen_eval_end_to_end(sd0, shots=5):
+    """The reference's eval path END TO END, its own code only: `CenterNet2Detector.init_model` (ref:fewx/modeling/fsod/
+    fsod_cen.py:309-408) executed in a scratch working directory holding a synthetic ./datasets/coco/10_shot_support_df.pkl (it walks
+    the dataframe, computes the support features, writes ./support_dir/support_feature.pkl and calls sys.exit), then
+    `CenterNet2Detector.inference` (ref:...:417-535, incl. `_postprocess` -> d2 detector_postprocess) on the two shipped demo images
+    (BASELINE configs[0]'s inputs, 320x320 -> 300x300 output) with that pickle as `support_dict`.  Only utils.read_image (no image
+    files) and MetadataCatalog (unused result) are stand-ins."""
+    import pickle
+    import tempfile
+    sd = R.synth_roi_state(sd0, SEED)
+    sd["roi_heads.box_head.0.fc1.weight"] = sd["roi_heads.box_head.0.fc1.weight"] * 0.02
+    sd["proposal_generator.centernet_head.agn_hm.bias"] = torch.full((1,), -2.0)
+    det, cfg, ns = reference_detector(sd, shots)
+    cen = shims.load_fsod_cen()
+    sys.modules["detectron2.structures"].ROIMasks = type("ROIMasks", (), {})
+    pp = shims.load("d2z.modeling.postprocessing", shims.d2_root() + "/modeling/postprocessing.py")
+    cen.detector_postprocess = pp.detector_postprocess
+    from oracle import ref_train as T
+    cen.utils = types.SimpleNamespace(read_image=T.eval_support_crop)
+    cen.MetadataCatalog = types.SimpleNamespace(get=lambda name: None)
+    det.eval()
+    df = T.eval_support_df(shots)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "datasets", "coco"))
+        df.to_pickle(os.path.join(tmp, "datasets", "coco", "10_shot_support_df.pkl"))
+        os.chdir(tmp)
+        try:
+            with torch.no_grad():
+                try:
+                    det.init_model()
+                    raise RuntimeError("init_model was expected to exit after writing the pickle")
+                except SystemExit:
+                    pass
+            with open(os.path.join(tmp, "support_dir", "support_feature.pkl"), "rb") as f:
+                support = pickle.load(f)
+        finally:
+            os.chdir(cwd)
+    det.support_dict = support
+    out = {f"support_{k}": np_(v[1]) for k, v in support.items()}
+    imgs = np.load(os.path.join(OUT, "demo_images_320.npz"))["images"]
+    for i in range(2):
+        with torch.no_grad():
+            res = det.inference([{"image": torch.from_numpy(imgs[i]), "height": 300, "width": 300}])[0]["instances"]
+        out[f"img{i}_boxes"] = np_(res.pred_boxes.tensor)
+        out[f"img{i}_scores"] = np_(res.scores)
+        out[f"img{i}_classes"] = np_(res.pred_classes)
+        print(f"  image {i}: {len(res)} detections, scores {res.scores[:4].tolist()}")
+    save("eval_end_to_end", shots=np.int64(shots), df_seed=np.int64(23), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        torch.manual_seed(0)
+        gen_eval_end_to_end(R.synth_state_dict(SEED))
+    else:
+        main()

@@ -928,6 +928,42 @@ def test_init_model_walks_the_support_dataframe(model, tmp_path):
         model.set_support_dict({k: {c: t.cpu() for c, t in v.items()} for k, v in old.items()})
 
 
+def test_eval_end_to_end_vs_reference_run(ore, golden, tmp_path):
+    """The product's whole eval path -- `init_model` walking a support dataframe, then `model([{image, height, width}])` -- against
+    the reference's own init_model + inference EXECUTED end to end (tests/golden/eval_end_to_end.npz, ref:fewx/modeling/fsod/
+    fsod_cen.py:309-408, :417-535) on the two shipped demo images: support features at 1e-4, detections as a set (boxes to 0.05 px on
+    the 300x300 output, scores to 1e-3 relative)."""
+    import os
+    from conftest import PKG
+    from fewx.config import get_cfg
+    from detectron2.modeling import build_model
+    from oracle import ref_train as RT
+    from test_oracle_golden import _match_detections, eval_end_to_end_state
+    g = golden("eval_end_to_end")
+    shots = int(g["shots"])
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(PKG, "configs", "fsod", "finetune_vovnet.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "INPUT.FS.SUPPORT_SHOT", shots])
+    cfg.freeze()
+    m = build_model(cfg).eval()
+    missing, unexpected = m.load_state_dict(eval_end_to_end_state(), strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m.init_model(support_file=str(tmp_path / "support_dir" / "support_feature.pkl"), support_df=RT.eval_support_df(shots),
+                 read_image=RT.eval_support_crop)
+    for k in ("p3", "p4", "p5", "rcnn_8", "rcnn_4"):
+        assert set(m.support_dict[k]) == {1}
+        assert rel_err(m.support_dict[k][1].cpu().numpy(), g["support_" + k]) < TOL, k
+    imgs = golden("demo_images_320")["images"]
+    for i in range(2):
+        for rep in range(2):                                                # second call = hipGraph replay
+            out = m([{"image": torch.from_numpy(imgs[i]), "height": 300, "width": 300}])[0]["instances"]
+        rb, rs = g[f"img{i}_boxes"], g[f"img{i}_scores"]
+        assert out.image_size == (300, 300) and abs(len(out) - len(rs)) <= 1, (len(out), len(rs))
+        ok = _match_detections(out.pred_boxes.tensor.cpu().numpy(), out.scores.cpu().numpy(), rb, rs, 0.05, 1e-3)
+        assert ok.mean() >= 0.97, (i, ok.mean())
+        assert (out.pred_classes == 0).all()
+
+
 def test_engine_batched_eval_matches_single_image_engines(ore, sd):
     """ore_engine_eval_batch_fwd: B independent images in one pass (dense stages batched, detection tail + second stage per image)
     against the bs = 1 path on each image: feature maps to 1e-5 (another tile plan = another summation order, never another result),

@@ -289,3 +289,58 @@ def test_product_state_dict_layout_matches_reference(golden):
     params = {k for k, _ in m.named_parameters()}
     assert params == {str(k) for k, p in zip(g["keys"], g["is_param"]) if p}
     assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 5058174
+
+
+def _match_detections(boxes, scores, ref_boxes, ref_scores, box_atol, score_rtol):
+    """Detections as a set (NMS / top-k order may swap on near-ties): every reference detection has a partner within tolerance."""
+    d = np.abs(boxes[None, :, :] - ref_boxes[:, None, :]).max(2)
+    j = d.argmin(1)
+    ok = (d[np.arange(len(ref_boxes)), j] <= box_atol) & (np.abs(scores[j] - ref_scores) <= score_rtol * ref_scores + 1e-6)
+    return ok
+
+
+def eval_end_to_end_state():
+    sd = _roi_sd()
+    sd["roi_heads.box_head.0.fc1.weight"] = sd["roi_heads.box_head.0.fc1.weight"] * 0.02
+    sd["proposal_generator.centernet_head.agn_hm.bias"] = torch.full((1,), -2.0)
+    return sd
+
+
+def test_eval_end_to_end_matches_reference_run(golden):
+    """The whole eval path against the reference's own `init_model` + `inference` executed end to end (tests/golden/
+    eval_end_to_end.npz; ref:fewx/modeling/fsod/fsod_cen.py:309-408 and :417-535): support dataframe walk -> support features, then
+    image -> backbone/FPN -> correlation -> CenterNet head -> decode/NMS -> second stage -> detector_postprocess to 300x300, on the two
+    shipped demo images (BASELINE configs[0]'s inputs)."""
+    from oracle import ref_train as RT
+    g = golden("eval_end_to_end")
+    sd = eval_end_to_end_state()
+    shots = int(g["shots"])
+    df = RT.eval_support_df(shots)
+    rows = df.loc[df["category_id"] == 1].reset_index().iloc[:shots]
+    crops = torch.stack([torch.from_numpy(RT.eval_support_crop("./datasets/coco/" + p).transpose(2, 0, 1).copy()) for p in rows["file_path"]])
+    sbox = torch.tensor(rows["support_box"].tolist(), dtype=torch.float32)
+    with torch.no_grad():
+        sf = R.backbone_fpn(RT.preprocess_batch(crops.float()), sd)
+        support = {k: R.support_prototype(sf[k], sd, 3 + i) for i, k in enumerate(("p3", "p4", "p5"))}
+        for k in support:
+            assert rel_err(support[k].numpy(), g["support_" + k]) < 2e-5, k
+        rc8 = torch.cat([R.roi_pool_levels([sf[k][n:n + 1] for k in ("p3", "p4", "p5")], sbox[n:n + 1], 8) for n in range(shots)], 0)
+        rc4 = torch.cat([R.roi_pool_levels([sf[k][n:n + 1] for k in ("p3", "p4", "p5")], sbox[n:n + 1], 4) for n in range(shots)], 0)
+        assert rel_err(rc8.numpy(), g["support_rcnn_8"]) < 2e-5 and rel_err(rc4.numpy(), g["support_rcnn_4"]) < 2e-5
+        imgs = golden("demo_images_320")["images"]
+        for i in range(2):
+            o = R.eval_dense(torch.from_numpy(imgs[i]), sd, support)
+            hms = [h[0, 0].numpy() for h in o["hm"]]
+            regs = [r[0].permute(1, 2, 0).contiguous().numpy() for r in o["reg"]]
+            d = odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+            det = R.roi_head_eval([o["features"][k] for k in ("p3", "p4", "p5")], torch.from_numpy(d["boxes"]), rc8, sd, (320, 320), 0.0, 0.9, 100)
+            boxes = det["boxes"] * np.float32(300.0 / 320.0)                    # detector_postprocess: scale, clip, drop empty
+            boxes = np.clip(boxes, 0, 300)
+            keep = (boxes[:, 2] > boxes[:, 0]) & (boxes[:, 3] > boxes[:, 1])
+            boxes, scores = boxes[keep], det["scores"][keep]
+            rb, rs = g[f"img{i}_boxes"], g[f"img{i}_scores"]
+            assert abs(len(scores) - len(rs)) <= 1, (len(scores), len(rs))
+            ok = _match_detections(boxes, scores, rb, rs, 0.02, 2e-4)
+            assert ok.mean() >= 0.98, (i, ok.mean())
+            assert (g[f"img{i}_classes"] == 0).all()
+
