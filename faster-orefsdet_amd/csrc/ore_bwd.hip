@@ -265,12 +265,16 @@ __global__ __launch_bounds__(256) void k_relu_affine_bwd(const float* __restrict
 // column sums: stage 1 = 256-row chunks (64 channels x 4 row lanes per block, lanes combined in fixed order through LDS),
 // stage 2 = chunks in order.  Deterministic.
 constexpr int CS_ROWS = 256;
-__global__ __launch_bounds__(256) void k_colsum_chunks(const float* __restrict__ x, int ld, int coff, long long rows, int C,
+// Segmented form: the rows are `segments` equal runs of rows_per_seg; chunk boundaries restart with every segment, so a segment's
+// sums are bitwise those of a call on that segment alone.  blockIdx.x = segment * cps + chunk.
+__global__ __launch_bounds__(256) void k_colsum_chunks(const float* __restrict__ x, int ld, int coff, long long rows_per_seg, int cps, int C,
                                                        float* __restrict__ part) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
-    const long long r0 = (long long)blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    const int seg = blockIdx.x / cps, chunk = blockIdx.x - seg * cps;
+    const long long s0r = (long long)seg * rows_per_seg;
+    const long long r0 = s0r + (long long)chunk * CS_ROWS, r1 = min(s0r + rows_per_seg, r0 + CS_ROWS);
     float s0 = 0.f, s1 = 0.f;
     if (c < C) {
         long long r = r0 + rl;
@@ -281,13 +285,15 @@ __global__ __launch_bounds__(256) void k_colsum_chunks(const float* __restrict__
     __syncthreads();
     if (rl == 0 && c < C) part[(size_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
-__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int nchunks, int C, float beta, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int cps, int C, float beta, float* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    part += (size_t)blockIdx.y * cps * C;
+    out += (size_t)blockIdx.y * C;
     float s0 = 0.f, s1 = 0.f;
     int k = 0;
-    for (; k + 1 < nchunks; k += 2) { s0 += part[(size_t)k * C + c]; s1 += part[(size_t)(k + 1) * C + c]; }
-    if (k < nchunks) s0 += part[(size_t)k * C + c];
+    for (; k + 1 < cps; k += 2) { s0 += part[(size_t)k * C + c]; s1 += part[(size_t)(k + 1) * C + c]; }
+    if (k < cps) s0 += part[(size_t)k * C + c];
     const float s = s0 + s1;
     out[c] = beta != 0.0f ? beta * out[c] + s : s;
 }
@@ -301,7 +307,8 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
 struct CorrT {
     const float* q; int q_ld, q_coff;
     int H, W, C4, rows;
-    const float* k11; const float* k13; const float* k31;   // [C], [C][3], [C][3]
+    const float* k11; const float* k13; const float* k31;   // [C], [C][3], [C][3]; per image ([B][C], [B][C][3]) when kps = 1
+    int kps;
 };
 __device__ __forceinline__ f32x4 relu4b(f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
 __device__ __forceinline__ f32x4 gt0(f32x4 v, f32x4 g) { return f32x4{v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f}; }
@@ -316,9 +323,10 @@ __global__ __launch_bounds__(256) void k_corr_fwd_train(CorrT p, float* __restri
     const int c = (idx % p.C4) * 4, row = idx / p.C4;
     const int C = p.C4 * 4, H = p.H, W = p.W;
     const int b = row / (H * W), rr = row - b * H * W, y = rr / W, x = rr - y * W, base = b * H * W;
-    const f32x4 w11 = *reinterpret_cast<const f32x4*>(p.k11 + c);
+    const size_t ko = (size_t)b * p.kps * C;
+    const f32x4 w11 = *reinterpret_cast<const f32x4*>(p.k11 + ko + c);
     f32x4 w13[3], w31[3];
-    ld3(p.k13, c, w13); ld3(p.k31, c, w31);
+    ld3(p.k13 + 3 * ko, c, w13); ld3(p.k31 + 3 * ko, c, w31);
     auto Q = [&](int yy, int xx) -> f32x4 {
         if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
             return *reinterpret_cast<const f32x4*>(p.q + (size_t)(base + yy * W + xx) * p.q_ld + p.q_coff + c);
@@ -344,14 +352,14 @@ __global__ __launch_bounds__(256) void k_corr_fwd_train(CorrT p, float* __restri
 
 // g = dcat[..., :C] (row stride 2C)
 __global__ __launch_bounds__(256) void k_corr_bwd_a(CorrT p, const float* __restrict__ dcat, const float* __restrict__ T,
-                                                    const float* __restrict__ U, float* __restrict__ DT, float* __restrict__ P31) {
+                                                    const float* __restrict__ U, float* __restrict__ DT, float* __restrict__ P) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.rows * p.C4) return;
     const int c = (idx % p.C4) * 4, row = idx / p.C4;
     const int C = p.C4 * 4, H = p.H, W = p.W;
-    const int rr = row % (H * W), y = rr / W;
+    const int b = row / (H * W), rr = row - b * H * W, y = rr / W;
     f32x4 w31[3];
-    ld3(p.k31, c, w31);
+    ld3(p.k31 + (size_t)3 * b * p.kps * C, c, w31);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     auto DU = [&](int dy) -> f32x4 {                                    // dU at (y+dy, x)
         if ((unsigned)(y + dy) >= (unsigned)H) return z;
@@ -365,21 +373,22 @@ __global__ __launch_bounds__(256) void k_corr_bwd_a(CorrT p, const float* __rest
     const f32x4 du0 = DU(0), tc = TT(0);
     const f32x4 dt = w31[0] * DU(1) + w31[1] * du0 + w31[2] * DU(-1);
     *reinterpret_cast<f32x4*>(DT + (size_t)row * C + c) = gt0(tc, dt);
-    *reinterpret_cast<f32x4*>(P31 + (size_t)row * 3 * C + 0 * C + c) = du0 * TT(-1);
-    *reinterpret_cast<f32x4*>(P31 + (size_t)row * 3 * C + 1 * C + c) = du0 * tc;
-    *reinterpret_cast<f32x4*>(P31 + (size_t)row * 3 * C + 2 * C + c) = du0 * TT(1);
+    *reinterpret_cast<f32x4*>(P + (size_t)row * 7 * C + 4 * C + c) = du0 * TT(-1);      // P row = [P11 | P13 x3 | P31 x3]
+    *reinterpret_cast<f32x4*>(P + (size_t)row * 7 * C + 5 * C + c) = du0 * tc;
+    *reinterpret_cast<f32x4*>(P + (size_t)row * 7 * C + 6 * C + c) = du0 * TT(1);
 }
 
 __global__ __launch_bounds__(256) void k_corr_bwd_b(CorrT p, const float* __restrict__ dcat, const float* __restrict__ DT,
-                                                    float* __restrict__ dq, float* __restrict__ P13, float* __restrict__ P11) {
+                                                    float* __restrict__ dq, float* __restrict__ P) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.rows * p.C4) return;
     const int c = (idx % p.C4) * 4, row = idx / p.C4;
     const int C = p.C4 * 4, W = p.W;
     const int x = row % W;
-    const f32x4 w11 = *reinterpret_cast<const f32x4*>(p.k11 + c);
+    const size_t ko = (size_t)(row / (p.H * W)) * p.kps * C;
+    const f32x4 w11 = *reinterpret_cast<const f32x4*>(p.k11 + ko + c);
     f32x4 w13[3];
-    ld3(p.k13, c, w13);
+    ld3(p.k13 + 3 * ko, c, w13);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     auto Qx = [&](int dx) -> f32x4 {
         if ((unsigned)(x + dx) >= (unsigned)W) return z;
@@ -395,11 +404,11 @@ __global__ __launch_bounds__(256) void k_corr_bwd_b(CorrT p, const float* __rest
     const f32x4 s1 = w11 * qc, a1 = relu4b(s1);
     const f32x4 da2 = gt0(w11 * a1, g);
     const f32x4 da1 = gt0(s1, da2 * w11);
-    *reinterpret_cast<f32x4*>(P11 + (size_t)row * C + c) = da2 * a1 + da1 * qc;
+    *reinterpret_cast<f32x4*>(P + (size_t)row * 7 * C + c) = da2 * a1 + da1 * qc;
     *reinterpret_cast<f32x4*>(dq + (size_t)row * C + c) = g + g2 + da1 * w11 + w13[0] * D(1) + w13[1] * dtc + w13[2] * D(-1);
-    *reinterpret_cast<f32x4*>(P13 + (size_t)row * 3 * C + 0 * C + c) = dtc * Qx(-1);
-    *reinterpret_cast<f32x4*>(P13 + (size_t)row * 3 * C + 1 * C + c) = dtc * qc;
-    *reinterpret_cast<f32x4*>(P13 + (size_t)row * 3 * C + 2 * C + c) = dtc * Qx(1);
+    *reinterpret_cast<f32x4*>(P + (size_t)row * 7 * C + 1 * C + c) = dtc * Qx(-1);
+    *reinterpret_cast<f32x4*>(P + (size_t)row * 7 * C + 2 * C + c) = dtc * qc;
+    *reinterpret_cast<f32x4*>(P + (size_t)row * 7 * C + 3 * C + c) = dtc * Qx(1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256) void k_corr_bwd_b(CorrT p, const float* __rest
 //   GroupNorm(+ReLU) of the head tower with gradients; eSE scale with gradients; ceil-mode 3x3/s2 max-pool backward;
 //   2x2 sum-pool (backward of the FPN's nearest-2x top-down add).
 // xhat = x * r[c] + a[c] with r = rstd of the channel's group, a = -mean * rstd (from ore_groupnorm_affine_fwd with gamma=1, beta=0).
-__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, int ld, int coff, long long rows, int C,
+__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, int ld, int coff, long long rows, long long rpi, int C,
                                                   const float* __restrict__ r, const float* __restrict__ a, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int relu, float* __restrict__ y) {
     const int c4n = C / 4;
@@ -415,8 +424,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, i
     if (i >= rows * c4n) return;
     const long long row = i / c4n;
     const int c = (int)(i % c4n) * 4;
+    const size_t io = (size_t)(row / rpi) * C;                    // this row's image: r / a are [images][C]
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ld + coff + c);
-    const f32x4 rr = *reinterpret_cast<const f32x4*>(r + c), aa = *reinterpret_cast<const f32x4*>(a + c);
+    const f32x4 rr = *reinterpret_cast<const f32x4*>(r + io + c), aa = *reinterpret_cast<const f32x4*>(a + io + c);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
     f32x4 o = (v * rr + aa) * g + b;
     if (relu) o = relu4b(o);
@@ -425,32 +435,36 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, i
 
 // P[row][0:C] = dy' = dy * [y > 0 or !relu],  P[row][C:2C] = dy' * xhat
 __global__ __launch_bounds__(256) void k_gn_bwd_prod(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, int ld,
-                                                     int coff, long long rows, int C, const float* __restrict__ r, const float* __restrict__ a,
-                                                     int relu, float* __restrict__ P) {
+                                                     int coff, long long rows, long long rpi, int C, const float* __restrict__ r,
+                                                     const float* __restrict__ a, int relu, float* __restrict__ P) {
     const int c4n = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * c4n) return;
     const long long row = i / c4n;
     const int c = (int)(i % c4n) * 4;
+    const size_t io = (size_t)(row / rpi) * C;
     f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * C + c);
     if (relu) g = gt0(*reinterpret_cast<const f32x4*>(y + row * C + c), g);
-    const f32x4 xh = *reinterpret_cast<const f32x4*>(x + row * ld + coff + c) * *reinterpret_cast<const f32x4*>(r + c) +
-                     *reinterpret_cast<const f32x4*>(a + c);
+    const f32x4 xh = *reinterpret_cast<const f32x4*>(x + row * ld + coff + c) * *reinterpret_cast<const f32x4*>(r + io + c) +
+                     *reinterpret_cast<const f32x4*>(a + io + c);
     *reinterpret_cast<f32x4*>(P + row * 2 * C + c) = g;
     *reinterpret_cast<f32x4*>(P + row * 2 * C + C + c) = g * xh;
 }
 
 // dx = r * (gamma * dy' - (S1_g + xhat * S2_g) / n),  S1_g = sum_{c in g} gamma_c dbeta_c,  S2_g = sum_{c in g} gamma_c dgamma_c
 __global__ __launch_bounds__(256) void k_gn_bwd_dx(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, int ld,
-                                                   int coff, long long rows, int C, int cpg, const float* __restrict__ r,
+                                                   int coff, long long rows, long long rpi, int C, int cpg, const float* __restrict__ r,
                                                    const float* __restrict__ a, const float* __restrict__ gamma,
-                                                   const float* __restrict__ sums /* [2C]: dbeta | dgamma */, int relu, float* __restrict__ dx) {
+                                                   const float* __restrict__ sums /* [images][2C]: dbeta | dgamma */, int relu,
+                                                   float* __restrict__ dx) {
     const int c4n = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * c4n) return;
     const long long row = i / c4n;
     const int c = (int)(i % c4n) * 4;
-    const float inv_n = 1.0f / ((float)rows * (float)cpg);
+    const size_t img = (size_t)(row / rpi);
+    r += img * C; a += img * C; sums += img * 2 * C;
+    const float inv_n = 1.0f / ((float)rpi * (float)cpg);
     f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * C + c);
     if (relu) g = gt0(*reinterpret_cast<const f32x4*>(y + row * C + c), g);
     const f32x4 rr = *reinterpret_cast<const f32x4*>(r + c);
@@ -622,90 +636,102 @@ extern "C" int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_co
     return ore_launch_status("k_relu_affine_bwd");
 }
 
-extern "C" int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, float beta, float* out,
-                              float* workspace, size_t workspace_floats, void* stream) {
-    ORE_CHECK_ARG(x && out && workspace && rows > 0 && C > 0, "ore_colsum_fwd: bad args");
-    const long long nchunks = (rows + CS_ROWS - 1) / CS_ROWS;
-    if ((size_t)(nchunks * C) > workspace_floats) { ore_set_error("ore_colsum_fwd: workspace too small"); return ORE_ENOMEM; }
+extern "C" int ore_colsum_segments_fwd(const float* x, int32_t ld, int32_t coff, int32_t segments, int64_t rows_per_segment, int32_t C,
+                                       float beta, float* out, float* workspace, size_t workspace_floats, void* stream) {
+    ORE_CHECK_ARG(x && out && workspace && segments > 0 && rows_per_segment > 0 && C > 0, "ore_colsum_segments_fwd: bad args");
+    const long long cps = (rows_per_segment + CS_ROWS - 1) / CS_ROWS;
+    if ((size_t)(cps * segments * C) > workspace_floats) { ore_set_error("ore_colsum_segments_fwd: workspace too small"); return ORE_ENOMEM; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_colsum_chunks, dim3((unsigned)nchunks, ceil_div(C, 64)), dim3(256), 0, st, x, ld, coff, (long long)rows, C, workspace);
+    hipLaunchKernelGGL(k_colsum_chunks, dim3((unsigned)(cps * segments), ceil_div(C, 64)), dim3(256), 0, st, x, ld, coff, (long long)rows_per_segment,
+                       (int)cps, C, workspace);
     int rc = ore_launch_status("k_colsum_chunks");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(C, 256)), dim3(256), 0, st, workspace, (int)nchunks, C, beta, out);
+    hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(C, 256), segments), dim3(256), 0, st, workspace, (int)cps, C, beta, out);
     return ore_launch_status("k_colsum_final");
 }
 
+extern "C" int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, float beta, float* out,
+                              float* workspace, size_t workspace_floats, void* stream) {
+    return ore_colsum_segments_fwd(x, ld, coff, 1, rows, C, beta, out, workspace, workspace_floats, stream);
+}
+
 static int corr_fill(CorrT& p, const float* q, int q_ld, int q_coff, int B, int H, int W, int C, const float* k11, const float* k13,
-                     const float* k31) {
+                     const float* k31, int k_per_image) {
     p.q = q; p.q_ld = q_ld; p.q_coff = q_coff; p.H = H; p.W = W; p.C4 = C / 4; p.rows = B * H * W;
-    p.k11 = k11; p.k13 = k13; p.k31 = k31;
+    p.k11 = k11; p.k13 = k13; p.k31 = k31; p.kps = k_per_image ? 1 : 0;
     return ceil_div(p.rows * p.C4, 256);
 }
 
 extern "C" int ore_correlation_train_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
-                                         const float* k11, const float* k13, const float* k31, float* cat2c, float* t_save,
-                                         float* u_save, void* stream) {
+                                         const float* k11, const float* k13, const float* k31, int32_t k_per_image, float* cat2c,
+                                         float* t_save, float* u_save, void* stream) {
     ORE_CHECK_ARG(q && k11 && k13 && k31 && cat2c && t_save && u_save && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && q_ld % 4 == 0 &&
                   q_coff % 4 == 0, "ore_correlation_train_fwd: bad args");
     CorrT p{};
-    const int nb = corr_fill(p, q, q_ld, q_coff, B, H, W, C, k11, k13, k31);
+    const int nb = corr_fill(p, q, q_ld, q_coff, B, H, W, C, k11, k13, k31, k_per_image);
     hipLaunchKernelGGL(k_corr_fwd_train, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, cat2c, t_save, u_save);
     return ore_launch_status("k_corr_fwd_train");
 }
 
 extern "C" int ore_correlation_train_bwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
-                                         const float* k11, const float* k13, const float* k31, const float* dcat2c,
-                                         const float* t_save, const float* u_save, float* dq, float* dk11, float* dk13_3c,
-                                         float* dk31_3c, float* workspace, size_t workspace_floats, void* stream) {
-    ORE_CHECK_ARG(q && k11 && k13 && k31 && dcat2c && t_save && u_save && dq && dk11 && dk13_3c && dk31_3c && workspace && B > 0 && H > 0 &&
+                                         const float* k11, const float* k13, const float* k31, int32_t k_per_image,
+                                         const float* dcat2c, const float* t_save, const float* u_save, float* dq, float* dk_7c,
+                                         float* workspace, size_t workspace_floats, void* stream) {
+    ORE_CHECK_ARG(q && k11 && k13 && k31 && dcat2c && t_save && u_save && dq && dk_7c && workspace && B > 0 && H > 0 &&
                   W > 0 && C > 0 && C % 4 == 0 && q_ld % 4 == 0 && q_coff % 4 == 0, "ore_correlation_train_bwd: bad args");
     const size_t rows = (size_t)B * H * W;
-    const size_t need = rows * C * 8 + ((rows + 63) / 64) * 3 * C;
+    const int segs = k_per_image ? B : 1;
+    const size_t rps = rows / segs;
+    const size_t need = rows * C * 8 + (size_t)segs * ((rps + CS_ROWS - 1) / CS_ROWS) * 7 * C;
     if (workspace_floats < need) { ore_set_error("ore_correlation_train_bwd: workspace %zu < %zu floats", workspace_floats, need); return ORE_ENOMEM; }
-    float* DT = workspace; float* P31 = DT + rows * C; float* P13 = P31 + rows * 3 * C; float* P11 = P13 + rows * 3 * C;
-    float* cs = P11 + rows * C;
+    float* DT = workspace; float* P = DT + rows * C;
+    float* cs = P + rows * 7 * C;
     const size_t cs_floats = workspace_floats - rows * C * 8;
     CorrT p{};
-    const int nb = corr_fill(p, q, q_ld, q_coff, B, H, W, C, k11, k13, k31);
+    const int nb = corr_fill(p, q, q_ld, q_coff, B, H, W, C, k11, k13, k31, k_per_image);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_corr_bwd_a, dim3(nb), dim3(256), 0, st, p, dcat2c, t_save, u_save, DT, P31);
+    hipLaunchKernelGGL(k_corr_bwd_a, dim3(nb), dim3(256), 0, st, p, dcat2c, t_save, u_save, DT, P);
     int rc = ore_launch_status("k_corr_bwd_a");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_corr_bwd_b, dim3(nb), dim3(256), 0, st, p, dcat2c, DT, dq, P13, P11);
+    hipLaunchKernelGGL(k_corr_bwd_b, dim3(nb), dim3(256), 0, st, p, dcat2c, DT, dq, P);
     rc = ore_launch_status("k_corr_bwd_b");
     if (rc) return rc;
-    if ((rc = ore_colsum_fwd(P11, C, 0, (int64_t)rows, C, 0.f, dk11, cs, cs_floats, stream))) return rc;
-    if ((rc = ore_colsum_fwd(P13, 3 * C, 0, (int64_t)rows, 3 * C, 0.f, dk13_3c, cs, cs_floats, stream))) return rc;
-    return ore_colsum_fwd(P31, 3 * C, 0, (int64_t)rows, 3 * C, 0.f, dk31_3c, cs, cs_floats, stream);
+    return ore_colsum_segments_fwd(P, 7 * C, 0, segs, (int64_t)rps, 7 * C, 0.f, dk_7c, cs, cs_floats, stream);
 }
 
-extern "C" int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, const float* rstd_c,
-                                       const float* shift_c, const float* gamma, const float* beta, int32_t relu, float* y, void* stream) {
-    ORE_CHECK_ARG(x && rstd_c && shift_c && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && coff % 4 == 0,
-                  "ore_groupnorm_apply_fwd: bad args");
+extern "C" int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff, int32_t images, int64_t rows_per_image, int32_t C,
+                                       const float* rstd_c, const float* shift_c, const float* gamma, const float* beta, int32_t relu, float* y,
+                                       void* stream) {
+    ORE_CHECK_ARG(x && rstd_c && shift_c && gamma && beta && y && images > 0 && rows_per_image > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 &&
+                  coff % 4 == 0, "ore_groupnorm_apply_fwd: bad args");
+    const long long rows = (long long)images * rows_per_image;
     const long long n = rows * (C / 4);
-    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, coff, (long long)rows, C, rstd_c,
-                       shift_c, gamma, beta, relu, y);
+    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, coff, rows, (long long)rows_per_image,
+                       C, rstd_c, shift_c, gamma, beta, relu, y);
     return ore_launch_status("k_gn_apply");
 }
 
-extern "C" int ore_groupnorm_bwd(const float* dy, const float* y, const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C,
-                                 int32_t groups, const float* rstd_c, const float* shift_c, const float* gamma, int32_t relu, float* dx,
-                                 float* dbeta_dgamma_2c, float* workspace, size_t workspace_floats, void* stream) {
-    ORE_CHECK_ARG(dy && y && x && rstd_c && shift_c && gamma && dx && dbeta_dgamma_2c && workspace && rows > 0 && C > 0 && C % 4 == 0 &&
-                  groups > 0 && C % groups == 0 && ld % 4 == 0 && coff % 4 == 0, "ore_groupnorm_bwd: bad args");
-    const size_t need = (size_t)rows * 2 * C + (size_t)((rows + CS_ROWS - 1) / CS_ROWS) * 2 * C;
+extern "C" int ore_groupnorm_bwd(const float* dy, const float* y, const float* x, int32_t ld, int32_t coff, int32_t images,
+                                 int64_t rows_per_image, int32_t C, int32_t groups, const float* rstd_c, const float* shift_c,
+                                 const float* gamma, int32_t relu, float* dx, float* dbeta_dgamma_2c, float* workspace, size_t workspace_floats,
+                                 void* stream) {
+    ORE_CHECK_ARG(dy && y && x && rstd_c && shift_c && gamma && dx && dbeta_dgamma_2c && workspace && images > 0 && rows_per_image > 0 && C > 0 &&
+                  C % 4 == 0 && groups > 0 && C % groups == 0 && ld % 4 == 0 && coff % 4 == 0, "ore_groupnorm_bwd: bad args");
+    const long long rows = (long long)images * rows_per_image;
+    const size_t need = (size_t)rows * 2 * C + (size_t)images * ((rows_per_image + CS_ROWS - 1) / CS_ROWS) * 2 * C;
     if (workspace_floats < need) { ore_set_error("ore_groupnorm_bwd: workspace %zu < %zu floats", workspace_floats, need); return ORE_ENOMEM; }
     float* P = workspace;
     float* cs = P + (size_t)rows * 2 * C;
     const long long n = rows * (C / 4);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gn_bwd_prod, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, x, ld, coff, (long long)rows, C, rstd_c, shift_c, relu, P);
+    hipLaunchKernelGGL(k_gn_bwd_prod, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, x, ld, coff, rows, (long long)rows_per_image, C,
+                       rstd_c, shift_c, relu, P);
     int rc = ore_launch_status("k_gn_bwd_prod");
     if (rc) return rc;
-    if ((rc = ore_colsum_fwd(P, 2 * C, 0, rows, 2 * C, 0.f, dbeta_dgamma_2c, cs, workspace_floats - (size_t)rows * 2 * C, stream))) return rc;
-    hipLaunchKernelGGL(k_gn_bwd_dx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, x, ld, coff, (long long)rows, C, C / groups, rstd_c,
-                       shift_c, gamma, dbeta_dgamma_2c, relu, dx);
+    if ((rc = ore_colsum_segments_fwd(P, 2 * C, 0, images, rows_per_image, 2 * C, 0.f, dbeta_dgamma_2c, cs,
+                                      workspace_floats - (size_t)rows * 2 * C, stream))) return rc;
+    hipLaunchKernelGGL(k_gn_bwd_dx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, x, ld, coff, rows, (long long)rows_per_image, C,
+                       C / groups, rstd_c, shift_c, gamma, dbeta_dgamma_2c, relu, dx);
     return ore_launch_status("k_gn_bwd_dx");
 }
 

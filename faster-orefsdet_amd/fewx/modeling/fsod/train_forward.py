@@ -61,10 +61,7 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
     outs = []
     for l, x in enumerate(feats_nhwc):
         t = A.conv(x, tower.weight, tower.bias)
-        if t.shape[0] == 1:
-            t = A.group_norm_relu(t, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
-        else:                                                       # GroupNorm statistics are per image
-            t = torch.cat([A.group_norm_relu(tb, gn.weight, gn.bias, gn.num_groups, gn.eps, True) for tb in t.split(1, 0)], 0)
+        t = A.group_norm_relu(t, gn.weight, gn.bias, gn.num_groups, gn.eps, True)       # statistics per image, one launch per kernel
         o = A.conv(t, w5, b5)
         reg = F.relu(o[..., :4] * head.scales[l].scale)
         outs.append(torch.cat([reg, o[..., 4:5], torch.zeros(*o.shape[:3], 11, device=o.device)], -1))
@@ -93,10 +90,9 @@ def dense_part(model, xq: torch.Tensor, xs: torch.Tensor):
         k11 = F.adaptive_avg_pool2d(proto, (1, 1))[:, :, 0, 0]                  # support kernels (fsod_cen.py:229-231), [B,C]
         k13 = F.adaptive_avg_pool2d(proto, (1, 3))[:, :, 0, :]                  # [B,C,3]
         k31 = F.adaptive_avg_pool2d(proto, (3, 1))[:, :, :, 0]
-        q = nhwc_view(feats[k])
-        qs, k11s, k13s, k31s = q.split(1, 0), k11.unbind(0), k13.unbind(0), k31.unbind(0)
-        cats = [A.correlation_cat(qs[b], k11s[b], k13s[b], k31s[b]) for b in range(B)]     # [1,H,W,2C] = [attn | q] per image
-        pos.append(A.conv(cats[0] if B == 1 else torch.cat(cats, 0), model.conv3.weight, model.conv3.bias, None, None, True))
+        # [B,H,W,2C] = [attn | q], every image correlated with its own support kernels in one launch
+        cat = A.correlation_cat(nhwc_view(feats[k]), k11, k13, k31)
+        pos.append(A.conv(cat, model.conv3.weight, model.conv3.bias, None, None, True))
     heads = head_train(model.proposal_generator.centernet_head, pos)
     return tuple(nhwc_view(feats[k]) for k in LEVELS) + tuple(nhwc_view(sfeats[k]) for k in LEVELS) + tuple(heads)
 

@@ -69,7 +69,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
-           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
+           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_roi_predict_post_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
@@ -636,60 +636,66 @@ def colsum(x: torch.Tensor, *, coff: int = 0, Cc: Optional[int] = None, out: Opt
 
 
 def correlation_train_fwd(q: torch.Tensor, k11: torch.Tensor, k13: torch.Tensor, k31: torch.Tensor):
-    """q [B,H,W,C] -> (cat [B,H,W,2C] = [attn | q], t, u)."""
+    """q [B,H,W,C]; k11 [C], k13 / k31 [C,3] shared by the B images, or [B,C] / [B,C,3] = one support kernel set per image
+    -> (cat [B,H,W,2C] = [attn | q], t, u)."""
     _f32(q)
     B, H, W, Cc = q.shape
+    per_image = int(k11.dim() == 2)
+    assert k11.numel() == (B if per_image else 1) * Cc and k13.numel() == k31.numel() == 3 * k11.numel()
     cat = torch.empty(B, H, W, 2 * Cc, device=q.device, dtype=torch.float32)
     t = torch.empty(B, H, W, Cc, device=q.device, dtype=torch.float32)
     u = torch.empty_like(t)
     _chk(lib().ore_correlation_train_fwd(C.c_void_p(_ptr(q)), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(_f32(k11))), C.c_void_p(_ptr(_f32(k13))),
-                                         C.c_void_p(_ptr(_f32(k31))), C.c_void_p(_ptr(cat)), C.c_void_p(_ptr(t)), C.c_void_p(_ptr(u)),
-                                         _stream()), "ore_correlation_train_fwd")
+                                         C.c_void_p(_ptr(_f32(k31))), per_image, C.c_void_p(_ptr(cat)), C.c_void_p(_ptr(t)),
+                                         C.c_void_p(_ptr(u)), _stream()), "ore_correlation_train_fwd")
     return cat, t, u
 
 
 def correlation_train_bwd(q, k11, k13, k31, dcat, t, u):
-    """-> dq [B,H,W,C], dk11 [C], dk13 [C,3], dk31 [C,3]."""
+    """-> dq [B,H,W,C], dk11, dk13, dk31 shaped like k11 / k13 / k31."""
     B, H, W, Cc = q.shape
     rows = B * H * W
+    per_image = int(k11.dim() == 2)
+    S = B if per_image else 1
     dq = torch.empty_like(q)
-    dk11 = torch.empty(Cc, device=q.device, dtype=torch.float32)
-    d13 = torch.empty(3, Cc, device=q.device, dtype=torch.float32)
-    d31 = torch.empty(3, Cc, device=q.device, dtype=torch.float32)
-    ws = _wgrad_ws(q.device, rows * Cc * 8 + ((rows + 63) // 64) * 3 * Cc)
+    dk = torch.empty(S, 7, Cc, device=q.device, dtype=torch.float32)
+    ws = _wgrad_ws(q.device, rows * Cc * 8 + S * ((rows // S + 255) // 256) * 7 * Cc)
     _chk(lib().ore_correlation_train_bwd(C.c_void_p(_ptr(_f32(q))), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(_f32(k11))),
-                                         C.c_void_p(_ptr(_f32(k13))), C.c_void_p(_ptr(_f32(k31))), C.c_void_p(_ptr(_f32(dcat))),
-                                         C.c_void_p(_ptr(t)), C.c_void_p(_ptr(u)), C.c_void_p(_ptr(dq)), C.c_void_p(_ptr(dk11)),
-                                         C.c_void_p(_ptr(d13)), C.c_void_p(_ptr(d31)), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()),
-                                         _stream()), "ore_correlation_train_bwd")
-    return dq, dk11, d13.t().contiguous(), d31.t().contiguous()
+                                         C.c_void_p(_ptr(_f32(k13))), C.c_void_p(_ptr(_f32(k31))), per_image, C.c_void_p(_ptr(_f32(dcat))),
+                                         C.c_void_p(_ptr(t)), C.c_void_p(_ptr(u)), C.c_void_p(_ptr(dq)), C.c_void_p(_ptr(dk)),
+                                         C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_correlation_train_bwd")
+    d11, d13, d31 = dk[:, 0], dk[:, 1:4].transpose(1, 2).contiguous(), dk[:, 4:7].transpose(1, 2).contiguous()
+    if not per_image:
+        d11, d13, d31 = d11[0], d13[0], d31[0]
+    return dq, d11.contiguous(), d13, d31
 
 
 def groupnorm_apply(x: torch.Tensor, rstd_c: torch.Tensor, shift_c: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, relu: bool):
-    """x [1,H,W,C] (one image) -> relu?((x*rstd_c + shift_c)*gamma + beta)."""
+    """x [B,H,W,C], rstd_c / shift_c [B,C] (per image) -> relu?((x*rstd_c + shift_c)*gamma + beta)."""
     _f32(x)
-    Cc = x.shape[-1]
-    rows = x.numel() // Cc
+    B, Cc = x.shape[0], x.shape[-1]
+    rpi = x.numel() // (Cc * B)
+    assert rstd_c.numel() == B * Cc and shift_c.numel() == B * Cc
     y = torch.empty_like(x)
-    _chk(lib().ore_groupnorm_apply_fwd(C.c_void_p(_ptr(x)), Cc, 0, C.c_int64(rows), Cc, C.c_void_p(_ptr(_f32(rstd_c))), C.c_void_p(_ptr(_f32(shift_c))),
-                                       C.c_void_p(_ptr(_f32(gamma))), C.c_void_p(_ptr(_f32(beta))), int(relu), C.c_void_p(_ptr(y)), _stream()),
-         "ore_groupnorm_apply_fwd")
+    _chk(lib().ore_groupnorm_apply_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, C.c_int64(rpi), Cc, C.c_void_p(_ptr(_f32(rstd_c))),
+                                       C.c_void_p(_ptr(_f32(shift_c))), C.c_void_p(_ptr(_f32(gamma))), C.c_void_p(_ptr(_f32(beta))), int(relu),
+                                       C.c_void_p(_ptr(y)), _stream()), "ore_groupnorm_apply_fwd")
     return y
 
 
 def groupnorm_bwd(dy, y, x, groups: int, rstd_c, shift_c, gamma, relu: bool):
-    """-> dx like x, dbeta [C], dgamma [C]."""
+    """x [B,H,W,C], rstd_c / shift_c [B,C] -> dx like x, dbeta [B,C], dgamma [B,C] (per image; sum over B for the parameters)."""
     _f32(dy); _f32(y); _f32(x)
-    Cc = x.shape[-1]
-    rows = x.numel() // Cc
+    B, Cc = x.shape[0], x.shape[-1]
+    rpi = x.numel() // (Cc * B)
     dx = torch.empty_like(x)
-    sums = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
-    ws = _wgrad_ws(x.device, rows * 2 * Cc + ((rows + 255) // 256) * 2 * Cc)
-    _chk(lib().ore_groupnorm_bwd(C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(y)), C.c_void_p(_ptr(x)), Cc, 0, C.c_int64(rows), Cc, groups,
+    sums = torch.empty(B, 2 * Cc, device=x.device, dtype=torch.float32)
+    ws = _wgrad_ws(x.device, B * rpi * 2 * Cc + B * ((rpi + 255) // 256) * 2 * Cc)
+    _chk(lib().ore_groupnorm_bwd(C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(y)), C.c_void_p(_ptr(x)), Cc, 0, B, C.c_int64(rpi), Cc, groups,
                                  C.c_void_p(_ptr(_f32(rstd_c))), C.c_void_p(_ptr(_f32(shift_c))), C.c_void_p(_ptr(_f32(gamma))), int(relu),
                                  C.c_void_p(_ptr(dx)), C.c_void_p(_ptr(sums)), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()),
          "ore_groupnorm_bwd")
-    return dx, sums[:Cc], sums[Cc:]
+    return dx, sums[:, :Cc], sums[:, Cc:]
 
 
 def prod_colsum(p: torch.Tensor, q: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:

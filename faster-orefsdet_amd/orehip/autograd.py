@@ -189,17 +189,16 @@ def _unit_affine(C: int, device):
 
 
 class GroupNormReluFn(Function):
-    """relu?(GroupNorm(x)) for ONE image x [1,H,W,C] (head tower: GN(32,128) + ReLU).  Statistics by the engine's Chan-combine
-    kernels (ore_groupnorm_affine_fwd with unit gamma), apply + backward in ore_groupnorm_apply_fwd / ore_groupnorm_bwd."""
+    """relu?(GroupNorm(x)) for x [B,H,W,C], statistics per image (head tower: GN(32,128) + ReLU).  Statistics by the engine's
+    Chan-combine kernels (ore_groupnorm_affine_fwd with unit gamma), apply + backward in ore_groupnorm_apply_fwd / ore_groupnorm_bwd;
+    the B images of a batch go through each kernel in one launch."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, groups: int, eps: float, relu: bool):
-        assert x.shape[0] == 1, "one image per call (statistics are per image)"
         x = x.contiguous()
         C = x.shape[-1]
         one, zero = _unit_affine(C, x.device)
-        r, a = orehip.groupnorm_affine(x, groups, one, zero, eps)              # [1,C]: rstd, -mean*rstd of the channel's group
-        r, a = r.reshape(C).contiguous(), a.reshape(C).contiguous()
+        r, a = orehip.groupnorm_affine(x, groups, one, zero, eps)              # [B,C]: rstd, -mean*rstd of the channel's group
         y = orehip.groupnorm_apply(x, r, a, gamma.detach().contiguous(), beta.detach().contiguous(), relu)
         ctx.save_for_backward(x, y, r, a, gamma)
         ctx.meta = (groups, relu)
@@ -210,7 +209,9 @@ class GroupNormReluFn(Function):
         x, y, r, a, gamma = ctx.saved_tensors
         groups, relu = ctx.meta
         dx, dbeta, dgamma = orehip.groupnorm_bwd(dy.contiguous(), y, x, groups, r, a, gamma.detach().contiguous(), relu)
-        return dx, dgamma, dbeta, None, None, None
+        if dbeta.shape[0] == 1:
+            return dx, dgamma[0], dbeta[0], None, None, None
+        return dx, dgamma.sum(0), dbeta.sum(0), None, None, None
 
 
 def group_norm_relu(x, gamma, beta, groups, eps=1e-5, relu=True):
@@ -270,8 +271,9 @@ def maxpool(x):
 
 
 class CorrelationFn(Function):
-    """Depthwise support correlation (fsod_cen.py:229-245): q [1,H,W,C], k11 [C], k13 [C,3], k31 [C,3] -> [1,H,W,2C] = [attn | q],
-    the input of conv3 (no torch.cat)."""
+    """Depthwise support correlation (fsod_cen.py:229-245): q [B,H,W,C]; k11 [C], k13 [C,3], k31 [C,3] (shared) or [B,C], [B,C,3],
+    [B,C,3] (every image its own support kernels: a training batch in ONE launch per kernel) -> [B,H,W,2C] = [attn | q], the input
+    of conv3 (no torch.cat)."""
 
     @staticmethod
     def forward(ctx, q, k11, k13, k31):

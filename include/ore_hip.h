@@ -293,33 +293,42 @@ int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_coff, const f
 /* out[c] = beta * out[c] + sum_rows x[row][coff + c]; workspace >= ceil(rows/64) * C floats. */
 int ore_colsum_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, float beta, float* out,
                    float* workspace, size_t workspace_floats, void* stream);
+/* Segmented form: the rows are `segments` equal runs (the images of a batch); out [segments][C].  A segment's sums are bitwise those
+ * of ore_colsum_fwd on that run alone (chunking restarts per segment).  workspace >= segments * ceil(rows_per_segment/256) * C. */
+int ore_colsum_segments_fwd(const float* x, int32_t ld, int32_t coff, int32_t segments, int64_t rows_per_segment, int32_t C,
+                            float beta, float* out, float* workspace, size_t workspace_floats, void* stream);
 
 /* Depthwise support correlation with gradients (ref:fewx/modeling/fsod/fsod_cen.py:229-245, training branch).
+ * k_per_image = 0: one support kernel set k11 [C], k13 / k31 [C][3] for all B images; 1: every image its own ([B][C], [B][C][3]) --
+ * a training batch, where each query image comes with its own support crops.
  * fwd: cat2c [rows][2C] = [attn | q] (the input of conv3), t_save / u_save [rows][C] kept for the backward.
- * bwd: dcat2c [rows][2C] -> dq [rows][C] (both halves), dk11 [C], dk13_3c / dk31_3c [3][C] (tap-major; the kernels are [C][3]).
- * workspace >= rows*C*8 + ceil(rows/64)*3*C floats.  Deterministic (per-row products + ordered column sums). */
+ * bwd: dcat2c [rows][2C] -> dq [rows][C] (both halves) and dk_7c [S][7C] = (dk11 [C] | dk13 tap-major [3][C] | dk31 tap-major [3][C])
+ * with S = B if k_per_image else 1.  workspace >= rows*C*8 + S*ceil(rows/S/256)*7*C floats.  Deterministic (per-row products +
+ * ordered, per-image column sums). */
 int ore_correlation_train_fwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
-                              const float* k11, const float* k13, const float* k31, float* cat2c, float* t_save,
-                              float* u_save, void* stream);
+                              const float* k11, const float* k13, const float* k31, int32_t k_per_image, float* cat2c,
+                              float* t_save, float* u_save, void* stream);
 int ore_correlation_train_bwd(const float* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t H, int32_t W, int32_t C,
-                              const float* k11, const float* k13, const float* k31, const float* dcat2c,
-                              const float* t_save, const float* u_save, float* dq, float* dk11, float* dk13_3c,
-                              float* dk31_3c, float* workspace, size_t workspace_floats, void* stream);
+                              const float* k11, const float* k13, const float* k31, int32_t k_per_image, const float* dcat2c,
+                              const float* t_save, const float* u_save, float* dq, float* dk_7c, float* workspace,
+                              size_t workspace_floats, void* stream);
 
 /* Small HBM-bound training ops (NHWC fp32, channels multiple of 4), all deterministic:
  *   GroupNorm(+ReLU) with gradients (head tower, ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:86-100; torch
- *     F.group_norm backward).  rstd_c / shift_c [C] = per-channel rstd and -mean*rstd of the channel's group for ONE image: what
- *     ore_groupnorm_affine_fwd returns for gamma = 1, beta = 0.  ore_groupnorm_bwd writes dx [rows][C] and (dbeta | dgamma) [2C];
- *     workspace >= rows*2*C + ceil(rows/256)*2*C floats.
+ *     F.group_norm backward) for `images` images of rows_per_image rows each (statistics are per image).  rstd_c / shift_c
+ *     [images][C] = per-channel rstd and -mean*rstd of the channel's group: what ore_groupnorm_affine_fwd returns for gamma = 1,
+ *     beta = 0.  ore_groupnorm_bwd writes dx [rows][C] and per image (dbeta | dgamma) [images][2C] (the parameter gradient is their sum
+ *     over the images); workspace >= rows*2*C + images*ceil(rows_per_image/256)*2*C floats.
  *   eSE (d2z:modeling/backbone/vovnet.py:238-260) pieces: ore_prod_colsum_fwd = per-image column sums of p*q (q NULL: of p) times
  *     `scale` -> [B][C] (average pool, and d gate = sum_hw dy*x); ore_scale_add_channels_fwd = x*s[b][c] + v[b][c].
  *   ore_maxpool3x3s2_bwd: MaxPool2d(3, 2, ceil_mode=True) backward, first maximum in scan order owns the window (ATen).
  *   ore_sumpool2x2_fwd: backward of the FPN's nearest-2x top-down add (d2z:modeling/backbone/fpn.py:136-141). */
-int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C, const float* rstd_c,
-                            const float* shift_c, const float* gamma, const float* beta, int32_t relu, float* y, void* stream);
-int ore_groupnorm_bwd(const float* dy, const float* y, const float* x, int32_t ld, int32_t coff, int64_t rows, int32_t C,
-                      int32_t groups, const float* rstd_c, const float* shift_c, const float* gamma, int32_t relu, float* dx,
-                      float* dbeta_dgamma_2c, float* workspace, size_t workspace_floats, void* stream);
+int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff, int32_t images, int64_t rows_per_image, int32_t C,
+                            const float* rstd_c, const float* shift_c, const float* gamma, const float* beta, int32_t relu, float* y,
+                            void* stream);
+int ore_groupnorm_bwd(const float* dy, const float* y, const float* x, int32_t ld, int32_t coff, int32_t images,
+                      int64_t rows_per_image, int32_t C, int32_t groups, const float* rstd_c, const float* shift_c, const float* gamma,
+                      int32_t relu, float* dx, float* dbeta_dgamma_2c, float* workspace, size_t workspace_floats, void* stream);
 int ore_prod_colsum_fwd(const float* p, const float* q, int32_t B, int32_t rows, int32_t C, float scale, float* out_bc,
                         float* workspace, size_t workspace_floats, void* stream);
 int ore_scale_add_channels_fwd(const float* x, const float* scale_bc, const float* add_bc, int32_t B, int32_t rows, int32_t C,

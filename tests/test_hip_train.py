@@ -483,6 +483,22 @@ def test_correlation_fn_backward(oh):
         _close(qg.grad.permute(0, 3, 1, 2), q.grad)
         _close(pg.grad, proto.grad)
         _close(wg.grad, w3.grad)
+    # a training batch: every image with its OWN support kernels, one launch per kernel; each image bitwise the single-image call
+    B, C, H, W = 3, 128, 20, 24
+    q = torch.randn(B, H, W, C, generator=g).cuda()
+    k11, k13, k31 = (torch.randn(B, C, generator=g) * 0.7).cuda(), (torch.randn(B, C, 3, generator=g) * 0.5).cuda(), (torch.randn(B, C, 3, generator=g) * 0.5).cuda()
+    up = torch.randn(B, H, W, 2 * C, generator=g).cuda()
+    leaves = [t.clone().requires_grad_(True) for t in (q, k11, k13, k31)]
+    y = A.correlation_cat(*leaves)
+    (y * up).sum().backward()
+    for b in range(B):
+        one = [t[b:b + 1].clone().requires_grad_(True) if i == 0 else t[b].clone().requires_grad_(True) for i, t in enumerate((q, k11, k13, k31))]
+        yb = A.correlation_cat(*one)
+        (yb * up[b:b + 1]).sum().backward()
+        assert torch.equal(yb[0], y.detach()[b])
+        assert torch.equal(one[0].grad[0], leaves[0].grad[b])
+        for i in (1, 2, 3):
+            assert torch.equal(one[i].grad, leaves[i].grad[b]), (b, i)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -575,6 +591,19 @@ def test_small_training_ops_backward(oh):
     _close(y.permute(0, 3, 1, 2), ref)
     (y * _nhwc(up).cuda()).sum().backward()
     _close(xg.grad.permute(0, 3, 1, 2), x.grad); _close(gg.grad, gam.grad); _close(bg.grad, bet.grad)
+    # --- the same on a batch of 3 in one launch per kernel (statistics per image; 357 rows per image: chunks restart per image)
+    x = (torch.randn(3, 128, 21, 17, generator=g) * torch.tensor([1.0, 3.0, 0.2]).view(3, 1, 1, 1)).requires_grad_(True)
+    gam.grad = bet.grad = None
+    ref = F.relu(F.group_norm(x, 32, gam, bet, 1e-5))
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up).sum().backward()
+    xg, gg, bg = _nhwc(x.detach()).cuda().requires_grad_(True), gam.detach().cuda().requires_grad_(True), bet.detach().cuda().requires_grad_(True)
+    y = A.group_norm_relu(xg, gg, bg, 32, 1e-5, True)
+    _close(y.permute(0, 3, 1, 2), ref)
+    (y * _nhwc(up).cuda()).sum().backward()
+    _close(xg.grad.permute(0, 3, 1, 2), x.grad); _close(gg.grad, gam.grad); _close(bg.grad, bet.grad)
+    y1 = A.group_norm_relu(xg.detach()[1:2].contiguous(), gg.detach(), bg.detach(), 32, 1e-5, True)
+    assert torch.equal(y1[0], y.detach()[1])                                 # a batched image is bitwise the single-image call
     # --- eSE on a batch of 3
     C = 96
     x = torch.randn(3, C, 10, 12, generator=g).requires_grad_(True)
