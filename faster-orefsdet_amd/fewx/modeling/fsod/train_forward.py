@@ -220,78 +220,220 @@ def roi_stage_losses(rh, qf: List[torch.Tensor], sup8: torch.Tensor, roi_boxes, 
     return {"loss_cls_stage0": loss_cls, "loss_box_reg_stage0": loss_box}, dict(scores=scores, deltas=deltas, h=h)
 
 
+def first_stage_batch(pg, heads: List[torch.Tensor], gts: List[torch.Tensor], norm_avg: Optional[torch.Tensor] = None):
+    """CenterNet.forward, training branch, after the head, for the B images of a call (ref:fewx/modeling/fsod/fsod_rpn.py:658-700) with
+    NO host sync: ground truth of all images in one launch, the three losses over all rows in one (normalisers as the reference's
+    reduce_sum / num_gpus with every image counted as a GPU -- orehip.autograd.CenterNetLossFn), the *_TRAIN proposals per image.
+    heads[l] [B,H,W,16].  Returns (per-image detect outputs, losses dict, targets dict, this call's [reg rows, positives])."""
+    import orehip
+    from orehip import autograd as A
+    dev = heads[0].device
+    B = heads[0].shape[0]
+    shapes = [tuple(h.shape[1:3]) for h in heads]
+    rows = torch.cat([h.reshape(-1, h.shape[-1]) for h in heads], 0)       # level-major, the images of a level in order: the targets' rows
+    tg = orehip.centernet_targets(gts, shapes, pg.strides, pg.sizes_of_interest, pg.hm_min_overlap, pg.min_radius, device=dev)
+    hp = dict(gamma=pg.loss_gamma, beta=pg.hm_focal_beta, sigmoid_clamp=pg.sigmoid_clamp, ignore_high_fp=pg.ignore_high_fp,
+              alpha=pg.hm_focal_alpha, pos_weight=pg.pos_weight, neg_weight=pg.neg_weight, reg_weight=pg.reg_weight, images=B,
+              norm_avg=norm_avg)
+    l3, counts = A.centernet_losses(rows, tg["reg_targets"], tg["hm_targets"], tg["pos_inds"], tg["pos_count"], hp, with_counts=True)
+    with torch.no_grad():
+        outs = [orehip.detect([h[b].detach() for h in heads], pg.strides, pg.score_thresh, pg.pre_nms_topk_train, pg.nms_thresh_train,
+                              pg.post_nms_topk_train) for b in range(B)]
+    losses = {"loss_centernet_loc": l3[0], "loss_centernet_agn_pos": l3[1], "loss_centernet_agn_neg": l3[2]}
+    return outs, losses, tg, counts
+
+
+@torch.no_grad()
+def sample_rois_device(rh, prop: torch.Tensor, prop_n: torch.Tensor, gtp: torch.Tensor, gt_n: torch.Tensor):
+    """label_and_sample_proposals (d2z:modeling/roi_heads/roi_heads.py:181-295, sampling.py:10-53) for B images at once, entirely on
+    the device and without a host sync.  prop [B,cap,4] with prop_n [B] valid rows, gtp [B,G,4] with gt_n [B] valid rows.
+    Candidates = proposals then ground truth (proposal_append_gt); IoU matcher (>= IOUS[0] -> foreground = class 0, else background
+    = 1); BATCH_SIZE_PER_IMAGE samples with at most POSITIVE_FRACTION foreground, drawn uniformly: the n smallest of iid uniform
+    keys among the foreground (background) candidates = `randperm(n)[:k]` of the reference in distribution.
+    Returns boxes [B,R,4], labels [B,R], matched gt [B,R,4], valid [B,R] (rows beyond an image's sample count are padding)."""
+    B, cap, _ = prop.shape
+    G = gtp.shape[1]
+    dev = prop.device
+    R = int(rh.batch_size_per_image)
+    P = int(R * rh.positive_fraction)
+    pv = torch.arange(cap, device=dev)[None, :] < prop_n[:, None]
+    gv = torch.arange(G, device=dev)[None, :] < gt_n[:, None]
+    if rh.proposal_append_gt:
+        cand, cv = torch.cat([prop, gtp], 1), torch.cat([pv, gv], 1)
+    else:
+        cand, cv = prop, pv
+    N = cand.shape[1]
+    area_g = (gtp[:, :, 2] - gtp[:, :, 0]) * (gtp[:, :, 3] - gtp[:, :, 1])                     # pairwise_iou, batched
+    area_c = (cand[:, :, 2] - cand[:, :, 0]) * (cand[:, :, 3] - cand[:, :, 1])
+    wh = (torch.min(gtp[:, :, None, 2:], cand[:, None, :, 2:]) - torch.max(gtp[:, :, None, :2], cand[:, None, :, :2])).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    iou = torch.where(inter > 0, inter / (area_g[:, :, None] + area_c[:, None, :] - inter), torch.zeros((), device=dev))
+    iou = torch.where(gv[:, :, None], iou, torch.full((), -1.0, device=dev))
+    vals, midx = iou.max(1)                                                                    # [B,N]; no gt at all -> -1 -> background
+    labels = torch.where(vals >= rh.iou_threshold, 0, 1)
+    labels = torch.where(cv, labels, 2)
+    u = torch.rand(B, N, device=dev)
+    two = torch.full((), 2.0, device=dev)
+    pos_pick = torch.topk(torch.where(labels == 0, u, two), min(P, N), dim=1, largest=False).indices
+    neg_pick = torch.topk(torch.where(labels == 1, u, two), min(R, N), dim=1, largest=False).indices
+    n_pos = (labels == 0).sum(1).clamp(max=P)
+    n_neg = torch.minimum((labels == 1).sum(1), R - n_pos)
+    j = torch.arange(R, device=dev)[None, :]
+    pj = j.clamp(max=pos_pick.shape[1] - 1).expand(B, R)
+    nj = (j - n_pos[:, None]).clamp(min=0, max=neg_pick.shape[1] - 1)
+    pick = torch.where(j < n_pos[:, None], pos_pick.gather(1, pj), neg_pick.gather(1, nj))
+    valid = j < (n_pos + n_neg)[:, None]
+    boxes = cand.gather(1, pick[:, :, None].expand(B, R, 4))
+    lab = labels.gather(1, pick)
+    gt = gtp.gather(1, midx.gather(1, pick)[:, :, None].expand(B, R, 4))
+    pad = torch.tensor([0.0, 0.0, 8.0, 8.0], device=dev)
+    boxes = torch.where(valid[:, :, None], boxes, pad)
+    lab = torch.where(valid, lab, 1)
+    return boxes.contiguous(), lab, gt, valid
+
+
+_ROI_IMAGE = {}
+
+
+def _roi_image(B: int, R: int, dev) -> torch.Tensor:
+    key = (B, R, str(dev))
+    if key not in _ROI_IMAGE:
+        _ROI_IMAGE[key] = torch.arange(B, dtype=torch.int32).repeat_interleave(R).to(dev)
+    return _ROI_IMAGE[key]
+
+
+def roi_stage_losses_padded(rh, qf: List[torch.Tensor], sup8: torch.Tensor, boxes, labels, gt, valid, strides):
+    """_run_stage + CustomFastRCNNOutputLayers.losses for the single cascade stage (ref:fewx/modeling/fsod/fsod_roi_heads.py:459-520,
+    custom_fast_rcnn.py:52-81) for B images in ONE pass, fixed shapes, no host sync: qf[l] [B,H,W,C] query pyramid (NHWC), sup8
+    [B,N,P*P*C] pooled support features, boxes / gt [B,R,4], labels [B,R] (0 fg / 1 bg), valid [B,R].  Every image's losses keep their
+    own 1/R_b normaliser (R_b = its valid rows) and the result is the mean over the images (= the gradient-averaged data-parallel
+    result of B single-image ranks)."""
+    from orehip import autograd as A
+    B, R = labels.shape
+    C = qf[0].shape[-1]
+    P = rh.pooler_resolution
+    dev = boxes.device
+    rimg = _roi_image(B, R, dev)
+    img = rimg.long()
+    RT = B * R
+    bx, lb, gtf, vf = boxes.reshape(RT, 4), labels.reshape(RT), gt.reshape(RT, 4), valid.reshape(RT)
+    x = A.roi_align_batched(qf, bx, rimg, strides, P).reshape(RT * P * P, C)            # rows ordered [roi][pos], channels last
+    s = sup8.mean(1).reshape(B * P * P, C)                                              # each image's own support prototype
+    s_exp = s.reshape(B, P * P, C)[img].reshape(RT * P * P, C)
+    s2_exp = A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).reshape(B, P * P, C // 2)[img].reshape(RT * P * P, C // 2)
+    a = A.linear(torch.cat((x, s_exp), 1), rh.conv3.weight.flatten(1), rh.conv3.bias) + \
+        torch.cat((A.linear(x, rh.conv1.weight.flatten(1), rh.conv1.bias), s2_exp), 1)
+    a = a.reshape(RT, P * P, C).permute(0, 2, 1).reshape(RT, C * P * P)                 # NCHW flatten order of fc1's weight
+    fc1 = rh.box_head[0].fc1
+    h = A.linear(a.contiguous(), fc1.weight, fc1.bias, True)
+    pr = rh.box_predictor[0]
+    scores = A.linear(h, pr.cls_score.weight, pr.cls_score.bias)
+    deltas = A.linear(h, pr.bbox_pred.weight, pr.bbox_pred.bias)
+    n_b = valid.sum(1).clamp(min=1).to(torch.float32)
+    w = vf.to(torch.float32) / (n_b * B)[img]
+    loss_cls = (F.cross_entropy(scores, lb, reduction="none") * w).sum()
+    fg = (lb == 0) & vf
+    zero = torch.zeros((), device=dev)
+    tgt = torch.where(fg[:, None], get_deltas(bx, gtf, rh.bbox_reg_weights), zero)       # background / padding rows: no target
+    loss_box = (torch.where(fg[:, None], (deltas - tgt).abs(), zero).sum(1) * w).sum()    # smooth_l1, beta = 0
+    return {"loss_cls_stage0": loss_cls, "loss_box_reg_stage0": loss_box}, dict(scores=scores, deltas=deltas, h=h)
+
+
+def _pad_stack(ts: List[torch.Tensor], width: int, dev):
+    """[n_i, 4] tensors -> ([B, max(n,1), 4] zero padded on `dev`, counts [B] int64 on `dev`) without a blocking copy."""
+    import orehip
+    n = [int(t.shape[0]) for t in ts]
+    m = max(1, max(n))
+    if any(t.is_cuda for t in ts):
+        out = torch.zeros(len(ts), m, width, device=dev)
+        for i, t in enumerate(ts):
+            if n[i]:
+                out[i, :n[i]] = orehip.to_device(t.float(), dev)
+    else:
+        out = torch.zeros(len(ts), m, width)
+        for i, t in enumerate(ts):
+            out[i, :n[i]] = t.float()
+        out = orehip.to_device(out, dev)
+    return out, orehip.to_device(torch.tensor(n, dtype=torch.int64), dev)
+
+
 def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Tensor]] = None, return_aux: bool = False,
-                  roi_override: Optional[Dict[str, torch.Tensor]] = None):
+                  roi_override: Optional[Dict[str, torch.Tensor]] = None, cn_norm_avg: Optional[torch.Tensor] = None):
     """model: CenterNet2Detector in training mode.  batched_inputs[i]: image [3,H,W] (uint8/float BGR), instances (gt_boxes),
-    support_images [N,3,h,w], support_bboxes [N,4].  Returns the 5 losses (mean over the images of the call).
-    `perm(n)` replaces torch.randperm in the fg/bg subsampling; `roi_override` = {boxes, labels, gt} replaces the sampled set
-    altogether (parity tests pin the second stage on the oracle's sample so a 1-ulp heatmap difference cannot change the batch)."""
+    support_images [N,3,h,w], support_bboxes [N,4].  Returns the 5 losses of the call: B images on one rank give what B data-parallel
+    single-image ranks of the reference give after gradient averaging (CenterNet losses: sums over all images / the all-image
+    normalisers; second-stage losses: mean over the images).
+    No host sync between the first kernel and the last (the fg/bg subsample runs on the device, sample_rois_device), unless the caller
+    asks for it: `perm(n)` replaces torch.randperm in the subsampling (host-shaped legacy sampling, tests); `roi_override` = {boxes,
+    labels, gt} replaces the sampled set of every image (parity tests pin the second stage on the reference's sample so a 1-ulp heatmap
+    difference cannot change the batch); `cn_norm_avg` = the two averaged CenterNet normalisers of a larger virtual batch."""
+    import orehip
     from orehip import autograd as A
     dev = model.device
     pg, rh = model.proposal_generator, model.roi_heads
     mean, std = model.pixel_mean.view(-1), model.pixel_std.view(-1)
     div = model.backbone.size_divisibility
-    if perm is None:
-        perm = lambda n: torch.randperm(n, device=dev)          # noqa: E731  (subsample_labels, d2z:modeling/sampling.py:49-50)
-    acc: Dict[str, List[torch.Tensor]] = {}
     aux = {}
     B = len(batched_inputs)
     N = model.support_way * model.support_shot
     assert model.support_way == 1
-    imgs = [item["image"].to(dev).float() for item in batched_inputs]
+    # every small host -> device upload first (pinned, asynchronous), so nothing below waits for the stream to drain
+    gts, sbx = [], []
+    for item in batched_inputs:
+        inst = item["instances"]
+        gts.append(orehip.to_device((inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes).float(), dev))
+        sbx.append(torch.as_tensor(item["support_bboxes"], dtype=torch.float32))
+    sbx = orehip.to_device(torch.cat(sbx, 0), dev)
+    gtp, gt_n = _pad_stack(gts, 4, dev)
+    imgs = [orehip.to_device(item["image"], dev).float() for item in batched_inputs]
     Hm, Wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
     # ImageList.from_tensors semantics (d2z:structures/image_list.py:69-121): normalise each image, zero-pad bottom/right to the batch
     # maximum rounded up to the size divisibility; the whole batch goes through the backbone at once (fsod_cen.py:156,165)
     xq = torch.cat([F.pad(_normalise_pad(i[None], mean, std, 1), (0, Wm - i.shape[-1], 0, Hm - i.shape[-2])) for i in imgs], 0)
     xq = F.pad(xq, (0, (Wm + div - 1) // div * div - Wm, 0, (Hm + div - 1) // div * div - Hm)).contiguous()
-    sups = [item["support_images"].to(dev) for item in batched_inputs]
+    sups = [orehip.to_device(item["support_images"], dev) for item in batched_inputs]
     for s_ in sups:
         assert s_.shape[0] == N, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
     xs = _normalise_pad(torch.cat(sups, 0) if B > 1 else sups[0], mean, std, div)
     outs = graphed_dense_part(model, xq, xs) if getattr(model, "train_graph", False) else dense_part(model, xq, xs)
-    gts, sbx = [], []
-    for item in batched_inputs:
-        inst = item["instances"]
-        gts.append((inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes).to(dev).float())
-        sbx.append(torch.as_tensor(item["support_bboxes"], dtype=torch.float32, device=dev))
-    if B == 1:
-        gt_boxes, qf, sf_levels, heads = gts[0], [f[0] for f in outs[0:3]], list(outs[3:6]), list(outs[6:9])
-        # ---- first stage: ground truth, losses, proposals (no gradient through the proposals)
-        proposals, _scores, l_rpn, tg = proposal_losses_and_proposals(pg, heads, gt_boxes)
-        sampled, roi_boxes, roi_labels, roi_gt = label_and_sample(rh, proposals, gt_boxes, perm)
-        if roi_override is not None:
-            roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
-            roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
-        # ---- second stage: support rcnn_8 features (one box per support crop), DSA mix, fc1, predictor, losses
-        sup8 = A.roi_align_batched(sf_levels, sbx[0], torch.arange(N, dtype=torch.int32, device=dev), pg.strides, rh.pooler_resolution)
-        l_roi, a2 = roi_stage_losses(rh, qf, sup8, roi_boxes, roi_labels, roi_gt, pg.strides)
-        losses = {**l_roi, **l_rpn}
-        if return_aux:
-            aux = dict(proposals=proposals, sampled=sampled, roi_boxes=roi_boxes, roi_labels=roi_labels, pos_inds=tg["pos_inds"],
-                       pos_count=tg["pos_count"], features={k: f.permute(2, 0, 1)[None] for k, f in zip(LEVELS, qf)}, heads=heads, **a2)
-        return (losses, aux) if return_aux else losses
-    # ---- B > 1.  Phase 1 (no host sync): per image ground truth, first-stage losses, proposals
-    hd_b = [h.split(1, 0) for h in outs[6:9]]       # one split per level: its backward is ONE cat, not B zero-filled full-size adds
-    stage1 = [first_stage(pg, [h[b] for h in hd_b], gts[b]) for b in range(B)]
-    for _, l_rpn, _ in stage1:
-        for k, v in l_rpn.items():
-            acc.setdefault(k, []).append(v)
-    counts = torch.stack([o["counts"][1] for o, _, _ in stage1]).tolist()             # ONE sync for the B proposal counts
-    # ---- phase 2: label + sample per image (host-shaped, only tiny kernels queued behind its syncs)
-    rb, rl, rg, per_image = [], [], [], []
-    for b in range(B):
-        _, roi_boxes, roi_labels, roi_gt = label_and_sample(rh, stage1[b][0]["out_boxes"][:counts[b]], gts[b], perm)
-        if roi_override is not None:
-            roi_boxes = roi_override["boxes"].to(dev).float().contiguous()
-            roi_labels, roi_gt = roi_override["labels"].to(dev), roi_override["gt"].to(dev).float()
-        rb.append(roi_boxes); rl.append(roi_labels); rg.append(roi_gt); per_image.append(int(roi_boxes.shape[0]))
-    roi_image = torch.repeat_interleave(torch.arange(B, dtype=torch.int32), torch.tensor(per_image)).to(dev)
-    # ---- phase 3: the second stage of all B images in one pass (ROIAlign of every support crop's own box, then the ROI head)
-    sup8 = A.roi_align_batched(list(outs[3:6]), torch.cat(sbx, 0), torch.arange(B * N, dtype=torch.int32, device=dev), pg.strides,
-                               rh.pooler_resolution)
-    l_roi, a2 = roi_stage_losses(rh, list(outs[0:3]), sup8.reshape(B, N, -1), torch.cat(rb, 0), torch.cat(rl, 0), torch.cat(rg, 0),
-                                 pg.strides, roi_image, per_image)
-    if return_aux:
-        aux = dict(roi_boxes=rb, roi_labels=rl, roi_gt=rg, rois_per_image=per_image, **a2)
-    losses = {**l_roi, **{k: torch.stack(v).mean() for k, v in acc.items()}}
+    qf, sf_levels, heads = list(outs[0:3]), list(outs[3:6]), list(outs[6:9])
+    # ---- first stage: ground truth, losses, proposals (no gradient through the proposals)
+    dets, l_rpn, tg, cn_counts = first_stage_batch(pg, heads, gts, cn_norm_avg)
+    # ---- fg/bg sample per image
+    counts_host = None
+    if roi_override is not None:
+        rb = roi_override["boxes"].to(dev).float()
+        boxes = rb[None].expand(B, *rb.shape).contiguous()
+        labels = roi_override["labels"].to(dev)[None].expand(B, -1).contiguous()
+        roi_gt = roi_override["gt"].to(dev).float()[None].expand(B, *rb.shape).contiguous()
+        valid = torch.ones(B, rb.shape[0], dtype=torch.bool, device=dev)
+    elif perm is not None:                                   # legacy host-shaped sampling with an injected permutation (tests)
+        counts_host = torch.stack([o["counts"][1] for o in dets]).tolist()
+        per = [label_and_sample(rh, dets[b]["out_boxes"][:counts_host[b]], gts[b], perm)[1:] for b in range(B)]
+        R = max(1, max(int(p[0].shape[0]) for p in per))
+        boxes = torch.tensor([0.0, 0.0, 8.0, 8.0], device=dev).repeat(B, R, 1)
+        labels = torch.ones(B, R, dtype=torch.int64, device=dev)
+        roi_gt = torch.zeros(B, R, 4, device=dev)
+        valid = torch.zeros(B, R, dtype=torch.bool, device=dev)
+        for b, (bx, lb, rg) in enumerate(per):
+            n = int(bx.shape[0])
+            boxes[b, :n], labels[b, :n], roi_gt[b, :n], valid[b, :n] = bx, lb, rg, True
+    else:
+        prop = torch.stack([o["out_boxes"] for o in dets])
+        prop_n = torch.stack([o["counts"][1] for o in dets]).long()
+        boxes, labels, roi_gt, valid = sample_rois_device(rh, prop, prop_n, gtp, gt_n)
+    # ---- second stage of all B images in one pass: support rcnn_8 features (one box per support crop), DSA mix, fc1, predictor, losses
+    sup8 = A.roi_align_batched(sf_levels, sbx, _roi_image(B * N, 1, dev), pg.strides, rh.pooler_resolution)
+    l_roi, a2 = roi_stage_losses_padded(rh, qf, sup8.reshape(B, N, -1), boxes, labels, roi_gt, valid, pg.strides)
+    losses = {**l_roi, **l_rpn}
+    if return_aux:                                           # (host syncs from here on: only for callers that ask)
+        nv = valid.sum(1).tolist()
+        if counts_host is None:
+            counts_host = torch.stack([o["counts"][1] for o in dets]).tolist()
+        aux = dict(roi_boxes=[boxes[b, :nv[b]] for b in range(B)], roi_labels=[labels[b, :nv[b]] for b in range(B)],
+                   roi_gt=[roi_gt[b, :nv[b]] for b in range(B)], rois_per_image=nv, cn_counts=cn_counts, heads=heads,
+                   pos_inds=tg["pos_inds"], pos_count=tg["pos_count"], valid=valid, **a2)
+        if B == 1:
+            aux.update(proposals=dets[0]["out_boxes"][:counts_host[0]], roi_boxes=aux["roi_boxes"][0], roi_labels=aux["roi_labels"][0],
+                       roi_gt=aux["roi_gt"][0], features={k: f[0].permute(2, 0, 1)[None] for k, f in zip(LEVELS, qf)})
     return (losses, aux) if return_aux else losses

@@ -491,18 +491,37 @@ def roi_predict(h: torch.Tensor, cls_w, cls_b, box_w, box_b, boxes: torch.Tensor
     return o
 
 
+def to_device(t: torch.Tensor, dev) -> torch.Tensor:
+    """Host tensor -> device without a blocking pageable copy (a pageable hipMemcpy drains the stream first: one hidden host sync per
+    small upload): staged through torch's cached pinned allocator and issued asynchronously.  Device tensors pass through."""
+    dev = torch.device(dev)
+    if t.is_cuda:
+        return t if t.device == dev or dev.index is None else t.to(dev)
+    if dev.type != "cuda":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def centernet_targets(gt_boxes: Sequence[torch.Tensor], shapes: Sequence[Tuple[int, int]], strides=(8, 16, 32),
                       soi=((0, 64), (48, 192), (128, 1000000)), hm_min_overlap: float = 0.8, min_radius: float = 4.0,
                       device=None) -> Dict[str, torch.Tensor]:
     """CenterNet._get_ground_truth (ref:fewx/modeling/fsod/fsod_rpn.py:803-901) on device.  gt_boxes: per image [N_i,4]."""
     dev = torch.device(device or "cuda")
     B, L = len(gt_boxes), len(strides)
-    max_n = max(1, max(int(b.shape[0]) for b in gt_boxes))
-    gt = torch.zeros(B, max_n, 4, dtype=torch.float32)
-    for i, b in enumerate(gt_boxes):
-        gt[i, :b.shape[0]] = b.detach().float().cpu()
-    cnt = torch.tensor([int(b.shape[0]) for b in gt_boxes], dtype=torch.int32)
-    gt, cnt = gt.to(dev), cnt.to(dev)
+    ns = [int(b.shape[0]) for b in gt_boxes]
+    max_n = max(1, max(ns))
+    # no blocking copy in either direction: device boxes are padded on the device, host boxes go up through pinned memory
+    if any(b.is_cuda for b in gt_boxes):
+        gt = torch.zeros(B, max_n, 4, dtype=torch.float32, device=dev)
+        for i, b in enumerate(gt_boxes):
+            if ns[i]:
+                gt[i, :ns[i]] = to_device(b.detach().float(), dev)
+    else:
+        gt = torch.zeros(B, max_n, 4, dtype=torch.float32)
+        for i, b in enumerate(gt_boxes):
+            gt[i, :ns[i]] = b.detach().float()
+        gt = to_device(gt, dev)
+    cnt = to_device(torch.tensor(ns, dtype=torch.int32), dev)
     rows = sum(B * h * w for h, w in shapes)
     o = {"reg_targets": torch.empty(rows, 4, device=dev), "hm_targets": torch.empty(rows, device=dev),
          "pos_inds": torch.zeros(B * max_n * L, dtype=torch.int64, device=dev), "pos_count": torch.zeros(1, dtype=torch.int32, device=dev)}

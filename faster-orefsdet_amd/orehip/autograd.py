@@ -339,32 +339,42 @@ def roi_align_batched(feats, boxes, box_image, strides=(8, 16, 32), pooled: int 
 
 
 class CenterNetLossFn(Function):
-    """head [rows, ld>=5] (cols 0..3 ltrb after Scale+ReLU, col 4 heatmap logit) -> [loss_loc, loss_agn_pos, loss_agn_neg]
-    (ref:fewx/modeling/fsod/fsod_rpn.py:702-779).  The two normalisers are summed over ranks on device."""
+    """head [rows, ld>=5] (cols 0..3 ltrb after Scale+ReLU, col 4 heatmap logit) -> [loss_loc, loss_agn_pos, loss_agn_neg, reg rows,
+    positives] (ref:fewx/modeling/fsod/fsod_rpn.py:702-779; the last two are this rank's un-normalised counts, no gradient).
+    Normalisers as the reference's `reduce_sum(n) / num_gpus` (fsod_rpn.py:712-716,748-751) with every image counted as one of its
+    GPUs: a rank holding `images` images divides its sums by images * max(total / (world * images), 1), so that B images on one
+    rank, B ranks with one image each, or any mix give the same averaged gradient.  The totals are summed over ranks on device.
+    hp["norm_avg"] (2 floats, optional) replaces the averaged normalisers (tests: one image of a larger virtual batch)."""
 
     @staticmethod
     def forward(ctx, head, reg_targets, hm_targets, pos_inds, pos_count, hp):
         head = head.contiguous()
         sums = orehip.centernet_loss_sums(head, reg_targets, hm_targets, pos_inds, pos_count, hp["gamma"], hp["beta"],
                                           hp["sigmoid_clamp"], hp["ignore_high_fp"])
-        norm = torch.stack([sums[1], pos_count[0].to(torch.float32)])
-        world = 1
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            world = dist.get_world_size()
-            dist.all_reduce(norm)                                     # the only other exchange of the step: 2 scalars (SURVEY 8e)
-        norm = torch.clamp(norm / world, min=1.0)
-        coef = torch.stack([hp["reg_weight"] / norm[0], hp["pos_weight"] * hp["alpha"] / norm[1],
-                            hp["neg_weight"] * (1.0 - hp["alpha"]) / norm[1]])
+        local = torch.stack([sums[1], pos_count[0].to(torch.float32)])
+        images = float(hp.get("images", 1))
+        if hp.get("norm_avg") is not None:
+            avg = hp["norm_avg"].to(local.device, torch.float32)
+        else:
+            norm, world = local.clone(), 1
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                world = dist.get_world_size()
+                dist.all_reduce(norm)                                 # the only other exchange of the step: 2 scalars (SURVEY 8e)
+            avg = torch.clamp(norm / (world * images), min=1.0)
+        den = avg * images
+        coef = torch.stack([hp["reg_weight"] / den[0], hp["pos_weight"] * hp["alpha"] / den[1],
+                            hp["neg_weight"] * (1.0 - hp["alpha"]) / den[1]])
         ctx.save_for_backward(head, reg_targets, hm_targets, pos_inds, pos_count, coef)
         ctx.hp = hp
-        return torch.stack([coef[0] * sums[0], -coef[1] * sums[2], -coef[2] * sums[3]])
+        out = torch.cat([torch.stack([coef[0] * sums[0], -coef[1] * sums[2], -coef[2] * sums[3]]), local])
+        return out
 
     @staticmethod
     def backward(ctx, g):
         head, reg_targets, hm_targets, pos_inds, pos_count, coef = ctx.saved_tensors
         hp = ctx.hp
-        d = orehip.centernet_loss_grad(head, reg_targets, hm_targets, pos_inds, pos_count, (coef * g).contiguous(), hp["gamma"],
+        d = orehip.centernet_loss_grad(head, reg_targets, hm_targets, pos_inds, pos_count, (coef * g[:3]).contiguous(), hp["gamma"],
                                        hp["beta"], hp["sigmoid_clamp"], hp["ignore_high_fp"])
         return d, None, None, None, None, None
 
@@ -372,5 +382,6 @@ class CenterNetLossFn(Function):
 CN_HP = dict(gamma=2.0, beta=4.0, sigmoid_clamp=1e-4, ignore_high_fp=0.85, alpha=0.25, pos_weight=0.5, neg_weight=0.5, reg_weight=1.0)
 
 
-def centernet_losses(head, reg_targets, hm_targets, pos_inds, pos_count, hp=None):
-    return CenterNetLossFn.apply(head, reg_targets, hm_targets, pos_inds, pos_count, hp or CN_HP)
+def centernet_losses(head, reg_targets, hm_targets, pos_inds, pos_count, hp=None, with_counts: bool = False):
+    out = CenterNetLossFn.apply(head, reg_targets, hm_targets, pos_inds, pos_count, hp or CN_HP)
+    return (out[:3], out[3:].detach()) if with_counts else out[:3]

@@ -690,8 +690,9 @@ def test_graph_captured_dense_part_matches_eager(oh):
 
 
 def test_train_forward_batch_and_empty_gt(oh):
-    """A list of several images averages the per-image losses (documented deviation from the reference, which returns the last
-    image's: SURVEY App. C.1); an image without ground truth trains on background only (finite losses, no box-regression term)."""
+    """A list of B images gives what B data-parallel single-image ranks of the reference give after gradient averaging (the
+    reference itself returns the last image's losses for a longer list: SURVEY App. C.1); an image without ground truth trains on
+    background only (finite losses, no box-regression term)."""
     from oracle import ref_train as T
     from detectron2.structures import Boxes, Instances
     shots = 4
@@ -704,48 +705,105 @@ def test_train_forward_batch_and_empty_gt(oh):
         inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.ones(len(gt), dtype=torch.int64)     # forced to class 0 by the detector
         return {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
     a, b = item(1, 5), item(2, 0)
+    from fewx.modeling.fsod import train_forward as TF
     torch.manual_seed(0)
-    la = m([a])
-    torch.manual_seed(0)
-    lb = m([b])
+    la, lb = m([a]), m([b])
+    assert all(torch.isfinite(v) for v in la.values())
     assert float(lb["loss_box_reg_stage0"]) == 0.0 and all(torch.isfinite(v) for v in lb.values())
     assert float(lb["loss_centernet_agn_pos"]) == 0.0 and float(lb["loss_centernet_loc"]) == 0.0
     assert int(a["instances"].gt_classes.sum()) == 0                                           # gt_classes forced to 0 (fsod_cen.py:158-159)
+    # B images on one rank = B data-parallel ranks of the reference with one image each: the CenterNet normalisers are the all-image
+    # totals / B (fsod_rpn.py:712-716: reduce_sum / num_gpus), the second-stage losses the mean over the images.
     torch.manual_seed(0)
-    lab = m([a, b])
-    for k in la:
+    lab, aux = TF.train_forward(m, [a, b], return_aux=True)
+    navg = (aux["cn_counts"] / 2).clamp(min=1.0)
+    la1, lb1 = TF.train_forward(m, [a], cn_norm_avg=navg), TF.train_forward(m, [b], cn_norm_avg=navg)
+    for k in lab:
         if k.startswith("loss_centernet"):                                                      # deterministic part (no sampling)
-            assert abs(float(lab[k]) - 0.5 * (float(la[k]) + float(lb[k]))) <= 1e-5 * max(abs(float(lab[k])), 1e-3), k
+            want = 0.5 * (float(la1[k]) + float(lb1[k]))
+            assert abs(float(lab[k]) - want) <= 1e-5 * max(abs(want), 1e-3), k
     sum(lab.values()).backward()
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
     # the batched pass (two batched backbone passes, ONE second-stage pass over the ROIs of both images) against the two
     # single-image passes, with a deterministic fg/bg subsample so that all five losses and the gradients are comparable
-    from fewx.modeling.fsod import train_forward as TF
     c = item(3, 3)
     det = lambda n: torch.arange(n - 1, -1, -1)                                                 # noqa: E731
+    m.zero_grad(set_to_none=True)
+    l2, aux = TF.train_forward(m, [a, c], perm=det, return_aux=True)
+    assert len(aux["rois_per_image"]) == 2 and int(aux["valid"].sum()) == sum(aux["rois_per_image"])
+    sum(l2.values()).backward()
+    batch_grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    navg = (aux["cn_counts"] / 2).clamp(min=1.0)
     singles, grads = [], []
     for it in (a, c):
         m.zero_grad(set_to_none=True)
-        l1 = TF.train_forward(m, [it], perm=det)
+        l1 = TF.train_forward(m, [it], perm=det, cn_norm_avg=navg)
         sum(l1.values()).backward()
         singles.append({k: float(v) for k, v in l1.items()})
         grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
-    m.zero_grad(set_to_none=True)
-    l2, aux = TF.train_forward(m, [a, c], perm=det, return_aux=True)
-    assert len(aux["rois_per_image"]) == 2 and aux["scores"].shape[0] == sum(aux["rois_per_image"])
-    sum(l2.values()).backward()
     for k in singles[0]:
         want = 0.5 * (singles[0][k] + singles[1][k])
         assert abs(float(l2[k]) - want) <= 2e-4 * max(abs(want), 1e-3), (k, float(l2[k]), want)
     errs = []
     for n, p in m.named_parameters():
-        if p.grad is None:
+        if n not in batch_grads:
             assert n not in grads[0]
             continue
         want = 0.5 * (grads[0][n] + grads[1][n])
-        errs.append(float((p.grad - want).abs().max() / want.abs().max().clamp_min(1e-12)))
+        errs.append(float((batch_grads[n] - want).abs().max() / want.abs().max().clamp_min(1e-12)))
     errs.sort()
     assert errs[len(errs) // 2] <= 1e-4 and errs[int(len(errs) * 0.85)] <= 1e-3 and errs[-1] <= 2e-2, errs[-5:]
+
+
+def test_sample_rois_device_properties(oh):
+    """The sync-free fg/bg subsample (train_forward.sample_rois_device) against label_and_sample_proposals' contract
+    (d2z:modeling/roi_heads/roi_heads.py:181-295, sampling.py:10-53) on a batch with an image without ground truth and an image with
+    fewer candidates than the sample size: labels follow the IoU >= 0.6 matcher, the matched gt is the arg-max, at most 64 foreground
+    of 128, no candidate drawn twice, padding rows flagged; when nothing has to be dropped the sample is exactly the candidate set the
+    host-shaped reference logic (label_and_sample, pinned by tests/golden/roi_train_pieces.npz) returns."""
+    from fewx.modeling.fsod import train_forward as TF
+    m, sd, cfg = _train_model(4)
+    rh = m.roi_heads
+    g = torch.Generator().manual_seed(12)
+    B, cap = 3, 400
+    gts = [torch.tensor([[30., 40., 130., 160.], [200., 50., 290., 140.], [100., 180., 220., 250.]]), torch.zeros(0, 4),
+           torch.tensor([[50., 50., 150., 150.]])]
+    prop = torch.zeros(B, cap, 4)
+    n = [400, 300, 40]
+    for b in range(B):
+        c = torch.rand(cap, 2, generator=g) * 280 + 20
+        wh = torch.rand(cap, 2, generator=g) * 100 + 20
+        prop[b] = torch.cat([c - wh / 2, c + wh / 2], 1)
+        for k, gb in enumerate(gts[b]):                                   # jittered copies of the gt: plenty of foreground
+            prop[b, k * 30:(k + 1) * 30] = gb + torch.randn(30, 4, generator=g) * 4
+    gtp, gt_n = TF._pad_stack([t.cuda() for t in gts], 4, torch.device("cuda"))
+    torch.manual_seed(3)
+    boxes, labels, rgt, valid = TF.sample_rois_device(rh, prop.cuda(), torch.tensor(n).cuda(), gtp, gt_n)
+    assert boxes.shape == (B, 128, 4) and labels.shape == (B, 128) and valid.dtype == torch.bool
+    for b in range(B):
+        cand = torch.cat([prop[b, :n[b]], gts[b]], 0)
+        v = valid[b].cpu()
+        bx, lb, rg = boxes[b].cpu()[v], labels[b].cpu()[v], rgt[b].cpu()[v]
+        nfg_all = 0
+        if len(gts[b]):
+            iou = TF.pairwise_iou(gts[b], cand)
+            vals, midx = iou.max(0)
+            nfg_all = int((vals >= 0.6).sum())
+        assert int(v.sum()) == min(128, len(cand)) and int((lb == 0).sum()) == min(nfg_all, 64)
+        rows = [(cand == r).all(1).nonzero()[0, 0].item() for r in bx]     # every sampled box is a candidate ...
+        assert len(set(rows)) == len(rows)                                  # ... drawn once
+        if len(gts[b]):
+            assert torch.equal(lb, torch.where(vals[rows] >= 0.6, 0, 1)) and torch.equal(rg, gts[b][midx[rows]])
+            assert torch.all(lb[: int((lb == 0).sum())] == 0)               # foreground first, like cat([pos_idx, neg_idx])
+        else:
+            assert torch.all(lb == 1)
+        assert torch.all(labels[b].cpu()[~v] == 1)
+    # image 2 has 41 candidates: nothing is dropped, so the sample is the whole candidate set, as the reference logic returns it
+    _, rb, rl, _ = TF.label_and_sample(rh, prop[2, :40].cuda(), gts[2].cuda(), lambda k: torch.randperm(k))
+    v = valid[2].cpu()
+    assert int(v.sum()) == rb.shape[0] == 41
+    got = sorted(map(tuple, boxes[2].cpu()[v].tolist()))
+    assert got == sorted(map(tuple, rb.cpu().tolist())) and int((labels[2].cpu()[v] == 0).sum()) == int((rl == 0).sum())
 
 
 def test_default_trainer_loop_with_synthetic_loader(oh, tmp_path):
@@ -886,8 +944,8 @@ def test_train_iteration_vs_reference_run(oh, golden, tag):
 
 def test_train_forward_bs16_full_size(oh):
     """BASELINE configs[2] at its stated batch: 16 query images of 640x640 with 24 support crops each through ONE train_forward call.
-    The five losses equal the mean of the 16 single-image calls (the documented bs > 1 semantics), every gradient
-    is finite, and the flat gradient bucket has the size DESIGN 5 states (4,086,478 parameters with a gradient -> 16,365,568 bytes
+    The five losses equal the mean of the 16 single-image calls run as 16 data-parallel ranks of the reference would run them
+    (CenterNet normalisers = all-image totals / 16), every gradient is finite, and the flat gradient bucket has the size DESIGN 5 states (4,086,478 parameters with a gradient -> 16,365,568 bytes
     in 256-float chunks)."""
     from detectron2.structures import Boxes, Instances
     from fewx.modeling.fsod.train_forward import train_forward
@@ -903,10 +961,11 @@ def test_train_forward_bs16_full_size(oh):
         items.append({"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()})
     torch.manual_seed(5)
     losses, aux = train_forward(m, items, return_aux=True)
+    navg = (aux["cn_counts"] / B).clamp(min=1.0)                         # the reference's reduce_sum / num_gpus over B one-image ranks
     singles = []
     for b in range(B):                                                   # each image alone, on the ROIs the batched call sampled for it
         over = {"boxes": aux["roi_boxes"][b], "labels": aux["roi_labels"][b], "gt": aux["roi_gt"][b]}
-        l1, _ = train_forward(m, [items[b]], return_aux=True, roi_override=over)
+        l1, _ = train_forward(m, [items[b]], return_aux=True, roi_override=over, cn_norm_avg=navg)
         singles.append({k: float(v.detach()) for k, v in l1.items()})
     for k, v in losses.items():
         want = sum(s[k] for s in singles) / B
