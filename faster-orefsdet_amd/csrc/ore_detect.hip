@@ -283,12 +283,12 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
 // ahead: while block bi is being resolved, the diagonal word and the suppression rows of block bi+1 are already in
 // flight into registers (speculatively -- only the rows that survive are OR-ed into removed[] afterwards).
 template <int KW>   // 64-bit words per lane per row beyond the diagonal: KW*64 >= mask words
-__global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
-                                                  const int* __restrict__ s_order, const int* __restrict__ n_ptr,
-                                                  const unsigned long long* __restrict__ mask, int words, float nms_thresh,
-                                                  int post_topk, long long* __restrict__ keep_idx,
-                                                  float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                  int* __restrict__ n_keep_out) {
+__device__ __forceinline__ void nms_scan_body(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
+                                              const int* __restrict__ s_order, const int* __restrict__ n_ptr,
+                                              const unsigned long long* __restrict__ mask, int words, float nms_thresh,
+                                              int post_topk, long long* __restrict__ keep_idx,
+                                              float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                              int* __restrict__ n_keep_out) {
     extern __shared__ unsigned long long diag_lds[];   // [nb*64] diagonal suppression word of every row, loaded once
     __shared__ unsigned long long removed[NMS_MAX_WORDS];
     __shared__ unsigned long long sh_misc[2];          // [0] = kept mask of the current block, [1] = final count (keeps LDS 8-byte sized)
@@ -386,6 +386,31 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_bo
         n_keep = cnt_sh;
     }
     if (tid == 0) *n_keep_out = n_keep;
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
+                                                  const int* __restrict__ s_order, const int* __restrict__ n_ptr,
+                                                  const unsigned long long* __restrict__ mask, int words, float nms_thresh,
+                                                  int post_topk, long long* __restrict__ keep_idx,
+                                                  float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                  int* __restrict__ n_keep_out) {
+    nms_scan_body<KW>(s_boxes, s_scores, s_order, n_ptr, mask, words, nms_thresh, post_topk, keep_idx, out_boxes, out_scores, n_keep_out);
+}
+
+// The scans of several independent images (a training batch: 16 x up to 12000 candidates, 140 us each as a one-block kernel) in ONE
+// launch: block b walks image b.  The per-image pointers travel by value in the kernel arguments.
+constexpr int SCAN_BATCH = 16;
+struct ScanArgs {
+    const float* s_boxes; const float* s_scores; const int* s_order; const int* n_ptr; const unsigned long long* mask;
+    long long* keep_idx; float* out_boxes; float* out_scores; int* n_keep_out;
+};
+struct ScanBatch { ScanArgs a[SCAN_BATCH]; int words; float thr; int post_topk; };
+template <int KW>
+__global__ __launch_bounds__(256) void k_nms_scan_multi(ScanBatch sb) {
+    const ScanArgs& a = sb.a[blockIdx.x];
+    nms_scan_body<KW>(a.s_boxes, a.s_scores, a.s_order, a.n_ptr, a.mask, sb.words, sb.thr, sb.post_topk, a.keep_idx, a.out_boxes,
+                      a.out_scores, a.n_keep_out);
 }
 
 // Column-streaming scan for n <= NMS_COL_CAP candidates (the eval path: <= 3000).  The mask is column-major ([word][row], written
@@ -590,17 +615,19 @@ extern "C" size_t ore_detect_workspace_bytes(int32_t n_levels, int32_t pre_topk)
     return det_layout(n_levels, pre_topk).total;
 }
 
-extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
+namespace {
+// everything of one image up to (not including) the scan; fills the scan's arguments
+static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa, DetLayout& lay, int& cap) {
     ORE_CHECK_ARG(d && d->n_levels > 0 && d->n_levels <= 8 && d->pre_topk > 0, "ore_detect_fwd: bad args");
     ORE_CHECK_ARG(d->head_ld >= 8 && d->head_ld % 4 == 0, "ore_detect_fwd: head_ld=%d (need >= 8, %%4)", d->head_ld);
     ORE_CHECK_ARG(d->pre_boxes && d->pre_scores && d->pre_loc && d->pre_level && d->keep_idx && d->counts && d->out_boxes &&
                       d->out_scores && d->workspace, "ore_detect_fwd: null pointer");
-    const DetLayout lay = det_layout(d->n_levels, d->pre_topk);
+    lay = det_layout(d->n_levels, d->pre_topk);
     if (d->workspace_bytes < lay.total) {
         ore_set_error("ore_detect_fwd: workspace %zu < %zu", d->workspace_bytes, lay.total);
         return ORE_ENOMEM;
     }
-    const int cap = d->n_levels * d->pre_topk;
+    cap = d->n_levels * d->pre_topk;
     ORE_CHECK_ARG((size_t)cap * 4 <= 150 * 1024 && lay.words <= NMS_MAX_WORDS, "ore_detect_fwd: cap %d too large", cap);
     ORE_CHECK_ARG(d->nms_thresh > 0.0f, "ore_detect_fwd: nms_thresh <= 0 (NMS disabled) is not supported");
     char* ws = (char*)d->workspace;
@@ -618,7 +645,6 @@ extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
     p.mask = (unsigned long long*)(ws + lay.mask); p.mask_words = lay.words;
     p.keep_idx = (long long*)d->keep_idx; p.counts = d->counts; p.out_boxes = d->out_boxes; p.out_scores = d->out_scores;
     p.cap = cap;
-    hipStream_t st = (hipStream_t)stream;
     int rc;
     int hw_max = 0;
     for (int l = 0; l < d->n_levels; ++l) hw_max = max(hw_max, d->H[l] * d->W[l]);
@@ -633,13 +659,61 @@ extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
         ORE_HIP(hipFuncSetAttribute((const void*)k_rank_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_bytes));
     hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(cap, 16)), dim3(256), sc_bytes, st, p);
     if ((rc = ore_launch_status("k_rank_scatter"))) return rc;
-    if (d->nms_thresh > 0.0f) {
-        hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(64), 0, st, p.s_boxes, p.counts, d->nms_thresh, p.mask,
-                           lay.words, nms_use_col(cap) ? cap : 0);
-        if ((rc = ore_launch_status("k_nms_mask"))) return rc;
+    hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(64), 0, st, p.s_boxes, p.counts, d->nms_thresh, p.mask,
+                       lay.words, nms_use_col(cap) ? cap : 0);
+    if ((rc = ore_launch_status("k_nms_mask"))) return rc;
+    sa = ScanArgs{p.s_boxes, p.s_scores, p.s_order, p.counts, p.mask, p.keep_idx, p.out_boxes, p.out_scores, p.counts + 1};
+    return ORE_OK;
+}
+
+}  // namespace
+
+extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
+    ScanArgs sa{};
+    DetLayout lay{};
+    int cap = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = detect_prepare(d, st, sa, lay, cap);
+    if (rc) return rc;
+    return launch_nms_scan(lay.words, st, sa.s_boxes, sa.s_scores, sa.s_order, sa.n_ptr, sa.mask, d->nms_thresh, d->post_topk, sa.keep_idx,
+                           sa.out_boxes, sa.out_scores, sa.n_keep_out, nms_use_col(cap) ? cap : 0);
+}
+
+extern "C" int ore_detect_batch_fwd(const ore_detect_desc* d, int32_t n_images, void* stream) {
+    ORE_CHECK_ARG(d && n_images > 0, "ore_detect_batch_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n_images; i0 += SCAN_BATCH) {
+        const int nb = min(SCAN_BATCH, n_images - i0);
+        ScanBatch sb{};
+        DetLayout lay{};
+        int cap = 0;
+        for (int i = 0; i < nb; ++i) {
+            const ore_detect_desc* di = d + i0 + i;
+            ORE_CHECK_ARG(di->n_levels == d->n_levels && di->pre_topk == d->pre_topk && di->nms_thresh == d->nms_thresh &&
+                              di->post_topk == d->post_topk, "ore_detect_batch_fwd: image %d differs in levels / thresholds", i0 + i);
+            const int rc = detect_prepare(di, st, sb.a[i], lay, cap);
+            if (rc) return rc;
+        }
+        if (nms_use_col(cap) || nb == 1) {                       // small candidate sets: the column scan is already short
+            for (int i = 0; i < nb; ++i) {
+                const ScanArgs& a = sb.a[i];
+                const int rc = launch_nms_scan(lay.words, st, a.s_boxes, a.s_scores, a.s_order, a.n_ptr, a.mask, d->nms_thresh, d->post_topk,
+                                               a.keep_idx, a.out_boxes, a.out_scores, a.n_keep_out, nms_use_col(cap) ? cap : 0);
+                if (rc) return rc;
+            }
+            continue;
+        }
+        sb.words = lay.words; sb.thr = d->nms_thresh; sb.post_topk = d->post_topk;
+        const size_t dl = (size_t)lay.words * 64 * 8;
+        const void* f = lay.words <= 64 ? (const void*)k_nms_scan_multi<1> : (lay.words <= 128 ? (const void*)k_nms_scan_multi<2> : (const void*)k_nms_scan_multi<4>);
+        if (dl > 48 * 1024) ORE_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
+        if (lay.words <= 64) hipLaunchKernelGGL(k_nms_scan_multi<1>, dim3(nb), dim3(256), dl, st, sb);
+        else if (lay.words <= 128) hipLaunchKernelGGL(k_nms_scan_multi<2>, dim3(nb), dim3(256), dl, st, sb);
+        else hipLaunchKernelGGL(k_nms_scan_multi<4>, dim3(nb), dim3(256), dl, st, sb);
+        const int rc = ore_launch_status("k_nms_scan_multi");
+        if (rc) return rc;
     }
-    return launch_nms_scan(lay.words, st, p.s_boxes, p.s_scores, p.s_order, p.counts, p.mask, d->nms_thresh, d->post_topk, p.keep_idx,
-                           p.out_boxes, p.out_scores, p.counts + 1, nms_use_col(cap) ? cap : 0);
+    return ORE_OK;
 }
 
 // ---- stand-alone NMS (same kernels; scores sorted by the rank kernel through a 1-level DetP) -------

@@ -237,8 +237,8 @@ def first_stage_batch(pg, heads: List[torch.Tensor], gts: List[torch.Tensor], no
               norm_avg=norm_avg)
     l3, counts = A.centernet_losses(rows, tg["reg_targets"], tg["hm_targets"], tg["pos_inds"], tg["pos_count"], hp, with_counts=True)
     with torch.no_grad():
-        outs = [orehip.detect([h[b].detach() for h in heads], pg.strides, pg.score_thresh, pg.pre_nms_topk_train, pg.nms_thresh_train,
-                              pg.post_nms_topk_train) for b in range(B)]
+        outs = orehip.detect_batch([[h[b].detach() for h in heads] for b in range(B)], pg.strides, pg.score_thresh,
+                                   pg.pre_nms_topk_train, pg.nms_thresh_train, pg.post_nms_topk_train)
     losses = {"loss_centernet_loc": l3[0], "loss_centernet_agn_pos": l3[1], "loss_centernet_agn_neg": l3[2]}
     return outs, losses, tg, counts
 

@@ -66,7 +66,7 @@ class ModelCfg(C.Structure):
 SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
-           "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd",
+           "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
            "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
@@ -361,9 +361,8 @@ def get_conv_precision() -> str:
     return ("fp32", "bf16")[int(lib().ore_conv_get_precision())]
 
 
-def detect(heads: Sequence[torch.Tensor], strides: Sequence[int], score_thresh: float, pre_topk: int, nms_thresh: float,
-           post_topk: int) -> Dict[str, torch.Tensor]:
-    """heads[l]: [H,W,ld>=8] fp32: channels 0..3 reg (after Scale+ReLU), 4 = heatmap logit.  No host sync inside."""
+def _detect_desc(heads: Sequence[torch.Tensor], strides, score_thresh, pre_topk, nms_thresh, post_topk, d: "DetectDesc"):
+    """Allocate one image's outputs + workspace and fill its descriptor."""
     L = len(heads)
     dev = heads[0].device
     cap = L * pre_topk
@@ -379,7 +378,6 @@ def detect(heads: Sequence[torch.Tensor], strides: Sequence[int], score_thresh: 
         off += nb
     wsb = lib().ore_detect_workspace_bytes(L, pre_topk)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    d = DetectDesc()
     d.n_levels, d.head_ld = L, heads[0].shape[-1]
     for l, h in enumerate(heads):
         _f32(h)
@@ -389,9 +387,28 @@ def detect(heads: Sequence[torch.Tensor], strides: Sequence[int], score_thresh: 
     for k in ("pre_boxes", "pre_scores", "pre_loc", "pre_level", "keep_idx", "counts", "out_boxes", "out_scores"):
         setattr(d, k, _ptr(o[k]))
     d.workspace, d.workspace_bytes = _ptr(ws), wsb
-    _chk(lib().ore_detect_fwd(C.byref(d), _stream()), "ore_detect_fwd")
     o["_ws"] = ws
     return o
+
+
+def detect(heads: Sequence[torch.Tensor], strides: Sequence[int], score_thresh: float, pre_topk: int, nms_thresh: float,
+           post_topk: int) -> Dict[str, torch.Tensor]:
+    """heads[l]: [H,W,ld>=8] fp32: channels 0..3 reg (after Scale+ReLU), 4 = heatmap logit.  No host sync inside."""
+    d = DetectDesc()
+    o = _detect_desc(heads, strides, score_thresh, pre_topk, nms_thresh, post_topk, d)
+    _chk(lib().ore_detect_fwd(C.byref(d), _stream()), "ore_detect_fwd")
+    return o
+
+
+def detect_batch(heads_per_image: Sequence[Sequence[torch.Tensor]], strides: Sequence[int], score_thresh: float, pre_topk: int,
+                 nms_thresh: float, post_topk: int) -> List[Dict[str, torch.Tensor]]:
+    """`detect` for B independent images (ore_detect_batch_fwd: the greedy scans of up to 16 images share one launch).  Per image the
+    outputs of `detect`, bit for bit.  No host sync inside."""
+    B = len(heads_per_image)
+    ds = (DetectDesc * B)()
+    outs = [_detect_desc(heads_per_image[b], strides, score_thresh, pre_topk, nms_thresh, post_topk, ds[b]) for b in range(B)]
+    _chk(lib().ore_detect_batch_fwd(ds, B, _stream()), "ore_detect_batch_fwd")
+    return outs
 
 
 def nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:

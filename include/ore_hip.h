@@ -179,6 +179,10 @@ typedef struct ore_detect_desc {
 } ore_detect_desc;
 size_t ore_detect_workspace_bytes(int32_t n_levels, int32_t pre_topk);
 int ore_detect_fwd(const ore_detect_desc* d, void* stream);
+/* n_images independent images (a training batch; every image its own desc, outputs and workspace, the same levels and thresholds):
+ * the per-image selection / sort / IoU-mask launches of ore_detect_fwd, then the greedy scans of up to 16 images in ONE launch (block b
+ * = image b) instead of 16 one-block kernels back to back.  Results are those of ore_detect_fwd image by image, bit for bit. */
+int ore_detect_batch_fwd(const ore_detect_desc* d, int32_t n_images, void* stream);
 
 /* Stand-alone NMS on n boxes (torchvision.ops.nms semantics, stable order): keep_idx int64 [n], count[0]. */
 size_t ore_nms_workspace_bytes(int32_t n);

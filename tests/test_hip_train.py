@@ -755,6 +755,31 @@ def test_train_forward_batch_and_empty_gt(oh):
     assert errs[len(errs) // 2] <= 1e-4 and errs[int(len(errs) * 0.85)] <= 1e-3 and errs[-1] <= 2e-2, errs[-5:]
 
 
+def test_detect_batch_equals_per_image_detect(oh):
+    """ore_detect_batch_fwd (the train-mode proposals of a batch: the greedy NMS scans of all images in one launch) returns, image by
+    image, exactly what ore_detect_fwd returns -- boxes, scores, keep indices and counts bit for bit (4000 / 0.9 / 2000 thresholds)."""
+    import orehip
+    g = torch.Generator().manual_seed(17)
+    B, shapes = 3, ((40, 48), (20, 24), (10, 12))
+    per_image = []
+    for b in range(B):
+        hs = []
+        for (H, W) in shapes:
+            h = torch.zeros(H, W, 16)
+            h[..., :4] = torch.rand(H, W, 4, generator=g) * (3.0 + b) + 0.3
+            h[..., 4] = torch.randn(H, W, generator=g) * 2.0 - 1.0
+            hs.append(h.cuda())
+        per_image.append(hs)
+    many = orehip.detect_batch(per_image, (8, 16, 32), 1e-5, 4000, 0.9, 2000)
+    torch.cuda.synchronize()
+    for b in range(B):
+        one = orehip.detect(per_image[b], (8, 16, 32), 1e-5, 4000, 0.9, 2000)
+        n = int(one["counts"][1])
+        assert n > 100 and torch.equal(one["counts"], many[b]["counts"])
+        for k in ("out_boxes", "out_scores", "keep_idx"):
+            assert torch.equal(one[k][:n], many[b][k][:n]), (b, k)
+
+
 def test_sample_rois_device_properties(oh):
     """The sync-free fg/bg subsample (train_forward.sample_rois_device) against label_and_sample_proposals' contract
     (d2z:modeling/roi_heads/roi_heads.py:181-295, sampling.py:10-53) on a batch with an image without ground truth and an image with
