@@ -228,17 +228,31 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     }
 }
 
-// dw_oihw[co][ci][tap] = beta * dw + sum_z slab[z][co][tap][ci]  (z ascending: fixed summation order)
+// dw_oihw[co][ci][tap] = beta * dw + sum_z slab[z][co][tap][ci]  (fixed summation order: even and odd slabs ascending, then their sum).
+// One thread = 4 consecutive ci (Cin % 4 == 0): 16-byte slab loads, two independent accumulator chains.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cout, int taps, int Cin, float beta,
                                                       float* __restrict__ dw) {
     const long long n = (long long)Cout * taps * Cin;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slab[(size_t)z * n + i];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int z = 0;
+    for (; z + 1 < S; z += 2) {
+        s0 += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n + i);
+        s1 += *reinterpret_cast<const f32x4*>(slab + (size_t)(z + 1) * n + i);
+    }
+    if (z < S) s0 += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n + i);
+    const f32x4 s = s0 + s1;
     const int ci = (int)(i % Cin), tap = (int)((i / Cin) % taps), co = (int)(i / ((long long)Cin * taps));
     float* o = dw + ((size_t)co * Cin + ci) * taps + tap;
-    *o = beta != 0.0f ? beta * *o + s : s;
+    if (taps == 1) {
+        f32x4 v = s;
+        if (beta != 0.0f) v += beta * *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[(size_t)k * taps] = beta != 0.0f ? beta * o[(size_t)k * taps] + s[k] : s[k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -285,17 +299,25 @@ __global__ __launch_bounds__(256) void k_colsum_chunks(const float* __restrict__
     __syncthreads();
     if (rl == 0 && c < C) part[(size_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
+// stage 2: one block = 64 channels x 4 chunk lanes of one segment (lane l sums chunks l, l+4, ... in order, lanes combined in fixed order)
 __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ part, int cps, int C, float beta, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     part += (size_t)blockIdx.y * cps * C;
     out += (size_t)blockIdx.y * C;
     float s0 = 0.f, s1 = 0.f;
-    int k = 0;
-    for (; k + 1 < cps; k += 2) { s0 += part[(size_t)k * C + c]; s1 += part[(size_t)(k + 1) * C + c]; }
-    if (k < cps) s0 += part[(size_t)k * C + c];
-    const float s = s0 + s1;
-    out[c] = beta != 0.0f ? beta * out[c] + s : s;
+    if (c < C) {
+        int k = kl;
+        for (; k + 4 < cps; k += 8) { s0 += part[(size_t)k * C + c]; s1 += part[(size_t)(k + 4) * C + c]; }
+        if (k < cps) s0 += part[(size_t)k * C + c];
+    }
+    red[kl][cl] = s0 + s1;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        const float s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        out[c] = beta != 0.0f ? beta * out[c] + s : s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -622,7 +644,7 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     else hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
     int rc = ore_launch_status("k_wgrad");
     if (rc || S == 1) return rc;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
     return ore_launch_status("k_wgrad_reduce");
 }
 
@@ -646,7 +668,7 @@ extern "C" int ore_colsum_segments_fwd(const float* x, int32_t ld, int32_t coff,
                        (int)cps, C, workspace);
     int rc = ore_launch_status("k_colsum_chunks");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(C, 256), segments), dim3(256), 0, st, workspace, (int)cps, C, beta, out);
+    hipLaunchKernelGGL(k_colsum_final, dim3(ceil_div(C, 64), segments), dim3(256), 0, st, workspace, (int)cps, C, beta, out);
     return ore_launch_status("k_colsum_final");
 }
 

@@ -319,13 +319,16 @@ def roi_stage_losses_padded(rh, qf: List[torch.Tensor], sup8: torch.Tensor, boxe
     bx, lb, gtf, vf = boxes.reshape(RT, 4), labels.reshape(RT), gt.reshape(RT, 4), valid.reshape(RT)
     x = A.roi_align_batched(qf, bx, rimg, strides, P).reshape(RT * P * P, C)            # rows ordered [roi][pos], channels last
     s = sup8.mean(1).reshape(B * P * P, C)                                              # each image's own support prototype
-    s_exp = s.reshape(B, P * P, C)[img].reshape(RT * P * P, C)
-    s2_exp = A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).reshape(B, P * P, C // 2)[img].reshape(RT * P * P, C // 2)
+    # the ROIs of image b are rows b*R .. (b+1)*R: broadcasting its prototype is an expand (backward = one sum over R), not a gather
+    s_exp = s.reshape(B, 1, P * P, C).expand(B, R, P * P, C).reshape(RT * P * P, C)
+    s2_exp = A.linear(s, rh.conv2.weight.flatten(1), rh.conv2.bias).reshape(B, 1, P * P, C // 2).expand(B, R, P * P, C // 2) \
+        .reshape(RT * P * P, C // 2)
     a = A.linear(torch.cat((x, s_exp), 1), rh.conv3.weight.flatten(1), rh.conv3.bias) + \
         torch.cat((A.linear(x, rh.conv1.weight.flatten(1), rh.conv1.bias), s2_exp), 1)
-    a = a.reshape(RT, P * P, C).permute(0, 2, 1).reshape(RT, C * P * P)                 # NCHW flatten order of fc1's weight
+    # fc1 reads the NCHW flatten [c][pos] of the reference; the rows here are [pos][c]: permute the 4 MB weight, not the activations
     fc1 = rh.box_head[0].fc1
-    h = A.linear(a.contiguous(), fc1.weight, fc1.bias, True)
+    w1 = fc1.weight.reshape(fc1.weight.shape[0], C, P * P).permute(0, 2, 1).reshape(fc1.weight.shape[0], P * P * C)
+    h = A.linear(a.reshape(RT, P * P * C), w1, fc1.bias, True)
     pr = rh.box_predictor[0]
     scores = A.linear(h, pr.cls_score.weight, pr.cls_score.bias)
     deltas = A.linear(h, pr.bbox_pred.weight, pr.bbox_pred.bias)
