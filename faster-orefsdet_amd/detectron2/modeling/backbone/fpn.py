@@ -49,9 +49,9 @@ class FPN(Backbone):
     def size_divisibility(self):
         return self._size_divisibility
 
-    def forward(self, x):
+    def forward(self, x, raw_norm=None):
         _require_gpu(x, "FPN")
-        feats = self.bottom_up(x)
+        feats = self.bottom_up(x) if raw_norm is None else self.bottom_up(x, raw_norm=raw_norm)
         results, prev = [], None
         if torch.is_grad_enabled() and any(p.requires_grad for c in self.lateral_convs + self.output_convs for p in c.parameters()):
             from orehip import autograd as A

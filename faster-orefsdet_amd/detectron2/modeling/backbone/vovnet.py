@@ -143,13 +143,21 @@ class VoVNet(Backbone):
                 p.requires_grad = False
 
     # ---- HIP forward -------------------------------------------------------------------------------------
-    def stem_hip(self, x_nchw):
-        """Normalised, padded NCHW input -> stem_3 output written into `dst` slice.  stem_1 uses the 3-channel kernel."""
+    def stem_hip(self, x_nchw, raw_norm=None):
+        """Normalised, padded NCHW input -> stem_1 output (the 3-channel kernel).  raw_norm = (mean, std, Hp, Wp): x_nchw is the RAW
+        image batch (uint8 or fp32, all of one size) and the kernel fuses (x - mean) / std and the zero padding to Hp x Wp
+        (ref:fewx/modeling/fsod/fsod_cen.py:540-555 + ImageList.from_tensors) -- no normalised copy of the batch is ever written."""
         import orehip
         s = self.stem
         c1, b1 = s._modules["stem_1/conv"], s._modules["stem_1/norm"]
         sc, sh = b1.scale_shift()
         B, _, H, W = x_nchw.shape
+        if raw_norm is not None:
+            mean, std, Hp, Wp = raw_norm
+            x = x_nchw.contiguous()
+            if x.dtype not in (torch.uint8, torch.float32):
+                x = x.float()
+            return orehip.stem1(x, Hp, Wp, mean, std, c1.weight.detach().contiguous(), sc.contiguous(), sh.contiguous())
         y = orehip.stem1(x_nchw.contiguous().float(), H, W, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), c1.weight.detach().contiguous(),
                          sc.contiguous(), sh.contiguous())
         return y
@@ -166,15 +174,16 @@ class VoVNet(Backbone):
             self._stem_units[name] = u
         return self._stem_units[name]
 
-    def forward(self, x):
+    def forward(self, x, raw_norm=None):
         """Frozen stages run as plain HIP launches; stages with trainable parameters (FREEZE_AT < stage) run through the autograd
-        bindings (orehip.autograd.OSAFn: forward + data/weight-gradient kernels) when gradients are enabled."""
+        bindings (orehip.autograd.OSAFn: forward + data/weight-gradient kernels) when gradients are enabled.
+        raw_norm: see stem_hip (the fused-preprocess entry used by the training forward)."""
         import orehip
         _require_gpu(x, "VoVNet")
         grad_on = torch.is_grad_enabled()
         outputs = {}
         with torch.no_grad():
-            y = self.stem_hip(x)
+            y = self.stem_hip(x, raw_norm)
             y = self._unit("stem_2").hip(y)
             first = getattr(self, "stage2").blocks()[0]
             B, H, W, _ = y.shape
@@ -199,10 +208,11 @@ class VoVNet(Backbone):
                 for bi, blk in enumerate(blocks):
                     if prev is not None:
                         if bi == 0 and stage.pool:
-                            pooled = orehip.maxpool3x3s2(prev, gate)          # gate folded: max commutes with the positive scale
-                            B, H, W, _ = pooled.shape
+                            B = prev.shape[0]
+                            H, W = orehip.maxpool3x3s2_out_hw(prev.shape[1], prev.shape[2])
                             cat = torch.empty(B, H, W, blk.cat_ch, device=x.device, dtype=torch.float32)
-                            cat[..., : blk.in_ch] = pooled
+                            # gate folded (max commutes with the positive scale); pooled straight into the concat buffer's first slice
+                            orehip.maxpool3x3s2(prev, gate, out=cat, out_coff=0)
                             ident = None
                         else:
                             fullp = orehip.scale_channels(prev, gate) if gate is not None else prev

@@ -68,16 +68,32 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
     return outs
 
 
-def dense_part(model, xq: torch.Tensor, xs: torch.Tensor):
+def _mean_std(model):
+    """pixel mean / std as host floats, read from the device once per model."""
+    ms = model.__dict__.get("_ore_mean_std")
+    if ms is None:
+        ms = model.__dict__["_ore_mean_std"] = (tuple(model.pixel_mean.view(-1).tolist()), tuple(model.pixel_std.view(-1).tolist()))
+    return ms
+
+
+def dense_part(model, xq: torch.Tensor, xs: torch.Tensor, raw: bool = False):
     """The shape-static part of a training iteration for B query images at once: query and support pyramids (two batched backbone
     passes, fsod_cen.py:165,179), per-image support prototypes and correlation (:197-275), conv3 and the head batched over B.
-    xq [B,3,H,W], xs [B*N,3,h,w] normalised + padded, image b owning support rows b*N..(b+1)*N.
+    xq [B,3,H,W], xs [B*N,3,h,w] normalised + padded (raw = False) or raw uint8 / fp32 images of one size each (raw = True), image b
+    owning support rows b*N..(b+1)*N.
     Returns (q3, q4, q5 [B,..], s3, s4, s5 [B*N,..] as NHWC, head3, head4, head5 [B,H,W,16])."""
     from orehip import autograd as A
     B = xq.shape[0]
     N = xs.shape[0] // B
-    feats = model.backbone(xq)
-    sfeats = model.backbone(xs)
+    if raw:                                             # raw image batches: normalisation + /32 zero padding fused into stem_1
+        mean, std = _mean_std(model)
+        div = model.backbone.size_divisibility
+        pad = lambda n: (n + div - 1) // div * div     # noqa: E731
+        feats = model.backbone(xq, raw_norm=(mean, std, pad(xq.shape[-2]), pad(xq.shape[-1])))
+        sfeats = model.backbone(xs, raw_norm=(mean, std, pad(xs.shape[-2]), pad(xs.shape[-1])))
+    else:
+        feats = model.backbone(xq)
+        sfeats = model.backbone(xs)
     pos = []
     for i, k in enumerate(LEVELS):
         size = (32, 16, 8)[i]
@@ -361,7 +377,8 @@ def _pad_stack(ts: List[torch.Tensor], width: int, dev):
 
 
 def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Tensor]] = None, return_aux: bool = False,
-                  roi_override: Optional[Dict[str, torch.Tensor]] = None, cn_norm_avg: Optional[torch.Tensor] = None):
+                  roi_override: Optional[Dict[str, torch.Tensor]] = None, cn_norm_avg: Optional[torch.Tensor] = None,
+                  fused_preprocess: bool = True):
     """model: CenterNet2Detector in training mode.  batched_inputs[i]: image [3,H,W] (uint8/float BGR), instances (gt_boxes),
     support_images [N,3,h,w], support_bboxes [N,4].  Returns the 5 losses of the call: B images on one rank give what B data-parallel
     single-image ranks of the reference give after gradient averaging (CenterNet losses: sums over all images / the all-image
@@ -369,7 +386,8 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
     No host sync between the first kernel and the last (the fg/bg subsample runs on the device, sample_rois_device), unless the caller
     asks for it: `perm(n)` replaces torch.randperm in the subsampling (host-shaped legacy sampling, tests); `roi_override` = {boxes,
     labels, gt} replaces the sampled set of every image (parity tests pin the second stage on the reference's sample so a 1-ulp heatmap
-    difference cannot change the batch); `cn_norm_avg` = the two averaged CenterNet normalisers of a larger virtual batch."""
+    difference cannot change the batch); `cn_norm_avg` = the two averaged CenterNet normalisers of a larger virtual batch;
+    `fused_preprocess=False` forces the generic normalise-then-pad input path (otherwise used for mixed sizes and graph capture)."""
     import orehip
     from orehip import autograd as A
     dev = model.device
@@ -388,17 +406,26 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
         sbx.append(torch.as_tensor(item["support_bboxes"], dtype=torch.float32))
     sbx = orehip.to_device(torch.cat(sbx, 0), dev)
     gtp, gt_n = _pad_stack(gts, 4, dev)
-    imgs = [orehip.to_device(item["image"], dev).float() for item in batched_inputs]
-    Hm, Wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
-    # ImageList.from_tensors semantics (d2z:structures/image_list.py:69-121): normalise each image, zero-pad bottom/right to the batch
-    # maximum rounded up to the size divisibility; the whole batch goes through the backbone at once (fsod_cen.py:156,165)
-    xq = torch.cat([F.pad(_normalise_pad(i[None], mean, std, 1), (0, Wm - i.shape[-1], 0, Hm - i.shape[-2])) for i in imgs], 0)
-    xq = F.pad(xq, (0, (Wm + div - 1) // div * div - Wm, 0, (Hm + div - 1) // div * div - Hm)).contiguous()
+    imgs = [orehip.to_device(item["image"], dev) for item in batched_inputs]
     sups = [orehip.to_device(item["support_images"], dev) for item in batched_inputs]
     for s_ in sups:
         assert s_.shape[0] == N, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
-    xs = _normalise_pad(torch.cat(sups, 0) if B > 1 else sups[0], mean, std, div)
-    outs = graphed_dense_part(model, xq, xs) if getattr(model, "train_graph", False) else dense_part(model, xq, xs)
+    graph = getattr(model, "train_graph", False)
+    same = all(i.shape == imgs[0].shape and i.dtype == imgs[0].dtype for i in imgs) and all(s_.shape == sups[0].shape for s_ in sups)
+    if same and not graph and fused_preprocess:
+        # one size per batch (the usual case): hand the RAW images to stem_1, which normalises and pads on the fly
+        xq = torch.stack(imgs) if B > 1 else imgs[0][None]
+        xs = torch.cat(sups, 0) if B > 1 else sups[0]
+        outs = dense_part(model, xq.contiguous(), xs.contiguous(), raw=True)
+    else:
+        imgs = [i.float() for i in imgs]
+        Hm, Wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+        # ImageList.from_tensors semantics (d2z:structures/image_list.py:69-121): normalise each image, zero-pad bottom/right to the
+        # batch maximum rounded up to the size divisibility; the whole batch goes through the backbone at once (fsod_cen.py:156,165)
+        xq = torch.cat([F.pad(_normalise_pad(i[None], mean, std, 1), (0, Wm - i.shape[-1], 0, Hm - i.shape[-2])) for i in imgs], 0)
+        xq = F.pad(xq, (0, (Wm + div - 1) // div * div - Wm, 0, (Hm + div - 1) // div * div - Hm)).contiguous()
+        xs = _normalise_pad(torch.cat(sups, 0) if B > 1 else sups[0], mean, std, div)
+        outs = graphed_dense_part(model, xq, xs) if graph else dense_part(model, xq, xs)
     qf, sf_levels, heads = list(outs[0:3]), list(outs[3:6]), list(outs[6:9])
     # ---- first stage: ground truth, losses, proposals (no gradient through the proposals)
     dets, l_rpn, tg, cn_counts = first_stage_batch(pg, heads, gts, cn_norm_avg)

@@ -277,7 +277,9 @@ def stem1(img: torch.Tensor, Hp: int, Wp: int, mean: Sequence[float], std: Seque
     return out
 
 
-def maxpool3x3s2(x: torch.Tensor, in_mul: Optional[torch.Tensor] = None) -> torch.Tensor:
+def maxpool3x3s2(x: torch.Tensor, in_mul: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+    """MaxPool2d(3, 2, ceil_mode=True) on NHWC (optionally of x * in_mul[b][c], in_mul > 0).  `out` [B,Ho,Wo,ld] + out_coff: write the
+    result into a channel slice of a wider buffer (the next block's concat buffer) instead of a fresh tensor."""
     _f32(x)
     B, H, W, Cc = x.shape
 
@@ -286,10 +288,23 @@ def maxpool3x3s2(x: torch.Tensor, in_mul: Optional[torch.Tensor] = None) -> torc
         if (o - 1) * 2 >= n:
             o -= 1
         return max(o, 1)
-    out = torch.empty(B, osz(H), osz(W), Cc, device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, osz(H), osz(W), Cc, device=x.device, dtype=torch.float32)
+    else:
+        _f32(out)
+        assert tuple(out.shape[:3]) == (B, osz(H), osz(W)) and out_coff + Cc <= out.shape[-1] and out_coff % 4 == 0
     _chk(lib().ore_maxpool3x3s2_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(in_mul)),
-                                    C.c_void_p(_ptr(out)), Cc, 0, _stream()), "ore_maxpool3x3s2_fwd")
+                                    C.c_void_p(_ptr(out)), out.shape[-1], out_coff, _stream()), "ore_maxpool3x3s2_fwd")
     return out
+
+
+def maxpool3x3s2_out_hw(H: int, W: int) -> Tuple[int, int]:
+    def osz(n):
+        o = (n - 3 + 1) // 2 + 1 if n >= 3 else 1
+        if (o - 1) * 2 >= n:
+            o -= 1
+        return max(o, 1)
+    return osz(H), osz(W)
 
 
 def ese_gate(x: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:

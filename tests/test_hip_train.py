@@ -724,6 +724,21 @@ def test_train_forward_batch_and_empty_gt(oh):
             assert abs(float(lab[k]) - want) <= 1e-5 * max(abs(want), 1e-3), k
     sum(lab.values()).backward()
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+    # images of different sizes in one call: ImageList.from_tensors semantics (normalise, zero-pad to the batch maximum) through the
+    # generic path; one size per batch goes through the fused-preprocess stem (raw images handed to stem_1) -- same numbers
+    img_d, gt_d, sup_d, sbox_d = T.synth_train_inputs(6, (224, 288), n_gt=3, shots=shots, support_hw=96)
+    inst_d = Instances((224, 288))
+    inst_d.gt_boxes, inst_d.gt_classes = Boxes(gt_d), torch.zeros(len(gt_d), dtype=torch.int64)
+    d_item = {"image": img_d, "instances": inst_d, "support_images": sup_d, "support_bboxes": sbox_d.numpy()}
+    m.zero_grad(set_to_none=True)
+    lmix = TF.train_forward(m, [a, d_item])
+    sum(lmix.values()).backward()
+    assert all(torch.isfinite(v) for v in lmix.values()) and all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+    over = {"boxes": aux["roi_boxes"][0], "labels": aux["roi_labels"][0], "gt": aux["roi_gt"][0]}
+    l_raw = TF.train_forward(m, [a], roi_override=over)
+    l_gen = TF.train_forward(m, [a], roi_override=over, fused_preprocess=False)
+    for k in l_raw:
+        assert abs(float(l_raw[k]) - float(l_gen[k])) <= 2e-5 * max(abs(float(l_gen[k])), 1e-3), k
     # the batched pass (two batched backbone passes, ONE second-stage pass over the ROIs of both images) against the two
     # single-image passes, with a deterministic fg/bg subsample so that all five losses and the gradients are comparable
     c = item(3, 3)
