@@ -19,6 +19,7 @@ struct ConvP {
     float* colsum;                       // [gridDim.x][Cout16] or null
     int splitk, steps_per_split, nchunks;
     float* ws; int* tile_cnt;
+    int xmap;                            // tile <-> block mapping of k_conv_kw: 0 = blockIdx, 1 / 2 = XCD-contiguous, M- / N-major (tile_of_block)
 };
 
 // ore_conv_kw.hip: wave-private K-split kernel fed by LDS-DMA.  Returns 1 when the layer is not covered (the caller falls back).
@@ -27,6 +28,7 @@ int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStrea
 int conv_kw_tile_rows(const ConvP& p);
 // tuning aid (ore_conv_set_plan_override(-3, bm, bn, ns, splitk)): force tile / ring depth / split of k_conv_kw; bm = 0 -> automatic
 void conv_kw_force(int bm, int bn, int ns, int splitk);
+void conv_xmap_force(int mode);                  // (-5, mode): -1 automatic, 0 / 1 / 2 force the block -> tile mapping of k_conv_kw
 void conv_gs_force(int bm, int bn, int ns);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic
 
 }  // namespace oreconv

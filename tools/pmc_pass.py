@@ -13,6 +13,9 @@ sys.path.insert(0, os.path.join(ROOT, "faster-orefsdet_amd"))
 import torch  # noqa: E402
 import bench  # noqa: E402
 
+if os.environ.get("ORE_XMAP"):                       # A/B aid: force the block -> tile mapping of k_conv_kw (0 = plain blockIdx)
+    import orehip
+    orehip.lib().ore_conv_set_plan_override(-5, int(os.environ["ORE_XMAP"]), 0, 0, 0)
 model, cfg = bench.build_model(torch.device("cuda", 0))
 img = bench.synth_image(0).cuda()
 eng = model.engine()
