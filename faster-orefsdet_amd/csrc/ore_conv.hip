@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = wave % WGK, wmn = wave / WGK;
     const int wm = wmn / WGN, wn = wmn % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int bx, by;
+    tile_of_block(p.xmap, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
     const int nsteps = (p.nchunks + WGK - 1) / WGK;
     const int s_begin = blockIdx.z * p.steps_per_split;
     const int s_end = min(s_begin + p.steps_per_split, nsteps);
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     }
 
     // accumulator element (i, j, r) of this lane is row m0 + wm*WM + i*16 + (lane>>4)*4 + r, column n0 + wn*WN + j*16 + (lane&15)
-    const int ntile = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ntile = by * gridDim.x + bx;
     if (p.splitk > 1) {
         // ---- publish this slice's tile, elect the last arriver (cdna guide: split-K slab reducer recipe)
         float* slab = p.ws + ((size_t)ntile * p.splitk + blockIdx.z) * (BM * BN);
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + wn * WN + j * 16 + cg4 + r;
-                    if (n < p.Cout16) p.colsum[(size_t)blockIdx.x * p.Cout16 + n] = csum[j][r];
+                    if (n < p.Cout16) p.colsum[(size_t)bx * p.Cout16 + n] = csum[j][r];
                 }
     }
     ORE_TR(62);
@@ -479,6 +481,7 @@ struct PatchP {
     const float* w; int Cout, Cout16, K;
     const float* scale; const float* shift; int ep_stride, relu_cout;
     float* out; int out_ld, out_coff;
+    int xmap;                               // tile_of_block mode (1: an XCD owns a contiguous band of tiles -> halo rows re-read inside its L2)
 };
 
 template <int TH, bool BF = false>
@@ -495,16 +498,18 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(PatchP p) {
     float* Bs = plds + NPIX * LDA;          // [9][BN][LDA]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- which tile
+    int pbx, pby;
+    tile_of_block(p.xmap, pbx, pby);
     int lvl = 0;
 #pragma unroll
     for (int l = 1; l < 4; ++l)
-        if (l < p.nlev && (int)blockIdx.x >= p.tile0[l]) lvl = l;
+        if (l < p.nlev && pbx >= p.tile0[l]) lvl = l;
     const Lvl L = p.lv[lvl];
-    const int tl = blockIdx.x - p.tile0[lvl];
+    const int tl = pbx - p.tile0[lvl];
     const int tpi = p.tiles_x[lvl] * p.tiles_y[lvl];
     const int b = tl / tpi, tr = tl - b * tpi;
     const int ty0 = (tr / p.tiles_x[lvl]) * TH, tx0 = (tr % p.tiles_x[lvl]) * TW;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = pby * BN;
     const int ibase = L.irow0 + b * L.H * L.W, obase = L.orow0 + b * L.H * L.W;
     const float* zero = g_zero16;
     auto sel = [&](bool ok, const float* ptr) -> const f32x4* {
@@ -640,16 +645,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
     constexpr int BUF = (NPIX + 9 * BN) * LDA;                  // floats per buffer
     extern __shared__ __attribute__((aligned(16))) float plds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pbx, pby;
+    tile_of_block(p.xmap, pbx, pby);
     int lvl = 0;
 #pragma unroll
     for (int l = 1; l < 4; ++l)
-        if (l < p.nlev && (int)blockIdx.x >= p.tile0[l]) lvl = l;
+        if (l < p.nlev && pbx >= p.tile0[l]) lvl = l;
     const Lvl L = p.lv[lvl];
-    const int tl = blockIdx.x - p.tile0[lvl];
+    const int tl = pbx - p.tile0[lvl];
     const int tpi = p.tiles_x[lvl] * p.tiles_y[lvl];
     const int b = tl / tpi, tr = tl - b * tpi;
     const int ty0 = (tr / p.tiles_x[lvl]) * TH, tx0 = (tr % p.tiles_x[lvl]) * TW;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = pby * BN;
     const int ibase = L.irow0 + b * L.H * L.W, obase = L.orow0 + b * L.H * L.W;
     const float* zero = g_zero16;
     auto sel = [&](bool ok, const float* ptr) -> const f32x4* {
@@ -839,14 +846,21 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
         for (int i = 0; i < A_IT; ++i)
             if (s_lds[i] >= 0) *reinterpret_cast<f32x4*>(buf + s_lds[i]) = ra[i];
     };
-    int t = blockIdx.x;
-    TileGeo cur_g = decode(t < ntiles ? t : 0);
-    if (t < ntiles) { gload(cur_g); lstore(plds); }
+    // persistent walk.  p.xmap: the blocks of one residue class (blockIdx.x % 8 = one XCD) share a CONTIGUOUS band of tiles (row-major,
+    // so the halo rows two vertically adjacent tiles both read stay in that XCD's L2) and walk it with stride gridDim.x / 8.
+    int t = blockIdx.x, t_end = ntiles, t_step = gridDim.x;
+    if (p.xmap && (gridDim.x & 7) == 0) {
+        const int r = blockIdx.x & 7, q = ntiles >> 3, rem = ntiles & 7;
+        const int base = r * q + min(r, rem);
+        t = base + (blockIdx.x >> 3); t_end = base + q + (r < rem ? 1 : 0); t_step = gridDim.x >> 3;
+    }
+    TileGeo cur_g = decode(t < t_end ? t : 0);
+    if (t < t_end) { gload(cur_g); lstore(plds); }
     __syncthreads();
     int cur = 0, parity = 0;
-    for (; t < ntiles; t += gridDim.x) {
-        const int tn = t + gridDim.x;
-        const bool has_next = tn < ntiles;
+    for (; t < t_end; t += t_step) {
+        const int tn = t + t_step;
+        const bool has_next = tn < t_end;
         TileGeo nxt_g = cur_g;
         if (has_next) { nxt_g = decode(tn); gload(nxt_g); }       // the next halo patch flies under this tile's MFMAs
         const float* As = plds + cur * BUF + kh * 64;
@@ -957,6 +971,7 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
     p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
     const dim3 grid(tiles, c.Cout16 / 64);
+    { const int xf = conv_xmap_forced(); p.xmap = xf >= 0 ? (xf ? 1 : 0) : (tiles >= 16 ? 1 : 0); }   // M-major bands of tiles per XCD
     if (ws) {
         // 64-channel layers: 4 waves, 2 blocks per CU; 128-channel layers: 8 waves (K split in wave pairs), 1 block per CU
         const bool wide = c.Cin == 128;
@@ -1216,6 +1231,7 @@ static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t worksp
     p.splitk = S; p.steps_per_split = sps;
     p.tile_cnt = reinterpret_cast<int*>(workspace);
     p.ws = workspace ? workspace + ORE_CONV_CNT_INTS : nullptr;
+    p.xmap = conv_choose_xmap(p, gx, gy);
     const int rc = dispatch(p, t, dim3(gx, gy, S), st);
     if (rc != ORE_OK) {
         ore_set_error("ore_conv2d_fwd: no %skernel for tile %dx%d (%d,%d,%d)", g_conv_bf16 ? "bf16 " : "", t.BM, t.BN, t.WGM, t.WGN, t.WGK);

@@ -22,13 +22,33 @@ struct ConvP {
     int xmap;                            // tile <-> block mapping of k_conv_kw: 0 = blockIdx, 1 / 2 = XCD-contiguous, M- / N-major (tile_of_block)
 };
 
+// Which tile does this block compute?  Workgroups are dealt round-robin over the 8 XCDs in linear block order (observed, MI355X guide),
+// each XCD has its own 4 MB L2, and with the plain (blockIdx.x, blockIdx.y) mapping the N tiles of one M tile -- the same activation
+// rows -- usually land on different XCDs, and every XCD reads every weight column: the L2 -> fabric traffic of a small-M layer is up
+// to 8x its operands.  xmap gives the blocks of one residue class (lin % 8 = one XCD) a CONTIGUOUS run of tiles in M-major (1: an
+// XCD owns a range of rows and reads them once) or N-major order (2: an XCD owns a range of output channels and reads those weights
+// once).  A pure relabelling: every tile is computed exactly once by exactly the same code, results are bit-identical.
+__device__ __forceinline__ void tile_of_block(int xmap, int& bx, int& by) {
+    bx = blockIdx.x; by = blockIdx.y;
+    if (xmap == 0) return;
+    const int gx = gridDim.x, gy = gridDim.y, T = gx * gy;
+    const int lin = by * gx + bx, r = lin & 7, k = lin >> 3;
+    const int q = T >> 3, rem = T & 7;
+    const int t = r * q + min(r, rem) + k;               // residue class r holds q (+1 if r < rem) blocks
+    if (xmap == 1) { bx = t / gy; by = t - bx * gy; }
+    else { by = t / gx; bx = t - by * gx; }
+}
+
+
 // ore_conv_kw.hip: wave-private K-split kernel fed by LDS-DMA.  Returns 1 when the layer is not covered (the caller falls back).
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st);
 // tile of the kw plan for (M, Cout): used by ore_conv_colsum_rows so the eSE reduction knows how many partial rows to expect
 int conv_kw_tile_rows(const ConvP& p);
 // tuning aid (ore_conv_set_plan_override(-3, bm, bn, ns, splitk)): force tile / ring depth / split of k_conv_kw; bm = 0 -> automatic
 void conv_kw_force(int bm, int bn, int ns, int splitk);
-void conv_xmap_force(int mode);                  // (-5, mode): -1 automatic, 0 / 1 / 2 force the block -> tile mapping of k_conv_kw
+int conv_choose_xmap(const ConvP& p, int gx, int gy);   // the mapping for a gx x gy tile grid of this layer
+void conv_xmap_force(int mode);
+int conv_xmap_forced();                          // -1 when automatic                  // (-5, mode): -1 automatic, 0 / 1 / 2 force the block -> tile mapping of k_conv_kw
 void conv_gs_force(int bm, int bn, int ns);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic
 
 }  // namespace oreconv

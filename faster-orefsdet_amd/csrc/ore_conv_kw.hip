@@ -30,23 +30,6 @@ using namespace oreconv;
 __device__ __attribute__((aligned(256))) float g_zero_kw[64] = {};
 
 
-// Which tile does this block compute?  Workgroups are dealt round-robin over the 8 XCDs in linear block order (observed, MI355X guide),
-// each XCD has its own 4 MB L2, and with the plain (blockIdx.x, blockIdx.y) mapping the N tiles of one M tile -- the same activation
-// rows -- usually land on different XCDs, and every XCD reads every weight column: the L2 -> fabric traffic of a small-M layer is up
-// to 8x its operands.  xmap gives the blocks of one residue class (lin % 8 = one XCD) a CONTIGUOUS run of tiles in M-major (1: an
-// XCD owns a range of rows and reads them once) or N-major order (2: an XCD owns a range of output channels and reads those weights
-// once).  A pure relabelling: every tile is computed exactly once by exactly the same code, results are bit-identical.
-__device__ __forceinline__ void tile_of_block(int xmap, int& bx, int& by) {
-    bx = blockIdx.x; by = blockIdx.y;
-    if (xmap == 0) return;
-    const int gx = gridDim.x, gy = gridDim.y, T = gx * gy;
-    const int lin = by * gx + bx, r = lin & 7, k = lin >> 3;
-    const int q = T >> 3, rem = T & 7;
-    const int t = r * q + min(r, rem) + k;               // residue class r holds q (+1 if r < rem) blocks
-    if (xmap == 1) { bx = t / gy; by = t - bx * gy; }
-    else { by = t / gx; bx = t - by * gx; }
-}
-
 __device__ __forceinline__ void decode_row(const ConvP& p, int m, int& lvl, int& b, int& oy, int& ox) {
     lvl = 0;
 #pragma unroll
@@ -732,6 +715,21 @@ static int conv_gs_launch(ConvP& p, hipStream_t st) {
 }
 
 void conv_xmap_force(int mode) { g_xmap_force = mode; }
+int conv_xmap_forced() { return g_xmap_force; }
+
+// block -> tile mapping (tile_of_block): fabric bytes if every XCD reads what its tiles need once
+int conv_choose_xmap(const ConvP& p, int gx, int gy) {
+    if (g_xmap_force >= 0) return g_xmap_force;
+    const int blocks = gx * gy;
+    if (blocks < 16) return 0;
+    const double A = (double)p.M * p.Cin, Wb = (double)p.Cout16 * p.K;
+    const int per_xcd = ceil_div(blocks, 8);
+    const double cost_m = A + 8.0 * Wb;                                        // an XCD = a range of rows x all output channels
+    const int spanned = per_xcd >= gx ? ceil_div(per_xcd, gx) + 1 : 2;         // N tiles an XCD's run touches in N-major order
+    const double cost_n = (double)(gy < 8 ? gy : 8) * A + 8.0 * Wb * (spanned < gy ? spanned : gy) / gy;
+    if (cost_n < cost_m) return 2;
+    return (gx & 7) == 0 ? 0 : 1;                                              // plain mapping already keeps an M tile on one XCD
+}
 void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] = bn; if (ns > 0) g_gs_ns = ns; }
 
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
@@ -753,17 +751,7 @@ int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStrea
         if (!workspace || workspace_floats < need || blocks > ORE_CONV_CNT_INTS) { S = 1; sps = steps; }
     }
     p.splitk = S; p.steps_per_split = sps;
-    {   // block -> tile mapping: fabric bytes if every XCD reads what its tiles need once (tile_of_block)
-        const double A = (double)p.M * p.Cin, Wb = (double)p.Cout16 * p.K;
-        const int per_xcd = ceil_div(blocks, 8);
-        const double cost_m = A + 8.0 * Wb;                                        // an XCD = a range of rows x all output channels
-        const int spanned = per_xcd >= gx ? ceil_div(per_xcd, gx) + 1 : 2;         // N tiles an XCD's run touches in N-major order
-        const double cost_n = (double)(gy < 8 ? gy : 8) * A + 8.0 * Wb * (spanned < gy ? spanned : gy) / gy;
-        const bool plain_ok = (gx & 7) == 0;                                       // plain mapping already keeps an M tile on one XCD
-        p.xmap = cost_n < cost_m ? 2 : (plain_ok ? 0 : 1);
-        if (blocks < 16) p.xmap = 0;
-        if (g_xmap_force >= 0) p.xmap = g_xmap_force;
-    }
+    p.xmap = conv_choose_xmap(p, gx, gy);
     p.tile_cnt = reinterpret_cast<int*>(workspace);
     p.ws = workspace ? workspace + ORE_CONV_CNT_INTS : nullptr;
     const dim3 grid(gx, gy, S);

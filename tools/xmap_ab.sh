@@ -17,7 +17,8 @@ for m in ("0","auto"):
     line=[]
     for i in ids:
         if i<start: continue
-        fam = "kw" if "k_conv_kw" in names[i] else ("other conv" if "k_conv" in names[i] else "rest")
+        n=names[i]
+        fam = "kw" if "k_conv_kw" in n else ("ws" if "k_conv3x3_ws" in n else ("patch" if "k_conv3x3_patch" in n else ("igemm" if "k_conv_igemm" in n else ("gs" if "k_conv_gs" in n else "rest"))))
         tot[fam]+=per[i]*2*1024/1e6
         if fam=="kw": line.append("%.1f"%(per[i]*2*1024/1e6))
     print(m, {k:round(v,1) for k,v in tot.items()}, "kw launches MB:", " ".join(line))
