@@ -39,7 +39,18 @@ struct WgradP {
     int M, chunk;            // rows, rows per split (multiple of 16)
     float* slab;             // [S][Cout][taps][Cin]
     float* dw; float beta;   // S == 1: write OIHW directly (no slab, no reduce launch)
+    int bf16;                // ore_conv_set_precision(ORE_CONV_BF16): both operands rounded to bf16 (nearest even) as they are staged
 };
+
+// bf16-operand mode of the weight gradient: dZ and X are rounded to bf16 on their way into LDS and multiplied on the fp32 MFMA --
+// a product of two bf16 values is exact in fp32 and the accumulation is fp32 either way, so the result is that of a bf16 MFMA up to
+// the summation order (the precision class of configs[4]; no speed-up here, the forward / data-gradient convs use the bf16 MFMA).
+__device__ __forceinline__ float bf16_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+__device__ __forceinline__ f32x4 bf16_rne4(f32x4 v) { return f32x4{bf16_rne(v.x), bf16_rne(v.y), bf16_rne(v.z), bf16_rne(v.w)}; }
 
 constexpr int WG_T = 64;     // block tile: 64 output channels x 64 input channels of one tap
 constexpr int WG_K = 16;     // rows per step
@@ -84,6 +95,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     load(m_begin, va, vb);
     int buf = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+        if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); }
         *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
         *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
         __syncthreads();
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     load(m_begin, va, vb, vb2, msk);
     int buf = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+        if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); vb2 = bf16_rne4(vb2); }
         *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
         *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
         if (lr < 2) *reinterpret_cast<f32x4*>(&sB[buf][WG_K + lr][lc]) = vb2;
@@ -639,6 +652,7 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     S = ceil_div((int)M, p.chunk);
     p.slab = workspace;
     if (S == 1) { p.dw = dw_oihw; p.beta = beta; }
+    p.bf16 = ore_conv_get_precision();
     hipStream_t st = (hipStream_t)stream;
     if (kh == 3 && kw == 3) hipLaunchKernelGGL(k_wgrad3, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * 3, S), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);

@@ -46,31 +46,74 @@ VOVNET_SPECS = {
 # even) at the point where they enter the convolution; accumulation, FrozenBN, eSE, GroupNorm, the depthwise correlation and
 # everything after the head stay fp32.
 _OPERANDS = "fp32"
+_LINEARS = False
 
 
 class operand_precision:
-    """with operand_precision("bf16"): ... -- scoped switch of the dense-conv operand rounding."""
+    """with operand_precision("bf16"): ... -- scoped switch of the dense-conv operand rounding.
+    train=True is the TRAINING form of the mode (tests/test_hip_bf16.py, 5-shot iteration): (i) the Linear / 1x1 layers that the
+    product's training forward also runs on the MFMA conv kernel -- SM_Block's Linears, the second stage's DSA convs, fc1 and the
+    predictors -- round their operands too; (ii) the backward of every such layer rounds ITS operands: dY and W for the data
+    gradient, X and dY for the weight gradient (bias gradients and everything element-wise stay fp32)."""
 
-    def __init__(self, mode: str):
+    def __init__(self, mode: str, train: bool = False):
         assert mode in ("fp32", "bf16")
-        self.mode = mode
+        self.mode, self.train = mode, train
 
     def __enter__(self):
-        global _OPERANDS
-        self.saved, _OPERANDS = _OPERANDS, self.mode
+        global _OPERANDS, _LINEARS
+        self.saved, _OPERANDS, _LINEARS = (_OPERANDS, _LINEARS), self.mode, self.train and self.mode == "bf16"
 
     def __exit__(self, *exc):
-        global _OPERANDS
-        _OPERANDS = self.saved
+        global _OPERANDS, _LINEARS
+        _OPERANDS, _LINEARS = self.saved
 
 
 def _rnd(t: Tensor) -> Tensor:
     return t.bfloat16().float() if _OPERANDS == "bf16" else t
 
 
+class _Bf16ConvFn(torch.autograd.Function):
+    """conv2d on bf16-rounded operands whose backward rounds its operands as well (the product's data- and weight-gradient kernels
+    in ORE_CONV_BF16 mode); products exact in fp32, accumulation fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        xr, wr = x.bfloat16().float(), w.bfloat16().float()
+        ctx.save_for_backward(xr, wr)
+        ctx.sp = (stride, padding)
+        return F.conv2d(xr, wr, None, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        stride, padding = ctx.sp
+        dyr = dy.bfloat16().float()
+        dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, stride=stride, padding=padding) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, stride=stride, padding=padding) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
 def dense_conv(x: Tensor, w: Tensor, b=None, stride: int = 1, padding: int = 0) -> Tensor:
     """F.conv2d with the operand rounding of the current mode (bias and accumulation in fp32)."""
+    if _LINEARS and (x.requires_grad or w.requires_grad):
+        y = _Bf16ConvFn.apply(x, w, stride, padding)
+        return y if b is None else y + b.view(1, -1, 1, 1)
     return F.conv2d(_rnd(x), _rnd(w), b, stride, padding)
+
+
+def dense_linear(x: Tensor, w: Tensor, b=None) -> Tensor:
+    """F.linear; in the training form of the bf16 mode a 1x1 convolution over the rows like the product's (operand_precision)."""
+    if not _LINEARS:
+        return F.linear(x, w, b)
+    shp = x.shape
+    y = dense_conv(x.reshape(-1, shp[-1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1), b)
+    return y.reshape(*shp[:-1], w.shape[0])
+
+
+def dense_conv1x1(x: Tensor, w: Tensor, b=None) -> Tensor:
+    """A 1x1 F.conv2d of the second stage: fp32 unless the training form of the bf16 mode is on."""
+    return dense_conv(x, w, b) if _LINEARS else F.conv2d(x, w, b)
 
 
 PIXEL_MEAN = (103.530, 116.280, 123.675)  # d2z:config/defaults.py PIXEL_MEAN (BGR)
@@ -187,18 +230,18 @@ def sm_block(x: Tensor, sd: SD, prefix: str, seg_dim: int) -> Tensor:
     B, H, W, C = x.shape
     S = C // seg_dim
     h = x.reshape(B, H, W, seg_dim, S).permute(0, 3, 2, 1, 4).reshape(B, seg_dim, W, H * S)
-    h = F.linear(h, sd[prefix + "mlp_h.weight"])
+    h = dense_linear(h, sd[prefix + "mlp_h.weight"])
     h = h.reshape(B, seg_dim, W, H, S).permute(0, 3, 2, 1, 4).reshape(B, H, W, C)
     w = x.reshape(B, H, W, seg_dim, S).permute(0, 3, 1, 2, 4).reshape(B, seg_dim, H, W * S)
-    w = F.linear(w, sd[prefix + "mlp_w.weight"])
+    w = dense_linear(w, sd[prefix + "mlp_w.weight"])
     w = w.reshape(B, seg_dim, H, W, S).permute(0, 2, 3, 1, 4).reshape(B, H, W, C)
     a = (h + w).permute(0, 3, 1, 2).flatten(2).mean(2)
-    a = F.linear(a, sd[prefix + "reweighting.fc1.weight"], sd[prefix + "reweighting.fc1.bias"])
+    a = F.linear(a, sd[prefix + "reweighting.fc1.weight"], sd[prefix + "reweighting.fc1.bias"])   # [B,C]-sized: fp32 in every mode
     a = F.gelu(a)
     a = F.linear(a, sd[prefix + "reweighting.fc2.weight"], sd[prefix + "reweighting.fc2.bias"])
     a = a.reshape(B, C, 2).permute(2, 0, 1).softmax(0).unsqueeze(2).unsqueeze(2)
     y = w * a[0] + h * a[1]
-    return F.linear(y, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
+    return dense_linear(y, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])
 
 
 def support_prototype(p_feat: Tensor, sd: SD, level: int) -> Tensor:
@@ -440,10 +483,10 @@ def roi_head_features(box_feat: Tensor, support_8: Tensor, sd: SD, prefix: str =
     """_run_stage (fsod_roi_heads.py:459-520), the live branch: DSA mix with the mean support feature -> fc1 -> ReLU.
     box_feat [R,C,8,8], support_8 [N,C,8,8].  (attn_4 / fc2 / fc3 are dead compute in the reference: SURVEY App. C.5.)"""
     s = support_8.mean(0, True).expand_as(box_feat)
-    a = F.conv2d(torch.cat((box_feat, s), 1), sd[prefix + "conv3.weight"], sd[prefix + "conv3.bias"]) + \
-        torch.cat((F.conv2d(box_feat, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"]),
-                   F.conv2d(s, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])), 1)
-    return F.relu(F.linear(a.flatten(1), sd[prefix + "box_head.0.fc1.weight"], sd[prefix + "box_head.0.fc1.bias"]))
+    a = dense_conv1x1(torch.cat((box_feat, s), 1), sd[prefix + "conv3.weight"], sd[prefix + "conv3.bias"]) + \
+        torch.cat((dense_conv1x1(box_feat, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"]),
+                   dense_conv1x1(s, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])), 1)
+    return F.relu(dense_linear(a.flatten(1), sd[prefix + "box_head.0.fc1.weight"], sd[prefix + "box_head.0.fc1.bias"]))
 
 
 def roi_head_eval(feats: Sequence[Tensor], proposals: Tensor, support_8: Tensor, sd: SD, image_hw: Tuple[int, int],

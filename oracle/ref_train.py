@@ -99,8 +99,8 @@ def second_stage_losses(feats: Sequence[Tensor], roi_boxes: Tensor, roi_labels: 
     box_feat = R.roi_pool_levels(feats, roi_boxes, 8)
     h = R.roi_head_features(box_feat, sup8, sd, prefix)
     p = prefix + "box_predictor.0."
-    scores = F.linear(h, sd[p + "cls_score.weight"], sd[p + "cls_score.bias"])
-    deltas = F.linear(h, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"])
+    scores = R.dense_linear(h, sd[p + "cls_score.weight"], sd[p + "cls_score.bias"])
+    deltas = R.dense_linear(h, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"])
     loss_cls = F.cross_entropy(scores, roi_labels, reduction="mean")
     fg = torch.nonzero(roi_labels == 0).squeeze(1)
     tgt = get_deltas(roi_boxes[fg], roi_gt[fg])
