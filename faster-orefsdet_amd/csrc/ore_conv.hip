@@ -1187,8 +1187,9 @@ extern "C" int32_t ore_conv_get_precision(void) { return g_conv_bf16; }
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
-    if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !g_conv_bf16 && !d->in_mul && d->Cin % 16 == 0) {
+    if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !d->in_mul && d->Cin % 16 == 0) {
         ConvP q{};
+        q.bf16 = g_conv_bf16;
         q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (d->Cin / 16); q.kh = d->kh;
         const int bm = conv_kw_tile_rows(q);
         if (bm > 0) return ceil_div(q.M, bm);                 // the layer runs on k_conv_kw (same test as conv_launch)
@@ -1202,10 +1203,11 @@ static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t worksp
     if (g_override.BM == 0 && req_splitk <= 1) {
         // several pyramid levels in one launch (the head tower): the 16-pixel-wide patch tiles waste 17-37 % on the 40- and 20-wide
         // levels, k_conv_kw takes it (47 -> 39 us, profiles/r02_kw_sweep.txt)
-        const bool kw_first = g_kw_mode == 2 || (g_kw_mode == 1 && !g_conv_bf16 && p.nlev > 1);
+        p.bf16 = g_conv_bf16;
+        const bool kw_first = g_kw_mode == 2 || (g_kw_mode == 1 && p.nlev > 1);
         const int prc = kw_first ? 1 : patch_launch(p, st);
         if (prc != 1) return prc;
-        if (g_kw_mode && !g_conv_bf16) {                      // small / medium M: the wave-private K-split LDS-DMA kernel (ore_conv_kw.hip)
+        if (g_kw_mode) {                                      // small / medium M: the wave-private K-split LDS-DMA kernel (ore_conv_kw.hip)
             const int krc = conv_kw_launch(p, workspace, workspace_floats, st);
             if (krc != 1) return krc;
             if (kw_first && g_kw_mode != 2) {                 // not covered after all: the patch kernels get their turn

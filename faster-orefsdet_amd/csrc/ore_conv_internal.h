@@ -19,6 +19,7 @@ struct ConvP {
     float* colsum;                       // [gridDim.x][Cout16] or null
     int splitk, steps_per_split, nchunks;
     float* ws; int* tile_cnt;
+    int bf16;                            // ORE_CONV_BF16: operands rounded to bf16 as the fragments leave LDS, one 16x16x16 bf16 MFMA per 16 channels
     int xmap;                            // tile <-> block mapping of k_conv_kw: 0 = blockIdx, 1 / 2 = XCD-contiguous, M- / N-major (tile_of_block)
 };
 

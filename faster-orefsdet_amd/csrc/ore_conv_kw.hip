@@ -88,7 +88,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // lane group (rows {0-3, 12-15} of quad q with rows 4-11 of quad q+1, and its mirror) touches 16 distinct 4-bank groups.
 __device__ __forceinline__ int swz(int r16) { return (0x1320 >> (((r16 >> 2) & 3) * 4)) & 3; }   // {0, 2, 3, 1}
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restrict__ zero_page) {
     constexpr int GA = BM / 16, GB = BN / 16, G = GA + GB;        // DMA instructions (= 16-row groups) per stage
     constexpr int STAGE_F = (BM + BN) * 16;                       // floats per stage
@@ -229,13 +229,25 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
         for (int i = 0; i < GA; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + i * 256 + foff);
 #pragma unroll
         for (int j = 0; j < GB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + (GA + j) * 256 + foff);
+        if constexpr (BF) {                                       // bf16-operand mode: round as the fragments leave LDS, one MFMA per 16 channels
+            s16x4 ah[GA], bh[GB];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+            for (int i = 0; i < GA; ++i) ah[i] = to_bf16x4(af[i]);
+#pragma unroll
+            for (int j = 0; j < GB; ++j) bh[j] = to_bf16x4(bf[j]);
 #pragma unroll
             for (int i = 0; i < GA; ++i)
 #pragma unroll
-                for (int j = 0; j < GB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);   // D^T: lane = pixel
+                for (int j = 0; j < GB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int i = 0; i < GA; ++i)
+#pragma unroll
+                    for (int j = 0; j < GB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);   // D^T: lane = pixel
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this step's fragment reads are done before the slot is refilled
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
@@ -625,7 +637,7 @@ KwTile kw_tile(int M, int C16, int nchunks) {
     return best;
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool BF = false>
 int launch_kw_ns(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
     constexpr int G = (BM + BN) / 16;
     if constexpr ((NS - 1) * G > 63) {
@@ -638,10 +650,10 @@ int launch_kw_ns(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
         } else {
             static bool attr = false;
             if (!attr) {
-                ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kw<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kw<BM, BN, NS, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr = true;
             }
-            hipLaunchKernelGGL((k_conv_kw<BM, BN, NS>), grid, dim3(256), lds, st, p, zero);
+            hipLaunchKernelGGL((k_conv_kw<BM, BN, NS, BF>), grid, dim3(256), lds, st, p, zero);
             return ORE_OK;
         }
     }
@@ -652,6 +664,7 @@ int g_xmap_force = -1;                  // tuning aid: block -> tile mapping of 
 
 template <int BM, int BN>
 int launch_kw(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
+    if (p.bf16) return launch_kw_ns<BM, BN, 2, true>(p, zero, grid, st);
     int ns = 2;                          // (see kw_tile: the minimal ring wins)
     if (g_kw_force[0] > 0 && g_kw_force[2] > 0) ns = g_kw_force[2];
     if (ns == 2) return launch_kw_ns<BM, BN, 2>(p, zero, grid, st);
@@ -669,7 +682,7 @@ int conv_kw_tile_rows(const ConvP& p) {         // rows per block of the kernel 
     if (g_kw_force[0] > 0) return g_kw_force[0];
     if (g_gs_force[0] > 0) return g_gs_force[0];
     if (p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256)) {
-        if (p.M < 6400 || p.kh != 1) return 0;
+        if (p.bf16 || p.M < 6400 || p.kh != 1) return 0;      // (k_conv_gs has no bf16-operand build)
         return (p.Cout16 == 112 || p.Cout16 % 128 == 0 || p.Cout16 == 64) ? 64 : 0;
     }
     return g_kw_force[0] > 0 ? g_kw_force[0] : kw_tile(p.M, p.Cout16, p.nchunks).BM;
@@ -734,7 +747,7 @@ void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] =
 
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
-    if (g_kw_force[0] == 0 && (g_gs_force[0] > 0 || p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256))) return conv_gs_launch(p, st);
+    if (g_kw_force[0] == 0 && (g_gs_force[0] > 0 || p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256))) return p.bf16 ? 1 : conv_gs_launch(p, st);
     KwTile t = kw_tile(p.M, p.Cout16, p.nchunks);
     if (g_kw_force[0] > 0) t = {g_kw_force[0], g_kw_force[1] < p.Cout16 ? g_kw_force[1] : p.Cout16, g_kw_force[3]};
     if (t.BM == 0) return 1;
