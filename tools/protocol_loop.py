@@ -10,6 +10,10 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+if os.environ.get("ORE_XMAP"):                       # A/B aid: force the block -> tile mapping of the conv kernels (0 = plain blockIdx)
+    sys.path.insert(0, os.path.join(ROOT, "faster-orefsdet_amd"))
+    import orehip
+    orehip.lib().ore_conv_set_plan_override(-5, int(os.environ["ORE_XMAP"]), 0, 0, 0)
 model, cfg = bench.build_model(torch.device("cuda", 0))
 imgs = [bench.synth_image(i).cuda() for i in range(4)]
 for i in range(n):

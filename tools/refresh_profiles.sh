@@ -1,0 +1,27 @@
+#!/bin/bash
+# Regenerate the committed measurement artifacts of a round on the GPU box (run from the repo root through gpurun):
+#   bash tools/refresh_profiles.sh r02
+# Writes everything under gpurun_out/<tag>/; copy what should be judged into profiles/ (the last lines print the cp commands).
+set -e -o pipefail
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+# 1. PMC traffic first (bench.py reads profiles/<tag>_pmc_traffic.json for roofline.traffic): two separate counter passes
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_pass.py > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/pmc_pass.py > $OUT/pmc_write.log 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt
+cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+# 2. the default bench command under the kernel trace (the judged line + its rocprof summary)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+cp $(ls $OUT/bench/bench_kernel_stats.csv $OUT/bench/*/bench_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+# 3. one image of the headline protocol, kernel by kernel, and the per-layer conv table
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proto -o proto -- python3 tools/protocol_loop.py 300 > $OUT/proto.log 2>&1
+cp $(ls $OUT/proto/proto_kernel_stats.csv $OUT/proto/*/proto_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_protocol_kernel_stats.csv
+python3 tools/trace_summary.py $OUT/proto 30 > $OUT/${TAG}_bench_image_timeline.txt
+python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline.txt $OUT/${TAG}_conv_layers.txt
+# 4. the same without the profiler (the numbers quoted in DESIGN.md), fp32 and bf16-operand mode
+timeout -k 10 300 python3 bench.py > $OUT/${TAG}_bench_noprof.json 2> $OUT/bench_noprof.err
+timeout -k 10 300 python3 bench.py --conv-operands bf16 --no-cpu-baseline > $OUT/${TAG}_bench_bf16.json 2> $OUT/bench_bf16.err
+tail -3 $OUT/${TAG}_conv_layers.txt
+echo "done: $OUT"
