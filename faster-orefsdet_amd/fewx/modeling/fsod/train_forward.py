@@ -70,10 +70,11 @@ def head_train(head, feats_nhwc: List[torch.Tensor]) -> List[torch.Tensor]:
 
 def _mean_std(model):
     """pixel mean / std as host floats, read from the device once per model."""
+    tag = (model.pixel_mean._version, model.pixel_mean.data_ptr(), model.pixel_std._version, model.pixel_std.data_ptr())
     ms = model.__dict__.get("_ore_mean_std")
-    if ms is None:
-        ms = model.__dict__["_ore_mean_std"] = (tuple(model.pixel_mean.view(-1).tolist()), tuple(model.pixel_std.view(-1).tolist()))
-    return ms
+    if ms is None or ms[0] != tag:                     # (a checkpoint load rewrites the buffers in place: the version counter moves)
+        ms = model.__dict__["_ore_mean_std"] = (tag, tuple(model.pixel_mean.view(-1).tolist()), tuple(model.pixel_std.view(-1).tolist()))
+    return ms[1], ms[2]
 
 
 def dense_part(model, xq: torch.Tensor, xs: torch.Tensor, raw: bool = False):
