@@ -240,41 +240,52 @@ __global__ __launch_bounds__(256) void k_rank_scatter(DetP p) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ n_ptr,
-                                                  float thr, unsigned long long* __restrict__ mask, int words, int col_ld) {
+// One block = one 64 x 64 tile of the IoU matrix, 4 waves: wave q tests the tile's rows against columns 16q .. 16q+15 (a quarter of
+// the serial IoU chain of the one-wave form: 12 -> ~6 us at n = 3000), the four partial words of a row are OR-ed through LDS.
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ n_ptr,
+                                                   float thr, unsigned long long* __restrict__ mask, int words, int col_ld) {
     const int n = *n_ptr;
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
     __shared__ float cb[64 * 4];
     __shared__ float ca[64];
-    const int t = threadIdx.x;
-    const int j = bj * 64 + t;
-    if (j < n) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(boxes + (size_t)j * 4);
-        cb[t * 4 + 0] = b.x; cb[t * 4 + 1] = b.y; cb[t * 4 + 2] = b.z; cb[t * 4 + 3] = b.w;
-        ca[t] = (b.z - b.x) * (b.w - b.y);
+    __shared__ unsigned long long part[4][64];
+    const int t = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (q == 0) {
+        const int j = bj * 64 + t;
+        if (j < n) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(boxes + (size_t)j * 4);
+            cb[t * 4 + 0] = b.x; cb[t * 4 + 1] = b.y; cb[t * 4 + 2] = b.z; cb[t * 4 + 3] = b.w;
+            ca[t] = (b.z - b.x) * (b.w - b.y);
+        }
     }
     __syncthreads();
     const int i = bi * 64 + t;
-    if (i >= n) return;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(boxes + (size_t)i * 4);
-    const float ai = (a.z - a.x) * (a.w - a.y);
     unsigned long long bits = 0;
-    const int jmax = min(64, n - bj * 64);
-    // off-diagonal block (bj > bi): bit c = "row i suppresses row bj*64+c".  Diagonal block: the TRANSPOSED word, bit c (c < t) =
-    // "row i is suppressed by row bi*64+c" (IoU is symmetric and computed from the same operands, so this is exactly the transpose
-    // of the upper triangle): the scan resolves a block with one AND + ballot per fixpoint iteration instead of a scalar loop
-    // over the suppressing rows.
-    const bool dg = bi == bj;
-    for (int c = 0; c < jmax; ++c) {
-        if (dg && c >= t) continue;
-        const float xx1 = fmaxf(a.x, cb[c * 4 + 0]), yy1 = fmaxf(a.y, cb[c * 4 + 1]);
-        const float xx2 = fminf(a.z, cb[c * 4 + 2]), yy2 = fminf(a.w, cb[c * 4 + 3]);
-        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-        const float inter = w * h;
-        const float ovr = inter / (ai + ca[c] - inter);
-        if (ovr > thr) bits |= 1ull << c;
+    if (i < n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(boxes + (size_t)i * 4);
+        const float ai = (a.z - a.x) * (a.w - a.y);
+        const int jmax = min(64, n - bj * 64);
+        // off-diagonal block (bj > bi): bit c = "row i suppresses row bj*64+c".  Diagonal block: the TRANSPOSED word, bit c (c < t) =
+        // "row i is suppressed by row bi*64+c" (IoU is symmetric and computed from the same operands, so this is exactly the transpose
+        // of the upper triangle): the scan resolves a block with one AND + ballot per fixpoint iteration instead of a scalar loop
+        // over the suppressing rows.
+        const bool dg = bi == bj;
+        const int c1 = min(jmax, q * 16 + 16);
+        for (int c = q * 16; c < c1; ++c) {
+            if (dg && c >= t) continue;
+            const float xx1 = fmaxf(a.x, cb[c * 4 + 0]), yy1 = fmaxf(a.y, cb[c * 4 + 1]);
+            const float xx2 = fminf(a.z, cb[c * 4 + 2]), yy2 = fminf(a.w, cb[c * 4 + 3]);
+            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+            const float inter = w * h;
+            const float ovr = inter / (ai + ca[c] - inter);
+            if (ovr > thr) bits |= 1ull << c;
+        }
     }
+    part[q][t] = bits;
+    __syncthreads();
+    if (q != 0 || i >= n) return;
+    bits = (part[0][t] | part[1][t]) | (part[2][t] | part[3][t]);
     if (col_ld > 0) mask[(size_t)bj * col_ld + i] = bits;        // column-major [word][row]: what k_nms_scan_col streams into LDS
     else mask[(size_t)i * words + bj] = bits;
 }
@@ -659,7 +670,7 @@ static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa
         ORE_HIP(hipFuncSetAttribute((const void*)k_rank_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_bytes));
     hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(cap, 16)), dim3(256), sc_bytes, st, p);
     if ((rc = ore_launch_status("k_rank_scatter"))) return rc;
-    hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(64), 0, st, p.s_boxes, p.counts, d->nms_thresh, p.mask,
+    hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(256), 0, st, p.s_boxes, p.counts, d->nms_thresh, p.mask,
                        lay.words, nms_use_col(cap) ? cap : 0);
     if ((rc = ore_launch_status("k_nms_mask"))) return rc;
     sa = ScanArgs{p.s_boxes, p.s_scores, p.s_order, p.counts, p.mask, p.keep_idx, p.out_boxes, p.out_scores, p.counts + 1};
@@ -801,7 +812,7 @@ static int nms_pipeline(const float* boxes, const float* scores, int n, const in
                        s_scores, s_order, n_dev);
     if ((rc = ore_launch_status("k_nms_prep"))) return rc;
     if (thr > 0.0f && n > 0) {
-        hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(64), 0, st, s_boxes, n_dev, thr, mask, lay.words,
+        hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(256), 0, st, s_boxes, n_dev, thr, mask, lay.words,
                            nms_use_col(n) ? n : 0);
         if ((rc = ore_launch_status("k_nms_mask"))) return rc;
     }
