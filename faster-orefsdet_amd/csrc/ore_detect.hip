@@ -438,9 +438,10 @@ __global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_col(const float* __restr
                                                             long long* __restrict__ keep_idx, float* __restrict__ out_boxes,
                                                             float* __restrict__ out_scores, int* __restrict__ n_keep_out,
                                                             const unsigned long long* __restrict__ zero_page) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long cl[];    // ring [RING][SLOT] + kept[64] + misc[8] + scores[CAP] (float)
+    extern __shared__ __attribute__((aligned(16))) unsigned long long cl[];    // ring [RING][SLOT] + kept[64] + part[64] + misc[8] + scores[CAP] (float)
     unsigned long long* kept_w = cl + NMS_COL_RING * NMS_COL_SLOT;
-    unsigned long long* misc = kept_w + 64;                  // [0] removed word under construction, [2] stop flag, [3] survivors
+    unsigned long long* part = kept_w + 64;                  // [64] part[w]: column w reduced over the survivors of blocks 0 .. w-2
+    unsigned long long* misc = part + 64;                    // [0], [1] stop flag of even / odd steps, [3] survivors, [4..6] final broadcast
     float* sc = reinterpret_cast<float*>(misc + 8);          // the sorted scores: the threshold logic never touches global memory
     int* pre = reinterpret_cast<int*>(sc + NMS_COL_CAP);     // [64] exclusive prefix of the kept counts per block
     const int n = min(*n_ptr, NMS_COL_CAP);
@@ -462,38 +463,47 @@ __global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_col(const float* __restr
     };
     // scores first (ordinary loads: issued and retired before any DMA is in flight)
     for (int i = tid; i < n; i += NMS_COL_T) sc[i] = s_scores[i];
-    if (tid < 64) kept_w[tid] = 0ull;
-    if (tid == 0) { misc[0] = 0ull; misc[2] = 0ull; misc[3] = 0ull; misc[6] = 0ull; }
+    if (tid < 64) { kept_w[tid] = 0ull; part[tid] = 0ull; }
+    if (tid == 0) { misc[0] = 0ull; misc[1] = 0ull; misc[3] = 0ull; misc[6] = 0ull; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int c = 0; c < NMS_COL_RING - 1; ++c) issue(c);
     int n_keep = 0;
     float thr_score = 0.f;
     bool have_thr = false;
+    // Two-stage pipeline, ONE barrier per 64-row block.  In step w wave 0 resolves block w while waves 1..15 already reduce column
+    // w+1 over the survivors of blocks 0..w-1 (known since the previous step) into part[w+1]; what block w itself contributes to
+    // column w+1 -- 64 words -- wave 0 adds in step w+1, right after it has decided block w (hoisting those reads in front of
+    // the barrier does not help: the barrier needs lgkmcnt(0) first -- measured 33.8 vs 31.4 us).  The all-thread reduction and its
+    // second barrier are off wave 0's dependent chain (0.86 -> ~0.45 us per block).
     for (int w = 0; w < nb; ++w) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this wave's pieces of column w have landed (2 younger columns in flight)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // this wave's pieces of columns w and w+1 have landed (column w+2 in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // everybody's have; everybody left step w-1; wave 0 published its verdict
-        if (misc[2]) break;                                    // post_topk survivors (and their score ties) are known
-        issue(w + NMS_COL_RING - 1);                           // into the slot of column w-1
-        const unsigned long long* col = cl + (w % NMS_COL_RING) * NMS_COL_SLOT;
-        // removed[w] = OR of col[r] over the kept rows r < 64 w (a compact list of the survivors read by fewer threads + per-lane LDS
-        // atomics measured SLOWER: 50 vs 41 us)
-        unsigned long long v = 0ull;
-        for (int r = tid; r < w * 64; r += NMS_COL_T)
-            if ((kept_w[r >> 6] >> (r & 63)) & 1ull) v |= col[r];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const unsigned lo = __shfl_xor((unsigned)v, d), hi = __shfl_xor((unsigned)(v >> 32), d);
-            v |= ((unsigned long long)hi << 32) | lo;
-        }
-        if (lane == 0 && v) atomicOr(&misc[0], v);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (wave == 0) {
+        __builtin_amdgcn_s_barrier();                          // everybody's have; step w-1 is over: kept_w[w-1], part[w] and the verdict are published
+        if (misc[(w + 1) & 1]) break;                          // verdict of step w-1 (parity slots: wave 0 may already be writing step w's)
+        issue(w + NMS_COL_RING - 1);                           // into the slot of column w-1 (last read in step w-1)
+        if (wave != 0) {
+            if (w + 1 < nb) {
+                const unsigned long long* col = cl + ((w + 1) % NMS_COL_RING) * NMS_COL_SLOT;
+                // survivors are few (<= post_topk of thousands): the lanes that hold one OR its word straight into part[w+1]; a 64-bit
+                // shuffle reduction per wave (24 cross-lane LDS ops x 15 waves per block) kept the CU's LDS pipe busy under wave 0's feet
+                for (int r = tid - 64; r < w * 64; r += NMS_COL_T - 64)
+                    if ((kept_w[r >> 6] >> (r & 63)) & 1ull) {
+                        const unsigned long long v = col[r];
+                        if (v) atomicOr(&part[w + 1], v);
+                    }
+            }
+        } else {
+            const unsigned long long* col = cl + (w % NMS_COL_RING) * NMS_COL_SLOT;
             const int row = w * 64 + lane;
             const unsigned long long diag = row < n ? col[row] : 0ull;
-            unsigned long long rem = misc[0];
+            if (w > 0) {                                          // the survivors of block w-1 (decided in the previous step): a handful of
+                if ((kept_w[w - 1] >> lane) & 1ull) {             // lanes OR their word into part[w] (LDS atomics of ONE wave execute in
+                    const unsigned long long v = col[(w - 1) * 64 + lane];   // order, the read below sees them)
+                    if (v) atomicOr(&part[w], v);
+                }
+            }
+            unsigned long long rem = part[w];
             const int nvalid = min(64, n - w * 64);
             if (nvalid < 64) rem |= ~0ull << nvalid;
             const unsigned long long cand = ~rem;
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_col(const float* __restr
                 const int last = min(n, (w + 1) * 64) - 1;
                 if (sc[last] < thr_score) stop = true;                // later rows are all below the threshold score
             }
-            if (lane == 0) { kept_w[w] = kept; pre[w] = n_keep - kc; misc[0] = 0ull; misc[2] = stop ? 1ull : 0ull; misc[3] = (unsigned long long)n_keep; }
+            if (lane == 0) { kept_w[w] = kept; pre[w] = n_keep - kc; misc[w & 1] = stop ? 1ull : 0ull; misc[3] = (unsigned long long)n_keep; }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -567,7 +577,7 @@ static int launch_nms_scan(int words, hipStream_t st, const float* s_boxes, cons
         ORE_HIP(hipGetDevice(&dev));
         ORE_CHECK_ARG(dev >= 0 && dev < 16, "launch_nms_scan: device %d", dev);
         if (!zp[dev]) { void* q = nullptr; ORE_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_nms))); zp[dev] = (const unsigned long long*)q; }
-        const size_t lds = ((size_t)NMS_COL_RING * NMS_COL_SLOT + 64 + 8) * sizeof(unsigned long long) + (size_t)NMS_COL_CAP * 4 + 64 * 4;
+        const size_t lds = ((size_t)NMS_COL_RING * NMS_COL_SLOT + 64 + 64 + 8) * sizeof(unsigned long long) + (size_t)NMS_COL_CAP * 4 + 64 * 4;
         static bool attr = false;
         if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_nms_scan_col, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
         hipLaunchKernelGGL(k_nms_scan_col, dim3(1), dim3(NMS_COL_T), lds, st, s_boxes, s_scores, s_order, n_ptr, mask, col_cap, post_topk,
