@@ -417,8 +417,9 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
     __shared__ __attribute__((aligned(16))) float sb[ROI_FUSED_CAP * 4];    // sorted by score (desc, stable)
     __shared__ float sa[ROI_FUSED_CAP];                                     // areas, sorted order
     __shared__ int sord[ROI_FUSED_CAP];                                     // sorted position -> compacted index
-    __shared__ unsigned long long diagT[ROI_FUSED_CAP];                     // bit c: row is suppressed by row (blk*64+c), c < own lane
-    __shared__ unsigned long long up[ROI_FUSED_CAP * (ROI_FUSED_CAP / 64)]; // [row][word]: bit c: row suppresses row word*64+c (word > blk)
+    // supT[row][b]: bit r = sorted row b*64+r suppresses `row` (IoU > threshold; in the row's own block only earlier rows).  The word is
+    // indexed by the SUPPRESSED row, so the greedy walk needs no cross-lane reduction: lane = row tests its own words against the kept masks.
+    __shared__ unsigned long long supT[ROI_FUSED_CAP * (ROI_FUSED_CAP / 64)];
     __shared__ int wsum[T / 64];
     __shared__ int keep_pos[ROI_FUSED_CAP];
     __shared__ int sh_keep;
@@ -469,8 +470,11 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
         }
     }
     __syncthreads();
-    // ---- suppression bits.  Unit of work = 16 rows of one 64x64 tile (bi <= w); lane = COLUMN of the tile, the row box is a
-    // broadcast LDS read, one ballot per row gives its 64-bit word.  Same float ops as k_nms_mask (row box = `a`, column box = `q`).
+    // ---- suppression bits.  Unit of work = 16 rows of one 64x64 tile (bi <= w); lane = COLUMN of the tile = the candidate that may be
+    // suppressed, the row box is a broadcast LDS read; the lane collects the 16 rows' verdicts in its own word and ORs it into supT (the
+    // four units of a tile own disjoint bit ranges).  Same float ops as k_nms_mask (row box = `a`, column box = `q`).
+    for (int i = tid; i < m * WPR; i += T) supT[i] = 0ull;
+    __syncthreads();
     {
         const int ntile = words * (words + 1) / 2;
         for (int u = wave; u < ntile * 4; u += NW) {
@@ -482,6 +486,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
             const f32x4 q = cvalid ? *reinterpret_cast<const f32x4*>(sb + col * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             const float aq = cvalid ? sa[col] : 0.f;
             const bool dg = w == bi;
+            unsigned long long acc = 0ull;
 #pragma unroll 4
             for (int rr = 0; rr < 16; ++rr) {
                 const int row = bi * 64 + rq + rr;
@@ -493,42 +498,43 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
                 const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
                 const float inter = ww * hh;
                 const float ovr = inter / (ai + aq - inter);
-                const unsigned long long bits = __ballot(cvalid && ovr > p.nms_thresh);
-                if (lane == 0) {
-                    if (dg) diagT[row] = bits & ((1ull << (rq + rr)) - 1ull);   // earlier rows of the block that suppress this row
-                    else up[row * WPR + w] = bits;
-                }
+                if (cvalid && ovr > p.nms_thresh && (!dg || rq + rr < lane)) acc |= 1ull << (rq + rr);   // own block: earlier rows only
             }
+            if (acc) atomicOr(&supT[col * WPR + bi], acc);
         }
     }
     __syncthreads();
-    // ---- greedy resolution, wave 0: lane = row of the current 64-row block; removed words live in lane w of `rem`
+    // ---- greedy resolution, wave 0: lane = row of the current 64-row block; kept masks of the earlier blocks are wave-uniform registers
     if (wave == 0) {
-        unsigned long long rem = 0ull;            // lane w (< words) holds removed[w]
+        unsigned long long keptw[WPR];
+#pragma unroll
+        for (int b2 = 0; b2 < WPR; ++b2) keptw[b2] = 0ull;
         int n_keep = 0;
-        for (int bi = 0; bi < words; ++bi) {
-            const int row = bi * 64 + lane;
-            const unsigned long long diag = row < m ? diagT[row] : 0ull;
-            const unsigned rlo = __shfl((unsigned)rem, bi), rhi = __shfl((unsigned)(rem >> 32), bi);
-            unsigned long long rm = ((unsigned long long)rhi << 32) | rlo;       // removed[bi], wave-uniform
-            const int nvalid = min(64, m - bi * 64);
-            if (nvalid < 64) rm |= ~0ull << nvalid;
-            const unsigned long long cand = ~rm;
-            unsigned long long kept = cand;
-            if (__ballot(diag != 0ull) != 0ull) {
-                for (int it = 0; it < 64; ++it) {
-                    const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
-                    if (kn == kept) break;
-                    kept = kn;
+#pragma unroll
+        for (int bi = 0; bi < WPR; ++bi) {
+            if (bi < words) {
+                const int row = bi * 64 + lane;
+                const bool rvalid = row < m;
+                unsigned long long hit = 0ull;
+#pragma unroll
+                for (int b2 = 0; b2 < WPR; ++b2)
+                    if (b2 < bi) hit |= (rvalid ? supT[row * WPR + b2] : 0ull) & keptw[b2];
+                const unsigned long long diag = rvalid ? supT[row * WPR + bi] : 0ull;
+                unsigned long long rm = __ballot(hit != 0ull);                   // removed by a survivor of an earlier block
+                const int nvalid = min(64, m - bi * 64);
+                if (nvalid < 64) rm |= ~0ull << nvalid;
+                const unsigned long long cand = ~rm;
+                unsigned long long kept = cand;
+                if (__ballot(diag != 0ull) != 0ull) {
+                    for (int it = 0; it < 64; ++it) {
+                        const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
+                        if (kn == kept) break;
+                        kept = kn;
+                    }
                 }
-            }
-            if ((kept >> lane) & 1ull) keep_pos[n_keep + __popcll(kept & ((1ull << lane) - 1ull))] = row;
-            n_keep += __popcll(kept);
-            // OR the kept rows' words into removed[bi+1 ..]: lane = row, one wave-wide OR per later word
-            for (int w = bi + 1; w < words; ++w) {
-                const unsigned long long v = (((kept >> lane) & 1ull) && row < m) ? up[row * WPR + w] : 0ull;
-                const unsigned long long o = wave_or64(v);
-                if (lane == w) rem |= o;
+                if ((kept >> lane) & 1ull) keep_pos[n_keep + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+                n_keep += __popcll(kept);
+                keptw[bi] = kept;
             }
         }
         if (lane == 0) sh_keep = n_keep;
