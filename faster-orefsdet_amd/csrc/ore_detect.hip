@@ -82,7 +82,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds_w, int* total) {
 
 __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     extern __shared__ __attribute__((aligned(16))) float sv[];   // sigmoid of every location of this level (computed once)
-    __shared__ int hist[256];
+    __shared__ int hist[1024];
     __shared__ int wsum[SEL_T / 64];
     __shared__ int sh_i[4];
     const int l = blockIdx.x;
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     block_excl_scan(cnt, wsum, &nc);   // (its barriers also publish sv[])
     const int k = nc < p.pre_topk ? nc : p.pre_topk;
 
-    // ---- exact k-th largest sigmoid (bits are order-preserving for positive floats): 4 x 8-bit radix select
+    // ---- exact k-th largest sigmoid (bits are order-preserving for positive floats): a sigmoid is in (0, 1], so its key is below 2^30:
+    // 3 x 10-bit radix select (1024 bins: a quarter of the same-bin LDS atomic collisions of 256 bins, and one pass fewer)
     unsigned T = 0;      // threshold key; select key > T, plus `quota` lowest-index elements with key == T
     int quota = 0;
     bool take_all = true;
@@ -109,20 +110,21 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
         take_all = false;
         unsigned prefix = 0, pmask = 0;
         int remaining = k;
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            for (int i = tid; i < 256; i += SEL_T) hist[i] = 0;
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = 20 - 10 * pass;
+            for (int i = tid; i < 1024; i += SEL_T) hist[i] = 0;
             __syncthreads();
             for (int i = tid; i < HW; i += SEL_T) {
                 const float s = sv[i];
                 const unsigned key = __float_as_uint(s);
-                if (s > p.score_thresh && (key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+                if (s > p.score_thresh && (key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 1023], 1);
             }
             __syncthreads();
             if (tid < 64) {
-                // lane L owns bins 4L..4L+3; suffix sums over lanes locate the bin where the count from the top reaches `remaining`
-                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-                const int t = h0 + h1 + h2 + h3;
+                // lane L owns bins 16L..16L+15; suffix sums over lanes locate the lane where the count from the top reaches `remaining`
+                int h[16], t = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { h[j] = hist[16 * tid + j]; t += h[j]; }
                 int suf = t;                                   // inclusive suffix sum over lanes >= tid
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
@@ -131,19 +133,21 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
                 }
                 const int above = suf - t;
                 if (suf >= remaining && above < remaining) {   // exactly one lane
-                    int acc = above, dsel, rem;
-                    if (acc + h3 >= remaining) { dsel = 3; rem = remaining - acc; }
-                    else { acc += h3;
-                        if (acc + h2 >= remaining) { dsel = 2; rem = remaining - acc; }
-                        else { acc += h2;
-                            if (acc + h1 >= remaining) { dsel = 1; rem = remaining - acc; }
-                            else { acc += h1; dsel = 0; rem = remaining - acc; } } }
-                    sh_i[0] = 4 * tid + dsel; sh_i[1] = rem;
+                    int acc = above, dsel = 0, rem = remaining;
+                    bool found = false;
+#pragma unroll
+                    for (int j = 15; j >= 0; --j) {
+                        if (!found) {
+                            if (acc + h[j] >= remaining) { dsel = j; rem = remaining - acc; found = true; }
+                            else acc += h[j];
+                        }
+                    }
+                    sh_i[0] = 16 * tid + dsel; sh_i[1] = rem;
                 }
             }
             __syncthreads();
             prefix |= (unsigned)sh_i[0] << shift;
-            pmask |= 255u << shift;
+            pmask |= 1023u << shift;
             remaining = sh_i[1];
             __syncthreads();
         }
