@@ -9,7 +9,7 @@
 //
 // Kernels
 //   k_level_select  one 1024-thread block per FPN level: candidate count, exact k-th value by a
-//                   4x8-bit radix select on the sigmoid bits (wavefront ballots + LDS histogram),
+//                   3x10-bit radix select on the sigmoid bits (LDS histogram + wavefront suffix scan),
 //                   ties resolved by ascending flat index through an ordered block scan, decode.
 //   k_rank_scatter  rank of every candidate by counting (score desc, concatenated index asc) with
 //                   16 lanes per candidate; scatters boxes/scores into sorted order.
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
             __syncthreads();
             prefix |= (unsigned)sh_i[0] << shift;
             pmask |= 1023u << shift;
-            remaining = sh_i[1];
-            __syncthreads();
+            remaining = sh_i[1];                   // (sh_i is rewritten only behind the next pass's two barriers: no barrier needed here)
         }
         T = prefix; quota = remaining;  // `remaining` of the elements equal to T are taken
     }
@@ -157,28 +156,31 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     // ---- ordered selection + decode (ascending flat index); one packed scan per tile: low 16 bits = ties, high = greater
     const float st = (float)p.stride[l];
     const float half = (float)(p.stride[l] / 2);
-    int tie_base = 0, out_base = 0;
     long long loc_base = 0;
     for (int j = 0; j < l; ++j) loc_base += (long long)p.H[j] * p.W[j];
-    for (int i0 = 0; i0 < HW; i0 += SEL_T) {
-        const int i = i0 + tid;
-        float s = 0.f;
-        bool gt = false, tie = false;
-        if (i < HW) {
-            s = sv[i];
-            const bool cand = s > p.score_thresh;
-            const unsigned key = __float_as_uint(s);
-            gt = cand && (take_all || key > T);
-            tie = cand && !take_all && key == T;
-        }
-        int tot;
-        const int pre = block_excl_scan((gt ? 65536 : 0) | (tie ? 1 : 0), wsum, &tot);
-        const int tie_pre = pre & 0xffff, gt_pre = pre >> 16;
-        const int ties_taken_before_tile = min(tie_base, quota);
-        const int ties_taken_before_me = min(tie_base + tie_pre, quota) - ties_taken_before_tile;
-        const bool sel = gt || (tie && tie_base + tie_pre < quota);
-        if (sel) {
-            const int pos = out_base + gt_pre + ties_taken_before_me;
+    // thread t owns the CONTIGUOUS locations [t * per, (t + 1) * per): one block scan of (greater, tie) counts for the whole level
+    // (a strided ownership needs one scan -- two barriers -- per 1024 locations), then every thread emits its own run in index order
+    const int per = (HW + SEL_T - 1) / SEL_T;
+    const int i_lo = min(tid * per, HW), i_hi = min(i_lo + per, HW);
+    int my_gt = 0, my_tie = 0;
+    for (int i = i_lo; i < i_hi; ++i) {
+        const float s = sv[i];
+        const bool cand = s > p.score_thresh;
+        const unsigned key = __float_as_uint(s);
+        my_gt += (cand && (take_all || key > T)) ? 1 : 0;
+        my_tie += (cand && !take_all && key == T) ? 1 : 0;
+    }
+    int tot;
+    const int pre = block_excl_scan((my_gt << 16) | my_tie, wsum, &tot);
+    int tie_before = pre & 0xffff, gt_before = pre >> 16;
+    for (int i = i_lo; i < i_hi; ++i) {
+        const float s = sv[i];
+        const bool cand = s > p.score_thresh;
+        const unsigned key = __float_as_uint(s);
+        const bool gt = cand && (take_all || key > T);
+        const bool tie = cand && !take_all && key == T;
+        if (gt || (tie && tie_before < quota)) {
+            const int pos = gt_before + min(tie_before, quota);
             const float gx = (float)((i % p.W[l]) * p.stride[l]) + half;
             const float gy = (float)((i / p.W[l]) * p.stride[l]) + half;
             const f32x4 r = *reinterpret_cast<const f32x4*>(hd + (size_t)i * p.head_ld);
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
             p.lvl_scores[o] = sqrtf(s);
             p.lvl_loc[o] = loc_base + i;
         }
-        const int tile_ties = tot & 0xffff, tile_gt = tot >> 16;
-        out_base += tile_gt + (min(tie_base + tile_ties, quota) - ties_taken_before_tile);
-        tie_base += tile_ties;
+        gt_before += gt ? 1 : 0;
+        tie_before += tie ? 1 : 0;
     }
+    const int out_base = (tot >> 16) + min(tot & 0xffff, quota);
     if (tid == 0) p.lvl_cnt[l] = out_base;
 }
 
