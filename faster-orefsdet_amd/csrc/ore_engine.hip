@@ -61,6 +61,7 @@ struct ore_engine {
     Buf s1, s2, cat[4], sout[4], lat[3];
     Buf pcat, pos, tow, head;                    // all pyramid levels in ONE level-major matrix each ([level][b][y][x])
     float* gate[4] = {};
+    float* lat_scaled[3] = {};                   // bs = 1: the lateral weights times the stage's eSE gate (written by the gate kernel)
     float* gn_mul = nullptr, *gn_add = nullptr;  // [3*B][C]
     float* ws = nullptr; size_t ws_floats = 0;   // conv split-K counters + slabs (include/ore_hip.h workspace contract)
     float* ese_ws = nullptr;
@@ -259,6 +260,7 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
     r.flops += 2.0 * g.B * g.h[1] * g.w[1] * 27.0 * c.stem_ch[0];
     r.conv(e->stem2, e->s1.p, e->s1.ld, 0, g.B, g.h[1], g.w[1], e->s2.p, e->s2.ld, 0);
     r.conv(e->stem3, e->s2.p, e->s2.ld, 0, g.B, g.h[1], g.w[1], e->cat[0].p, e->cat[0].ld, 0);
+    bool lat_scaled_ok[3] = {false, false, false};         // this forward wrote lat_scaled[l] (bs = 1 with the fused column sums)
     for (int s = 0; s < 4 && !r.rc; ++s) {
         auto& S = e->stage[s];
         const int k = s + 2;
@@ -277,7 +279,11 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
         r.conv(S.concat, cat.p, cat.ld, 0, g.B, g.h[k], g.w[k], e->sout[s].p, e->sout[s].ld, 0, nullptr, nullptr, 0, nullptr, 0, 0,
                g.B == 1 ? e->colsum : nullptr, &cs_rows);   // eSE average pool fused into the concat conv's epilogue
         if (r.rc) break;
-        if (cs_rows > 0)
+        if (cs_rows > 0 && s >= 1 && e->lat_scaled[s - 1]) { // bs = 1: gate + the gate-scaled lateral weight of this stage in one launch
+            lat_scaled_ok[s - 1] = true;
+            r.rc = ore_ese_gate_scaled_weight_fwd(e->colsum, cs_rows, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws,
+                                                  e->lateral[s - 1].w, round_up(e->lateral[s - 1].Cout, 16), e->lat_scaled[s - 1], st);
+        } else if (cs_rows > 0)
             r.rc = ore_ese_gate_from_colsum_fwd(e->colsum, cs_rows, 1, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws, st);
         else
             r.rc = ore_ese_gate_fwd(e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s],
@@ -288,8 +294,14 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
     for (int l = 2; l >= 0 && !r.rc; --l) {
         const int k = l + 3, s = l + 1;
         const float* add = l < 2 ? e->lat[l + 1].p : nullptr;
-        r.conv(e->lateral[l], e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, e->gate[s], nullptr, 0,
-               add, F, 0);
+        if (lat_scaled_ok[l]) {                             // x * (g W): plain conv on the gate-scaled weights (k_conv_kw)
+            Conv lc = e->lateral[l];
+            lc.w = e->lat_scaled[l];
+            r.conv(lc, e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, nullptr, nullptr, 0, add, F, 0);
+        } else {
+            r.conv(e->lateral[l], e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, e->gate[s], nullptr, 0,
+                   add, F, 0);
+        }
         r.conv(e->output[l], e->lat[l].p, F, 0, g.B, g.h[k], g.w[k], e->pcat.p + (size_t)lvl_row0(g, l) * 2 * F, 2 * F, F);
     }
     *flops = r.flops;
@@ -571,6 +583,7 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
         if ((rc = alloc_buf(e, &e->cat[s], M, e->stage[s].cat_ch))) return rc;
         if ((rc = alloc_buf(e, &e->sout[s], M, e->stage[s].out_ch))) return rc;
         if ((rc = e->dalloc(&e->gate[s], B * e->stage[s].out_ch))) return rc;
+        if (s >= 1 && (rc = e->dalloc(&e->lat_scaled[s - 1], (size_t)round_up(e->cfg.fpn_ch, 16) * e->stage[s].out_ch))) return rc;
         if ((size_t)e->stage[s].out_ch > cmax) cmax = e->stage[s].out_ch;
         const size_t cs = (M / 16 + 1) * (size_t)e->stage[s].out_ch;     // worst case: 16-row tiles
         if (cs > cs_need) cs_need = cs;

@@ -171,20 +171,36 @@ __global__ __launch_bounds__(256) void k_colmean(const float* __restrict__ part,
 }
 
 // pass 2b: gate = relu6(fc(mean) + 3) / 6; one wave per output channel (coalesced weight row), 4 outputs per block.
+// Optional (bs = 1 engine): the block also writes the four gate-scaled COLUMNS of a consumer's packed 1x1 weight, lws[n][o] =
+// lw[n][o] * gate[o] (n < lrows, 16 bytes per row and block) -- the FPN lateral of this stage then reads x * (g W) instead of
+// (x * g) W: the same product with the per-channel multiplier moved onto the weights, so the lateral runs on the DMA-fed conv kernel
+// (which cannot touch its A operand) instead of k_conv_igemm's input-affine path.
 __global__ __launch_bounds__(256) void k_ese_gate(const float* __restrict__ mean, int C, const float* __restrict__ fw,
-                                                  const float* __restrict__ fb, float* __restrict__ gate) {
+                                                  const float* __restrict__ fb, float* __restrict__ gate,
+                                                  const float* __restrict__ lw, float* __restrict__ lws, int lrows) {
+    __shared__ float g4[4];
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + wave;
-    if (o >= C) return;
-    const float* m = mean + (size_t)b * C;
-    float s = 0.f;
-    for (int k = lane; k < C; k += 64) s += fw[(size_t)o * C + k] * m[k];
+    if (o < C) {
+        const float* m = mean + (size_t)b * C;
+        float s = 0.f;
+        for (int k = lane; k < C; k += 64) s += fw[(size_t)o * C + k] * m[k];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-    if (lane == 0) {
-        const float v = s + fb[o] + 3.0f;
-        gate[b * C + o] = fminf(fmaxf(v, 0.f), 6.0f) / 6.0f;
+        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0) {
+            const float v = s + fb[o] + 3.0f;
+            const float gv = fminf(fmaxf(v, 0.f), 6.0f) / 6.0f;
+            gate[b * C + o] = gv;
+            g4[wave] = gv;
+        }
+    }
+    if (!lws) return;                                   // (uniform)
+    __syncthreads();
+    const int o0 = blockIdx.x * 4;                      // C % 4 == 0: the four columns of this block are all real
+    for (int n = threadIdx.x; n < lrows; n += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lw + (size_t)n * C + o0);
+        *reinterpret_cast<f32x4*>(lws + (size_t)n * C + o0) = f32x4{w.x * g4[0], w.y * g4[1], w.z * g4[2], w.w * g4[3]};
     }
 }
 
@@ -507,7 +523,7 @@ extern "C" int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_
     float* mean = workspace + (size_t)B * P * C;
     hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), B), dim3(256), 0, st, workspace, P, HW, C, mean);
     if ((rc = ore_launch_status("k_colmean"))) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean, C, fc_w, fc_b, gate);
+    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean, C, fc_w, fc_b, gate, (const float*)nullptr, (float*)nullptr, 0);
     return ore_launch_status("k_ese_gate");
 }
 
@@ -519,7 +535,20 @@ extern "C" int ore_ese_gate_from_colsum_fwd(const float* part, int32_t P, int32_
     hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), B), dim3(256), 0, st, part, P, HW, C, mean_ws);
     int rc = ore_launch_status("k_colmean");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate);
+    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, (const float*)nullptr, (float*)nullptr, 0);
+    return ore_launch_status("k_ese_gate");
+}
+
+extern "C" int ore_ese_gate_scaled_weight_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
+                                              float* gate, float* mean_ws, const float* w_packed, int32_t w_rows, float* w_scaled,
+                                              void* stream) {
+    ORE_CHECK_ARG(part && fc_w && fc_b && gate && mean_ws && w_packed && w_scaled && P > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096 &&
+                      w_rows > 0, "ore_ese_gate_scaled_weight_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), 1), dim3(256), 0, st, part, P, HW, C, mean_ws);
+    int rc = ore_launch_status("k_colmean");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), 1), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, w_packed, w_scaled, (int)w_rows);
     return ore_launch_status("k_ese_gate");
 }
 

@@ -124,6 +124,11 @@ int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_
  * mean_ws >= B*C floats. */
 int ore_ese_gate_from_colsum_fwd(const float* part, int32_t P, int32_t B, int32_t HW, int32_t C,
                                  const float* fc_w, const float* fc_b, float* gate, float* mean_ws, void* stream);
+/* The same for ONE image, and in the same launch the gate-scaled copy of a consumer's packed 1x1 weight: w_scaled[n][c] = w_packed[n][c] *
+ * gate[c], n < w_rows (ore_pack_conv_weight layout [Cout16][C]).  The FPN lateral of the stage (d2z:modeling/backbone/fpn.py:136,
+ * fed with x * gate by vovnet.py:238-260) then computes x * (g W) instead of (x * g) W on the plain conv path. */
+int ore_ese_gate_scaled_weight_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
+                                   float* gate, float* mean_ws, const float* w_packed, int32_t w_rows, float* w_scaled, void* stream);
 
 /* y = x * gate[b][c]  (materialises the eSE output; the fused engine folds the gate into consumers). */
 int ore_scale_channels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
