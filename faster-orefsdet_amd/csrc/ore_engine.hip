@@ -423,7 +423,7 @@ extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const
         ORE_HIP(hipMemset(e->fin_count, 0, MB * 4 * sizeof(int32_t)));
         ORE_HIP(hipHostMalloc((void**)&e->pin_count, 64, hipHostMallocMapped));
         ORE_HIP(hipHostGetDevicePointer((void**)&e->pin_count_dev, e->pin_count, 0));
-        e->pin_count[0] = 0;
+        e->pin_count[0] = 0; e->pin_count[2] = 0; e->pin_count[3] = 0;   // [0] count (device -> host), [2..3] result record address (host -> device)
         ORE_HIP(hipHostMalloc((void**)&e->pin_post, 64, hipHostMallocDefault));
         e->post_host[0] = e->post_host[1] = 1.f; e->post_host[2] = e->post_host[3] = 3.0e38f;   // identity until a size is requested
         ORE_HIP(hipMemcpy(e->post, e->post_host, 4 * sizeof(float), hipMemcpyHostToDevice));
@@ -666,12 +666,33 @@ extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_
         ORE_HIP(hipMemcpyAsync(e->post, e->pin_post, sizeof(pp), hipMemcpyHostToDevice, st));
         memcpy(e->post_host, pp, sizeof(pp));
     }
+    // the caller's freshly allocated result record is filled by the LAST KERNEL of the graph: its address travels in the pinned,
+    // device-mapped word behind the count (k_roi_tail reads it with a system-scope load), so nothing is queued behind the replay
+    volatile unsigned long long* rec_word = reinterpret_cast<volatile unsigned long long*>(e->pin_count) + 1;
+    *rec_word = (unsigned long long)(uintptr_t)out_record;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    volatile int32_t* cnt_word = e->pin_count;
+    *cnt_word = -1;                                          // sentinel: the last kernel of the graph overwrites it with the count (>= 0)
+    __atomic_thread_fence(__ATOMIC_RELEASE);
     int rc = ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, 1, stream);
-    if (rc) return rc;
-    if (out_record)         // the caller's freshly allocated result record is filled behind the graph, before the one host sync
-        ORE_HIP(hipMemcpyAsync(out_record, e->fin_pack, (size_t)e->roi_cap * 28, hipMemcpyDeviceToDevice, st));
-    ORE_HIP(hipStreamSynchronize(st));
-    *n_det = e->pin_count[0];                                // written by the last kernel of the graph through the device-mapped pointer
+    if (rc) { *rec_word = 0ull; return rc; }
+    // Wait for the count word instead of the stream: the kernel writes it as its very last action (after its result stores), and a
+    // poll of pinned memory sees it a wake-up latency earlier than hipStreamSynchronize returns.  Everything the caller does with the
+    // record afterwards is stream-ordered behind the kernel anyway.  Bounded spin, then the ordinary synchronise (also the error path).
+    int32_t n = -1;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        n = *cnt_word;
+        if (n >= 0) break;
+        __builtin_ia32_pause();
+    }
+    if (n < 0) {
+        const hipError_t se = hipStreamSynchronize(st);
+        if (se != hipSuccess) { *rec_word = 0ull; ore_set_error("ore_engine_detect_fwd: %s", hipGetErrorString(se)); return ORE_EHIP; }
+        n = *cnt_word;
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    *rec_word = 0ull;                                        // no later replay of this engine may write into the caller's tensor
+    *n_det = n;
     return ORE_OK;
 }
 

@@ -553,6 +553,16 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
     if (tid == 0) *p.det_count = nk;
     if (p.post != nullptr) {
         const float sx = p.post[0], sy = p.post[1], ow = p.post[2], oh = p.post[3];
+        // The caller's result record (boxes [cap][4] f32 | scores [cap] f32 | classes [cap] i64): its device address is handed over in
+        // the 64-bit word behind the pinned count word (written by the host before the launch, read here with a system-scope load):
+        // the last kernel of the graph fills the caller's own tensor, no copy behind the graph.  0 = none.
+        char* rec = nullptr;
+        if (p.host_count)
+            rec = reinterpret_cast<char*>(__hip_atomic_load(reinterpret_cast<unsigned long long*>(p.host_count) + 1, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_SYSTEM));
+        float* rec_boxes = reinterpret_cast<float*>(rec);
+        float* rec_scores = rec ? reinterpret_cast<float*>(rec + (size_t)p.cap * 16) : nullptr;
+        long long* rec_cls = rec ? reinterpret_cast<long long*>(rec + (size_t)p.cap * 20) : nullptr;
         int fbase = 0;
         for (int i0 = 0; i0 < nk; i0 += T) {
             const int i = i0 + tid;
@@ -580,12 +590,18 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
                 const int pos = pre + inc - 1;
                 *reinterpret_cast<f32x4*>(p.fin_boxes + (size_t)pos * 4) = b;
                 p.fin_scores[pos] = sc;
+                if (rec) {
+                    *reinterpret_cast<f32x4*>(rec_boxes + (size_t)pos * 4) = b;
+                    rec_scores[pos] = sc;
+                    rec_cls[pos] = 0ll;                         // one foreground class (fsod_cen.py:158-159)
+                }
             }
             fbase += tot;
         }
         if (tid == 0) {
             *p.fin_count = fbase;
-            if (p.host_count) *p.host_count = fbase;      // pinned, device-mapped host word: the caller reads it after the stream sync
+            if (p.host_count) *p.host_count = fbase;      // pinned, device-mapped host word, this kernel's last store: the caller polls it
+                                                          // (whatever it does with the record next is stream-ordered behind this kernel)
         }
     }
 }

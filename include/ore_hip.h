@@ -232,7 +232,9 @@ int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const flo
  * ref:fewx/modeling/fsod/fsod_cen.py:557-571) in the same launch when post_dev != NULL: post_dev = device {sx, sy, out_w, out_h}
  * (sx = out_w / img_w, sy = out_h / img_h as float); the detections are scaled, clipped to the output size and the empty ones
  * dropped (order kept) into fin_boxes [cap][4] / fin_scores [cap] / fin_count [1]; host_count (may be NULL) is a device-mapped
- * pinned host word that receives the same count, so the caller needs no device-to-host copy.  cap <= 512 with post_dev. */
+ * pinned host word that receives the same count, so the caller needs no device-to-host copy; the 64-bit word at host_count + 2 is
+ * read by the kernel (system scope): when non-zero it is the device address of a caller-owned record -- boxes [cap][4] f32 | scores
+ * [cap] f32 | classes [cap] i64 -- that the kernel fills as well.  cap <= 512 with post_dev. */
 int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
                              const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
                              const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
