@@ -42,7 +42,7 @@ for bm in (16, 32):
     for bn in (16, 32, 48, 64, 80):
         if bn > (Cout + 15) // 16 * 16:
             continue
-        for ns in (2, 3, 4, 6):
+        for ns in (2, 3, 4):
             for S in (1, 2, 4, 8):
                 L.ore_conv_set_plan_override(-3, bm, bn, ns, S)
                 try:
