@@ -259,6 +259,22 @@ def ese_gate_from_colsum(part: torch.Tensor, HW: int, fc_w: torch.Tensor, fc_b: 
     return gate
 
 
+def ese_gate_scaled_weight(part: torch.Tensor, HW: int, fc_w: torch.Tensor, fc_b: torch.Tensor, w_packed: torch.Tensor):
+    """ese_gate_from_colsum for one image plus, in the same launch, the gate-scaled copy of a consumer's packed 1x1 weight [rows, C]
+    (ore_ese_gate_scaled_weight_fwd).  Returns (gate [1, C], w_packed * gate[None, :])."""
+    _f32(part); _f32(w_packed)
+    P, Cc = part.shape
+    assert w_packed.dim() == 2 and w_packed.shape[1] == Cc
+    gate = torch.empty(1, Cc, device=part.device, dtype=torch.float32)
+    mean_ws = torch.empty(Cc, device=part.device, dtype=torch.float32)
+    ws = torch.empty_like(w_packed)
+    _chk(lib().ore_ese_gate_scaled_weight_fwd(C.c_void_p(_ptr(part)), P, HW, Cc, C.c_void_p(_ptr(_f32(fc_w.reshape(Cc, Cc)))),
+                                              C.c_void_p(_ptr(_f32(fc_b))), C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(mean_ws)),
+                                              C.c_void_p(_ptr(w_packed)), w_packed.shape[0], C.c_void_p(_ptr(ws)), _stream()),
+         "ore_ese_gate_scaled_weight_fwd")
+    return gate, ws
+
+
 _WS: Dict[str, torch.Tensor] = {}
 
 
@@ -690,6 +706,20 @@ def colsum(x: torch.Tensor, *, coff: int = 0, Cc: Optional[int] = None, out: Opt
     ws = _wgrad_ws(x.device, ((rows + 63) // 64) * Cc)
     _chk(lib().ore_colsum_fwd(C.c_void_p(_ptr(x)), ld, coff, C.c_int64(rows), Cc, C.c_float(beta), C.c_void_p(_ptr(out)),
                               C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_colsum_fwd")
+    return out
+
+
+def colsum_segments(x: torch.Tensor, segments: int) -> torch.Tensor:
+    """x [rows, C] made of `segments` equal runs of rows (the images of a batch) -> [segments, C] per-run column sums; each run's sums
+    are bitwise those of `colsum` on that run alone (ore_colsum_segments_fwd)."""
+    _f32(x)
+    rows, Cc = x.shape
+    assert rows % segments == 0
+    rps = rows // segments
+    out = torch.empty(segments, Cc, device=x.device, dtype=torch.float32)
+    ws = _wgrad_ws(x.device, segments * ((rps + 255) // 256) * Cc)
+    _chk(lib().ore_colsum_segments_fwd(C.c_void_p(_ptr(x)), Cc, 0, segments, C.c_int64(rps), Cc, C.c_float(0.0), C.c_void_p(_ptr(out)),
+                                       C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_colsum_segments_fwd")
     return out
 
 

@@ -770,6 +770,31 @@ def test_train_forward_batch_and_empty_gt(oh):
     assert errs[len(errs) // 2] <= 1e-4 and errs[int(len(errs) * 0.85)] <= 1e-3 and errs[-1] <= 2e-2, errs[-5:]
 
 
+def test_colsum_segments_and_scaled_gate_weight(oh):
+    """ore_colsum_segments_fwd: per-image column sums of a batch, each image bitwise the unsegmented call on its rows, and equal to a
+    float64 sum at 1e-5.  ore_ese_gate_scaled_weight_fwd: the eSE gate of one image (vs the reference formula relu6(fc(mean) + 3) / 6,
+    d2z:modeling/backbone/vovnet.py:238-260) and the gate-scaled copy of a packed 1x1 weight, exactly w * gate."""
+    import orehip
+    g = torch.Generator().manual_seed(23)
+    S, rps, Cc = 5, 700, 224
+    x = torch.randn(S * rps, Cc, generator=g).cuda()
+    got = orehip.colsum_segments(x, S)
+    for s_ in range(S):
+        assert torch.equal(got[s_], orehip.colsum(x[s_ * rps:(s_ + 1) * rps].contiguous()))
+    ref = x.double().reshape(S, rps, Cc).sum(1)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    P, HW, Cc = 25, 400, 512
+    part = torch.randn(P, Cc, generator=g).cuda() * 3.0
+    fw, fb = (torch.randn(Cc, Cc, generator=g) / Cc ** 0.5).cuda(), (torch.randn(Cc, generator=g) * 2.0).cuda()
+    wl = torch.randn(128, Cc, generator=g).cuda()
+    gate, ws = orehip.ese_gate_scaled_weight(part, HW, fw, fb, wl)
+    mean = part.double().sum(0) / HW
+    want = torch.clamp(fw.double() @ mean + fb.double() + 3.0, 0.0, 6.0) / 6.0
+    assert float((gate[0].double() - want).abs().max()) < 1e-5
+    assert torch.equal(gate, orehip.ese_gate_from_colsum(part, HW, fw, fb))
+    assert torch.equal(ws, wl * gate)
+
+
 def test_detect_batch_equals_per_image_detect(oh):
     """ore_detect_batch_fwd (the train-mode proposals of a batch: the greedy NMS scans of all images in one launch) returns, image by
     image, exactly what ore_detect_fwd returns -- boxes, scores, keep indices and counts bit for bit (4000 / 0.9 / 2000 thresholds)."""
