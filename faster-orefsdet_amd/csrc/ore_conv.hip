@@ -1164,7 +1164,8 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -2) { g_kw_mode = BN; g_override = {0, 0, 0, 0, 0}; return ORE_OK; }
     if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
-    if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }                                   // BM = -5: block -> tile mapping of k_conv_kw (-1 auto, 0, 1, 2)                           // BM = -4: tile of k_conv_gs                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
+    if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
+    if (BM == -6) { conv_kw_nw_force(BN); return ORE_OK; }                                  // BM = -6: waves per block of k_conv_kw (4 / 8 / 16)                                   // BM = -5: block -> tile mapping of k_conv_kw (-1 auto, 0, 1, 2)                           // BM = -4: tile of k_conv_gs                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
     g_override = {BM, BN, WGM, WGN, WGK};
     return ORE_OK;
 }

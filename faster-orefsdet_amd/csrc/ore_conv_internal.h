@@ -48,6 +48,7 @@ int conv_kw_tile_rows(const ConvP& p);
 // tuning aid (ore_conv_set_plan_override(-3, bm, bn, ns, splitk)): force tile / ring depth / split of k_conv_kw; bm = 0 -> automatic
 void conv_kw_force(int bm, int bn, int ns, int splitk);
 int conv_choose_xmap(const ConvP& p, int gx, int gy);   // the mapping for a gx x gy tile grid of this layer
+void conv_kw_nw_force(int nw);                   // (-6, nw): waves per block of k_conv_kw; 0 -> automatic
 void conv_xmap_force(int mode);
 int conv_xmap_forced();                          // -1 when automatic                  // (-5, mode): -1 automatic, 0 / 1 / 2 force the block -> tile mapping of k_conv_kw
 void conv_gs_force(int bm, int bn, int ns);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic

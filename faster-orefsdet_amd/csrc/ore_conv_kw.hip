@@ -88,12 +88,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // lane group (rows {0-3, 12-15} of quad q with rows 4-11 of quad q+1, and its mirror) touches 16 distinct 4-bank groups.
 __device__ __forceinline__ int swz(int r16) { return (0x1320 >> (((r16 >> 2) & 3) * 4)) & 3; }   // {0, 2, 3, 1}
 
-template <int BM, int BN, int NS, bool BF = false, bool INCR = true>
-__global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restrict__ zero_page) {
+template <int BM, int BN, int NS, bool BF = false, bool INCR = true, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __restrict__ zero_page) {
+    // NW = waves per block = the in-block K split (chunk c -> wave c % NW).  4 is the workhorse; 8 / 16 cut the dependent K chain of the
+    // latency-bound small layers (18 steps per wave at K = 1152 with 4 waves) at no cross-block cost: the partial tiles meet in LDS.
+    constexpr int T = NW * 64;
     constexpr int GA = BM / 16, GB = BN / 16, G = GA + GB;        // DMA instructions (= 16-row groups) per stage
     constexpr int STAGE_F = (BM + BN) * 16;                       // floats per stage
-    constexpr int RING_F = 4 * NS * STAGE_F;
-    constexpr int RED_F = 4 * GA * GB * 256;                      // the four partial tiles, [wave][tile][lane][4]
+    constexpr int RING_F = NW * NS * STAGE_F;
+    constexpr int RED_F = NW * GA * GB * 256;                     // the NW partial tiles, [wave][tile][lane][4]
     constexpr int CS_F = GA * GB * 16;                            // per-tile column sums (fused eSE average pool)
     constexpr int LDS_F = RING_F > RED_F + CS_F ? RING_F : RED_F + CS_F;
     static_assert(BM % 16 == 0 && BN % 16 == 0 && NS >= 2 && (NS - 1) * G <= 63, "tile");
@@ -107,8 +110,8 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
     const int m0 = bx * BM, n0 = by * BN;
     const int cpt = p.Cin >> 4;                                   // 16-channel chunks per tap
     // chunk range of this block (cross-block split-K), then this wave's chunks: c_begin + wave, + 4, ...
-    const int c_begin = blockIdx.z * p.steps_per_split * 4;
-    const int c_end = min(c_begin + p.steps_per_split * 4, p.nchunks);
+    const int c_begin = blockIdx.z * p.steps_per_split * NW;
+    const int c_end = min(c_begin + p.steps_per_split * NW, p.nchunks);
     const int nst = p.steps_per_split;                            // same trip count for every wave (short waves multiply zeros)
 
     // ---- per-lane DMA sources: lane L of a group's instruction fills LDS slot L = (row L>>2, physical quad L&3)
@@ -175,10 +178,10 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(dst + (GA + j) * 256), 16, 0, 0);
             }
-            i_c += 4;
-            i_cc += 4;
+            i_c += NW;
+            i_cc += NW;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const bool wrap = i_cc >= cpt;
                 i_cc -= wrap ? cpt : 0;
                 i_dx += wrap ? 1 : 0;
@@ -195,13 +198,13 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
             for (int i = 0; i < GA; ++i) {
                 const bool ok = (a_taps[i] & tapbit) != 0u;
                 a_cur[i] = ok ? a_base[i] + (i_dy * a_rs[i] + uoff) : zero_page;
-                a_inc[i] = ok ? 64 : 0;
+                a_inc[i] = ok ? 16 * NW : 0;
             }
 #pragma unroll
             for (int j = 0; j < GB; ++j) {
                 const bool ok = live && b_base[j] != nullptr;
                 b_cur[j] = ok ? b_base[j] + ((size_t)i_c << 4) : zero_page;
-                b_inc[j] = ok ? 64 : 0;
+                b_inc[j] = ok ? 16 * NW : 0;
             }
             fresh = false;
         }
@@ -219,12 +222,12 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
         }
         // advance by 4 chunks; crossing a tap boundary (or the end of this block's K range) asks for fresh pointers
         const bool was_live = i_c < c_end;
-        i_c += 4;
-        i_cc += 4;
+        i_c += NW;
+        i_cc += NW;
         if (i_cc >= cpt || (was_live && i_c >= c_end)) {
             fresh = true;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const bool wrap = i_cc >= cpt;
                 i_cc -= wrap ? cpt : 0;
                 i_dx += wrap ? 1 : 0;
@@ -299,14 +302,14 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
     if (p.splitk <= 1) {
         float* cs = lds + RED_F;
 #pragma unroll
-        for (int q0 = 0; q0 < NT * 64; q0 += 256) {
+        for (int q0 = 0; q0 < NT * 64; q0 += T) {
             const int q = q0 + tid;                               // a wave's 64 items are one 16x16 tile: lane = accumulator lane
             if (q < NT * 64) {
                 const int tl = q >> 6, ln = q & 63;
                 const int j2 = tl % GB, i2 = tl / GB;
                 f32x4 a = *reinterpret_cast<const f32x4*>(lds + (0 * NT + tl) * 256 + ln * 4);
 #pragma unroll
-                for (int g = 1; g < 4; ++g) a += *reinterpret_cast<const f32x4*>(lds + (g * NT + tl) * 256 + ln * 4);
+                for (int g = 1; g < NW; ++g) a += *reinterpret_cast<const f32x4*>(lds + (g * NT + tl) * 256 + ln * 4);
                 f32x4 vo = {0.f, 0.f, 0.f, 0.f};
                 if (!finish4(p, a, m0 + i2 * 16 + (ln & 15), n0 + j2 * 16 + (ln >> 4) * 4, vec_ok, vo)) vo = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (p.colsum) {                                   // column sums of the tile: the 16 pixel lanes of a channel quad
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256) void k_conv_kw(ConvP p, const float* __restric
             for (int j = 0; j < GB; ++j) {
                 f32x4 a = acc[i][j];
 #pragma unroll
-                for (int g = 1; g < 4; ++g) a += *reinterpret_cast<const f32x4*>(lds + (g * NT + i * GB + j) * 256 + lane * 4);
+                for (int g = 1; g < NW; ++g) a += *reinterpret_cast<const f32x4*>(lds + (g * NT + i * GB + j) * 256 + lane * 4);
                 acc[i][j] = a;
             }
     }
@@ -631,7 +634,7 @@ int launch_gs_ns(const ConvP& p, const float* zero, hipStream_t st) {
 
 int g_gs_force[2] = {0, 0};             // tuning aid: {BM, BN}; 0 -> automatic
 
-struct KwTile { int BM, BN, S; };      // S = cross-block split-K (0: decide from the block count), BM = 0: layer left to k_conv_igemm / patch
+struct KwTile { int BM, BN, S; int NW = 4; };      // S = cross-block split-K (0: decide from the block count), BM = 0: layer left to k_conv_igemm / patch
 
 // Tile plan, from tools/conv_kw_sweep.py on MI355X (profiles/r02_kw_sweep.txt).  What the sweep says: the minimal ring (NS = 2) wins
 // almost everywhere -- more resident blocks per CU hide the DMA latency better than a deeper ring --, cross-block split-K pays only
@@ -646,10 +649,12 @@ KwTile kw_tile(int M, int C16, int nchunks) {
     } else if (M >= 1024) {
         if (C16 == 96) return {16, 48, 1};
         if (C16 == 128) return {16, 32, 1};
-        if (C16 >= 256) return {16, 80, 1};
+        if (C16 >= 256) return {32, 80, 1};
     } else {
-        if (C16 <= 128 && steps >= 96) return {16, 48, 4};           // the second-stage GEMM: 320 x 8192 -> 128
-        if (C16 <= 128 && steps >= 32) return {16, 32, 4};           // stage-5 layer 0
+        // the second-stage GEMM, 320 x 8192 -> 128: 8 waves split K inside the block (64 steps per wave) and NO cross-block split --
+        // the release fence of a split-K block costs more than the longer chain (19.6 vs 24 us with {16, 48} x S 4)
+        if (C16 <= 128 && steps >= 96) return {16, 16, 1, 8};
+        if (C16 <= 128 && steps >= 32) return {16, 16, 1};           // stage-5 layer 0 (15.7 vs 17.4+ us with any cross-block split)
         if (C16 <= 128) return {16, 16, 1};
         return {16, 32, 1};
     }
@@ -669,23 +674,23 @@ KwTile kw_tile(int M, int C16, int nchunks) {
     return best;
 }
 
-template <int BM, int BN, int NS, bool BF = false, bool INCR = true>
+template <int BM, int BN, int NS, bool BF = false, bool INCR = true, int NW = 4>
 int launch_kw_ns(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
     constexpr int G = (BM + BN) / 16;
     if constexpr ((NS - 1) * G > 63) {
         return ORE_EINVAL;
     } else {
-        constexpr int RING_F = 4 * NS * (BM + BN) * 16, RED_F = 4 * (BM / 16) * (BN / 16) * 256 + (BM / 16) * (BN / 16) * 16;
+        constexpr int RING_F = NW * NS * (BM + BN) * 16, RED_F = NW * (BM / 16) * (BN / 16) * 256 + (BM / 16) * (BN / 16) * 16;
         constexpr size_t lds = ((size_t)(RING_F > RED_F ? RING_F : RED_F) + 8) * sizeof(float);
         if constexpr (lds > 160 * 1024) {
             return ORE_EINVAL;
         } else {
             static bool attr = false;
             if (!attr) {
-                ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kw<BM, BN, NS, BF, INCR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kw<BM, BN, NS, BF, INCR, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr = true;
             }
-            hipLaunchKernelGGL((k_conv_kw<BM, BN, NS, BF, INCR>), grid, dim3(256), lds, st, p, zero);
+            hipLaunchKernelGGL((k_conv_kw<BM, BN, NS, BF, INCR, NW>), grid, dim3(NW * 64), lds, st, p, zero);
             return ORE_OK;
         }
     }
@@ -694,10 +699,19 @@ int launch_kw_ns(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
 int g_kw_force[4] = {0, 0, 0, 0};       // tuning aid: {BM, BN, NS, split-K}; BM = 0 -> automatic
 int g_xmap_force = -1;                  // tuning aid: block -> tile mapping of k_conv_kw; -1 -> automatic
 
+int g_kw_nw_force = 0;                   // tuning aid (-6, nw): waves per block of k_conv_kw (4 / 8 / 16); 0 -> the plan's
+
 template <int BM, int BN>
-int launch_kw(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
+int launch_kw(const ConvP& p, const float* zero, dim3 grid, hipStream_t st, int nw) {
     // incremental DMA addressing pays when a tap holds >= 16 chunks (4+ steps between pointer rebuilds): 1x1 layers, deep 3x3 layers
-    const bool incr = (p.Cin >> 4) >= 16;
+    const bool incr = (p.Cin >> 4) >= 4 * nw;
+    if constexpr (BM == 16 && BN <= 48) {                  // the small tiles also come with 8 / 16 waves (in-block K split)
+        if (nw == 8 && !p.bf16) return incr ? launch_kw_ns<BM, BN, 2, false, true, 8>(p, zero, grid, st) : launch_kw_ns<BM, BN, 2, false, false, 8>(p, zero, grid, st);
+        if constexpr (BN <= 32) {
+            if (nw == 16 && !p.bf16) return incr ? launch_kw_ns<BM, BN, 2, false, true, 16>(p, zero, grid, st) : launch_kw_ns<BM, BN, 2, false, false, 16>(p, zero, grid, st);
+        }
+    }
+    if (nw != 4) return ORE_EINVAL;
     if (p.bf16) return incr ? launch_kw_ns<BM, BN, 2, true, true>(p, zero, grid, st) : launch_kw_ns<BM, BN, 2, true, false>(p, zero, grid, st);
     int ns = 2;                          // (see kw_tile: the minimal ring wins)
     if (g_kw_force[0] > 0 && g_kw_force[2] > 0) ns = g_kw_force[2];
@@ -761,6 +775,7 @@ static int conv_gs_launch(ConvP& p, hipStream_t st) {
 }
 
 void conv_xmap_force(int mode) { g_xmap_force = mode; }
+void conv_kw_nw_force(int nw) { g_kw_nw_force = nw; }
 int conv_xmap_forced() { return g_xmap_force; }
 
 // block -> tile mapping (tile_of_block): fabric bytes if every XCD reads what its tiles need once
@@ -786,7 +801,10 @@ int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStrea
     if (t.BM == 0) return 1;
     const int gx = ceil_div(p.M, t.BM), gy = ceil_div(p.Cout16, t.BN);
     const int blocks = gx * gy;
-    const int steps = ceil_div(p.nchunks, 4);                             // steps per wave without a cross-block split
+    int nw = t.NW;
+    if (g_kw_nw_force > 0) nw = g_kw_nw_force;
+    if (p.bf16 || t.BM != 16 || t.BN > 48 || (nw == 16 && t.BN > 32)) nw = 4;    // the 8- / 16-wave builds exist for the small fp32 tiles only
+    const int steps = ceil_div(p.nchunks, nw);                            // steps per wave without a cross-block split
     int S = t.S;
     if (S <= 0) S = (blocks < 128 && steps >= 32) ? 4 : 1;
     if (S > steps) S = steps;
@@ -803,7 +821,7 @@ int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStrea
     const dim3 grid(gx, gy, S);
     const float* zero = nullptr;
     { const int zrc = zero_page_of(&zero); if (zrc) return zrc; }
-#define KW_CASE(bm, bn) if (t.BM == bm && t.BN == bn) { const int rc = launch_kw<bm, bn>(p, zero, grid, st); return rc ? rc : ore_launch_status("k_conv_kw"); }
+#define KW_CASE(bm, bn) if (t.BM == bm && t.BN == bn) { const int rc = launch_kw<bm, bn>(p, zero, grid, st, nw); return rc ? rc : ore_launch_status("k_conv_kw"); }
     KW_CASE(16, 16) KW_CASE(16, 32) KW_CASE(16, 48) KW_CASE(16, 64) KW_CASE(16, 80)
     KW_CASE(32, 16) KW_CASE(32, 32) KW_CASE(32, 48) KW_CASE(32, 64) KW_CASE(32, 80)
 #undef KW_CASE

@@ -42,17 +42,22 @@ for bm in (16, 32):
     for bn in (16, 32, 48, 64, 80):
         if bn > (Cout + 15) // 16 * 16:
             continue
-        for ns in (2, 3, 4):
-            for S in (1, 2, 4, 8):
-                L.ore_conv_set_plan_override(-3, bm, bn, ns, S)
-                try:
-                    us = t(20)
-                except orehip.OreError:
-                    continue
-                err = float((out - ref).abs().max() / ref.abs().max())
-                res.append((us, bm, bn, ns, S, err))
+        for nw in (4, 8, 16):                          # waves per block (in-block K split): 8 / 16 exist for the small fp32 tiles
+            if nw > 4 and (bm != 16 or bn > 48 or (nw == 16 and bn > 32)):
+                continue
+            L.ore_conv_set_plan_override(-6, nw, 0, 0, 0)
+            for ns in ((2, 3, 4) if nw == 4 else (2,)):
+                for S in (1, 2, 4, 8):
+                    L.ore_conv_set_plan_override(-3, bm, bn, ns, S)
+                    try:
+                        us = t(20)
+                    except orehip.OreError:
+                        continue
+                    err = float((out - ref).abs().max() / ref.abs().max())
+                    res.append((us, bm, bn, ns, S, err, nw))
+L.ore_conv_set_plan_override(-6, 0, 0, 0, 0)
 L.ore_conv_set_plan_override(-3, 0, 0, 0, 0)
 L.ore_conv_set_plan_override(-2, 1, 0, 0, 0)
 res.sort()
-for us, bm, bn, ns, S, err in res[:14]:
-    print("%6.2f us  %5.1f TF/s  tile %2dx%2d ns %d S %d  relerr %.1e" % (us, flops / us / 1e6, bm, bn, ns, S, err))
+for us, bm, bn, ns, S, err, nw in res[:10]:
+    print("%6.2f us  %5.1f TF/s  tile %2dx%2d ns %d S %d nw %2d  relerr %.1e" % (us, flops / us / 1e6, bm, bn, ns, S, nw, err))
