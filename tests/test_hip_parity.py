@@ -145,6 +145,30 @@ def test_conv_kw_kernel_vs_oracle(ore, kw_forced, B, H, W, Cin, Cout, k, stride)
     assert torch.equal(y, y2)                       # split-K slabs are summed in slice order: bit-reproducible
 
 
+@pytest.mark.parametrize("nw,tile", [(8, (16, 16)), (8, (16, 32)), (8, (16, 48)), (16, (16, 16)), (16, (16, 32))])
+@pytest.mark.parametrize("H,W,Cin,Cout,k,S", [(20, 20, 112, 112, 3, 1), (1, 96, 2048, 128, 1, 1), (13, 11, 48, 48, 3, 1), (20, 20, 384, 112, 3, 2)])
+def test_conv_kw_wave_counts(ore, kw_forced, nw, tile, H, W, Cin, Cout, k, S):
+    """k_conv_kw with the K dimension split over 8 / 16 waves of one block (template NW; the production plan uses 8 waves for the
+    second-stage GEMM): every instantiated (tile, NW) pair, few and many chunks per tap, with and without a cross-block split, against
+    F.conv2d at 1e-4, bit-reproducible."""
+    L = ore.lib()
+    g = torch.Generator().manual_seed(H + Cin + nw)
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, sh, 1, k // 2))
+    L.ore_conv_set_plan_override(-6, nw, 0, 0, 0)
+    L.ore_conv_set_plan_override(-3, tile[0], tile[1], 2, S)
+    try:
+        y = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, 1, shift=dev(sh), relu_cout=Cout)
+        y2 = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, 1, shift=dev(sh), relu_cout=Cout)
+    finally:
+        L.ore_conv_set_plan_override(-3, 0, 0, 0, 0)
+        L.ore_conv_set_plan_override(-6, 0, 0, 0, 0)
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert torch.equal(y, y2)
+
+
 def test_conv_kw_slices_add_colsum_levels(ore, kw_forced):
     """k_conv_kw with everything the engine asks of it: channel-slice input and output inside wider buffers (OSA concat), the FPN
     nearest-2x top-down add, partial ReLU, fused per-tile column sums (eSE average pool), several pyramid levels in one launch with
