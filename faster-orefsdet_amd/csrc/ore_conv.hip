@@ -943,7 +943,7 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     if (g_patch_mode == 0) return 1;
     if (g_conv_bf16 && g_patch_mode > 0 && g_patch_mode != 4 && g_patch_mode != 102) return 1;   // bf16 builds: patch<4> and ws<2,64,1> only
     int TH = g_patch_mode > 0 ? g_patch_mode : 4;
-    const bool db = TH == 16;
+    bool db = TH == 16;
     if (db) TH = 8;
     bool ws = TH == 102;                                     // TH = 4 needs > 256 VGPRs (spills): only the 2-row tile is built
     if (ws) { TH = 2; if (c.Cin != 64 && (c.Cin != 128 || g_conv_bf16)) return 1; }
@@ -957,6 +957,9 @@ static int patch_launch(const ConvP& c, hipStream_t st) {
     // 256-VGPR block per CU leaves no room for another stream's kernel: with several passes in flight the folded-serving rate DROPS
     // 2 %.  Used for training-sized launches only.
     if (g_patch_mode < 0 && c.Cin == 128 && c.nlev == 1 && !g_conv_bf16 && ws_tiles >= 8192) { ws = true; TH = 2; }
+    // plan: one image of stage 2 (64 output channels, 160 x 160): the double-buffered 8-wave patch kernel beats the 4-wave one by 7-8 %
+    // (64 -> 64: 27.9 -> 25.9 us, 128 -> 64: 47.0 -> 43.3 us; tools/ws_s2_exp.py); at 128 output channels / 80 x 80 it loses (42 vs 26 us)
+    if (g_patch_mode < 0 && !ws && !g_conv_bf16 && c.nlev == 1 && c.Cout16 == 64 && c.M >= 16384 && c.M <= 65536) { db = true; TH = 8; }
     PatchP p{};
     p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = c.nlev;
     int tiles = 0;
