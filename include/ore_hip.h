@@ -392,10 +392,12 @@ int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32
 /* The reference's eval call for ONE image, end to end (ref:fewx/modeling/fsod/fsod_cen.py:417-452 `inference` + :557-571
  * `_postprocess` -> d2z:modeling/postprocessing.py:10-75): copies the image in (device OR host pointer), replays the graph of both
  * stages with detector_postprocess in its last kernel (scale to out_h x out_w, clip, drop empty boxes), which also writes the
- * detection count to a device-mapped pinned host word, and waits for the stream: ONE host sync per image.  *n_det detections are then
- * in the engine buffers "final_boxes" [n,4] / "final_scores" [n] (valid until the next forward of this engine) and, when out_record
- * != NULL, in the caller's own device memory: out_record = ORE_DET_RECORD_BYTES bytes laid out [320][4] f32 boxes | [320] f32 scores
- * | [320] int64 classes (all 0: one foreground class), filled by ONE copy queued behind the graph.  Needs ore_engine_set_roi_head. */
+ * detection count to a device-mapped pinned host word; the call returns when that word has been written (bounded poll, then an
+ * ordinary stream synchronise): ONE host wait per image.  *n_det detections are then in the engine buffers "final_boxes" [n,4] /
+ * "final_scores" [n] (valid until the next forward of this engine) and, when out_record != NULL, in the caller's own device memory:
+ * out_record = ORE_DET_RECORD_BYTES bytes laid out [320][4] f32 boxes | [320] f32 scores | [320] int64 classes (all 0: one
+ * foreground class), written by the graph's last kernel (the address travels in a pinned word next to the count); whatever the
+ * caller queues on `stream` afterwards is ordered behind that kernel.  Needs ore_engine_set_roi_head. */
 #define ORE_DET_RECORD_ROWS 320
 #define ORE_DET_RECORD_BYTES (ORE_DET_RECORD_ROWS * 28)
 int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
