@@ -431,8 +431,8 @@ def main():
                 "traffic_note": "HBM-side bytes per image over the same conv launches: (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 "
                                 "--pmc passes (tools/pmc_pass.py -> profiles/%s)" % traffic_src,
                 "kernel": ("the MFMA conv kernels with bf16 operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) + the fp32 ROI fc GEMM" if bf16 else
-                           "the fp32 MFMA conv kernels (v_mfma_f32_16x16x4_f32 implicit GEMM: k_conv_igemm, k_conv3x3_patch, k_conv3x3_ws, "
-                           "incl. in-kernel split-K) + the ROI fc GEMM"),
+                           "the fp32 MFMA conv kernels (v_mfma_f32_16x16x4_f32 implicit GEMM: k_conv_kw, k_conv_gs, k_conv_igemm, "
+                           "k_conv3x3_patch / _patch_db, k_conv3x3_ws) + the second-stage GEMM"),
                 "launches_per_image": nl // npp, "gflop_per_image": round(fl / npp / 1e9, 3),
                 "kernel_ms_per_image": round(ms / npp, 4), "kernel_ms_per_image_calibrated": round(ms_cal / npp, 4),
                 "event_pair_overhead_us": round(ev_us, 3), "achieved_calibrated": round(fl / (ms_cal * 1e-3) / 1e12, 2),
