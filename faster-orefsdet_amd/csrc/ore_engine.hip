@@ -689,6 +689,7 @@ extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_
         const hipError_t se = hipStreamSynchronize(st);
         if (se != hipSuccess) { *rec_word = 0ull; ore_set_error("ore_engine_detect_fwd: %s", hipGetErrorString(se)); return ORE_EHIP; }
         n = *cnt_word;
+        if (n < 0) { *rec_word = 0ull; ore_set_error("ore_engine_detect_fwd: the pass finished without writing the detection count"); return ORE_EHIP; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     *rec_word = 0ull;                                        // no later replay of this engine may write into the caller's tensor
