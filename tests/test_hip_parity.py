@@ -489,6 +489,39 @@ def test_engine_eval_non_divisible_size(engine, sd):
         assert rel_err(hd[:, 4:5].numpy(), ref["hm"][l].numpy()) < TOL
 
 
+@pytest.mark.parametrize("hw", [(480, 640), (544, 736), (600, 800)])
+def test_engine_eval_other_sizes_vs_oracle(ore, sd, hw):
+    """Sizes whose layer shapes select other kernels / tile mappings than 640x640 (stage 2 on the double-buffered patch kernel with
+    partial tiles in W, tile grids that are not multiples of 8 under the XCD mapping, a non-/32 input that stem_1 pads): the whole first
+    stage against the oracle at 1e-4, the detection tail bit-exact on the engine's own head outputs."""
+    H, W = hw
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    img = R.synth_image(5 + H, H, W)
+    ref = R.eval_dense(img, sd, R.synth_support(0))
+    e = ore.Engine(max_batch=1, max_h=Hp, max_w=Wp)
+    e.load_state_dict(sd)
+    e.set_support(R.synth_support(0))
+    e.finalize()
+    try:
+        for use_graph in (False, True):
+            e.eval_forward(img.cuda(), use_graph=use_graph)
+            torch.cuda.synchronize()
+            hms, regs = [], []
+            for l, k in enumerate(("p3", "p4", "p5")):
+                hh, ww = Hp >> (l + 3), Wp >> (l + 3)
+                assert rel_err(e.buffer(k, (1, hh, ww)).cpu().numpy(), ref["features"][k].numpy()) < TOL, (k, use_graph)
+                hd = e.buffer(f"head{l + 3}", (1, hh, ww)).cpu()
+                assert rel_err(hd[:, :4].numpy(), ref["reg"][l].numpy()) < TOL and rel_err(hd[:, 4:5].numpy(), ref["hm"][l].numpy()) < TOL
+                raw = e.buffer(f"head{l + 3}").cpu().numpy().reshape(hh, ww, 5)
+                hms.append(np.ascontiguousarray(raw[..., 4]))
+                regs.append(np.ascontiguousarray(raw[..., :4]))
+            want = odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+            boxes, scores, keep = e.proposals()
+            assert np.array_equal(keep.cpu().numpy(), want["keep"]) and np.array_equal(boxes.cpu().numpy(), want["boxes"])
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------------------------------------------ module surface (fewx registry)
 @pytest.fixture(scope="module")
 def model(ore, sd):
