@@ -225,6 +225,63 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
     return out
 
 
+def self_launch(n):
+    """One fresh process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, the same argv.  Children are started as
+    subprocesses of the same interpreter (no fork of a GPU-initialised process, no exec from one)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        for p in procs:
+            rc = p.wait()
+            if rc != 0 and worst == 0:
+                worst = rc
+                for q in procs:                                 # one rank died: the others would wait in a collective forever
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return worst if 0 <= worst < 256 else 1
+
+
+def dry_run(args, world, rank):
+    """--dry: everything around the GPU legs (rendezvous, barrier, max-over-ranks, the one JSON line from rank 0) on gloo / CPU."""
+    import torch.distributed as dist
+    from detectron2.utils import comm
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("ORE_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    K = max(args.steps, 1)
+    comm.synchronize()
+    t0 = time.perf_counter()
+    time.sleep(0.001 * K * (1 + rank))                          # ranks differ: the slowest one defines the job time
+    comm.synchronize()
+    el = comm.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    seen = int(comm.sum_over_ranks(1, torch.device("cpu")))
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU legs)", "value": round(world * K / el, 2), "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / K * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry": True, "ranks_seen": seen,
+                          "config": {"workload": "dry", "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,11 +301,21 @@ def main():
                     help="also time the same requests folded F at a time into one engine pass (\"folded_serving\" in the output); 0/1 = skip")
     ap.add_argument("--inflight", type=int, default=4,
                     help="\"in_flight\" leg: images kept in flight per GPU, each a bs=1 forward on its own engine + HIP stream")
+    ap.add_argument("--dry", action="store_true",
+                    help="rehearse the launch / rendezvous / max-over-ranks / JSON plumbing only (no GPU legs; CPU test of --gpus N)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (ref:fsod_train_net.py:108-118 does the same through
+        # d2z:engine/launch.py:27-82).  Nothing in this process has touched the GPU yet (import torch does not), and it never will: it
+        # only waits for its children and returns the worst exit code; rank 0's JSON line goes to the inherited stdout.
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry:
+        return dry_run(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     # ORE_BENCH_BACKEND=gloo: rehearsal of the N-rank code path on a box with fewer GPUs than ranks (ranks share the cards; the
     # exchange then runs over gloo, so its timings say nothing about RCCL).  The driver's runs use the default, nccl = RCCL.
@@ -415,11 +482,16 @@ def main():
         ms = ms_raw
         ms_cal = max(ms_raw - nl * ev_us * 1e-3, 1e-6)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_src = None, None               # HBM bytes of the conv launches of one image, from the committed PMC passes
+        # HBM bytes of the conv launches of one image, from the committed PMC passes -- only if they were taken with THIS library version
+        traffic, traffic_src, lib_ver = None, None, int(orehip.lib().ore_version())
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             try:
                 with open(tf) as f:
-                    traffic = float(json.load(f)["conv_hbm_bytes_per_image"])
+                    tj = json.load(f)
+                if int(tj.get("ore_version", -1)) != lib_ver:
+                    traffic_src = "%s is from ore_version %s, library is %d: stale, not reported" % (os.path.basename(tf), tj.get("ore_version"), lib_ver)
+                    break
+                traffic = float(tj["conv_hbm_bytes_per_image"])
                 traffic_src = os.path.basename(tf)
                 break
             except Exception:
@@ -463,14 +535,17 @@ def main():
                                    "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]), the reference's FPS protocol: "
                                    "model([{image,height,width}]) + torch.cuda.synchronize() per image; preprocess+VoVNet-19-slim-eSE+FPN -> "
                                    "correlation -> CenterNet head -> top-k/NMS proposals -> ROIAlign + cascade ROI head -> NMS -> detections",
-                       "parallelism": f"dp{world} (images sharded, no data-path collective)", "hipgraph": use_graph,
+                       "parallelism": f"dp{world} (images sharded, no data-path collective)",
+                       "hipgraph": True,                        # model() -> ore_engine_detect_fwd always replays the captured graph
+                       "extra_legs_hipgraph": use_graph,       # --no-graph only affects engine_sequential / in_flight / folded_serving
                        "images_in_flight_per_gpu": 1, "timed_steps": n_steps, "timed_region_s": round(elapsed, 3),
-                       "input": "uint8 BGR CHW image resident in HBM", "proposals_last_image": n_prop, "detections_last_image": n_det,
+                       "input": "uint8 BGR CHW image resident in HBM when the timed region starts (the tier rule for `value`); the same protocol fed the "
+                                "dataloader's host tensor, PCIe copy inside the step, is \"protocol_host_image\"", "proposals_last_image": n_prop, "detections_last_image": n_det,
                        "detections_returned": n_det_proto},
             **extras, "roofline": roof, **train,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, host_imgs[0])
+        if not args.no_cpu_baseline:                           # rank 0 only; the other ranks wait in the final barrier meanwhile
+            out["cpu_baseline"] = cpu_baseline(model, host_imgs[0], budget_s=12.0 if world == 1 else 6.0)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -14,9 +14,10 @@
 // The four partial tiles are summed through LDS in wave order; cross-block split-K (grid.z) uses the same slab + agent-scope
 // release/acquire ticket as k_conv_igemm (last arriver sums the slabs in slice order: bitwise deterministic).
 // Epilogue = k_conv_igemm's: y = acc*scale[n] + shift[n] (+ nearest-2x top-down add) (+ ReLU on n < relu_cout), per-tile column sums
-// (eSE average pool), channel-slice output.  Optional per-(image, channel) input multiplier (the eSE gate folded into the FPN
-// laterals) applied to the A fragments.  Not covered (the caller falls back to k_conv_igemm): input affine with add / ReLU (the
-// GroupNorm fold of the head's last conv), bf16 operand mode, Cin % 16 != 0.
+// (eSE average pool), channel-slice output.  BF build: both operands rounded to bf16 as the fragments leave LDS (ORE_CONV_BF16).
+// Not covered (conv_kw_launch returns 1 and the caller falls back to k_conv_igemm): any input-side affine (in_mul / in_add / in_relu:
+// the eSE gate of the FPN laterals reaches this kernel pre-multiplied into the weights instead, ore_ese_gate_scaled_weight_fwd; the
+// GroupNorm fold of the head's last conv stays on k_conv_igemm), Cin % 16 != 0.
 //
 // Replaces F.conv2d + FrozenBatchNorm2d + ReLU / bias of d2z:modeling/backbone/vovnet.py:205-219,310-332, fpn.py:113-154,
 // ref:fewx/modeling/fsod/fsod_cen.py:470 (conv3), fsod_roi_heads.py:500-520 (composed DSA + fc1).

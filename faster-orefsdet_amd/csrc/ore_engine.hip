@@ -73,7 +73,7 @@ struct ore_engine {
     void* det_ws = nullptr; size_t det_ws_bytes = 0;
     // second stage (optional: ore_engine_set_roi_head)
     bool roi_set = false;
-    int roi_cap = 320, roi_fc = 0, roi_pooled = 8, roi_topk = 100;
+    int roi_cap = ORE_DET_RECORD_ROWS, roi_fc = 0, roi_pooled = 8, roi_topk = 100;   // roi_cap IS the record's row count (k_roi_tail, Engine.detect)
     float roi_score_thresh = 0.f, roi_nms_thresh = 0.9f, roi_reg_w[4] = {10.f, 10.f, 5.f, 5.f};
     float* roi_W = nullptr; float* roi_b = nullptr; float* roi_cls_w = nullptr; float* roi_cls_b = nullptr;
     float* roi_box_w = nullptr; float* roi_box_b = nullptr;
@@ -392,6 +392,11 @@ extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const
     ORE_CHECK_ARG(e && e->finalized && W_host && b_host && cls_w_host && cls_b_host && box_w_host && box_b_host && reg_weights4_host,
                   "ore_engine_set_roi_head: engine must be finalized, pointers non-null");
     ORE_CHECK_ARG(fc_dim % 16 == 0 && fc_dim > 0 && pooled >= 1 && pooled <= 16 && nms_thresh > 0.f, "ore_engine_set_roi_head: bad args");
+    // the engine's second stage always ends in the fused predict + tail kernels (they write the result record and the polled count):
+    // refuse here what they do not cover instead of failing every image later (ore_roi_predict_post_fwd has the same bound)
+    ORE_CHECK_ARG((size_t)fc_dim * 4 * 71 + 6 * 64 * 4 <= 60 * 1024,
+                  "ore_engine_set_roi_head: fc width %d: the fused second-stage kernels cover fc widths up to 208 (FC_DIM/8 = 128 in finetune_vovnet.yaml)", fc_dim);
+    static_assert(ORE_DET_RECORD_ROWS <= 512, "k_roi_tail<1024> sorts at most 512 candidates");
     ORE_HIP(hipSetDevice(e->device));
     const size_t K = (size_t)pooled * pooled * e->cfg.fpn_ch;
     int rc;

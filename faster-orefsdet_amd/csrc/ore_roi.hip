@@ -712,6 +712,10 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
         hipLaunchKernelGGL(k_roi_tail<1024>, dim3(1), dim3(1024), 0, st, t);
         return ore_launch_status("k_roi_tail");
     }
+    // general path (wide fc / large caps): it produces det_* only.  A caller that asked for the fused postprocess (the engine's detect
+    // call polls host_count) must not get ORE_OK from a path that never writes fin_* / host_count.
+    ORE_CHECK_ARG(!post_dev, "ore_roi_predict_post_fwd: the fused postprocess covers fc width <= %d (got %d) and cap <= %d (got %d)",
+                  (int)((60 * 1024 - 6 * 64 * 4) / (4 * 71)), C, ROI_FUSED_CAP, cap);
     const size_t lds = ((size_t)256 * (C + 1) + 6 * (size_t)C) * sizeof(float);
     ORE_CHECK_ARG(lds <= 150 * 1024, "ore_roi_predict_fwd: fc width %d too large", C);
     if (lds > 48 * 1024) ORE_HIP(hipFuncSetAttribute((const void*)k_roi_predict, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -100,3 +100,13 @@ class TrainingSampler(torchdata.Sampler):
         g.manual_seed(self._seed)
         while True:
             yield from (torch.randperm(self._size, generator=g) if self._shuffle else torch.arange(self._size)).tolist()
+
+
+def DatasetMapper(cfg, is_train=True, **kw):
+    """d2z:data/dataset_mapper.py DatasetMapper(cfg, is_train) for box-only configs: read the image, ResizeShortestEdge (+ RandomFlip
+    when training), annotations -> Instances.  Implemented by the few-shot mapper with its support branch switched off."""
+    from fewx.data.dataset_mapper import DatasetMapperWithSupport
+    import pandas as pd
+    m = DatasetMapperWithSupport(cfg, is_train, support_df=pd.DataFrame() if is_train else None, **kw)
+    m.support_on = False
+    return m

@@ -237,12 +237,27 @@ class CenterNet2Detector(nn.Module):
     # ---- engine -------------------------------------------------------------------------------------------------
     def _state_key(self):
         """Changes whenever any parameter or buffer is written through torch (optimizer steps -- FlatSGD bumps the version counters
-        for its raw-pointer kernel --, load_state_dict, in-place edits).  Version counters only grow, so their sum is a valid key;
-        the tensor list is collected once (the module tree is fixed after construction)."""
+        for its raw-pointer kernel --, load_state_dict, in-place edits).  Version counters only grow, so their sum is a valid key
+        for a fixed set of tensor objects; the list is collected once and dropped whenever tensors may have been REPLACED
+        (`_apply`: .to() / .float() / .cuda(); `load_state_dict(assign=True)`), together with an epoch that enters the key."""
         ts = self.__dict__.get("_key_tensors")
         if ts is None:
             ts = self.__dict__["_key_tensors"] = list(self.parameters()) + list(self.buffers())
-        return sum([t._version for t in ts])
+        return (self.__dict__.get("_key_epoch", 0), sum([t._version for t in ts]))
+
+    def _invalidate_state_key(self):
+        self.__dict__.pop("_key_tensors", None)
+        self.__dict__["_key_epoch"] = self.__dict__.get("_key_epoch", 0) + 1
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate_state_key()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._invalidate_state_key()
+        return out
 
     def make_engine(self, max_batch: int = 1):
         """A fresh engine (own buffers, own hipGraph) for the current parameters and support set.  `engine()` caches one; a server

@@ -63,7 +63,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -959,7 +959,7 @@ class Engine:
         Returns (boxes [n,4], scores [n], classes [n] int64) -- the caller's own tensors, nothing of the engine aliases them."""
         assert img.is_contiguous() and img.dim() == 3
         _, H, W = img.shape
-        R = 320                                                        # ORE_DET_RECORD_ROWS
+        R = int(lib().ore_det_record_rows())                           # ORE_DET_RECORD_ROWS of the loaded library (= the engine's roi_cap)
         rec = torch.empty(R * 7, dtype=torch.float32, device=self.device)  # [R][4] f32 | [R] f32 | [R] i64, written by the last kernel
         n = C.c_int32(0)
         _chk(lib().ore_engine_detect_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W, int(out_h), int(out_w),

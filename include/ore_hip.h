@@ -400,6 +400,8 @@ int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32
  * caller queues on `stream` afterwards is ordered behind that kernel.  Needs ore_engine_set_roi_head. */
 #define ORE_DET_RECORD_ROWS 320
 #define ORE_DET_RECORD_BYTES (ORE_DET_RECORD_ROWS * 28)
+/* ORE_DET_RECORD_ROWS as the library was built (bindings size the record from this, not from a literal). */
+int32_t ore_det_record_rows(void);
 int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
                           void* out_record, void* stream, int32_t* n_det);
 /* The same for B images of one size in ONE pass (B <= cfg.max_batch; img [B][3][H][W] contiguous): the dense stages -- backbone, FPN,

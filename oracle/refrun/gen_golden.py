@@ -266,6 +266,7 @@ def main():
     gen_state_dict_layout()
     gen_demo_images()
     gen_generate_support()
+    gen_dataset_split()
     gen_eval_end_to_end(sd)
 
 
@@ -525,6 +526,57 @@ def gen_generate_support():
     save("generate_support", seed=np.int64(7), **out)
 
 
+def synth_dataset_dicts(seed=11, n_img=9):
+    """A small detectron2-format dataset (list of dicts) with several categories per image, crowd annotations and an image whose
+    annotations are all crowd: the input of the reference's per-category split."""
+    rng = np.random.default_rng(seed)
+    out, aid = [], 100
+    for i in range(n_img):
+        anns = []
+        for _ in range(int(rng.integers(1, 6))):
+            x, y, w, h = [float(v) for v in rng.integers(5, 200, 4)]
+            anns.append({"id": aid, "bbox": [x, y, w, h], "bbox_mode": 1, "category_id": int(rng.integers(0, 3)),
+                         "iscrowd": int(rng.random() < 0.2), "segmentation": [[x, y, x + w, y, x + w, y + h]], "keypoints": [1, 2, 3]})
+            aid += 1
+        if i == 4:
+            for a in anns:
+                a["iscrowd"] = 1
+        out.append({"file_name": f"img_{i}.png", "height": 300 + i, "width": 400 + i, "image_id": 1000 + i, "annotations": anns})
+    return out
+
+
+def gen_dataset_split():
+    """b/f3: the reference's own `fsod_get_detection_dataset_dicts` (ref:fewx/data/build.py:27-106) executed on a synthetic registered
+    dataset: for a name containing 'train' every image record is split into one record per category (image_id dropped, segmentation /
+    keypoints popped, crowd-only records filtered twice); any other name passes through.  Stored as JSON inside the npz."""
+    import copy
+    import json
+    D2 = shims.d2_root()
+    shims.setup()
+    shims.mod("termcolor", colored=lambda s, *a, **k: s)
+    shims.mod("fvcore.common", file_io=None)
+    shims.mod("fvcore.common.file_io", PathManager=None)
+    shims.mod("detectron2.utils.file_io", PathManager=None)
+    sys.modules["detectron2.utils.logger"]._log_api_usage = lambda *a, **k: None
+    sys.modules["detectron2.utils.env"].seed_all_rng = None
+    shims.pkg("detectron2.data", D2 + "/data")
+    cat = shims.load("detectron2.data.catalog", D2 + "/data/catalog.py")
+    shims.mod("detectron2.data.common", AspectRatioGroupedDataset=None, DatasetFromList=None, MapDataset=None)
+    shims.mod("detectron2.data.dataset_mapper", DatasetMapper=None)
+    shims.mod("detectron2.data.detection_utils", check_metadata_consistency=lambda *a, **k: None)
+    shims.mod("detectron2.data.samplers", InferenceSampler=None, RepeatFactorTrainingSampler=None, TrainingSampler=None)
+    shims.load("detectron2.data.build", D2 + "/data/build.py")
+    shims.pkg("fewx.data", shims.REF + "/fewx/data")
+    fb = shims.load("fewx.data.build", shims.REF + "/fewx/data/build.py")
+    dicts = synth_dataset_dicts()
+    cat.DatasetCatalog.register("synth_ore_train", lambda: copy.deepcopy(dicts))
+    cat.DatasetCatalog.register("synth_ore_val", lambda: copy.deepcopy(dicts))
+    tr = fb.fsod_get_detection_dataset_dicts(["synth_ore_train"], filter_empty=True)
+    va = fb.fsod_get_detection_dataset_dicts(["synth_ore_val"], filter_empty=False)
+    print(f"  dataset split: {len(dicts)} images -> {len(tr)} per-category training records, {len(va)} test records")
+    save("dataset_split", input_json=np.array(json.dumps(dicts)), train_json=np.array(json.dumps(tr)), test_json=np.array(json.dumps(va)))
+
+
 def gen_eval_end_to_end(sd0, shots=5):
     """The reference's eval path END TO END, its own code only: `CenterNet2Detector.init_model` (ref:fewx/modeling/fsod/
     fsod_cen.py:309-408) executed in a scratch working directory holding a synthetic ./datasets/coco/10_shot_support_df.pkl (it walks
@@ -577,7 +629,9 @@ def gen_eval_end_to_end(sd0, shots=5):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+    if len(sys.argv) > 1 and sys.argv[1] == "split":
+        gen_dataset_split()
+    elif len(sys.argv) > 1 and sys.argv[1] == "eval":
         torch.manual_seed(0)
         gen_eval_end_to_end(R.synth_state_dict(SEED))
     else:

@@ -53,3 +53,38 @@ def test_two_rank_rehearsal_line_carries_the_dp_train_leg():
 def test_bf16_line_is_labelled_as_such():
     d = _line("r01_bench_bf16.json")
     assert d["dtype"] == "bf16" and "bf16" in d["config"]["workload"] and d["roofline"]["peak"] == 2500.0
+
+
+def test_bench_self_launches_its_ranks_dry():
+    """`python bench.py --gpus 2` with no launcher in the environment must start its own two ranks (VERDICT r02 missing #1; the twin of
+    ref:fsod_train_net.py:108-118 -> d2z:engine/launch.py:27-82) and rank 0 prints the one JSON line.  --dry skips the GPU legs, so
+    this runs here on gloo."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ORE_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry"] is True and d["scaling"] == "weak"
+
+
+def test_bench_under_an_external_launcher_dry():
+    """The driver's form: the launcher sets RANK / WORLD_SIZE; bench.py must NOT spawn again."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rk in range(2):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ORE_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--dry"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    lines = [l for o in outs for l in o[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2

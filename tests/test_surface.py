@@ -210,3 +210,73 @@ def test_coco_json_registration_and_loader(tmp_path):
     assert d[1]["file_name"].endswith("img/a.png") and [x["id"] for x in a] == [11, 12] and a[0]["category_id"] == 0 and a[0]["bbox_mode"] == 1
     assert MetadataCatalog.get("ore_test_split").thing_classes == ["ore"] and MetadataCatalog.get("ore_test_split").evaluator_type == "coco"
     DatasetCatalog.remove("ore_test_split")
+
+
+def test_per_category_split_matches_reference_run(golden):
+    """ref:fewx/data/build.py:27-106 executed on a synthetic registered dataset (oracle/refrun/gen_golden.py::gen_dataset_split):
+    the product's fsod_get_detection_dataset_dicts returns the same records, in the same order, for a 'train' name (split per
+    category, crowd-only records dropped, segmentation / keypoints / image_id gone) and for any other name (pass-through)."""
+    import copy
+    import json
+    from detectron2.data import DatasetCatalog
+    from fewx.data.build import fsod_get_detection_dataset_dicts
+    g = golden("dataset_split")
+    dicts = json.loads(str(g["input_json"]))
+    for n in ("synth_ore_train", "synth_ore_val"):
+        if n in DatasetCatalog:
+            DatasetCatalog.remove(n)
+        DatasetCatalog.register(n, lambda: copy.deepcopy(dicts))
+    try:
+        assert fsod_get_detection_dataset_dicts(["synth_ore_train"], filter_empty=True) == json.loads(str(g["train_json"]))
+        assert fsod_get_detection_dataset_dicts(["synth_ore_val"], filter_empty=False) == json.loads(str(g["test_json"]))
+    finally:
+        DatasetCatalog.remove("synth_ore_train")
+        DatasetCatalog.remove("synth_ore_val")
+
+
+def test_loader_builders_accept_the_reference_call_forms(tmp_path):
+    """ref:fsod_train_net.py:36-57 calls `build_detection_train_loader(cfg, DatasetMapperWithSupport(cfg))` and
+    `build_detection_test_loader(cfg, dataset_name)` -- the latter with NO mapper (ref:fewx/data/build.py:188-189 defaults it to
+    DatasetMapper(cfg, False)).  Both forms must work and yield the list-of-dicts batches the model consumes."""
+    from PIL import Image
+    from detectron2.data import DatasetCatalog
+    from fewx.config import get_cfg
+    from fewx.data.build import build_detection_test_loader, build_detection_train_loader
+    from fewx.data.dataset_mapper import DatasetMapperWithSupport
+    rng = np.random.default_rng(1)
+    files = []
+    for i in range(3):
+        f = str(tmp_path / f"im{i}.png")
+        Image.fromarray(rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)).save(f)
+        files.append(f)
+    df = _synth_support_df()
+    ids = df["id"].tolist()
+    recs = [{"file_name": files[i], "height": 120, "width": 160, "image_id": int(df.iloc[i]["image_id"]),
+             "annotations": [{"id": int(ids[i]), "bbox": [10.0, 20.0, 50.0, 40.0], "bbox_mode": 1, "category_id": int(df.iloc[i]["category_id"]), "iscrowd": 0}]}
+            for i in range(3)]
+    import copy
+    for n in ("ore_unit_train", "ore_unit_val"):
+        if n in DatasetCatalog:
+            DatasetCatalog.remove(n)
+        DatasetCatalog.register(n, lambda: copy.deepcopy(recs))
+    cfg = get_cfg()
+    cfg.merge_from_list(["DATASETS.TRAIN", ("ore_unit_train",), "DATASETS.TEST", ("ore_unit_val",), "DATALOADER.NUM_WORKERS", 0,
+                         "INPUT.FS.SUPPORT_WAY", 1, "INPUT.FS.SUPPORT_SHOT", 2, "SOLVER.IMS_PER_BATCH", 1,
+                         "INPUT.MIN_SIZE_TEST", 96, "INPUT.MAX_SIZE_TEST", 160, "INPUT.MIN_SIZE_TRAIN", (96,), "INPUT.MAX_SIZE_TRAIN", 160])
+
+    def reader(path, format=None):
+        if path in files:
+            return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+        return _synth_crop(path)
+    try:
+        test_loader = build_detection_test_loader(cfg, "ore_unit_val")                 # the reference's form: no mapper
+        batches = list(test_loader)
+        assert len(batches) == 3 and all(len(b) == 1 for b in batches)
+        d = batches[0][0]
+        assert tuple(d["image"].shape) == (3, 96, 128) and d["height"] == 120 and d["width"] == 160 and "annotations" not in d
+        train_loader = build_detection_train_loader(cfg, DatasetMapperWithSupport(cfg, support_df=df, read_image=reader))
+        b = next(iter(train_loader))
+        assert len(b) == 1 and tuple(b[0]["support_images"].shape) == (2, 3, 240, 240) and len(b[0]["instances"]) == 1
+    finally:
+        DatasetCatalog.remove("ore_unit_train")
+        DatasetCatalog.remove("ore_unit_val")

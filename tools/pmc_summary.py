@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sum FETCH_SIZE / WRITE_SIZE per kernel family over the LAST forward of tools/pmc_pass.py.
-usage: pmc_summary.py <fetch_dir> <write_dir> <out.json>.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts
+usage: pmc_summary.py <fetch_dir> <write_dir> <out.json> [ore_version].  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts
 128-B read requests at 64 B -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Units: the counters are in KiB? -- no:
 rocprofv3 reports the raw derived value in BYTES/1024; we calibrate on k_maxpool (known bytes) and store the factor used."""
 import csv
@@ -33,6 +33,7 @@ def fam(n):
 
 def main():
     fd, wd, out = sys.argv[1:4]
+    ver = int(sys.argv[4]) if len(sys.argv) > 4 else -1        # ore_version() of the library the passes ran with (bench.py checks it)
     fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     res = defaultdict(lambda: {"launches": 0, "fetch_raw": 0.0, "write_raw": 0.0})
     for n, v in fetch:
@@ -45,7 +46,7 @@ def main():
         v["hbm_bytes"] = (2.0 * v["fetch_raw"] + v["write_raw"]) * 1024.0      # KiB -> bytes, FETCH_SIZE doubled on gfx950
         tot[k] = v
     conv = sum(res[k]["hbm_bytes"] for k in ("k_conv_igemm", "k_conv_kw", "k_conv_gs", "k_conv3x3_patch", "k_conv3x3_ws") if k in res)
-    json.dump({"per_image": tot, "conv_hbm_bytes_per_image": conv,
+    json.dump({"per_image": tot, "conv_hbm_bytes_per_image": conv, "ore_version": ver,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over eager forwards (tools/pmc_pass.py), last "
                          "forward; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md: FETCH_SIZE halves wide reads on gfx950)"},
               open(out, "w"), indent=1)
