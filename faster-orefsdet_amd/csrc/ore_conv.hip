@@ -1168,6 +1168,7 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
     if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
+    if (BM == -7) { conv_wino_mode(BN); return ORE_OK; }                                    // BM = -7: Winograd kernel 0 off / 1 automatic / 2 forced
     if (BM == -6) { conv_kw_nw_force(BN); return ORE_OK; }                                  // BM = -6: waves per block of k_conv_kw (4 / 8 / 16)                                   // BM = -5: block -> tile mapping of k_conv_kw (-1 auto, 0, 1, 2)                           // BM = -4: tile of k_conv_gs                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
     g_override = {BM, BN, WGM, WGN, WGK};
     return ORE_OK;
@@ -1208,6 +1209,8 @@ static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t worksp
         // several pyramid levels in one launch (the head tower): the 16-pixel-wide patch tiles waste 17-37 % on the 40- and 20-wide
         // levels, k_conv_kw takes it (47 -> 39 us, profiles/r02_kw_sweep.txt)
         p.bf16 = g_conv_bf16;
+        const int wrc = conv_wino_launch(p, st);              // Winograd F(2x2,3x3): large-M 3x3 layers that were handed transformed weights
+        if (wrc != 1) return wrc;
         const bool kw_first = g_kw_mode == 2 || (g_kw_mode == 1 && p.nlev > 1);
         const int prc = kw_first ? 1 : patch_launch(p, st);
         if (prc != 1) return prc;
@@ -1269,6 +1272,7 @@ static void fill_common(ConvP& p, const ore_conv_desc* d) {
     p.out = d->out; p.out_ld = d->out_ld; p.out_coff = d->out_coff;
     p.nchunks = d->kh * d->kw * (d->Cin / 16);
     p.colsum = d->colsum;
+    p.wino = d->w_wino;
 }
 
 extern "C" int ore_conv2d_fwd(const ore_conv_desc* d, void* stream) {

@@ -21,6 +21,7 @@ struct ConvP {
     float* ws; int* tile_cnt;
     int bf16;                            // ORE_CONV_BF16: operands rounded to bf16 as the fragments leave LDS, one 16x16x16 bf16 MFMA per 16 channels
     int xmap;                            // tile <-> block mapping of k_conv_kw: 0 = blockIdx, 1 / 2 = XCD-contiguous, M- / N-major (tile_of_block)
+    const float* wino;                   // Winograd F(2x2,3x3) transformed weights [16][Cout16][Cin] (ore_winograd_weight_fwd) or null
 };
 
 // Which tile does this block compute?  Workgroups are dealt round-robin over the 8 XCDs in linear block order (observed, MI355X guide),
@@ -51,6 +52,9 @@ int conv_choose_xmap(const ConvP& p, int gx, int gy);   // the mapping for a gx 
 void conv_kw_nw_force(int nw);                   // (-6, nw): waves per block of k_conv_kw; 0 -> automatic
 void conv_xmap_force(int mode);
 int conv_xmap_forced();                          // -1 when automatic                  // (-5, mode): -1 automatic, 0 / 1 / 2 force the block -> tile mapping of k_conv_kw
+// ore_conv_wino.hip: Winograd F(2x2,3x3) kernel for the large-M 3x3 stride-1 layers.  1 = not covered.
+int conv_wino_launch(const ConvP& p, hipStream_t st);
+void conv_wino_mode(int mode);                  // (-7, mode): 0 off, 1 automatic (M >= 6000), 2 wherever it applies
 void conv_gs_force(int bm, int bn, int ns);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic
 
 }  // namespace oreconv

@@ -24,6 +24,7 @@ struct HostTensor { std::vector<float> v; std::vector<int64_t> shape; };
 
 struct Conv {
     float* w = nullptr; float* scale = nullptr; float* shift = nullptr;
+    float* wino = nullptr;               // Winograd F(2x2,3x3) form of w for the 3x3 stride-1 layers with Cin 64 / 128 (else null)
     int Cin = 0, Cout = 0, k = 1, stride = 1, pad = 0, relu_cout = 0;
 };
 
@@ -139,6 +140,16 @@ int need(const ore_engine* e, const std::string& name, const HostTensor** out, s
     return ORE_OK;
 }
 
+// 3x3 stride-1 layers the Winograd kernel covers (ore_conv_wino.hip) also get their transformed weights, once
+int make_wino(ore_engine* e, Conv* c) {
+    if (c->k != 3 || c->stride != 1 || (c->Cin != 64 && c->Cin != 128) || c->Cout % 64 != 0) return ORE_OK;
+    int rc = e->dalloc(&c->wino, ore_winograd_weight_floats(c->Cout, c->Cin));
+    if (rc) return rc;
+    if ((rc = ore_winograd_weight_fwd(c->w, c->Cout, c->Cin, c->wino, nullptr))) return rc;
+    ORE_HIP(hipDeviceSynchronize());
+    return ORE_OK;
+}
+
 // conv (no bias) + FrozenBN folded to (scale, shift) applied in the epilogue; weights stay unscaled.
 int make_conv_bn(ore_engine* e, const std::string& name, int Cin, int Cout, int k, int stride, Conv* c) {
     const HostTensor *w, *g, *b, *m, *v;
@@ -159,7 +170,7 @@ int make_conv_bn(ore_engine* e, const std::string& name, int Cin, int Cout, int 
     if ((rc = e->upload(&c->scale, sc))) return rc;
     if ((rc = e->upload(&c->shift, sh))) return rc;
     c->Cin = Cin; c->Cout = Cout; c->k = k; c->stride = stride; c->pad = k / 2; c->relu_cout = Cout;
-    return ORE_OK;
+    return make_wino(e, c);
 }
 
 int make_conv_bias(ore_engine* e, const std::string& name, int Cin, int Cout, int k, int relu, Conv* c) {
@@ -173,7 +184,7 @@ int make_conv_bias(ore_engine* e, const std::string& name, int Cin, int Cout, in
     if ((rc = e->upload(&c->shift, b->v))) return rc;
     c->scale = nullptr;
     c->Cin = Cin; c->Cout = Cout; c->k = k; c->stride = 1; c->pad = k / 2; c->relu_cout = relu ? Cout : 0;
-    return ORE_OK;
+    return make_wino(e, c);
 }
 
 int alloc_buf(ore_engine* e, Buf* b, size_t rows, int ld) {
@@ -207,6 +218,7 @@ struct Run {
         d.in_mul = in_mul; d.in_add = in_add; d.in_relu = in_relu;
         d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
         d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
+        d.w_wino = c.wino;
         double rows = 0;
         for (int l = 0; l < 3; ++l) rows += (double)B * H[l] * W[l];
         const double fl = 2.0 * rows * (double)c.Cout * c.Cin * c.k * c.k;
@@ -229,6 +241,7 @@ struct Run {
         d.add = add; d.add_ld = add_ld; d.add_coff = add_coff;
         d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
         d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
+        d.w_wino = c.wino;
         if (colsum) {
             const int rows = ore_conv_colsum_rows(&d);
             if ((size_t)rows * round_up(c.Cout, 16) <= e->colsum_floats) { d.colsum = colsum; *colsum_rows = rows; }

@@ -42,7 +42,8 @@ class ConvDesc(C.Structure):
                 ("in_mul", C.c_void_p), ("in_add", C.c_void_p), ("in_relu", C.c_int32),
                 ("add", C.c_void_p), ("add_ld", C.c_int32), ("add_coff", C.c_int32),
                 ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_coff", C.c_int32),
-                ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("colsum", C.c_void_p)]
+                ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("colsum", C.c_void_p),
+                ("w_wino", C.c_void_p)]
 
 
 class DetectDesc(C.Structure):
@@ -63,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -85,6 +86,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         L.ore_last_error.restype = C.c_char_p
         L.ore_packed_weight_floats.restype = C.c_size_t
+        L.ore_winograd_weight_floats.restype = C.c_size_t
         L.ore_conv_workspace_floats.restype = C.c_size_t
         L.ore_conv_colsum_rows.restype = C.c_int32
         L.ore_detect_workspace_bytes.restype = C.c_size_t
@@ -151,11 +153,21 @@ def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     return torch.from_numpy(dst).to(w_oihw.device)
 
 
+def winograd_weight(w_packed: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+    """Packed 3x3 weights ([Cout16][9][Cin], pack_weight) -> their Winograd F(2x2,3x3) form U [16][Cout16][Cin] on the device."""
+    _f32(w_packed)
+    U = torch.empty(int(lib().ore_winograd_weight_floats(Cout, Cin)), device=w_packed.device, dtype=torch.float32)
+    _chk(lib().ore_winograd_weight_fwd(C.c_void_p(_ptr(w_packed)), Cout, Cin, C.c_void_p(_ptr(U)), _stream()), "ore_winograd_weight_fwd")
+    return U
+
+
 def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: int = 1, pad: Optional[int] = None, *,
            in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, relu_cout: int = 0, in_mul=None,
            in_add=None, in_relu: bool = False, add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           out_coff: int = 0, splitk: int = 0, workspace: Optional[torch.Tensor] = None, want_colsum: bool = False):
-    """x: [B,H,W,ld] NHWC fp32.  Returns `out` ([B,Ho,Wo,out_ld]); only channels [out_coff, out_coff+Cout) are written."""
+           out_coff: int = 0, splitk: int = 0, workspace: Optional[torch.Tensor] = None, want_colsum: bool = False,
+           w_wino: Optional[torch.Tensor] = None):
+    """x: [B,H,W,ld] NHWC fp32.  Returns `out` ([B,Ho,Wo,out_ld]); only channels [out_coff, out_coff+Cout) are written.
+    w_wino: the same weights in Winograd F(2x2,3x3) form (winograd_weight); lets the large-M 3x3 layers run on the Winograd kernel."""
     _f32(x)
     B, H, W, ld = x.shape
     Cin = Cin if Cin is not None else ld - in_coff
@@ -180,6 +192,7 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
         d.add, d.add_ld, d.add_coff = _ptr(add), add.shape[-1], 0
     d.out, d.out_ld, d.out_coff = _ptr(out), out.shape[-1], out_coff
     d.splitk = splitk
+    d.w_wino = _ptr(w_wino)
     if workspace is not None:
         d.workspace, d.workspace_floats = _ptr(workspace), workspace.numel()
     colsum = None
@@ -194,7 +207,7 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
 def conv2d_levels(x_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, w_packed: torch.Tensor, Cout: int, k: int, *,
                   in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, ep_stride: int = 0, relu_cout: int = 0,
                   in_mul=None, in_add=None, in_relu: bool = False, out: Optional[torch.Tensor] = None, out_coff: int = 0,
-                  splitk: int = 0) -> torch.Tensor:
+                  splitk: int = 0, w_wino: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One launch over several pyramid levels: x_rows [sum_l B*H_l*W_l, ld] level-major."""
     _f32(x_rows)
     rows, ld = x_rows.shape
@@ -212,6 +225,7 @@ def conv2d_levels(x_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, w
     d.in_mul, d.in_add, d.in_relu = _ptr(in_mul), _ptr(in_add), int(in_relu)
     d.out, d.out_ld, d.out_coff = _ptr(_f32(out)), out.shape[-1], out_coff
     d.splitk, d.workspace, d.workspace_floats = splitk, _ptr(ws), ws.numel()
+    d.w_wino = _ptr(w_wino)
     L = len(HW)
     Hs = (C.c_int32 * L)(*[h for h, _ in HW])
     Ws = (C.c_int32 * L)(*[w for _, w in HW])

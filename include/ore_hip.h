@@ -63,7 +63,16 @@ typedef struct ore_conv_desc {
     int32_t splitk;       /* 0 = choose automatically, 1 = none */
     float* workspace;  size_t workspace_floats;
     float* colsum;        /* optional [ore_conv_colsum_rows()][Cout16]: per-row-tile column sums of y (eSE average pool) */
+    const float* w_wino;  /* optional: the same weights in Winograd F(2x2,3x3) form (ore_winograd_weight_fwd).  When given, 3x3
+                           * stride-1 pad-1 layers with Cin 64 / 128, Cout % 64 == 0 and M >= 6000 rows run on the Winograd kernel
+                           * (2.25x fewer multiplies, fp32 throughout); NULL = direct kernels only */
 } ore_conv_desc;
+
+/* Winograd F(2x2,3x3) form of packed 3x3 weights: U[16][Cout16][Cin] = G g G^T per (Cout, Cin) pair, computed on the device in fp32
+ * (the halves in G are exact).  `packed_w` is ore_pack_conv_weight_host's layout for kh = kw = 3; U needs
+ * ore_winograd_weight_floats(Cout, Cin) floats.  Call again whenever the weights change. */
+size_t ore_winograd_weight_floats(int32_t Cout, int32_t Cin);
+int ore_winograd_weight_fwd(const float* packed_w, int32_t Cout, int32_t Cin, float* U, void* stream);
 
 /* Workspace contract: the first ORE_CONV_CNT_INTS 32-bit words are split-K arrival counters and must be ZERO on entry;
  * every launch leaves them zero again (the last arriver resets its counter).  The rest holds the fp32 partial slabs. */
@@ -75,8 +84,8 @@ int32_t ore_conv_colsum_rows(const ore_conv_desc* d);   /* number of row tiles (
 int ore_conv2d_fwd(const ore_conv_desc* d, void* stream);
 /* Tuning aid (tools/conv_tune.py): force the block tile (BM x BN, waves WGM x WGN x WGK) of subsequent conv calls;
  * BM = 0 restores the automatic plan; BM = -1 sets the 3x3 patch-kernel mode to BN (-1 automatic, 0 off, 4 / 8 forced tile
- * height, 16 = double-buffered 8-wave variant, 102 = weight-stationary persistent kernel for Cin = 64 / 128).  The product path
- * never calls it. */
+ * height, 16 = double-buffered 8-wave variant, 102 = weight-stationary persistent kernel for Cin = 64 / 128); BM = -7 sets the
+ * Winograd mode to BN (0 off, 1 automatic, 2 wherever it applies).  The product path never calls it. */
 int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN, int32_t WGK);
 /* Operand precision of the MFMA conv kernels for all subsequent ore_conv2d*_fwd launches (BASELINE configs[4], "bf16 MFMA conv
  * path + fp32 NMS"; the reference itself is fp32 only, ref:configs/fsod/finetune_vovnet.yaml).  ORE_CONV_FP32 (default): fp32

@@ -110,6 +110,84 @@ def test_conv_slices_inmul_add_partial_relu(ore):
 
 
 @pytest.fixture
+def wino_forced(ore):
+    """Winograd F(2x2,3x3) kernel (csrc/ore_conv_wino.hip) wherever it applies -- the automatic plan only takes it from 6000 rows."""
+    ore.lib().ore_conv_set_plan_override(-7, 2, 0, 0, 0)
+    yield
+    ore.lib().ore_conv_set_plan_override(-7, 1, 0, 0, 0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 32, 32, 64, 64),      # stem_2 / stage-2 64 -> 64 shape class, whole batches
+    (1, 20, 24, 128, 64),     # stage-2 layer 0 class (two K wave groups, 32 channels per block), partial column batch
+    (2, 13, 11, 64, 128),     # odd sizes: tiles hanging over the right and bottom edge, two images, two channel blocks
+    (1, 10, 40, 128, 128),    # FPN output / head tower class
+    (1, 3, 5, 64, 64),        # smaller than one batch
+])
+def test_conv_winograd_kernel_vs_oracle(ore, wino_forced, B, H, W, Cin, Cout):
+    """k_conv3x3_wino against F.conv2d at the fp32 tolerance, with FrozenBN scale / shift + ReLU, and bit-reproducible."""
+    g = torch.Generator().manual_seed(B * 100 + H + W + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    sc = torch.rand(Cout, generator=g) + 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wp = ore.pack_conv_weight(w).cuda()
+    U = ore.winograd_weight(wp, Cout, Cin)
+    y = ore.conv2d(nhwc(x), wp, Cout, 3, 1, scale=dev(sc), shift=dev(sh), relu_cout=Cout, w_wino=U)
+    direct = ore.conv2d(nhwc(x), wp, Cout, 3, 1, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    assert not torch.equal(y, direct), "the Winograd kernel did not run (results identical to the direct kernel bit for bit)"
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert rel_err(nchw(y).numpy(), nchw(direct).numpy()) < 2e-5
+    y2 = ore.conv2d(nhwc(x), wp, Cout, 3, 1, scale=dev(sc), shift=dev(sh), relu_cout=Cout, w_wino=U)
+    assert torch.equal(y, y2)
+
+
+def test_conv_winograd_weight_transform(ore):
+    """U = G g G^T per (Cout, Cin) pair, laid out [16][Cout16][Cin]."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(48, 64, 3, 3, generator=g)
+    U = ore.winograd_weight(ore.pack_conv_weight(w).cuda(), 48, 64).cpu().view(4, 4, 48, 64)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    want = torch.einsum("xa,ncab,yb->xync", G, w.double(), G)
+    assert float((U.double() - want).abs().max()) < 1e-6
+
+
+def test_conv_winograd_slices_levels_bias(ore, wino_forced):
+    """What the engine asks of it: channel-slice input and output inside wider buffers (the OSA concat buffer), bias without scale, no
+    ReLU, three pyramid levels in one launch (the head tower), and the automatic plan taking it at 6400 rows."""
+    g = torch.Generator().manual_seed(12)
+    buf = torch.randn(1, 192, 20, 24, generator=g)                                 # read channels 64..127
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.04
+    sh = torch.randn(64, generator=g) * 0.1
+    out = torch.full((1, 20, 24, 160), 7.0).cuda()
+    wp = ore.pack_conv_weight(w).cuda()
+    U = ore.winograd_weight(wp, 64, 64)
+    ore.conv2d(nhwc(buf), wp, 64, 3, 1, in_coff=64, Cin=64, shift=dev(sh), relu_cout=0, out=out, out_coff=32, w_wino=U)
+    ref = F.conv2d(buf[:, 64:128], w, sh, 1, 1)
+    assert rel_err(nchw(out[..., 32:96].contiguous()).numpy(), ref.numpy()) < TOL
+    assert float(out[..., :32].min()) == 7.0 and float(out[..., 96:].max()) == 7.0   # the neighbours of the slice are untouched
+    HW = [(12, 16), (6, 8), (3, 4)]
+    xs = [torch.randn(1, 128, h, w_, generator=g) for h, w_ in HW]
+    w2 = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    b2 = torch.randn(128, generator=g) * 0.1
+    rows = torch.cat([nhwc(t).reshape(-1, 128) for t in xs], 0).contiguous()
+    wp2 = ore.pack_conv_weight(w2).cuda()
+    U2 = ore.winograd_weight(wp2, 128, 128)
+    y = ore.conv2d_levels(rows, HW, 1, wp2, 128, 3, shift=dev(b2), w_wino=U2).cpu()
+    r0 = 0
+    for (h, w_), t in zip(HW, xs):
+        ref_l = F.conv2d(t, w2, b2, 1, 1)[0].permute(1, 2, 0).reshape(-1, 128)
+        assert rel_err(y[r0:r0 + h * w_].numpy(), ref_l.numpy()) < TOL
+        r0 += h * w_
+    ore.lib().ore_conv_set_plan_override(-7, 1, 0, 0, 0)                              # automatic: M = 6400 qualifies
+    x3 = torch.randn(1, 64, 80, 80, generator=g)
+    y3 = ore.conv2d(nhwc(x3), wp, 64, 3, 1, shift=dev(sh), w_wino=U)
+    d3 = ore.conv2d(nhwc(x3), wp, 64, 3, 1, shift=dev(sh))
+    assert not torch.equal(y3, d3) and rel_err(nchw(y3).numpy(), F.conv2d(x3, w, sh, 1, 1).numpy()) < TOL
+
+
+@pytest.fixture
 def kw_forced(ore):
     """Force the wave-private K-split LDS-DMA kernel (k_conv_kw, csrc/ore_conv_kw.hip) wherever it applies, then restore the plan."""
     ore.lib().ore_conv_set_plan_override(-2, 2, 0, 0, 0)
