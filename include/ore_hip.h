@@ -68,8 +68,8 @@ typedef struct ore_conv_desc {
                            * (2.25x fewer multiplies, fp32 throughout); NULL = direct kernels only */
 } ore_conv_desc;
 
-/* Winograd F(2x2,3x3) form of packed 3x3 weights: U[16][Cout16][Cin] = G g G^T per (Cout, Cin) pair, computed on the device in fp32
- * (the halves in G are exact).  `packed_w` is ore_pack_conv_weight_host's layout for kh = kw = 3; U needs
+/* Winograd F(2x2,3x3) form of packed 3x3 weights: U_p = G g G^T per (Cout, Cin) pair for the 16 positions p, computed on the device in
+ * fp32 (the halves in G are exact), stored in the kernel's MFMA-fragment order [16][Cout16/16][Cin/16][64 lanes][4] (opaque to callers).  `packed_w` is ore_pack_conv_weight_host's layout for kh = kw = 3; U needs
  * ore_winograd_weight_floats(Cout, Cin) floats.  Call again whenever the weights change. */
 size_t ore_winograd_weight_floats(int32_t Cout, int32_t Cin);
 int ore_winograd_weight_fwd(const float* packed_w, int32_t Cout, int32_t Cin, float* U, void* stream);

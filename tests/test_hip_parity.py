@@ -144,10 +144,11 @@ def test_conv_winograd_kernel_vs_oracle(ore, wino_forced, B, H, W, Cin, Cout):
 
 
 def test_conv_winograd_weight_transform(ore):
-    """U = G g G^T per (Cout, Cin) pair, laid out [16][Cout16][Cin]."""
+    """U = G g G^T per (Cout, Cin) pair, stored in MFMA-fragment order [16 pos][Cout16 / 16][Cin / 16][(c % 16) / 4][n % 16][c % 4]."""
     g = torch.Generator().manual_seed(5)
     w = torch.randn(48, 64, 3, 3, generator=g)
-    U = ore.winograd_weight(ore.pack_conv_weight(w).cuda(), 48, 64).cpu().view(4, 4, 48, 64)
+    U = ore.winograd_weight(ore.pack_conv_weight(w).cuda(), 48, 64).cpu()
+    U = U.view(16, 3, 4, 4, 16, 4).permute(0, 1, 4, 2, 3, 5).reshape(4, 4, 48, 64)
     G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
     want = torch.einsum("xa,ncab,yb->xync", G, w.double(), G)
     assert float((U.double() - want).abs().max()) < 1e-6
