@@ -24,12 +24,16 @@
 //           Z[xi][kh][j][tile][co] goes to LDS.
 //   P3      thread = (tile, j, 4 output channels): y_i = sum_xi A^T[i][xi] Z (4 or 8 ds_read_b128), FrozenBN / bias / ReLU epilogue,
 //           two 16-byte NHWC stores.
-// Two barriers per batch (P1 | P2 | P3; P3 of batch n overlaps P1 of batch n+1).  LDS: V 64 / 128 KB + Z 32 KB.
+// Two barriers per batch (P1 | P2 | P3; P3 of batch n runs into P1 of batch n+1).  LDS: V 64 / 128 KB + Z 32 KB.
+// The phases are deliberately serial.  Round 3 built two overlapped forms (git history: k_conv3x3_wino_pipe -- the two wave groups in
+// anti-phase, one multiplying while the other transforms --, and k_conv3x3_wino64 -- the same with the raw halo patch staged by LDS-DMA
+// one phase ahead and K split between the groups) and timed every phase with skip flags (profiles/EXPERIMENTS.md): phase times ADD
+// whatever the arrangement (6.5 us per batch = 3.7 MFMA + 0.9..1.5 input transform + 0.6 output transform + barriers), i.e. on gfx950
+// an fp32 MFMA and the other wave's VALU work do not overlap on a SIMD -- the fp32 matrix op runs at, and evidently on, the vector
+// FMA rate.  With nothing to hide behind, the arrangement with the fewest barriers and instructions wins.
 //
 // Replaces F.conv2d(3x3, pad 1) + FrozenBatchNorm2d + ReLU of d2z:modeling/backbone/vovnet.py:205-219,408-412 (stem_2, OSA2 layers),
 // fpn.py:139-145 (fpn_output3) and conv3x3 + bias of ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:141-150 (tower).
-#include <stdlib.h>
-#include <type_traits>
 #include "ore_conv_internal.h"
 
 namespace {
@@ -42,8 +46,6 @@ struct WinoP {
     const float* scale; const float* shift; int ep_stride, relu_cout;
     float* out; int out_ld, out_coff;
     int nbat;
-    const float* zero;   // device zero page (16 bytes): LDS-DMA source of out-of-image pixels
-    int dbg;          // timing experiments only (ORE_WINO_DBG): bit 0 skip P1, bit 1 skip the MFMAs, bit 2 skip P3
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_wino[4] = {0.f, 0.f, 0.f, 0.f};
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
         const int byi = r1 / p.nbx[lvl], bxi = r1 - byi * p.nbx[lvl];
         const int H = L.H, W = L.W;
         // ---------------- P1: input transform -> V
-        if (!(p.dbg & 1)) {
+        {
             const int iy0 = (byi * 2 + ty1) * 2 - 1, ix0 = (bxi * 8 + tx1) * 2 - 1;
             const float* base = p.in + (ptrdiff_t)(L.irow0 + b * H * W) * p.in_ld + p.in_coff + q1 * 4;
 #pragma unroll
@@ -184,7 +186,6 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg) acc[nu][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* vb = V + ((xi * 4) * 16 + li) * CIN;
-            if (!(p.dbg & 2))
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int qoff = ((((cin_w0 >> 2) + c * 4 + g) ^ li) << 2);
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
         }
         lds_barrier();
         // ---------------- P3: xi half of the output transform, epilogue, store
-        if (p3_on && !(p.dbg & 4)) {
+        if (p3_on) {
             f32x4 z[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
@@ -239,408 +240,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
     }
 }
 
-// ---- pipelined build (the production kernel).  Same roles, same arithmetic (bit-identical results), but the two wave groups
-// A = waves 0-3 and B = waves 4-7 -- one of each per SIMD -- work in anti-phase, so that the matrix pipe always has one group's
-// MFMAs while the other group's wave on the same SIMD does the transforms (VALU + LDS + global loads):
-//     X(i):  A: MFMA(batch i) -> z registers       | B: input transform part 1 for the NEXT MFMA of B / A, output transform part 0 of batch i-1
-//     Y(i):  B: MFMA(batch i) -> z registers       | A: input transform part 2,                          output transform part 1 of batch i-1
-//     W(i):  everybody parks its z registers in Z (Z(i-1) has been consumed), barrier.
-// CIN = 64:  V is double buffered (2 x 64 KB): B writes the rows xi = 0,1 of V(i+1) in X(i), A the rows xi = 2,3 in Y(i).
-// CIN = 128: the two groups split K, so A only ever reads V's quads 0-15 ("V0") and B quads 16-31 ("V1"): B writes V1(i) in X(i)
-//            -- right before it multiplies it in Y(i) --, A writes V0(i+1) in Y(i) after it has finished with V0(i).  Single 128 KB buffer.
-// Three barriers per batch; a batch costs two MFMA phases of 128 MFMAs per wave (2 x 4096 clocks) instead of MFMA + transforms in series.
-template <int CIN>
-__global__ __launch_bounds__(512, 2) void k_conv3x3_wino_pipe(WinoP p) {
-    constexpr int KH = CIN / 64, COUTB = 64 / KH, QZ = COUTB / 4;
-    constexpr int VF = 16 * 16 * CIN, NVB = CIN == 64 ? 2 : 1;
-    extern __shared__ __attribute__((aligned(16))) float wl[];
-    float* Vbase = wl;
-    float* Z = wl + NVB * VF;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
-    const int xi = w & 3, grp = w >> 2, lt = tid & 255;
-    const int cb = KH == 1 ? grp * 32 : 0;
-    const int cin_w0 = KH == 2 ? grp * 64 : 0;
-    auto zs = [](int t) -> int { return QZ == 16 ? (t & 7) : ((t >> 1) & 3); };
-    const float* zero = g_zero_wino;
-
-    f32x4 wf[4][2][4];
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-            const int n16 = (blockIdx.y * COUTB + cb) / 16 + cg;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) wf[nu][cg][c] = wino_u_frag(p.U, xi * 4 + nu, n16, (cin_w0 >> 4) + c, p.Cout16, CIN, lane);
-        }
-
-    struct Geo { int lvl, b, byi, bxi, H, W, irow, orow; };
-    auto decode = [&](int bat) -> Geo {
-        Geo q;
-        q.lvl = 0;
-#pragma unroll
-        for (int l = 1; l < 4; ++l)
-            if (l < p.nlev && bat >= p.bat0[l]) q.lvl = l;
-        const Lvl& L = p.lv[q.lvl];
-        const int r0 = bat - p.bat0[q.lvl], per = p.nbx[q.lvl] * p.nby[q.lvl];
-        q.b = r0 / per;
-        const int r1 = r0 - q.b * per;
-        q.byi = r1 / p.nbx[q.lvl]; q.bxi = r1 - q.byi * p.nbx[q.lvl];
-        q.H = L.H; q.W = L.W; q.irow = L.irow0 + q.b * L.H * L.W; q.orow = L.orow0 + q.b * L.H * L.W;
-        return q;
-    };
-    // input transform of the group's 256 threads: tile t = lt >> 4, quad qbase + (lt & 15), row combinations xi_0 .. xi_0 + NX - 1
-    auto p1 = [&](const Geo& q, float* V, int qbase, int xi_0, auto nx_tag) {
-        constexpr int NX = decltype(nx_tag)::value;
-        const int t1 = lt >> 4, q1 = qbase + (lt & 15);
-        const int iy0 = (q.byi * 2 + (t1 >> 3)) * 2 - 1, ix0 = (q.bxi * 8 + (t1 & 7)) * 2 - 1;
-        const float* base = p.in + (ptrdiff_t)q.irow * p.in_ld + p.in_coff + q1 * 4;
-#pragma unroll
-        for (int it = 0; it < NX; ++it) {
-            const int x1 = xi_0 + it;
-            const int ra = (0x1210 >> (x1 * 4)) & 3, rb = (0x3122 >> (x1 * 4)) & 3;
-            const float sgn = x1 == 1 ? 1.0f : -1.0f;
-            f32x4 da[4], db[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ix = ix0 + c, iya = iy0 + ra, iyb = iy0 + rb;
-                const bool okx = (unsigned)ix < (unsigned)q.W;
-                const bool oka = okx && (unsigned)iya < (unsigned)q.H, okb = okx && (unsigned)iyb < (unsigned)q.H;
-                const float* pa = oka ? base + (ptrdiff_t)(iya * q.W + ix) * p.in_ld : zero;
-                const float* pb = okb ? base + (ptrdiff_t)(iyb * q.W + ix) * p.in_ld : zero;
-                da[c] = *reinterpret_cast<const f32x4*>(pa);
-                db[c] = *reinterpret_cast<const f32x4*>(pb);
-            }
-            f32x4 X[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) X[c] = da[c] + sgn * db[c];
-            float* vrow = V + ((x1 * 4) * 16 + t1) * CIN + ((q1 ^ t1) << 2);
-            *reinterpret_cast<f32x4*>(vrow) = X[0] - X[2];
-            *reinterpret_cast<f32x4*>(vrow + 16 * CIN) = X[1] + X[2];
-            *reinterpret_cast<f32x4*>(vrow + 32 * CIN) = X[2] - X[1];
-            *reinterpret_cast<f32x4*>(vrow + 48 * CIN) = X[1] - X[3];
-        }
-    };
-    // output transform, part h of two: CIN 64 -> the 8 quads of channel half h for all 16 tiles; CIN 128 -> tiles 8h .. 8h+7, all 8 quads
-    auto p3 = [&](const Geo& q, int h) {
-        int cq, j3, t3;
-        if (CIN == 64) { cq = h * 8 + (lt & 7); j3 = (lt >> 3) & 1; t3 = lt >> 4; }
-        else { if (lt >= 128) return; cq = lt & 7; j3 = (lt >> 3) & 1; t3 = h * 8 + (lt >> 4); }
-        f32x4 z[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float* zr = Z + (((x * KH) * 2 + j3) * 16 + t3) * COUTB + ((cq ^ zs(t3)) << 2);
-            z[x] = *reinterpret_cast<const f32x4*>(zr);
-            if (KH == 2) z[x] += *reinterpret_cast<const f32x4*>(zr + 2 * 16 * COUTB);
-        }
-        const f32x4 y0 = (z[0] + z[1]) + z[2], y1 = (z[1] - z[2]) - z[3];
-        const int n = blockIdx.y * COUTB + cq * 4;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + q.lvl * p.ep_stride + n);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + q.lvl * p.ep_stride + n);
-        f32x4 v0 = y0 * sc + sh, v1 = y1 * sc + sh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < p.relu_cout) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
-        const int oy = (q.byi * 2 + (t3 >> 3)) * 2, ox = (q.bxi * 8 + (t3 & 7)) * 2 + j3;
-        if (ox < q.W && oy < q.H) {
-            float* o = p.out + (size_t)(q.orow + oy * q.W + ox) * p.out_ld + p.out_coff + n;
-            *reinterpret_cast<f32x4*>(o) = v0;
-            if (oy + 1 < q.H) *reinterpret_cast<f32x4*>(o + (size_t)q.W * p.out_ld) = v1;
-        }
-    };
-    f32x4 zreg[2][2];                               // [j][cg]: the nu-reduced accumulators of the last MFMA phase
-    auto mfma_phase = [&](const float* V) {
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-            for (int cg = 0; cg < 2; ++cg) acc[nu][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* vb = V + ((xi * 4) * 16 + li) * CIN;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int qoff = ((((cin_w0 >> 2) + c * 4 + g) ^ li) << 2);
-            f32x4 bf[4];
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) bf[nu] = *reinterpret_cast<const f32x4*>(vb + nu * 16 * CIN + qoff);
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int cg = 0; cg < 2; ++cg)
-                        acc[nu][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nu][cg][c][k], bf[nu][k], acc[nu][cg], 0, 0, 0);
-        }
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-            zreg[0][cg] = (acc[0][cg] + acc[1][cg]) + acc[2][cg];
-            zreg[1][cg] = (acc[1][cg] - acc[2][cg]) - acc[3][cg];
-        }
-    };
-    using I2 = std::integral_constant<int, 2>;
-    using I4 = std::integral_constant<int, 4>;
-
-    int bat = blockIdx.x;
-    if (bat >= p.nbat) return;
-    Geo cur_g = decode(bat), prev_g = cur_g;
-    // prologue: what the first X phase needs.  CIN 64: all of V(first) (group g writes rows xi = 2g, 2g+1); CIN 128: V0(first) by A.
-    if (CIN == 64) p1(cur_g, Vbase, 0, grp * 2, I2{});
-    else if (grp == 0) p1(cur_g, Vbase, 0, 0, I4{});
-    lds_barrier();
-    int cur = 0;
-    bool have_prev = false;
-    for (; bat < p.nbat; bat += gridDim.x) {
-        const int nxt = bat + gridDim.x;
-        const bool has_next = nxt < p.nbat;
-        Geo next_g = cur_g;
-        if (has_next) next_g = decode(nxt);
-        float* Vc = Vbase + (CIN == 64 ? cur * VF : 0);
-        float* Vn = Vbase + (CIN == 64 ? (cur ^ 1) * VF : 0);
-        // ---- X
-        if (grp == 0) {
-            mfma_phase(Vc);
-        } else {
-            if (CIN == 64) { if (has_next) p1(next_g, Vn, 0, 0, I2{}); }
-            else p1(cur_g, Vc, 16, 0, I4{});
-            if (have_prev) p3(prev_g, 0);
-        }
-        lds_barrier();
-        // ---- Y
-        if (grp == 1) {
-            mfma_phase(Vc);
-        } else {
-            if (has_next) {
-                if (CIN == 64) p1(next_g, Vn, 0, 2, I2{});
-                else p1(next_g, Vn, 0, 0, I4{});
-            }
-            if (have_prev) p3(prev_g, 1);
-        }
-        lds_barrier();
-        // ---- W: park the z registers (Z of the previous batch has been consumed in X / Y)
-        {
-            float* zb = Z + (((xi * KH + (KH == 2 ? grp : 0)) * 2) * 16 + li) * COUTB;
-#pragma unroll
-            for (int cg = 0; cg < 2; ++cg) {
-                const int quad = ((cb >> 2) + cg * 4 + g) ^ zs(li);
-                *reinterpret_cast<f32x4*>(zb + (quad << 2)) = zreg[0][cg];
-                *reinterpret_cast<f32x4*>(zb + 16 * COUTB + (quad << 2)) = zreg[1][cg];
-            }
-        }
-        lds_barrier();
-        prev_g = cur_g; cur_g = next_g; have_prev = true;
-        cur ^= 1;
-    }
-    p3(prev_g, grp);                                // the last batch: both halves at once
-}
-
-// ---- CIN = 64, staged + pipelined (the production kernel of stem_2 and the 64 -> 64 layers of stage 2).
-// Measured on the serial build (tools/wino_time.py, ORE_WINO_DBG): of a 6.9 us batch the MFMAs take 3.9 us, the input transform 1.5 us
-// -- nearly all of it waiting for its 16 global loads per thread --, the output transform 0.7, barriers / bookkeeping 0.8; overlapping
-// the groups as in k_conv3x3_wino_pipe did not help because the transform side, waiting on global memory, became the long pole.
-// Here the raw 6 x 18 pixel halo patch of a batch travels global -> LDS by LDS-DMA one phase AHEAD of its use (27 wave-instructions
-// of 1 KB, no registers, out-of-image pixels from a zero page), so the input transform is LDS -> LDS with constant offsets, and the
-// two wave groups split K (A: input channels 0-31, B: 32-63; 4 positions x 64 output channels x 32 input channels = 128 VGPRs
-// of weights each), which lets ONE 64 KB V buffer be refilled half by half behind the MFMAs:
-//     X(i): A: MFMA on V[ch 0-31](i)               | B: DMA raw(i+1); transform raw(i) -> V[ch 32-63](i); output transform of batch i-1
-//     Y(i): B: MFMA on V[ch 32-63](i), park z in Z | A: transform raw(i+1) -> V[ch 0-31](i+1)
-//     W(i): A: Z += its own z (the K halves meet in LDS, slot by slot, no cross-lane traffic)
-// LDS: V 64 KB + Z 32 KB + raw 2 x 27 KB = 150 KB, one block per CU.
-constexpr int WINO_RAW_F = 108 * 64;                // floats of one raw patch (6 x 18 pixels x 64 channels)
-
-__global__ __launch_bounds__(512, 2) void k_conv3x3_wino64(WinoP p) {
-    constexpr int CIN = 64, VF = 16 * 16 * CIN, ZF = 4 * 2 * 16 * 64;
-    extern __shared__ __attribute__((aligned(16))) float wl[];
-    float* V = wl;
-    float* Z = wl + VF;                             // [4 xi][2 j][16 tiles][64], quad q of row (.., t) at q ^ (t & 7)
-    float* Rw = wl + VF + ZF;                       // [2][108 pixels][64]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, g = lane >> 4;
-    const int xi = w & 3, grp = w >> 2, lt = tid & 255;
-    const float* zero = p.zero;
-
-    f32x4 wf[4][4][2];                              // [nu][16-channel group][chunk of this group's K half]
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-        for (int cg = 0; cg < 4; ++cg)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) wf[nu][cg][c] = wino_u_frag(p.U, xi * 4 + nu, blockIdx.y * 4 + cg, grp * 2 + c, p.Cout16, CIN, lane);
-
-    struct Geo { int lvl, byi, bxi, H, W, irow, orow; };
-    auto decode = [&](int bat) -> Geo {
-        Geo q;
-        q.lvl = 0;
-#pragma unroll
-        for (int l = 1; l < 4; ++l)
-            if (l < p.nlev && bat >= p.bat0[l]) q.lvl = l;
-        const Lvl& L = p.lv[q.lvl];
-        const int r0 = bat - p.bat0[q.lvl], per = p.nbx[q.lvl] * p.nby[q.lvl];
-        const int b = r0 / per, r1 = r0 - b * per;
-        q.byi = r1 / p.nbx[q.lvl]; q.bxi = r1 - q.byi * p.nbx[q.lvl];
-        q.H = L.H; q.W = L.W; q.irow = L.irow0 + b * L.H * L.W; q.orow = L.orow0 + b * L.H * L.W;
-        return q;
-    };
-    // raw patch of batch q -> R (LDS-DMA): piece = 4 pixels x 16 quads; the group's four waves take pieces w', w'+4, ... < 27
-    auto dma = [&](const Geo& q, float* R, int nwaves, int wv) {
-        const int gy0 = q.byi * 4 - 1, gx0 = q.bxi * 16 - 1;
-        const float* base = p.in + (ptrdiff_t)q.irow * p.in_ld + p.in_coff + (lane & 15) * 4;
-        for (int piece = wv; piece < 27; piece += nwaves) {
-            const int pi = piece * 4 + (lane >> 4);
-            const int py = (pi * 57) >> 10, px = pi - py * 18;         // pi / 18 for pi < 108
-            const int gy = gy0 + py, gx = gx0 + px;
-            const bool ok = (unsigned)gy < (unsigned)q.H && (unsigned)gx < (unsigned)q.W;
-            const float* src = ok ? base + (ptrdiff_t)(gy * q.W + gx) * p.in_ld : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(R + piece * 256), 16, 0, 0);
-        }
-    };
-    // input transform of K half `kh` by the calling group's 256 threads: (tile t, quad q8 of the half, xi pair xh)
-    auto p1 = [&](const float* R, int kh) {
-        const int q = kh * 8 + (lt & 7), t = (lt >> 3) & 15;
-        const int xh = __builtin_amdgcn_readfirstlane(lt >> 7);
-        const float* rb = R + (((t >> 3) * 2 + xh) * 18 + (t & 7) * 2) * 64 + q * 4;
-        f32x4 d[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[r][c] = *reinterpret_cast<const f32x4*>(rb + (r * 18 + c) * 64);
-        f32x4 Xa[4], Xb[4];                         // xi = 2 xh and 2 xh + 1
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (xh == 0) { Xa[c] = d[0][c] - d[2][c]; Xb[c] = d[1][c] + d[2][c]; }        // rows 0,1,2: xi 0 = d0 - d2, xi 1 = d1 + d2
-            else { Xa[c] = d[1][c] - d[0][c]; Xb[c] = d[0][c] - d[2][c]; }                // rows 1,2,3: xi 2 = d2 - d1, xi 3 = d1 - d3
-        }
-        float* va = V + (((2 * xh) * 4) * 16 + t) * CIN + ((q ^ t) << 2);
-        *reinterpret_cast<f32x4*>(va) = Xa[0] - Xa[2];
-        *reinterpret_cast<f32x4*>(va + 16 * CIN) = Xa[1] + Xa[2];
-        *reinterpret_cast<f32x4*>(va + 32 * CIN) = Xa[2] - Xa[1];
-        *reinterpret_cast<f32x4*>(va + 48 * CIN) = Xa[1] - Xa[3];
-        float* vb2 = va + 64 * CIN;
-        *reinterpret_cast<f32x4*>(vb2) = Xb[0] - Xb[2];
-        *reinterpret_cast<f32x4*>(vb2 + 16 * CIN) = Xb[1] + Xb[2];
-        *reinterpret_cast<f32x4*>(vb2 + 32 * CIN) = Xb[2] - Xb[1];
-        *reinterpret_cast<f32x4*>(vb2 + 48 * CIN) = Xb[1] - Xb[3];
-    };
-    // output transform item (tile t3, column j3, quad cq) from the K-summed Z
-    auto p3 = [&](const Geo& q, int item) {
-        const int cq = item & 15, j3 = (item >> 4) & 1, t3 = item >> 5;
-        f32x4 z[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) z[x] = *reinterpret_cast<const f32x4*>(Z + ((x * 2 + j3) * 16 + t3) * 64 + ((cq ^ (t3 & 7)) << 2));
-        const f32x4 y0 = (z[0] + z[1]) + z[2], y1 = (z[1] - z[2]) - z[3];
-        const int n = blockIdx.y * 64 + cq * 4;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + q.lvl * p.ep_stride + n);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + q.lvl * p.ep_stride + n);
-        f32x4 v0 = y0 * sc + sh, v1 = y1 * sc + sh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < p.relu_cout) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
-        const int oy = (q.byi * 2 + (t3 >> 3)) * 2, ox = (q.bxi * 8 + (t3 & 7)) * 2 + j3;
-        if (ox < q.W && oy < q.H) {
-            float* o = p.out + (size_t)(q.orow + oy * q.W + ox) * p.out_ld + p.out_coff + n;
-            *reinterpret_cast<f32x4*>(o) = v0;
-            if (oy + 1 < q.H) *reinterpret_cast<f32x4*>(o + (size_t)q.W * p.out_ld) = v1;
-        }
-    };
-    f32x4 zreg[2][4];
-    auto mfma_phase = [&]() {
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc[nu][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* vb = V + ((xi * 4) * 16 + li) * CIN;
-        f32x4 bf[2][4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) bf[c][nu] = *reinterpret_cast<const f32x4*>(vb + nu * 16 * CIN + (((grp * 8 + c * 4 + g) ^ li) << 2));
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int cg = 0; cg < 4; ++cg)
-                        acc[nu][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nu][cg][c][k], bf[c][nu][k], acc[nu][cg], 0, 0, 0);
-#pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            zreg[0][cg] = (acc[0][cg] + acc[1][cg]) + acc[2][cg];
-            zreg[1][cg] = (acc[1][cg] - acc[2][cg]) - acc[3][cg];
-        }
-    };
-    float* zslot = Z + ((xi * 2) * 16 + li) * 64;   // this lane's rows of Z: j = 0 at zslot, j = 1 at zslot + 16 * 64
-
-    int bat = blockIdx.x;
-    if (bat >= p.nbat) return;
-    const bool no_p1 = p.dbg & 1, no_mm = p.dbg & 2, no_p3 = p.dbg & 4, no_dma = p.dbg & 8;
-    Geo cur_g = decode(bat), prev_g = cur_g;
-    // prologue: raw(first) by all 8 waves; then A transforms its K half of the first batch and starts the DMA of the second
-    dma(cur_g, Rw, 8, w);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    Geo next_g = cur_g;
-    bool has_next = bat + (int)gridDim.x < p.nbat;
-    if (has_next) next_g = decode(bat + gridDim.x);
-    if (grp == 0) {
-        p1(Rw, 0);
-        if (has_next) dma(next_g, Rw + WINO_RAW_F, 4, w);
-    }
-    lds_barrier();
-    int cur = 0;
-    bool have_prev = false;
-    for (; bat < p.nbat; bat += gridDim.x) {
-        // raw(i) in buffer cur, raw(i+1) (in flight, issued by A one phase ago) in buffer cur ^ 1
-        const int nn = bat + 2 * gridDim.x;
-        const bool has_nn = nn < p.nbat;
-        Geo nn_g = next_g;
-        if (has_nn) nn_g = decode(nn);
-        float* Rc = Rw + cur * WINO_RAW_F;
-        float* Rn = Rw + (cur ^ 1) * WINO_RAW_F;
-        // ---- X
-        if (grp == 0) {
-            if (!no_mm) mfma_phase();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // raw(i+1) has landed (issued before the previous two barriers)
-        } else {
-            if (have_prev && !no_p3) { p3(prev_g, lt); p3(prev_g, lt + 256); }   // stores first: nothing waits for them
-            if (!no_p1) p1(Rc, 1);
-        }
-        lds_barrier();
-        // ---- Y
-        if (grp == 1) {
-            if (!no_mm) mfma_phase();
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                const int qd = ((cg * 4 + g) ^ (li & 7)) << 2;
-                *reinterpret_cast<f32x4*>(zslot + qd) = zreg[0][cg];
-                *reinterpret_cast<f32x4*>(zslot + 16 * 64 + qd) = zreg[1][cg];
-            }
-        } else if (has_next) {
-            if (!no_p1) p1(Rn, 0);
-            // raw(i+2) -> the buffer of raw(i): its readers (A in Y(i-1), B in X(i)) are behind barriers
-            if (has_nn && !no_dma) dma(nn_g, Rc, 4, w);
-        }
-        lds_barrier();
-        // ---- W: the K halves meet
-        if (grp == 0) {
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                const int qd = ((cg * 4 + g) ^ (li & 7)) << 2;
-                *reinterpret_cast<f32x4*>(zslot + qd) += zreg[0][cg];
-                *reinterpret_cast<f32x4*>(zslot + 16 * 64 + qd) += zreg[1][cg];
-            }
-        }
-        lds_barrier();
-        prev_g = cur_g; cur_g = next_g; next_g = nn_g; has_next = has_nn; have_prev = true;
-        cur ^= 1;
-    }
-    p3(prev_g, tid);                                // the last batch: all 512 threads, one item each
-}
-
-int g_wino_mode = 1;          // ore_conv_set_plan_override(-7, mode): 0 off, 1 automatic (M >= 6000), 2 wherever it applies; A/B aids: 3 = phase-serial build everywhere, 4 = k_conv3x3_wino_pipe everywhere
+int g_wino_mode = 1;          // ore_conv_set_plan_override(-7, mode): 0 off, 1 automatic (M >= 6000), 2 wherever it applies
 
 }  // namespace
 
@@ -671,42 +271,19 @@ int conv_wino_launch(const ConvP& c, hipStream_t st) {
     p.U = c.wino; p.Cout = c.Cout; p.Cout16 = c.Cout16;
     p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
     p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORE_WINO_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const int gy = c.Cout / coutb;
     int gx = 256 / gy;                                  // one resident block per CU
     if (gx > nb) gx = nb;
     if (gx < 1) gx = 1;
-    // builds: 64 input channels -> the staged, pipelined kernel; 128 -> the phase-serial kernel (its pipelined form, mode 4, loses:
-    // the transform side waits on global memory and cannot be staged -- V alone is 128 KB)
-    const bool staged = c.Cin == 64 && g_wino_mode != 3 && g_wino_mode != 4;
-    const bool pipe = !staged && g_wino_mode == 4;
+    const size_t lds = ((size_t)16 * 16 * c.Cin + 4 * 2 * 16 * 64) * sizeof(float);      // V + Z (32 KB for both builds)
     static bool attr = false;
-    static const float* zero_page = nullptr;
     if (!attr) {
         ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
         ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino_pipe<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino_pipe<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        void* zp = nullptr;
-        ORE_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_wino)));
-        zero_page = (const float*)zp;
         attr = true;
     }
-    p.zero = zero_page;
-    if (staged) {
-        const size_t lds = ((size_t)16 * 16 * 64 + 4 * 2 * 16 * 64 + 2 * WINO_RAW_F) * sizeof(float);
-        hipLaunchKernelGGL(k_conv3x3_wino64, dim3(gx, gy), dim3(512), lds, st, p);
-        return ore_launch_status("k_conv3x3_wino64");
-    }
-    const size_t lds = ((size_t)16 * 16 * c.Cin * (pipe && c.Cin == 64 ? 2 : 1) + 4 * 2 * 16 * 64) * sizeof(float);   // V (+ V') + Z (32 KB)
-    if (pipe) {
-        if (c.Cin == 64) hipLaunchKernelGGL(k_conv3x3_wino_pipe<64>, dim3(gx, gy), dim3(512), lds, st, p);
-        else hipLaunchKernelGGL(k_conv3x3_wino_pipe<128>, dim3(gx, gy), dim3(512), lds, st, p);
-    } else {
-        if (c.Cin == 64) hipLaunchKernelGGL(k_conv3x3_wino<64>, dim3(gx, gy), dim3(512), lds, st, p);
-        else hipLaunchKernelGGL(k_conv3x3_wino<128>, dim3(gx, gy), dim3(512), lds, st, p);
-    }
+    if (c.Cin == 64) hipLaunchKernelGGL(k_conv3x3_wino<64>, dim3(gx, gy), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(k_conv3x3_wino<128>, dim3(gx, gy), dim3(512), lds, st, p);
     return ore_launch_status("k_conv3x3_wino");
 }
 

@@ -51,10 +51,15 @@ class _Unit(nn.Sequential):
         key = (conv.weight.data_ptr(), conv.weight._version, bn.weight._version, bn.running_var._version, str(conv.weight.device))
         if self._cache is None or self._cache[0] != key:
             sc, sh = bn.scale_shift()
-            self._cache = (key, orehip.pack_conv_weight(conv.weight), sc.contiguous(), sh.contiguous())
-        _, w, sc, sh = self._cache
+            w = orehip.pack_conv_weight(conv.weight)
+            # 3x3 stride-1 layers with 64 / 128 input channels also get the Winograd form of their weights: the library then runs the
+            # large-M launches (stem_2, stage 2; every frozen layer of a training step) on k_conv3x3_wino
+            wino_ok = conv.kernel_size[0] == 3 and conv.stride[0] == 1 and conv.in_channels in (64, 128) and conv.out_channels % 64 == 0
+            U = orehip.winograd_weight(w, conv.out_channels, conv.in_channels) if wino_ok and w.is_cuda else None
+            self._cache = (key, w, sc.contiguous(), sh.contiguous(), U)
+        _, w, sc, sh, U = self._cache
         return orehip.conv2d(x_nhwc, w, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0], scale=sc,
-                             shift=sh, relu_cout=conv.out_channels, **kw)
+                             shift=sh, relu_cout=conv.out_channels, w_wino=U, **kw)
 
 
 class eSEModule(nn.Module):

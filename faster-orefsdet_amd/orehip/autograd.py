@@ -58,12 +58,33 @@ def _c16(n: int) -> int:
     return (n + 15) // 16 * 16
 
 
+def packed_wino(w: torch.Tensor, dgrad: bool):
+    """Winograd F(2x2,3x3) form of packed(w, dgrad) for the 3x3 layers k_conv3x3_wino covers (64 / 128 channels on the conv's input
+    side, a multiple of 64 on its output side), else None.  Cached next to the packed copy, same tag."""
+    if w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+        return None
+    cout, cin = (w.shape[1], _c16(w.shape[0])) if dgrad else (w.shape[0], w.shape[1])     # of the conv that will be launched
+    if cin not in (64, 128) or cout % 64 != 0:
+        return None
+    pw = packed(w, dgrad)
+    base = _base_param(w)
+    if base is None:
+        return orehip.winograd_weight(pw, cout, cin)
+    cache = base.__dict__.setdefault("_ore_wino", {})
+    key = (tuple(w.shape), tuple(w.stride()), w.storage_offset(), bool(dgrad))
+    tag = (_EPOCH[0], base._version, base.data_ptr())
+    e = cache.get(key)
+    if e is None or e[0] != tag:
+        cache[key] = e = (tag, orehip.winograd_weight(pw, cout, cin))
+    return e[1]
+
+
 def _conv_backward(x, x_coff, Cin, weight, dz, k, need_x: bool, need_w: bool, need_b: bool):
     """dz [B,H,W,Cout16] contiguous -> (dX [B,H,W,Cin] | None, dW | None, db | None)."""
     Cout = weight.shape[0]
     gx = gw = gb = None
     if need_x:
-        gx = orehip.conv2d(dz, packed(weight, True), Cin, k, 1, k // 2)
+        gx = orehip.conv2d(dz, packed(weight, True), Cin, k, 1, k // 2, w_wino=packed_wino(weight, True) if k == 3 else None)
     if need_w:
         gw = orehip.conv2d_wgrad(x, dz, k, x_coff=x_coff, Cin=Cin)[:Cout]
     if need_b:
@@ -86,7 +107,7 @@ class ConvFn(Function):
             out.zero_()
         assert add is None or (co16 == Cout and not relu)
         y = orehip.conv2d(x, packed(weight, False), Cout, k, 1, k // 2, scale=scale, shift=sh, relu_cout=Cout if relu else 0, out=out,
-                          add=add.contiguous() if add is not None else None)
+                          add=add.contiguous() if add is not None else None, w_wino=packed_wino(weight, False) if k == 3 and add is None else None)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
         ctx.meta = (k, relu, bias is not None, Cout, Cin, co16)
         ctx.has_add = add is not None
