@@ -48,3 +48,20 @@ __device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
     const u32x2 u = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
     return __builtin_bit_cast(s16x4, u);
 }
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// 4 bf16 (packed as s16x4) -> 4 fp32, exact
+__device__ __forceinline__ f32x4 from_bf16x4(s16x4 h) {
+    const u32x2 u = __builtin_bit_cast(u32x2, h);
+    return f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                 __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+// storage-type helpers for the kernels that exist for fp32 and bf16 tensors (T = float or ore_bf16_t)
+struct ore_bf16_t { unsigned short v; };
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const ore_bf16_t* p) { return from_bf16x4(*reinterpret_cast<const s16x4*>(p)); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(ore_bf16_t* p, f32x4 v) { *reinterpret_cast<s16x4*>(p) = to_bf16x4(v); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const ore_bf16_t* p) { return bf16_bits_to_f32(p->v); }

@@ -20,6 +20,7 @@
 // Rows may span several pyramid levels (level-major), so p3/p4/p5 run as ONE launch with per-level epilogue params.
 //
 // Replaces F.conv2d + FrozenBatchNorm2d + ReLU / bias / Scale of the reference (see include/ore_hip.h).
+#include <string.h>
 #include "ore_common.h"
 #include "ore_conv_internal.h"
 
@@ -1158,6 +1159,28 @@ extern "C" int ore_pack_conv_weight_host(const float* w, int32_t Cout, int32_t C
     return ORE_OK;
 }
 
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays a (quiet) NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+extern "C" size_t ore_packed_weight_bf16_elems(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw) {
+    return (size_t)round_up(Cout, 16) * kh * kw * round_up(Cin, 32);
+}
+
+extern "C" int ore_pack_conv_weight_bf16_host(const float* w, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, uint16_t* dst) {
+    ORE_CHECK_ARG(w && dst && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "ore_pack_conv_weight_bf16_host: bad args");
+    const int C32 = round_up(Cin, 32), C16 = round_up(Cout, 16);
+    const size_t K = (size_t)kh * kw * C32;
+    for (int n = 0; n < C16; ++n)
+        for (int t = 0; t < kh * kw; ++t)
+            for (int c = 0; c < C32; ++c)
+                dst[(size_t)n * K + (size_t)t * C32 + c] = (n < Cout && c < Cin) ? f32_to_bf16_rne(w[((size_t)n * Cin + c) * kh * kw + t]) : (uint16_t)0;
+    return ORE_OK;
+}
+
 extern "C" size_t ore_conv_workspace_floats(void) { return ORE_CONV_WS_FLOATS; }
 
 // Tuning aid (tools/conv_tune.py): force the tile configuration of subsequent ore_conv2d*_fwd calls; BM = 0 restores the
@@ -1192,6 +1215,12 @@ extern "C" int32_t ore_conv_get_precision(void) { return g_conv_bf16; }
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    if (d->storage) {                                         // bf16 storage: always the DMA-fed kernels (conv_kw_launch's sb branch)
+        ConvP q{};
+        q.sb = 1;
+        q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (round_up(d->Cin, 32) / 32); q.kh = d->kh;
+        return ceil_div(q.M, conv_kw_tile_rows(q));
+    }
     if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !d->in_mul && d->Cin % 16 == 0) {
         ConvP q{};
         q.bf16 = g_conv_bf16;
@@ -1205,6 +1234,12 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
 }
 
 static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t workspace_floats, hipStream_t st) {
+    if (p.sb & 1) {                                           // bf16 storage: the DMA-fed kernels only (k_conv_gs / k_conv_kw, SB builds)
+        p.bf16 = 0;
+        const int krc = conv_kw_launch(p, workspace, workspace_floats, st);
+        if (krc == 1) { ore_set_error("ore_conv2d_fwd: no bf16-storage kernel for this layer (input affine?)"); return ORE_EINVAL; }
+        return krc;
+    }
     if (g_override.BM == 0 && req_splitk <= 1) {
         // several pyramid levels in one launch (the head tower): the 16-pixel-wide patch tiles waste 17-37 % on the 40- and 20-wide
         // levels, k_conv_kw takes it (47 -> 39 us, profiles/r02_kw_sweep.txt)
@@ -1258,6 +1293,10 @@ static int conv_common_checks(const ore_conv_desc* d) {
     ORE_CHECK_ARG(d->B > 0 && d->kh > 0 && d->kw > 0 && d->kh * d->kw <= 32 && d->stride > 0 && d->pad >= 0, "ore_conv2d_fwd: bad geometry (kernel up to 32 taps)");
     ORE_CHECK_ARG(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->w & 15) == 0, "ore_conv2d_fwd: 16-byte alignment");
     ORE_CHECK_ARG(d->in_mul || !d->in_add, "ore_conv2d_fwd: in_add needs in_mul");
+    ORE_CHECK_ARG(d->storage >= 0 && d->storage <= ORE_ST_BF16_F32OUT, "ore_conv2d_fwd: storage %d", d->storage);
+    if (d->storage) {
+        ORE_CHECK_ARG(d->in_ld % 8 == 0 && d->in_coff % 8 == 0 && !d->in_mul, "ore_conv2d_fwd: bf16 storage needs 16-byte aligned input slices and no input affine");
+    }
     return ORE_OK;
 }
 
@@ -1273,6 +1312,18 @@ static void fill_common(ConvP& p, const ore_conv_desc* d) {
     p.nchunks = d->kh * d->kw * (d->Cin / 16);
     p.colsum = d->colsum;
     p.wino = d->w_wino;
+    p.sb = 0;
+    if (d->storage == ORE_ST_BF16 || d->storage == ORE_ST_BF16_F32OUT) {
+        // bf16 tensors: the input side is handed to the kernels in 4-byte units (pairs of channels); the packed weights hold
+        // round_up(Cin, 32) channels per tap (zero beyond Cin), so a 64-byte K chunk is 32 channels and a chunk that starts inside the
+        // last 16 real channels reads 16 channels of whatever follows in the row -- finite activations -- against zero weights
+        p.sb = 1 | (d->storage == ORE_ST_BF16 ? 2 : 0) | (d->add ? 4 : 0);
+        const int cin32 = round_up(d->Cin, 32);
+        p.in_ld = d->in_ld / 2; p.in_coff = d->in_coff / 2; p.Cin = cin32 / 2;
+        p.K = d->kh * d->kw * p.Cin;
+        p.nchunks = d->kh * d->kw * (p.Cin / 16);
+        p.wino = nullptr;
+    }
 }
 
 extern "C" int ore_conv2d_fwd(const ore_conv_desc* d, void* stream) {

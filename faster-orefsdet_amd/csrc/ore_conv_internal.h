@@ -21,6 +21,8 @@ struct ConvP {
     float* ws; int* tile_cnt;
     int bf16;                            // ORE_CONV_BF16: operands rounded to bf16 as the fragments leave LDS, one 16x16x16 bf16 MFMA per 16 channels
     int xmap;                            // tile <-> block mapping of k_conv_kw: 0 = blockIdx, 1 / 2 = XCD-contiguous, M- / N-major (tile_of_block)
+    int sb;                              // bf16 STORAGE mode (ore_conv_desc.storage): bit 0 = in / w are bf16 (in_ld, in_coff, Cin, K then count
+                                         // PAIRS of bf16 = 4-byte units, a K chunk is 32 channels), bit 1 = out is bf16, bit 2 = add is bf16
     const float* wino;                   // Winograd F(2x2,3x3) transformed weights [16][Cout16][Cin] (ore_winograd_weight_fwd) or null
 };
 

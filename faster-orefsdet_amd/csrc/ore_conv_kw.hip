@@ -50,7 +50,10 @@ __device__ __forceinline__ float epilogue_one(const ConvP& p, float acc, int m, 
     if (p.ep_stride || p.add) decode_row(p, m, lvl, b, oy, ox);
     if (p.scale) v = v * p.scale[lvl * p.ep_stride + n];
     if (p.shift) v = v + p.shift[lvl * p.ep_stride + n];
-    if (p.add) v += p.add[(size_t)((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + n];
+    if (p.add) {
+        const size_t ai = (size_t)((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + n;
+        v += (p.sb & 4) ? bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.add)[ai]) : p.add[ai];
+    }
     if (n < p.relu_cout) v = fmaxf(v, 0.0f);
     return v;
 }
@@ -67,6 +70,19 @@ __device__ __forceinline__ bool finish4(const ConvP& p, f32x4 a, int m, int n, b
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = n + r < p.Cout ? epilogue_one(p, a[r], m, n + r) : 0.0f;
+    }
+    if (p.sb & 2) {                                       // bf16 output tensor: round once, here; what is summed for the eSE pool is the
+        const s16x4 h = to_bf16x4(v);                     // ROUNDED value (the stored tensor is the layer's output in this mode)
+        unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.out_ld + p.out_coff + n;
+        if (vec_ok && n + 3 < p.Cout) {
+            *reinterpret_cast<s16x4*>(o) = h;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.Cout) o[r] = (unsigned short)h[r];
+        }
+        vout = from_bf16x4(h);
+        return true;
     }
     float* o = p.out + (size_t)m * p.out_ld + p.out_coff + n;
     if (vec_ok && n + 3 < p.Cout) {
@@ -89,7 +105,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // lane group (rows {0-3, 12-15} of quad q with rows 4-11 of quad q+1, and its mirror) touches 16 distinct 4-bank groups.
 __device__ __forceinline__ int swz(int r16) { return (0x1320 >> (((r16 >> 2) & 3) * 4)) & 3; }   // {0, 2, 3, 1}
 
-template <int BM, int BN, int NS, bool BF = false, bool INCR = true, int NW = 4>
+// SB: bf16 STORAGE build -- the tensors are bf16 in HBM and in LDS, the host passes the input-side sizes in 4-byte units (pairs of
+// channels), so the whole staging path below is byte-identical to the fp32 build: a K chunk is 64 bytes = 32 channels, a ds_read_b128
+// fragment is 8 consecutive channels per lane -- exactly the operand of v_mfma_f32_16x16x32_bf16, ONE of which replaces the four
+// v_mfma_f32_16x16x4_f32 of a step (16x their rate, half the bytes per channel).
+template <int BM, int BN, int NS, bool BF = false, bool INCR = true, int NW = 4, bool SB = false>
 __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __restrict__ zero_page) {
     // NW = waves per block = the in-block K split (chunk c -> wave c % NW).  4 is the workhorse; 8 / 16 cut the dependent K chain of the
     // latency-bound small layers (18 steps per wave at K = 1152 with 4 waves) at no cross-block cost: the partial tiles meet in LDS.
@@ -265,7 +285,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
         for (int i = 0; i < GA; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + i * 256 + foff);
 #pragma unroll
         for (int j = 0; j < GB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + (GA + j) * 256 + foff);
-        if constexpr (BF) {                                       // bf16-operand mode: round as the fragments leave LDS, one MFMA per 16 channels
+        if constexpr (SB) {
+#pragma unroll
+            for (int i = 0; i < GA; ++i)
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+        } else if constexpr (BF) {                                // bf16-operand mode: round as the fragments leave LDS, one MFMA per 16 channels
             s16x4 ah[GA], bh[GB];
 #pragma unroll
             for (int i = 0; i < GA; ++i) ah[i] = to_bf16x4(af[i]);
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
         for (int j = 0; j < GB; ++j)
             *reinterpret_cast<f32x4*>(lds + ((wave * NT) + i * GB + j) * 256 + lane * 4) = acc[i][j];
     __syncthreads();
-    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & ((p.sb & 2) ? 7 : 15)) == 0;
     const int ntile = by * gridDim.x + bx;
     if (p.splitk <= 1) {
         float* cs = lds + RED_F;
@@ -420,7 +446,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
 // byte feeds four times the MFMAs of k_conv_kw.  One raw s_barrier per 16-channel step: a wave waits for its own DMA of stage t
 // (counted vmcnt, stage t+1 stays in flight), the barrier publishes everybody's, the DMA of stage t+2 is issued right behind it
 // (its slot was read at step t-1, which every wave has left), then fragments + MFMAs.  Same swizzle, same epilogue.
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, bool SB = false>
 __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restrict__ zero_page) {
     constexpr int GA = BM / 16, GB = BN / 16, G = GA + GB;
     constexpr int NI = (G + 3) / 4;                                // DMA instructions per wave and stage (short waves issue dummies)
@@ -543,6 +569,13 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
         for (int i = 0; i < TM; ++i) an[i] = *reinterpret_cast<const f32x4*>(st + (wm * TM + i) * 256 + foff);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bn[j] = *reinterpret_cast<const f32x4*>(st + (GA + wn * TN + j) * 256 + foff);
+        if constexpr (SB) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[j]), __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -550,7 +583,9 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);
+        }
         // interleave: one DMA piece or one fragment read behind every second MFMA
+        if constexpr (!SB) {
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, MPER, 0);
@@ -561,6 +596,7 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
             __builtin_amdgcn_sched_group_barrier(0x008, MPER, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = an[i];
 #pragma unroll
@@ -570,7 +606,7 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
     wait_vmcnt<0>();
 
     // ---- epilogue straight from the accumulators: this lane = pixel row (lane & 15), channels (lane >> 4) * 4 .. + 3 of each tile
-    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & ((p.sb & 2) ? 7 : 15)) == 0;
     const int cg4 = (lane >> 4) * 4;
     f32x4 csum[TN];
 #pragma unroll
@@ -607,28 +643,29 @@ __global__ __launch_bounds__(256) void k_conv_gs(ConvP p, const float* __restric
 
 int g_gs_ns = 3;                        // tuning aid: ring depth of k_conv_gs (3 / 4 / 6)
 
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, bool SB = false>
 int launch_gs_ns(const ConvP& p, const float* zero, hipStream_t st);
 
 template <int BM, int BN, int WGM, int WGN>
 int launch_gs(const ConvP& p, const float* zero, hipStream_t st) {
+    if (p.sb & 1) return launch_gs_ns<BM, BN, WGM, WGN, 3, true>(p, zero, st);
     if (g_gs_ns == 4) return launch_gs_ns<BM, BN, WGM, WGN, 4>(p, zero, st);
     if (g_gs_ns == 6) return launch_gs_ns<BM, BN, WGM, WGN, 6>(p, zero, st);
     return launch_gs_ns<BM, BN, WGM, WGN, 3>(p, zero, st);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS>
+template <int BM, int BN, int WGM, int WGN, int NS, bool SB>
 int launch_gs_ns(const ConvP& p, const float* zero, hipStream_t st) {
     if constexpr (((BM + BN) / 16 + 3) / 4 * (NS - 1) > 63 || (size_t)NS * (BM + BN) * 64 > 150 * 1024) return 1;
     else {
     constexpr size_t lds = ((size_t)NS * (BM + BN) * 16 + 4 * 256 + WGM * BN) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        ORE_HIP(hipFuncSetAttribute((const void*)k_conv_gs<BM, BN, WGM, WGN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ORE_HIP(hipFuncSetAttribute((const void*)k_conv_gs<BM, BN, WGM, WGN, NS, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const dim3 grid(ceil_div(p.M, BM), ceil_div(p.Cout16, BN), 1);
-    hipLaunchKernelGGL((k_conv_gs<BM, BN, WGM, WGN, NS>), grid, dim3(256), lds, st, p, zero);
+    hipLaunchKernelGGL((k_conv_gs<BM, BN, WGM, WGN, NS, SB>), grid, dim3(256), lds, st, p, zero);
     return ore_launch_status("k_conv_gs");
     }
 }
@@ -675,7 +712,7 @@ KwTile kw_tile(int M, int C16, int nchunks) {
     return best;
 }
 
-template <int BM, int BN, int NS, bool BF = false, bool INCR = true, int NW = 4>
+template <int BM, int BN, int NS, bool BF = false, bool INCR = true, int NW = 4, bool SB = false>
 int launch_kw_ns(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
     constexpr int G = (BM + BN) / 16;
     if constexpr ((NS - 1) * G > 63) {
@@ -688,10 +725,10 @@ int launch_kw_ns(const ConvP& p, const float* zero, dim3 grid, hipStream_t st) {
         } else {
             static bool attr = false;
             if (!attr) {
-                ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kw<BM, BN, NS, BF, INCR, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kw<BM, BN, NS, BF, INCR, NW, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr = true;
             }
-            hipLaunchKernelGGL((k_conv_kw<BM, BN, NS, BF, INCR, NW>), grid, dim3(NW * 64), lds, st, p, zero);
+            hipLaunchKernelGGL((k_conv_kw<BM, BN, NS, BF, INCR, NW, SB>), grid, dim3(NW * 64), lds, st, p, zero);
             return ORE_OK;
         }
     }
@@ -706,6 +743,10 @@ template <int BM, int BN>
 int launch_kw(const ConvP& p, const float* zero, dim3 grid, hipStream_t st, int nw) {
     // incremental DMA addressing pays when a tap holds >= 16 chunks (4+ steps between pointer rebuilds): 1x1 layers, deep 3x3 layers
     const bool incr = (p.Cin >> 4) >= 4 * nw;
+    if (p.sb & 1) {                                        // bf16 storage: 4 waves, minimal ring
+        if (nw != 4) return ORE_EINVAL;
+        return incr ? launch_kw_ns<BM, BN, 2, false, true, 4, true>(p, zero, grid, st) : launch_kw_ns<BM, BN, 2, false, false, 4, true>(p, zero, grid, st);
+    }
     if constexpr (BM == 16 && BN <= 48) {                  // the small tiles also come with 8 / 16 waves (in-block K split)
         if (nw == 8 && !p.bf16) return incr ? launch_kw_ns<BM, BN, 2, false, true, 8>(p, zero, grid, st) : launch_kw_ns<BM, BN, 2, false, false, 8>(p, zero, grid, st);
         if constexpr (BN <= 32) {
@@ -729,6 +770,11 @@ namespace oreconv {
 int conv_kw_tile_rows(const ConvP& p) {         // rows per block of the kernel conv_kw_launch will pick (0: not covered) -- keep in step with it
     if (g_kw_force[0] > 0) return g_kw_force[0];
     if (g_gs_force[0] > 0) return g_gs_force[0];
+    if (p.sb & 1) {                                            // keep in step with conv_kw_launch's bf16-storage branch
+        if (p.M >= 6400 && (p.Cout16 == 64 || p.Cout16 == 112 || p.Cout16 % 128 == 0)) return 64;
+        const int bm = kw_tile(p.M, p.Cout16, p.nchunks).BM;
+        return bm ? bm : 32;
+    }
     if (p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256)) {
         if (p.bf16 || p.M < 6400 || p.kh != 1) return 0;      // (k_conv_gs has no bf16-operand build)
         return (p.Cout16 == 112 || p.Cout16 % 128 == 0 || p.Cout16 == 64) ? 64 : 0;
@@ -758,7 +804,7 @@ static int conv_gs_launch(ConvP& p, hipStream_t st) {
     if (bm == 0) {
         // measured (profiles/r02_kw_ab.txt): 2-5 % ahead of k_conv_igemm on the 1x1 concats, 3 % behind on stem_3 (3x3 stride 2) --
         // the staging mechanism is not what bounds these layers -- so only the 1x1 layers come here automatically
-        if (p.M < 6400 || p.kh != 1) return 1;
+        if (p.M < 6400 || (p.kh != 1 && !(p.sb & 1))) return 1;
         if (p.Cout16 == 112) { bm = 64; bn = 112; }
         else if (p.Cout16 % 128 == 0) { bm = 64; bn = p.M < 16384 ? 64 : 128; }      // s3cat: 64x64 21.8 us, 64x128 24.0 (400 vs 200 blocks)
         else if (p.Cout16 == 64) { bm = 64; bn = 64; }
@@ -796,15 +842,22 @@ void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] =
 
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
+    if (p.sb & 1) {                                                         // bf16 storage: every layer runs on one of the two DMA-fed kernels
+        if (g_kw_force[0] == 0 && p.M >= 6400 && (p.Cout16 == 64 || p.Cout16 == 112 || p.Cout16 % 128 == 0)) {
+            const int grc = conv_gs_launch(p, st);
+            if (grc != 1) return grc;
+        }
+    } else
     if (g_kw_force[0] == 0 && (g_gs_force[0] > 0 || p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256))) return p.bf16 ? 1 : conv_gs_launch(p, st);
     KwTile t = kw_tile(p.M, p.Cout16, p.nchunks);
+    if ((p.sb & 1) && t.BM == 0) t = {32, 64, 1};
     if (g_kw_force[0] > 0) t = {g_kw_force[0], g_kw_force[1] < p.Cout16 ? g_kw_force[1] : p.Cout16, g_kw_force[3]};
     if (t.BM == 0) return 1;
     const int gx = ceil_div(p.M, t.BM), gy = ceil_div(p.Cout16, t.BN);
     const int blocks = gx * gy;
     int nw = t.NW;
     if (g_kw_nw_force > 0) nw = g_kw_nw_force;
-    if (p.bf16 || t.BM != 16 || t.BN > 48 || (nw == 16 && t.BN > 32)) nw = 4;    // the 8- / 16-wave builds exist for the small fp32 tiles only
+    if (p.bf16 || (p.sb & 1) || t.BM != 16 || t.BN > 48 || (nw == 16 && t.BN > 32)) nw = 4;    // the 8- / 16-wave builds exist for the small fp32 tiles only
     const int steps = ceil_div(p.nchunks, nw);                            // steps per wave without a cross-block split
     int S = t.S;
     if (S <= 0) S = (blocks < 128 && steps >= 32) ? 4 : 1;

@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
                 ("add", C.c_void_p), ("add_ld", C.c_int32), ("add_coff", C.c_int32),
                 ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_coff", C.c_int32),
                 ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("colsum", C.c_void_p),
-                ("w_wino", C.c_void_p)]
+                ("w_wino", C.c_void_p), ("storage", C.c_int32)]
 
 
 class DetectDesc(C.Structure):
@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -87,6 +87,7 @@ def lib() -> C.CDLL:
         L.ore_last_error.restype = C.c_char_p
         L.ore_packed_weight_floats.restype = C.c_size_t
         L.ore_winograd_weight_floats.restype = C.c_size_t
+        L.ore_packed_weight_bf16_elems.restype = C.c_size_t
         L.ore_conv_workspace_floats.restype = C.c_size_t
         L.ore_conv_colsum_rows.restype = C.c_int32
         L.ore_detect_workspace_bytes.restype = C.c_size_t
@@ -153,6 +154,17 @@ def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     return torch.from_numpy(dst).to(w_oihw.device)
 
 
+def pack_conv_weight_bf16(w_oihw: torch.Tensor) -> torch.Tensor:
+    """OIHW fp32 (any device) -> bf16 packed [Cout16][kh*kw][round_up(Cin, 32)] on the weight's device (ORE_ST_BF16 convs)."""
+    w = w_oihw.detach().float().cpu().contiguous()
+    co, ci, kh, kw = w.shape
+    n = lib().ore_packed_weight_bf16_elems(co, ci, kh, kw)
+    dst = np.empty(n, dtype=np.uint16)
+    _chk(lib().ore_pack_conv_weight_bf16_host(C.c_void_p(w.data_ptr()), co, ci, kh, kw, dst.ctypes.data_as(C.c_void_p)),
+         "ore_pack_conv_weight_bf16_host")
+    return torch.from_numpy(dst.view(np.int16)).view(torch.bfloat16).to(w_oihw.device)
+
+
 def winograd_weight(w_packed: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
     """Packed 3x3 weights ([Cout16][9][Cin], pack_weight) -> their Winograd F(2x2,3x3) form U [16][Cout16][Cin] on the device."""
     _f32(w_packed)
@@ -165,17 +177,23 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
            in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, relu_cout: int = 0, in_mul=None,
            in_add=None, in_relu: bool = False, add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            out_coff: int = 0, splitk: int = 0, workspace: Optional[torch.Tensor] = None, want_colsum: bool = False,
-           w_wino: Optional[torch.Tensor] = None):
+           w_wino: Optional[torch.Tensor] = None, out_f32: bool = False):
     """x: [B,H,W,ld] NHWC fp32.  Returns `out` ([B,Ho,Wo,out_ld]); only channels [out_coff, out_coff+Cout) are written.
-    w_wino: the same weights in Winograd F(2x2,3x3) form (winograd_weight); lets the large-M 3x3 layers run on the Winograd kernel."""
-    _f32(x)
+    w_wino: the same weights in Winograd F(2x2,3x3) form (winograd_weight); lets the large-M 3x3 layers run on the Winograd kernel.
+    bf16 storage (ORE_ST_BF16): x / w_packed (pack_conv_weight_bf16) / add are torch.bfloat16; `out` is bf16, or fp32 when out_f32."""
+    st_bf16 = x.dtype == torch.bfloat16
+    if st_bf16:
+        assert x.is_contiguous() and w_packed.dtype == torch.bfloat16 and (add is None or add.dtype == torch.bfloat16)
+    else:
+        _f32(x)
     B, H, W, ld = x.shape
     Cin = Cin if Cin is not None else ld - in_coff
     pad = k // 2 if pad is None else pad
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out_dt = torch.bfloat16 if (st_bf16 and not out_f32) else torch.float32
     if out is None:
-        out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    _f32(out)
+        out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=out_dt)
+    assert out.dtype == out_dt and out.is_contiguous()
     assert out.shape[:3] == (B, Ho, Wo)
     M = B * Ho * Wo
     if workspace is None and splitk != 1:
@@ -183,12 +201,13 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
     d = ConvDesc()
     d.in_, d.in_ld, d.in_coff = _ptr(x), ld, in_coff
     d.B, d.H, d.W, d.Cin = B, H, W, Cin
-    d.w = _ptr(_f32(w_packed))
+    d.storage = (2 if out_f32 else 1) if st_bf16 else 0
+    d.w = _ptr(w_packed if st_bf16 else _f32(w_packed))
     d.Cout, d.kh, d.kw, d.stride, d.pad = Cout, k, k, stride, pad
     d.scale, d.shift, d.relu_cout = _ptr(scale), _ptr(shift), relu_cout
     d.in_mul, d.in_add, d.in_relu = _ptr(in_mul), _ptr(in_add), int(in_relu)
     if add is not None:
-        _f32(add)
+        assert add.is_contiguous()
         d.add, d.add_ld, d.add_coff = _ptr(add), add.shape[-1], 0
     d.out, d.out_ld, d.out_coff = _ptr(out), out.shape[-1], out_coff
     d.splitk = splitk
@@ -207,23 +226,28 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
 def conv2d_levels(x_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, w_packed: torch.Tensor, Cout: int, k: int, *,
                   in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, ep_stride: int = 0, relu_cout: int = 0,
                   in_mul=None, in_add=None, in_relu: bool = False, out: Optional[torch.Tensor] = None, out_coff: int = 0,
-                  splitk: int = 0, w_wino: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """One launch over several pyramid levels: x_rows [sum_l B*H_l*W_l, ld] level-major."""
-    _f32(x_rows)
+                  splitk: int = 0, w_wino: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """One launch over several pyramid levels: x_rows [sum_l B*H_l*W_l, ld] level-major (fp32, or bf16 = ORE_ST_BF16 storage)."""
+    st_bf16 = x_rows.dtype == torch.bfloat16
+    if not st_bf16:
+        _f32(x_rows)
     rows, ld = x_rows.shape
     assert rows == sum(B * h * w for h, w in HW)
     Cin = Cin if Cin is not None else ld - in_coff
+    out_dt = torch.bfloat16 if (st_bf16 and not out_f32) else torch.float32
     if out is None:
-        out = torch.empty(rows, Cout, device=x_rows.device, dtype=torch.float32)
+        out = torch.empty(rows, Cout, device=x_rows.device, dtype=out_dt)
+    assert out.dtype == out_dt and out.is_contiguous()
     ws = _default_ws(x_rows.device)
     d = ConvDesc()
     d.in_, d.in_ld, d.in_coff = _ptr(x_rows), ld, in_coff
     d.B, d.H, d.W, d.Cin = B, 0, 0, Cin
-    d.w = _ptr(_f32(w_packed))
+    d.storage = (2 if out_f32 else 1) if st_bf16 else 0
+    d.w = _ptr(w_packed)
     d.Cout, d.kh, d.kw, d.stride, d.pad = Cout, k, k, 1, k // 2
     d.scale, d.shift, d.relu_cout = _ptr(scale), _ptr(shift), relu_cout
     d.in_mul, d.in_add, d.in_relu = _ptr(in_mul), _ptr(in_add), int(in_relu)
-    d.out, d.out_ld, d.out_coff = _ptr(_f32(out)), out.shape[-1], out_coff
+    d.out, d.out_ld, d.out_coff = _ptr(out), out.shape[-1], out_coff
     d.splitk, d.workspace, d.workspace_floats = splitk, _ptr(ws), ws.numel()
     d.w_wino = _ptr(w_wino)
     L = len(HW)

@@ -66,7 +66,18 @@ typedef struct ore_conv_desc {
     const float* w_wino;  /* optional: the same weights in Winograd F(2x2,3x3) form (ore_winograd_weight_fwd).  When given, 3x3
                            * stride-1 pad-1 layers with Cin 64 / 128, Cout % 64 == 0 and M >= 6000 rows run on the Winograd kernel
                            * (2.25x fewer multiplies, fp32 throughout); NULL = direct kernels only */
+    int32_t storage;      /* ORE_ST_F32 (0): every tensor is fp32.  ORE_ST_BF16: `in`, `w` (ore_pack_conv_weight_bf16_host), `add` and `out`
+                           * are bf16 tensors (ld / coff count ELEMENTS), accumulation, scale / shift and colsum stay fp32, the output is
+                           * rounded once (nearest even) when it is stored and colsum sums the ROUNDED values.  ORE_ST_BF16_F32OUT: the
+                           * same with an fp32 `out` (the detection head's outputs).  The input buffer must extend 32 bytes past its
+                           * last row when Cin % 32 == 16 (the last K chunk of a row reads 16 channels further, against zero weights). */
 } ore_conv_desc;
+#define ORE_ST_F32 0
+#define ORE_ST_BF16 1
+#define ORE_ST_BF16_F32OUT 2
+/* bf16 packed weights for ORE_ST_BF16 convs: [Cout16][kh*kw][round_up(Cin, 32)] bf16 (nearest even), zero beyond Cout / Cin. */
+size_t ore_packed_weight_bf16_elems(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw);
+int ore_pack_conv_weight_bf16_host(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, uint16_t* dst);
 
 /* Winograd F(2x2,3x3) form of packed 3x3 weights: U_p = G g G^T per (Cout, Cin) pair for the 16 positions p, computed on the device in
  * fp32 (the halves in G are exact), stored in the kernel's MFMA-fragment order [16][Cout16/16][Cin/16][64 lanes][4] (opaque to callers).  `packed_w` is ore_pack_conv_weight_host's layout for kh = kw = 3; U needs

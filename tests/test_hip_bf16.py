@@ -243,3 +243,94 @@ def test_train_iteration_5shot_bf16_vs_oracle(ore, bf16):
     e32 = sorted(float((named[k].grad.cpu() - t.grad).abs().max()) / max(float(t.grad.abs().max()), 1e-8)
                  for k, t in leaf32.items() if t.requires_grad and t.grad is not None)
     assert errs[len(errs) // 2][0] < 0.7 * e32[len(e32) // 2], (errs[len(errs) // 2][0], e32[len(e32) // 2])
+
+
+# ---- bf16 STORAGE mode (BASELINE configs[4] as a byte-saving path): bf16 tensors in HBM and LDS, v_mfma_f32_16x16x32_bf16 ---------
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride", [
+    (1, 20, 20, 384, 112, 3, 1),    # deep K, Cout not a multiple of 32
+    (1, 20, 20, 112, 112, 3, 1),    # Cin % 32 == 16: the last K chunk of a tap reads 16 channels further, against zero weights
+    (1, 40, 40, 544, 384, 1, 1),    # 1x1 concat
+    (1, 80, 80, 80, 80, 3, 1),      # k_conv_kw at M = 6400, Cin = 80
+    (1, 80, 80, 352, 256, 1, 1),    # k_conv_gs 64x64 tiles
+    (2, 17, 23, 352, 256, 1, 1),    # odd sizes, two images
+    (1, 9, 7, 16, 5, 3, 1),         # tiny, Cout = 5
+    (3, 33, 31, 64, 80, 3, 2),      # stride 2
+    (1, 96, 96, 64, 64, 3, 1),      # k_conv_gs on a 3x3 layer (M = 9216)
+    (1, 80, 80, 128, 128, 3, 1),    # FPN output3 / tower class
+])
+def test_conv_bf16_storage_vs_oracle(B, H, W, Cin, Cout, k, stride):
+    """bf16 input / weight / output tensors.  A product of two bf16 numbers is exact in fp32 and the accumulation is fp32, so against
+    F.conv2d on the SAME bf16 values (upcast) the pre-rounding result differs by summation order only; the stored output may then
+    differ by one bf16 ulp where that difference straddles a rounding boundary."""
+    import orehip as ore
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + k)
+    x = _bf(torch.randn(B, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    sc = torch.rand(Cout, generator=g) + 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.float(), w.float(), None, stride, k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    xh = torch.zeros(B * H * W + 1, Cin, dtype=torch.bfloat16)                      # one spare row: the Cin % 32 == 16 over-read
+    xh[:-1] = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+    xd = xh.cuda()[:-1].view(B, H, W, Cin)
+    wp = ore.pack_conv_weight_bf16(w.float()).cuda()
+    y32 = ore.conv2d(xd, wp, Cout, k, stride, scale=sc.cuda(), shift=sh.cuda(), relu_cout=Cout, out_f32=True)
+    got32 = y32.cpu().permute(0, 3, 1, 2)
+    assert float((got32 - ref).abs().max() / ref.abs().max()) < 1e-4             # fp32 output: the fp32 tolerance
+    y = ore.conv2d(xd, wp, Cout, k, stride, scale=sc.cuda(), shift=sh.cuda(), relu_cout=Cout)
+    assert y.dtype == torch.bfloat16
+    assert torch.equal(y, y32.to(torch.bfloat16))                                 # the bf16 output is the fp32 result rounded once
+    y2 = ore.conv2d(xd, wp, Cout, k, stride, scale=sc.cuda(), shift=sh.cuda(), relu_cout=Cout)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.gpu
+def test_conv_bf16_storage_slices_add_colsum_levels():
+    """Channel-slice input / output inside wider bf16 buffers, the FPN top-down add from a bf16 tensor, fused column sums of the ROUNDED
+    output, three pyramid levels in one launch with per-level epilogue parameters and fp32 output (the head's last conv)."""
+    import orehip as ore
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 1, 20, 24
+    buf = _bf(torch.randn(B, 160, H, W, generator=g))                              # read channels 32..143 (112)
+    w = _bf(torch.randn(80, 112, 3, 3, generator=g) * 0.03)
+    sh = torch.randn(80, generator=g) * 0.1
+    out = torch.full((B, H, W, 128), 7.0, dtype=torch.bfloat16).cuda()
+    xin = buf.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = ore.pack_conv_weight_bf16(w.float()).cuda()
+    y, cs = ore.conv2d(xin, wp, 80, 3, 1, in_coff=32, Cin=112, shift=sh.cuda(), relu_cout=80, out=out, out_coff=16, want_colsum=True)
+    ref = F.relu(F.conv2d(buf[:, 32:144].float(), w.float(), sh, 1, 1))
+    got = out[..., 16:96].float().cpu().permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-2                # one bf16 rounding of the output
+    assert float(out[..., :16].float().min()) == 7.0 and float(out[..., 96:].float().max()) == 7.0
+    want_cs = out[..., 16:96].float().sum((0, 1, 2)).cpu()                         # column sums of what was STORED
+    assert float((cs.sum(0)[:80].cpu() - want_cs).abs().max() / want_cs.abs().max()) < 1e-5
+    # 1x1 lateral with the nearest-2x top-down add
+    top = _bf(torch.randn(B, 128, (H + 1) // 2, (W + 1) // 2, generator=g))
+    x2 = _bf(torch.randn(B, 256, H, W, generator=g))
+    w2 = _bf(torch.randn(128, 256, 1, 1, generator=g) * 0.05)
+    b2 = torch.randn(128, generator=g) * 0.1
+    y2 = ore.conv2d(x2.permute(0, 2, 3, 1).contiguous().cuda(), ore.pack_conv_weight_bf16(w2.float()).cuda(), 128, 1, 1, shift=b2.cuda(),
+                    add=top.permute(0, 2, 3, 1).contiguous().cuda(), out_f32=True)
+    ref2 = F.conv2d(x2.float(), w2.float(), b2) + F.interpolate(top.float(), scale_factor=2, mode="nearest")[:, :, :H, :W]
+    assert float((y2.cpu().permute(0, 3, 1, 2) - ref2).abs().max() / ref2.abs().max()) < 1e-4
+    # three levels, per-level scale / shift, Cout = 5, fp32 out
+    HW = [(12, 16), (6, 8), (3, 4)]
+    xs = [_bf(torch.randn(1, 128, h, w_, generator=g)) for h, w_ in HW]
+    w5 = _bf(torch.randn(5, 128, 3, 3, generator=g) * 0.05)
+    sc3, sh3 = torch.rand(3, 16, generator=g) + 0.5, torch.randn(3, 16, generator=g) * 0.1
+    rows = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, 128) for t in xs] + [torch.zeros(1, 128, dtype=torch.bfloat16)], 0).contiguous().cuda()
+    nrow = rows.shape[0] - 1
+    outh = torch.zeros(nrow, 8, device="cuda")
+    ore.conv2d_levels(rows[:nrow], HW, 1, ore.pack_conv_weight_bf16(w5.float()).cuda(), 5, 3, scale=sc3.cuda().contiguous(),
+                      shift=sh3.cuda().contiguous(), ep_stride=16, relu_cout=4, out=outh, out_f32=True)
+    r0 = 0
+    for l, ((h, w_), t) in enumerate(zip(HW, xs)):
+        r = F.conv2d(t.float(), w5.float(), None, 1, 1) * sc3[l, :5].view(1, -1, 1, 1) + sh3[l, :5].view(1, -1, 1, 1)
+        r[:, :4] = F.relu(r[:, :4])
+        want = r[0].permute(1, 2, 0).reshape(-1, 5)
+        assert float((outh[r0:r0 + h * w_, :5].cpu() - want).abs().max() / want.abs().max()) < 1e-4
+        r0 += h * w_
