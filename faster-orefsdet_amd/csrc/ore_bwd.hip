@@ -451,21 +451,22 @@ __global__ __launch_bounds__(256) void k_corr_bwd_b(CorrT p, const float* __rest
 //   GroupNorm(+ReLU) of the head tower with gradients; eSE scale with gradients; ceil-mode 3x3/s2 max-pool backward;
 //   2x2 sum-pool (backward of the FPN's nearest-2x top-down add).
 // xhat = x * r[c] + a[c] with r = rstd of the channel's group, a = -mean * rstd (from ore_groupnorm_affine_fwd with gamma=1, beta=0).
-__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, int ld, int coff, long long rows, long long rpi, int C,
+template <typename TS>
+__global__ __launch_bounds__(256) void k_gn_apply(const TS* __restrict__ x, int ld, int coff, long long rows, long long rpi, int C,
                                                   const float* __restrict__ r, const float* __restrict__ a, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, int relu, float* __restrict__ y) {
+                                                  const float* __restrict__ beta, int relu, TS* __restrict__ y) {
     const int c4n = C / 4;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * c4n) return;
     const long long row = i / c4n;
     const int c = (int)(i % c4n) * 4;
     const size_t io = (size_t)(row / rpi) * C;                    // this row's image: r / a are [images][C]
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ld + coff + c);
+    const f32x4 v = ld4(x + row * ld + coff + c);
     const f32x4 rr = *reinterpret_cast<const f32x4*>(r + io + c), aa = *reinterpret_cast<const f32x4*>(a + io + c);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
-    f32x4 o = (v * rr + aa) * g + b;
+    f32x4 o = v * rr + aa;
+    if (gamma) o = o * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
     if (relu) o = relu4b(o);
-    *reinterpret_cast<f32x4*>(y + row * C + c) = o;
+    st4(y + row * C + c, o);
 }
 
 // P[row][0:C] = dy' = dy * [y > 0 or !relu],  P[row][C:2C] = dy' * xhat
@@ -742,8 +743,22 @@ extern "C" int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff,
                   coff % 4 == 0, "ore_groupnorm_apply_fwd: bad args");
     const long long rows = (long long)images * rows_per_image;
     const long long n = rows * (C / 4);
-    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, coff, rows, (long long)rows_per_image,
+    hipLaunchKernelGGL(k_gn_apply<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, coff, rows, (long long)rows_per_image,
                        C, rstd_c, shift_c, gamma, beta, relu, y);
+    return ore_launch_status("k_gn_apply");
+}
+
+// bf16 storage: y[row][C] = act(x * mul[image] + add[image]) with the folded per-(image, channel) affine of ore_groupnorm_affine_levels_*
+// (gamma / beta already inside mul / add); `images` segments of rows_per_image rows share a (mul, add) row -- level-major head tensors
+// call it once per level.
+extern "C" int ore_groupnorm_apply_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t images, int64_t rows_per_image, int32_t C,
+                                            const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream) {
+    ORE_CHECK_ARG(x && mul_c && add_c && y && images > 0 && rows_per_image > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && coff % 4 == 0,
+                  "ore_groupnorm_apply_bf16_fwd: bad args");
+    const long long rows = (long long)images * rows_per_image;
+    const long long n = rows * (C / 4);
+    hipLaunchKernelGGL(k_gn_apply<ore_bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const ore_bf16_t*)x, ld, coff,
+                       rows, (long long)rows_per_image, C, mul_c, add_c, (const float*)nullptr, (const float*)nullptr, relu, (ore_bf16_t*)y);
     return ore_launch_status("k_gn_apply");
 }
 

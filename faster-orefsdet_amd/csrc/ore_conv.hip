@@ -935,6 +935,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
 }
 
 int g_conv_bf16 = 0;     // ore_conv_set_precision: 1 = bf16 MFMA operands (fp32 storage and accumulation)
+int g_conv_mode = 0;     // the mode as set (ORE_CONV_BF16S = 2 is an engine build mode, see ore_hip.h)
 int g_patch_mode = -1;   // tuning aid: -1 automatic, 0 never, 4 / 8 force TH, 16 = double-buffered 8-wave kernel, 102 = weight-stationary kernels (2-row tiles; Cin = 64 or 128)
 
 static int patch_launch(const ConvP& c, hipStream_t st) {
@@ -1205,12 +1206,14 @@ extern "C" int ore_debug_set_trace(unsigned long long* buf) {
 #endif
 
 extern "C" int ore_conv_set_precision(int32_t mode) {
-    ORE_CHECK_ARG(mode == ORE_CONV_FP32 || mode == ORE_CONV_BF16, "ore_conv_set_precision: mode must be ORE_CONV_FP32 or ORE_CONV_BF16");
-    g_conv_bf16 = mode;
+    ORE_CHECK_ARG(mode == ORE_CONV_FP32 || mode == ORE_CONV_BF16 || mode == ORE_CONV_BF16S,
+                  "ore_conv_set_precision: mode must be ORE_CONV_FP32, ORE_CONV_BF16 or ORE_CONV_BF16S");
+    g_conv_mode = mode;
+    g_conv_bf16 = mode == ORE_CONV_BF16;                          // BF16S changes what an ENGINE builds; plain fp32-tensor convs stay fp32
     return ORE_OK;
 }
 
-extern "C" int32_t ore_conv_get_precision(void) { return g_conv_bf16; }
+extern "C" int32_t ore_conv_get_precision(void) { return g_conv_mode; }
 
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;

@@ -24,6 +24,7 @@ struct HostTensor { std::vector<float> v; std::vector<int64_t> shape; };
 
 struct Conv {
     float* w = nullptr; float* scale = nullptr; float* shift = nullptr;
+    uint16_t* wh = nullptr;              // bf16 packed weights (engines created in ORE_CONV_BF16S mode)
     float* wino = nullptr;               // Winograd F(2x2,3x3) form of w for the 3x3 stride-1 layers with Cin 64 / 128 (else null)
     int Cin = 0, Cout = 0, k = 1, stride = 1, pad = 0, relu_cout = 0;
 };
@@ -61,6 +62,10 @@ struct ore_engine {
     void* img_in = nullptr; size_t img_bytes = 0;
     Buf s1, s2, cat[4], sout[4], lat[3];
     Buf pcat, pos, tow, head;                    // all pyramid levels in ONE level-major matrix each ([level][b][y][x])
+    Buf tn;                                      // bf16 storage only: GroupNorm + ReLU of the tower, materialised (the DMA-fed kernels cannot touch their A operand)
+    bool sb() const { return conv_precision == ORE_CONV_BF16S; }
+    // element offset into an ACTIVATION buffer (fp32, or bf16 in ORE_CONV_BF16S engines)
+    float* at(float* base, size_t elems) const { return sb() ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base) + elems) : base + elems; }
     float* gate[4] = {};
     float* lat_scaled[3] = {};                   // bs = 1: the lateral weights times the stage's eSE gate (written by the gate kernel)
     float* gn_mul = nullptr, *gn_add = nullptr;  // [3*B][C]
@@ -141,7 +146,18 @@ int need(const ore_engine* e, const std::string& name, const HostTensor** out, s
 }
 
 // 3x3 stride-1 layers the Winograd kernel covers (ore_conv_wino.hip) also get their transformed weights, once
+int make_bf16_w(ore_engine* e, Conv* c, const float* w_oihw) {
+    if (!e->sb()) return ORE_OK;
+    std::vector<uint16_t> h(ore_packed_weight_bf16_elems(c->Cout, c->Cin, c->k, c->k));
+    int rc = ore_pack_conv_weight_bf16_host(w_oihw, c->Cout, c->Cin, c->k, c->k, h.data());
+    if (rc) return rc;
+    if ((rc = e->dalloc(&c->wh, h.size()))) return rc;
+    ORE_HIP(hipMemcpy(c->wh, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return ORE_OK;
+}
+
 int make_wino(ore_engine* e, Conv* c) {
+    if (e->sb()) return ORE_OK;
     if (c->k != 3 || c->stride != 1 || (c->Cin != 64 && c->Cin != 128) || c->Cout % 64 != 0) return ORE_OK;
     int rc = e->dalloc(&c->wino, ore_winograd_weight_floats(c->Cout, c->Cin));
     if (rc) return rc;
@@ -170,6 +186,7 @@ int make_conv_bn(ore_engine* e, const std::string& name, int Cin, int Cout, int 
     if ((rc = e->upload(&c->scale, sc))) return rc;
     if ((rc = e->upload(&c->shift, sh))) return rc;
     c->Cin = Cin; c->Cout = Cout; c->k = k; c->stride = stride; c->pad = k / 2; c->relu_cout = Cout;
+    if ((rc = make_bf16_w(e, c, w->v.data()))) return rc;
     return make_wino(e, c);
 }
 
@@ -184,12 +201,18 @@ int make_conv_bias(ore_engine* e, const std::string& name, int Cin, int Cout, in
     if ((rc = e->upload(&c->shift, b->v))) return rc;
     c->scale = nullptr;
     c->Cin = Cin; c->Cout = Cout; c->k = k; c->stride = 1; c->pad = k / 2; c->relu_cout = relu ? Cout : 0;
+    if ((rc = make_bf16_w(e, c, w->v.data()))) return rc;
     return make_wino(e, c);
 }
 
-int alloc_buf(ore_engine* e, Buf* b, size_t rows, int ld) {
+int alloc_buf(ore_engine* e, Buf* b, size_t rows, int ld, bool activation = true) {
     b->ld = ld; b->rows = rows;
-    return e->dalloc(&b->p, rows * ld);
+    // bf16 storage: half the bytes, plus slack for the 32-byte over-read of a row's last K chunk when Cin % 32 == 16 (zero weights)
+    const size_t floats = (activation && e->sb()) ? (rows * ld + 1) / 2 + 16 : rows * ld;
+    int rc = e->dalloc(&b->p, floats);
+    if (rc) return rc;
+    if (activation && e->sb()) ORE_HIP(hipMemset(b->p, 0, floats * sizeof(float)));
+    return ORE_OK;
 }
 
 int pool_out(int n) { int o = (n - 3 + 1) / 2 + 1; if (n < 3) o = 1; if ((o - 1) * 2 >= n) --o; return o < 1 ? 1 : o; }
@@ -209,7 +232,7 @@ struct Run {
     // one launch over all pyramid levels (level-major rows)
     void conv_levels(const Conv& c, const float* in, int in_ld, int in_coff, int B, const int* H, const int* W, float* out,
                      int out_ld, int out_coff, int ep_stride = 0, const float* in_mul = nullptr, const float* in_add = nullptr,
-                     int in_relu = 0) {
+                     int in_relu = 0, bool out_f32 = false) {
         if (rc) return;
         ore_conv_desc d{};
         d.in = in; d.in_ld = in_ld; d.in_coff = in_coff; d.B = B; d.Cin = c.Cin;
@@ -219,6 +242,7 @@ struct Run {
         d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
         d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
         d.w_wino = c.wino;
+        if (e->sb()) { d.storage = out_f32 ? ORE_ST_BF16_F32OUT : ORE_ST_BF16; d.w = reinterpret_cast<const float*>(c.wh); }
         double rows = 0;
         for (int l = 0; l < 3; ++l) rows += (double)B * H[l] * W[l];
         const double fl = 2.0 * rows * (double)c.Cout * c.Cin * c.k * c.k;
@@ -242,6 +266,7 @@ struct Run {
         d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
         d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
         d.w_wino = c.wino;
+        if (e->sb() && c.wh) { d.storage = ORE_ST_BF16; d.w = reinterpret_cast<const float*>(c.wh); }
         if (colsum) {
             const int rows = ore_conv_colsum_rows(&d);
             if ((size_t)rows * round_up(c.Cout, 16) <= e->colsum_floats) { d.colsum = colsum; *colsum_rows = rows; }
@@ -267,8 +292,11 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
     const ore_model_cfg& c = e->cfg;
     Run r{e, st};
     r.prof = e->profiling;
-    int rc = ore_stem1_fwd(img, is_u8, g.B, g.H, g.W, g.Hp, g.Wp, c.pixel_mean, c.pixel_std, e->stem1_w, e->stem1_scale,
-                           e->stem1_shift, c.stem_ch[0], e->s1.p, e->s1.ld, 0, st);
+    const bool sb = e->sb();
+    int rc = sb ? ore_stem1_bf16_fwd(img, is_u8, g.B, g.H, g.W, g.Hp, g.Wp, c.pixel_mean, c.pixel_std, e->stem1_w, e->stem1_scale,
+                                     e->stem1_shift, c.stem_ch[0], reinterpret_cast<uint16_t*>(e->s1.p), e->s1.ld, 0, st)
+                : ore_stem1_fwd(img, is_u8, g.B, g.H, g.W, g.Hp, g.Wp, c.pixel_mean, c.pixel_std, e->stem1_w, e->stem1_scale,
+                                e->stem1_shift, c.stem_ch[0], e->s1.p, e->s1.ld, 0, st);
     if (rc) return rc;
     r.flops += 2.0 * g.B * g.h[1] * g.w[1] * 27.0 * c.stem_ch[0];
     r.conv(e->stem2, e->s1.p, e->s1.ld, 0, g.B, g.h[1], g.w[1], e->s2.p, e->s2.ld, 0);
@@ -279,8 +307,10 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
         const int k = s + 2;
         Buf& cat = e->cat[s];
         if (s > 0) {
-            r.rc = ore_maxpool3x3s2_fwd(e->sout[s - 1].p, e->sout[s - 1].ld, 0, g.B, g.h[k - 1], g.w[k - 1], S.in_ch,
-                                        e->gate[s - 1], cat.p, cat.ld, 0, st);
+            r.rc = sb ? ore_maxpool3x3s2_bf16_fwd(reinterpret_cast<const uint16_t*>(e->sout[s - 1].p), e->sout[s - 1].ld, 0, g.B, g.h[k - 1],
+                                                  g.w[k - 1], S.in_ch, e->gate[s - 1], reinterpret_cast<uint16_t*>(cat.p), cat.ld, 0, st)
+                      : ore_maxpool3x3s2_fwd(e->sout[s - 1].p, e->sout[s - 1].ld, 0, g.B, g.h[k - 1], g.w[k - 1], S.in_ch,
+                                             e->gate[s - 1], cat.p, cat.ld, 0, st);
             if (r.rc) break;
         }
         int src = 0, dst = S.in_ch;
@@ -294,10 +324,14 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
         if (r.rc) break;
         if (cs_rows > 0 && s >= 1 && e->lat_scaled[s - 1]) { // bs = 1: gate + the gate-scaled lateral weight of this stage in one launch
             lat_scaled_ok[s - 1] = true;
-            r.rc = ore_ese_gate_scaled_weight_fwd(e->colsum, cs_rows, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws,
-                                                  e->lateral[s - 1].w, round_up(e->lateral[s - 1].Cout, 16), e->lat_scaled[s - 1], st);
+            r.rc = sb ? ore_ese_gate_scaled_weight_bf16_fwd(e->colsum, cs_rows, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws,
+                                                            e->lateral[s - 1].w, round_up(e->lateral[s - 1].Cout, 16),
+                                                            reinterpret_cast<uint16_t*>(e->lat_scaled[s - 1]), st)
+                      : ore_ese_gate_scaled_weight_fwd(e->colsum, cs_rows, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws,
+                                                       e->lateral[s - 1].w, round_up(e->lateral[s - 1].Cout, 16), e->lat_scaled[s - 1], st);
         } else if (cs_rows > 0)
             r.rc = ore_ese_gate_from_colsum_fwd(e->colsum, cs_rows, 1, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws, st);
+        else if (sb) { ore_set_error("bf16-storage engine: the eSE pool must come fused from the concat conv (one image per pass)"); r.rc = ORE_EINVAL; }
         else
             r.rc = ore_ese_gate_fwd(e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s],
                                     e->ese_ws, st);
@@ -310,12 +344,15 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
         if (lat_scaled_ok[l]) {                             // x * (g W): plain conv on the gate-scaled weights (k_conv_kw)
             Conv lc = e->lateral[l];
             lc.w = e->lat_scaled[l];
+            lc.wh = reinterpret_cast<uint16_t*>(e->lat_scaled[l]);
             r.conv(lc, e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, nullptr, nullptr, 0, add, F, 0);
+        } else if (sb) {
+            ore_set_error("bf16-storage engine: the lateral needs the gate-scaled weights (one image per pass)"); r.rc = ORE_EINVAL;
         } else {
             r.conv(e->lateral[l], e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, e->gate[s], nullptr, 0,
                    add, F, 0);
         }
-        r.conv(e->output[l], e->lat[l].p, F, 0, g.B, g.h[k], g.w[k], e->pcat.p + (size_t)lvl_row0(g, l) * 2 * F, 2 * F, F);
+        r.conv(e->output[l], e->lat[l].p, F, 0, g.B, g.h[k], g.w[k], e->at(e->pcat.p, (size_t)lvl_row0(g, l) * 2 * F), 2 * F, F);
     }
     *flops = r.flops;
     return r.rc;
@@ -331,13 +368,31 @@ int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
     for (int l = 0; l < 3; ++l)
         if (!e->support_set[l]) { ore_set_error("support prototype for level %d not set", l + 3); return ORE_EINVAL; }
     // query<->support depthwise correlation, all levels: attn -> channels [0,F) of pcat (q sits in [F,2F))
-    r.rc = ore_correlation_levels_fwd(e->pcat.p, 2 * F, F, g.B, 3, H, W, F, e->k11, e->k13, e->k31, e->pcat.p, 2 * F, 0, st);
+    const bool sb = e->sb();
+    r.rc = sb ? ore_correlation_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->pcat.p), 2 * F, F, g.B, 3, H, W, F, e->k11, e->k13, e->k31,
+                                                reinterpret_cast<uint16_t*>(e->pcat.p), 2 * F, 0, st)
+              : ore_correlation_levels_fwd(e->pcat.p, 2 * F, F, g.B, 3, H, W, F, e->k11, e->k13, e->k31, e->pcat.p, 2 * F, 0, st);
     if (r.rc) return r.rc;
     const double rows = (double)g.B * (HW[0] + HW[1] + HW[2]);
     r.flops += 2.0 * 8.0 * rows * F;
     r.conv_levels(e->conv3, e->pcat.p, 2 * F, 0, g.B, H, W, e->pos.p, F, 0);            // relu(conv3(cat(attn, q)))
     r.conv_levels(e->tower, e->pos.p, F, 0, g.B, H, W, e->tow.p, F, 0);                 // bbox_tower conv (+bias)
     if (r.rc) return r.rc;
+    if (sb) {
+        // bf16 storage: statistics in fp32 from the bf16 tower output, then GroupNorm + ReLU materialised as a bf16 tensor (the DMA-fed conv
+        // kernels copy their A operand verbatim), then the (l,t,r,b | hm) conv with fp32 outputs -- the detection tail is fp32 as always
+        r.rc = ore_groupnorm_affine_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma,
+                                                    e->gn_beta, e->gn_mul, e->gn_add, e->gn_ws, st);
+        for (int l = 0; l < 3 && !r.rc; ++l) {
+            const size_t r0 = (size_t)lvl_row0(g, l) * F;
+            r.rc = ore_groupnorm_apply_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p) + r0, F, 0, g.B, HW[l], F, e->gn_mul + (size_t)l * g.B * F,
+                                                e->gn_add + (size_t)l * g.B * F, 1, reinterpret_cast<uint16_t*>(e->tn.p) + r0, st);
+        }
+        if (r.rc) return r.rc;
+        r.conv_levels(e->pred, e->tn.p, F, 0, g.B, H, W, e->head.p, 8, 0, 16, nullptr, nullptr, 0, true);
+        *flops = r.flops;
+        return r.rc;
+    }
     r.rc = ore_groupnorm_affine_levels_fwd(e->tow.p, F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->gn_mul, e->gn_add,
                                            e->gn_ws, st);
     if (r.rc) return r.rc;
@@ -372,10 +427,12 @@ int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops, int b = 
     int32_t* counts = e->counts + b * 4;
     const float* feat[3]; int ld[3], coff[3], H[3], W[3]; float sc[3];
     for (int l = 0; l < 3; ++l) {
-        feat[l] = e->pcat.p + ((size_t)lvl_row0(g, l) + (size_t)b * g.h[l + 3] * g.w[l + 3]) * 2 * F; ld[l] = 2 * F; coff[l] = F;
+        feat[l] = e->at(e->pcat.p, ((size_t)lvl_row0(g, l) + (size_t)b * g.h[l + 3] * g.w[l + 3]) * 2 * F); ld[l] = 2 * F; coff[l] = F;
         H[l] = g.h[l + 3]; W[l] = g.w[l + 3]; sc[l] = 1.0f / (float)c.strides[l];
     }
-    int rc = ore_roi_align_fwd(feat, ld, coff, H, W, sc, 3, 3, F, e->roi_pooled, out_boxes, counts + 1, 0, e->roi_cap, e->roi_feat, st);
+    int rc = e->sb() ? ore_roi_align_bf16_fwd(reinterpret_cast<const uint16_t* const*>(feat), ld, coff, H, W, sc, 3, 3, F, e->roi_pooled, out_boxes,
+                                              counts + 1, 0, e->roi_cap, e->roi_feat, st)
+                     : ore_roi_align_fwd(feat, ld, coff, H, W, sc, 3, 3, F, e->roi_pooled, out_boxes, counts + 1, 0, e->roi_cap, e->roi_feat, st);
     if (rc) return rc;
     const int K = e->roi_pooled * e->roi_pooled * F;
     Run r{e, st};
@@ -515,6 +572,7 @@ extern "C" int ore_engine_set_support(ore_engine* e, int32_t level, const float*
 
 extern "C" int ore_engine_finalize(ore_engine* e) {
     ORE_CHECK_ARG(e && !e->finalized, "ore_engine_finalize: bad state");
+    ORE_CHECK_ARG(!e->sb() || e->cfg.max_batch == 1, "ore_engine_finalize: a bf16-storage engine takes one image per pass (max_batch = 1)");
     ORE_HIP(hipSetDevice(e->device));
     const ore_model_cfg& c = e->cfg;
     int rc;
@@ -575,6 +633,7 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
         Conv& p = e->pred;
         if ((rc = e->upload(&p.w, packed))) return rc;
         p.Cin = F; p.Cout = 5; p.k = 3; p.stride = 1; p.pad = 1; p.relu_cout = 4;
+        if ((rc = make_bf16_w(e, &p, w5.data()))) return rc;
         std::vector<float> scale(3 * 16, 0.f), shift(3 * 16, 0.f);
         for (int l = 0; l < 3; ++l) {
             const HostTensor* sc;
@@ -614,7 +673,8 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
         if ((rc = alloc_buf(e, &e->lat[l], M, F))) return rc;
     }
     if ((rc = alloc_buf(e, &e->pcat, rows_all, 2 * F)) || (rc = alloc_buf(e, &e->pos, rows_all, F)) ||
-        (rc = alloc_buf(e, &e->tow, rows_all, F)) || (rc = alloc_buf(e, &e->head, rows_all, 8))) return rc;
+        (rc = alloc_buf(e, &e->tow, rows_all, F)) || (rc = alloc_buf(e, &e->head, rows_all, 8, false))) return rc;
+    if (e->sb() && (rc = alloc_buf(e, &e->tn, rows_all, F))) return rc;
     ORE_HIP(hipMemset(e->head.p, 0, rows_all * 8 * sizeof(float)));
     if ((rc = e->dalloc(&e->gn_mul, 3 * B * F)) || (rc = e->dalloc(&e->gn_add, 3 * B * F))) return rc;
     if ((rc = e->dalloc(&e->k11, (size_t)3 * F)) || (rc = e->dalloc(&e->k13, (size_t)3 * F * 3)) || (rc = e->dalloc(&e->k31, (size_t)3 * F * 3))) return rc;
@@ -662,7 +722,7 @@ extern "C" int ore_engine_backbone_fwd(ore_engine* e, const void* img, int32_t i
     ORE_CHECK_ARG(img, "null image");
     const Geo g = make_geo(B, H, W);
     e->last = g;
-    PrecisionScope ps(e->conv_precision);
+    PrecisionScope ps(e->sb() ? ORE_CONV_FP32 : e->conv_precision);
     return run_backbone(e, img, is_u8, g, (hipStream_t)stream, &e->last_flops);
 }
 
@@ -723,7 +783,7 @@ extern "C" int ore_engine_eval_batch_fwd(ore_engine* e, const void* img, int32_t
     hipStream_t st = (hipStream_t)stream;
     const Geo g = make_geo(B, H, W);
     e->last = g;
-    PrecisionScope ps(e->conv_precision);
+    PrecisionScope ps(e->sb() ? ORE_CONV_FP32 : e->conv_precision);
     const size_t bytes = (size_t)B * 3 * H * W * (is_u8 ? 1 : 4);
     ORE_CHECK_ARG(bytes <= e->img_bytes, "image batch exceeds the engine's input buffer");
     if (img != e->img_in) ORE_HIP(hipMemcpyAsync(e->img_in, img, bytes, hipMemcpyDefault, st));   // device or (pinned / pageable) host source
@@ -842,11 +902,11 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
         const std::string k = std::to_string(l + 3);
         const int64_t rows = (int64_t)g.B * g.h[l + 3] * g.w[l + 3];
         const size_t r0 = (size_t)lvl_row0(g, l);
-        if (n == "p" + k) return set(e->pcat.p + r0 * 2 * F, rows, F, 2 * F, F);
-        if (n == "attn" + k) return set(e->pcat.p + r0 * 2 * F, rows, F, 2 * F, 0);
+        if (n == "p" + k) return set(e->at(e->pcat.p, r0 * 2 * F), rows, F, 2 * F, F);
+        if (n == "attn" + k) return set(e->at(e->pcat.p, r0 * 2 * F), rows, F, 2 * F, 0);
         if (n == "lat" + k) return set(e->lat[l].p, rows, F, F, 0);
-        if (n == "pos" + k) return set(e->pos.p + r0 * F, rows, F, F, 0);
-        if (n == "tower" + k) return set(e->tow.p + r0 * F, rows, F, F, 0);
+        if (n == "pos" + k) return set(e->at(e->pos.p, r0 * F), rows, F, F, 0);
+        if (n == "tower" + k) return set(e->at(e->tow.p, r0 * F), rows, F, F, 0);
         if (n == "head" + k) return set(e->head.p + r0 * 8, rows, 5, 8, 0);
     }
     // per-image detection outputs: "name" = image 0, "name#b" = image b of the last batch
@@ -875,4 +935,12 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
     }
     ore_set_error("ore_engine_buffer: unknown buffer '%s'", name);
     return ORE_ENOENT;
+}
+
+extern "C" int32_t ore_engine_buffer_is_bf16(ore_engine* e, const char* name) {
+    if (!e || !name || !e->sb()) return 0;
+    const std::string n(name);
+    for (const char* pre : {"stem", "stage", "cat", "attn", "lat", "pos", "tower"})
+        if (n.rfind(pre, 0) == 0) return 1;
+    return n.size() == 2 && n[0] == 'p' ? 1 : 0;                 // "p3" .. "p5"
 }

@@ -10,11 +10,11 @@ namespace {
 // FrozenBN -> ReLU -> NHWC, as a K=28 GEMM on v_mfma_f32_16x16x4_f32: each lane gathers only the 7 taps it
 // feeds to the matrix core, the weights live in registers for the whole wave.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT>
+template <typename T, int NT, typename TO = float>
 __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B, int H, int W, int Ho, int Wo,
                                                float m0, float m1, float m2, float s0, float s1, float s2,
                                                const float* __restrict__ w, const float* __restrict__ scale,
-                                               const float* __restrict__ shift, int Cout, float* __restrict__ out,
+                                               const float* __restrict__ shift, int Cout, TO* __restrict__ out,
                                                int out_ld, int out_coff, int groups_per_wave) {
     // GEMM view: M = output pixels (16 per MFMA tile), N = Cout (NT tiles of 16), K = 27 padded to 28 = 7 k-steps of 4.
     // lane (i = lane&15, g = lane>>4) feeds A[pixel i][k = 4j+g] and B[k = 4j+g][n = i] in step j.
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n), sh = *reinterpret_cast<const f32x4*>(shift + n);
                     f32x4 v = acc[t] * sc + sh;
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    *reinterpret_cast<f32x4*>(out + (size_t)m * out_ld + out_coff + n) = v;
+                    st4(out + (size_t)m * out_ld + out_coff + n, v);
                 }
             }
         }
@@ -96,9 +96,10 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
 // MaxPool2d(3, 2, ceil_mode=True); thread = (output pixel, 4 channels).  Optional gate: the eSE
 // multiplier is >= 0 and fl(x*s) is monotone in x, so max_i fl(x_i*s) == fl(max_i(x_i)*s) exactly.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ in, int in_ld, int in_coff, int B, int H,
+template <typename TS>
+__global__ __launch_bounds__(256) void k_maxpool(const TS* __restrict__ in, int in_ld, int in_coff, int B, int H,
                                                  int W, int C4, int Ho, int Wo, const float* __restrict__ mul, int C,
-                                                 float* __restrict__ out, int out_ld, int out_coff) {
+                                                 TS* __restrict__ out, int out_ld, int out_coff) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int total = B * Ho * Wo * C4;
     if (idx >= total) return;
@@ -112,12 +113,12 @@ __global__ __launch_bounds__(256) void k_maxpool(const float* __restrict__ in, i
         for (int kx = 0; kx < 3; ++kx) {
             const int iy = oy * 2 + ky, ix = ox * 2 + kx;
             if (iy < H && ix < W) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (size_t)((b * H + iy) * W + ix) * in_ld + in_coff + c4 * 4);
+                const f32x4 v = ld4(in + (size_t)((b * H + iy) * W + ix) * in_ld + in_coff + c4 * 4);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
     if (mul) m = m * *reinterpret_cast<const f32x4*>(mul + b * C + c4 * 4);
-    *reinterpret_cast<f32x4*>(out + (size_t)pix * out_ld + out_coff + c4 * 4) = m;
+    st4(out + (size_t)pix * out_ld + out_coff + c4 * 4, m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_colmean(const float* __restrict__ part,
 // (which cannot touch its A operand) instead of k_conv_igemm's input-affine path.
 __global__ __launch_bounds__(256) void k_ese_gate(const float* __restrict__ mean, int C, const float* __restrict__ fw,
                                                   const float* __restrict__ fb, float* __restrict__ gate,
-                                                  const float* __restrict__ lw, float* __restrict__ lws, int lrows) {
+                                                  const float* __restrict__ lw, float* __restrict__ lws, int lrows, int lws_bf16 = 0) {
     __shared__ float g4[4];
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(256) void k_ese_gate(const float* __restrict__ mean
     const int o0 = blockIdx.x * 4;                      // C % 4 == 0: the four columns of this block are all real
     for (int n = threadIdx.x; n < lrows; n += 256) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(lw + (size_t)n * C + o0);
-        *reinterpret_cast<f32x4*>(lws + (size_t)n * C + o0) = f32x4{w.x * g4[0], w.y * g4[1], w.z * g4[2], w.w * g4[3]};
+        const f32x4 ws4 = f32x4{w.x * g4[0], w.y * g4[1], w.z * g4[2], w.w * g4[3]};
+        if (lws_bf16) st4(reinterpret_cast<ore_bf16_t*>(lws) + (size_t)n * C + o0, ws4);      // bf16 storage: the scaled weight is a bf16 tensor
+        else *reinterpret_cast<f32x4*>(lws + (size_t)n * C + o0) = ws4;
     }
 }
 
@@ -225,11 +228,12 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 
 struct CorrLv { int row0, H, W; };
 struct CorrP {
-    const float* q; int q_ld, q_coff; int B, C4, nlev; CorrLv lv[4]; int rows;
+    const void* q; int q_ld, q_coff; int B, C4, nlev; CorrLv lv[4]; int rows;
     const float* k11; const float* k13; const float* k31; int kstride;   // per-level stride (in channels) of the kernels
-    float* out; int out_ld, out_coff;
+    void* out; int out_ld, out_coff;
 };
 
+template <typename TS>
 __global__ __launch_bounds__(256) void k_correlation(CorrP p) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.rows * p.C4) return;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void k_correlation(CorrP p) {
     }
     auto Q = [&](int yy, int xx) -> f32x4 {
         if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-            return *reinterpret_cast<const f32x4*>(p.q + (size_t)(base + yy * W + xx) * p.q_ld + p.q_coff + c);
+            return ld4(reinterpret_cast<const TS*>(p.q) + (size_t)(base + yy * W + xx) * p.q_ld + p.q_coff + c);
         return f32x4{0.f, 0.f, 0.f, 0.f};
     };
     const f32x4 qc = Q(y, x);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void k_correlation(CorrP p) {
         }
     }
     const f32x4 res = a + relu4(bacc) + qc;
-    *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + p.out_coff + c) = res;
+    st4(reinterpret_cast<TS*>(p.out) + (size_t)row * p.out_ld + p.out_coff + c, res);
 }
 
 // support prototype [C][s][s] -> adaptive avg pools (1,1), (1,3), (3,1); one block per channel.
@@ -363,8 +367,8 @@ __global__ __launch_bounds__(256) void k_gn_chunk_stats(const float* __restrict_
 // cpg == 4 (GroupNorm(32, 128) of the head tower): a group at one pixel is ONE 16-byte vector.  Thread t owns group t % G of rows
 // t / G, t / G + 256 / G, ...: the chunk is read once (<= 8 float4 per thread, kept in registers), the group mean comes from a
 // fixed-order LDS reduction over the row lanes, M2 from the registers.  13.8 -> ~6 us for the three levels at 640x640.
-template <int RPT>   // float4 per thread = GN_ROWS * G / 256
-__global__ __launch_bounds__(256) void k_gn_chunk_stats4(const float* __restrict__ x, int ld, int coff, GnSeg sg, int G,
+template <int RPT, typename TS = float>   // float4 per thread = GN_ROWS * G / 256
+__global__ __launch_bounds__(256) void k_gn_chunk_stats4(const TS* __restrict__ x, int ld, int coff, GnSeg sg, int G,
                                                          float* __restrict__ stats /* [total chunks][G][2] */) {
     __shared__ float red[256];
     __shared__ float gmean[64];
@@ -372,13 +376,13 @@ __global__ __launch_bounds__(256) void k_gn_chunk_stats4(const float* __restrict
     gn_locate_chunk(sg, blockIdx.x, seg, HW, row0, chunk);
     const int g = threadIdx.x % G, rr = threadIdx.x / G, rpar = 256 / G;
     const int r0 = chunk * GN_ROWS, r1 = min(r0 + GN_ROWS, HW);
-    const float* base = x + (size_t)row0 * ld + coff + g * 4;
+    const TS* base = x + (size_t)row0 * ld + coff + g * 4;
     f32x4 v[RPT];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = r0 + rr + k * rpar;
-        v[k] = r < r1 ? *reinterpret_cast<const f32x4*>(base + (size_t)r * ld) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[k] = r < r1 ? ld4(base + (size_t)r * ld) : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
     red[threadIdx.x] = s;
@@ -468,10 +472,10 @@ __global__ __launch_bounds__(256) void k_gn_combine(const float* __restrict__ st
 
 }  // namespace
 
-extern "C" int ore_stem1_fwd(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp,
+static int stem1_launch(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp,
                              int32_t Wp, const float* mean3, const float* std3, const float* w_oihw,
-                             const float* scale, const float* shift, int32_t Cout, float* out, int32_t out_ld,
-                             int32_t out_coff, void* stream) {
+                             const float* scale, const float* shift, int32_t Cout, void* out, int32_t out_ld,
+                             int32_t out_coff, void* stream, int out_bf16) {
     ORE_CHECK_ARG(img && mean3 && std3 && w_oihw && scale && shift && out, "ore_stem1_fwd: null pointer");
     ORE_CHECK_ARG(B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W && Hp % 2 == 0 && Wp % 2 == 0, "ore_stem1_fwd: geometry");
     ORE_CHECK_ARG(Cout % 16 == 0 && Cout <= 128 && out_coff % 4 == 0 && out_ld % 4 == 0 && out_coff + Cout <= out_ld,
@@ -484,8 +488,10 @@ extern "C" int ore_stem1_fwd(const void* img, int32_t img_is_u8, int32_t B, int3
     const int gpw = ngroups >= 2048 ? 2 : 1;            // groups of 16 pixels per wave (measured at 640x640 with LDS-staged weights: 1 -> 17.6, 2 -> 17.5, 4 -> 20.4, 8 -> 28.0 us)
     const int blocks = ceil_div(ngroups, 4 * gpw);
 #define ORE_STEM1(T, NT)                                                                                              \
-    hipLaunchKernelGGL((k_stem1<T, NT>), dim3(blocks), dim3(256), 0, st, (const T*)img, B, H, W, Ho, Wo, mean3[0], mean3[1], \
-                       mean3[2], std3[0], std3[1], std3[2], w_oihw, scale, shift, Cout, out, out_ld, out_coff, gpw)
+    do { if (out_bf16) hipLaunchKernelGGL((k_stem1<T, NT, ore_bf16_t>), dim3(blocks), dim3(256), 0, st, (const T*)img, B, H, W, Ho, Wo, mean3[0], mean3[1], \
+                       mean3[2], std3[0], std3[1], std3[2], w_oihw, scale, shift, Cout, (ore_bf16_t*)out, out_ld, out_coff, gpw); \
+    else hipLaunchKernelGGL((k_stem1<T, NT, float>), dim3(blocks), dim3(256), 0, st, (const T*)img, B, H, W, Ho, Wo, mean3[0], mean3[1], \
+                       mean3[2], std3[0], std3[1], std3[2], w_oihw, scale, shift, Cout, (float*)out, out_ld, out_coff, gpw); } while (0)
     switch ((Cout >> 4) * 2 + (img_is_u8 ? 1 : 0)) {
         case 2: ORE_STEM1(float, 1); break;     case 3: ORE_STEM1(uint8_t, 1); break;
         case 4: ORE_STEM1(float, 2); break;     case 5: ORE_STEM1(uint8_t, 2); break;
@@ -497,6 +503,20 @@ extern "C" int ore_stem1_fwd(const void* img, int32_t img_is_u8, int32_t B, int3
     return ore_launch_status("k_stem1");
 }
 
+extern "C" int ore_stem1_fwd(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp,
+                             int32_t Wp, const float* mean3, const float* std3, const float* w_oihw,
+                             const float* scale, const float* shift, int32_t Cout, float* out, int32_t out_ld,
+                             int32_t out_coff, void* stream) {
+    return stem1_launch(img, img_is_u8, B, H, W, Hp, Wp, mean3, std3, w_oihw, scale, shift, Cout, out, out_ld, out_coff, stream, 0);
+}
+
+extern "C" int ore_stem1_bf16_fwd(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp,
+                                  int32_t Wp, const float* mean3, const float* std3, const float* w_oihw,
+                                  const float* scale, const float* shift, int32_t Cout, uint16_t* out, int32_t out_ld,
+                                  int32_t out_coff, void* stream) {
+    return stem1_launch(img, img_is_u8, B, H, W, Hp, Wp, mean3, std3, w_oihw, scale, shift, Cout, out, out_ld, out_coff, stream, 1);
+}
+
 extern "C" int ore_maxpool3x3s2_fwd(const float* in, int32_t in_ld, int32_t in_coff, int32_t B, int32_t H, int32_t W,
                                     int32_t C, const float* in_mul, float* out, int32_t out_ld, int32_t out_coff,
                                     void* stream) {
@@ -505,8 +525,20 @@ extern "C" int ore_maxpool3x3s2_fwd(const float* in, int32_t in_ld, int32_t in_c
     auto osz = [](int n) { int o = (n - 3 + 1) / 2 + 1; if (n < 3) o = 1; if ((o - 1) * 2 >= n) --o; return o < 1 ? 1 : o; };
     const int Ho = osz(H), Wo = osz(W);
     const int total = B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(k_maxpool, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, in, in_ld, in_coff, B, H,
+    hipLaunchKernelGGL(k_maxpool<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, in, in_ld, in_coff, B, H,
                        W, C / 4, Ho, Wo, in_mul, C, out, out_ld, out_coff);
+    return ore_launch_status("k_maxpool");
+}
+
+extern "C" int ore_maxpool3x3s2_bf16_fwd(const uint16_t* in, int32_t in_ld, int32_t in_coff, int32_t B, int32_t H, int32_t W,
+                                         int32_t C, const float* in_mul, uint16_t* out, int32_t out_ld, int32_t out_coff, void* stream) {
+    ORE_CHECK_ARG(in && out && B > 0 && H >= 1 && W >= 1 && C % 4 == 0, "ore_maxpool3x3s2_bf16_fwd: bad args");
+    ORE_CHECK_ARG(in_ld % 4 == 0 && in_coff % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0, "ore_maxpool3x3s2_bf16_fwd: align");
+    auto osz = [](int n) { int o = (n - 3 + 1) / 2 + 1; if (n < 3) o = 1; if ((o - 1) * 2 >= n) --o; return o < 1 ? 1 : o; };
+    const int Ho = osz(H), Wo = osz(W);
+    const int total = B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(k_maxpool<ore_bf16_t>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const ore_bf16_t*)in, in_ld,
+                       in_coff, B, H, W, C / 4, Ho, Wo, in_mul, C, (ore_bf16_t*)out, out_ld, out_coff);
     return ore_launch_status("k_maxpool");
 }
 
@@ -548,7 +580,21 @@ extern "C" int ore_ese_gate_scaled_weight_fwd(const float* part, int32_t P, int3
     hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), 1), dim3(256), 0, st, part, P, HW, C, mean_ws);
     int rc = ore_launch_status("k_colmean");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), 1), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, w_packed, w_scaled, (int)w_rows);
+    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), 1), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, w_packed, w_scaled, (int)w_rows, 0);
+    return ore_launch_status("k_ese_gate");
+}
+
+extern "C" int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
+                                                   float* gate, float* mean_ws, const float* w_packed_f32, int32_t w_rows,
+                                                   uint16_t* w_scaled_bf16, void* stream) {
+    ORE_CHECK_ARG(part && fc_w && fc_b && gate && mean_ws && w_packed_f32 && w_scaled_bf16 && P > 0 && HW > 0 && C > 0 && C % 32 == 0 &&
+                      C <= 4096 && w_rows > 0, "ore_ese_gate_scaled_weight_bf16_fwd: bad args (C must be a multiple of 32)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), 1), dim3(256), 0, st, part, P, HW, C, mean_ws);
+    int rc = ore_launch_status("k_colmean");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), 1), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, w_packed_f32,
+                       reinterpret_cast<float*>(w_scaled_bf16), (int)w_rows, 1);
     return ore_launch_status("k_ese_gate");
 }
 
@@ -571,7 +617,7 @@ extern "C" int ore_correlation_fwd(const float* q, int32_t q_ld, int32_t q_coff,
     CorrP p{};
     p.q = q; p.q_ld = q_ld; p.q_coff = q_coff; p.B = B; p.C4 = C / 4; p.nlev = 1; p.lv[0] = {0, H, W}; p.rows = B * H * W;
     p.k11 = k11; p.k13 = k13; p.k31 = k31; p.kstride = 0; p.out = out; p.out_ld = out_ld; p.out_coff = out_coff;
-    hipLaunchKernelGGL(k_correlation, dim3(ceil_div(p.rows * p.C4, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_correlation<float>, dim3(ceil_div(p.rows * p.C4, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_correlation");
 }
 
@@ -587,7 +633,23 @@ extern "C" int ore_correlation_levels_fwd(const float* q, int32_t q_ld, int32_t 
     for (int l = 0; l < n_levels; ++l) { p.lv[l] = {rows, H[l], W[l]}; rows += B * H[l] * W[l]; }
     p.rows = rows;
     p.k11 = k11; p.k13 = k13; p.k31 = k31; p.kstride = C; p.out = out; p.out_ld = out_ld; p.out_coff = out_coff;
-    hipLaunchKernelGGL(k_correlation, dim3(ceil_div(p.rows * p.C4, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_correlation<float>, dim3(ceil_div(p.rows * p.C4, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return ore_launch_status("k_correlation");
+}
+
+extern "C" int ore_correlation_levels_bf16_fwd(const uint16_t* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t n_levels,
+                                               const int32_t* H, const int32_t* W, int32_t C, const float* k11, const float* k13,
+                                               const float* k31, uint16_t* out, int32_t out_ld, int32_t out_coff, void* stream) {
+    ORE_CHECK_ARG(q && k11 && k13 && k31 && out && H && W && n_levels >= 1 && n_levels <= 4, "ore_correlation_levels_bf16_fwd: bad args");
+    ORE_CHECK_ARG(C % 4 == 0 && q_ld % 4 == 0 && q_coff % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0,
+                  "ore_correlation_levels_bf16_fwd: alignment");
+    CorrP p{};
+    p.q = q; p.q_ld = q_ld; p.q_coff = q_coff; p.B = B; p.C4 = C / 4; p.nlev = n_levels;
+    int rows = 0;
+    for (int l = 0; l < n_levels; ++l) { p.lv[l] = {rows, H[l], W[l]}; rows += B * H[l] * W[l]; }
+    p.rows = rows;
+    p.k11 = k11; p.k13 = k13; p.k31 = k31; p.kstride = C; p.out = out; p.out_ld = out_ld; p.out_coff = out_coff;
+    hipLaunchKernelGGL(k_correlation<ore_bf16_t>, dim3(ceil_div(p.rows * p.C4, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_correlation");
 }
 
@@ -598,9 +660,10 @@ extern "C" int ore_support_kernels_fwd(const float* proto_chw, int32_t C, int32_
     return ore_launch_status("k_support_kernels");
 }
 
-extern "C" int ore_groupnorm_affine_levels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
+static int gn_affine_levels(const void* xv, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
                                                const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
-                                               const float* beta, float* mul, float* add, float* workspace, void* stream) {
+                                               const float* beta, float* mul, float* add, float* workspace, void* stream, int x_bf16) {
+    const float* x = (const float*)xv;
     ORE_CHECK_ARG(x && HW && gamma && beta && mul && add && workspace && n_levels >= 1 && n_levels <= 4 && groups > 0 && groups <= 64 &&
                       C % groups == 0 && C <= 256 && 256 % C == 0, "ore_groupnorm_affine_levels_fwd: bad args (need C | 256, groups <= 64)");
     GnSeg sg{};
@@ -614,16 +677,33 @@ extern "C" int ore_groupnorm_affine_levels_fwd(const float* x, int32_t ld, int32
     if (C == groups * 4 && 256 % groups == 0 && GN_ROWS * groups / 256 >= 1 && GN_ROWS * groups % 256 == 0 && ld % 4 == 0 && coff % 4 == 0 &&
         ((uintptr_t)x & 15) == 0) {
         const int rpt = GN_ROWS * groups / 256;
+        if (x_bf16) {
+            ORE_CHECK_ARG(rpt == 8, "ore_groupnorm_affine_levels_bf16_fwd: built for GroupNorm(32, 128)");
+            hipLaunchKernelGGL((k_gn_chunk_stats4<8, ore_bf16_t>), dim3(chunks), dim3(256), 0, st, (const ore_bf16_t*)xv, ld, coff, sg, groups, workspace);
+        } else
         if (rpt == 8) hipLaunchKernelGGL(k_gn_chunk_stats4<8>, dim3(chunks), dim3(256), 0, st, x, ld, coff, sg, groups, workspace);
         else if (rpt == 4) hipLaunchKernelGGL(k_gn_chunk_stats4<4>, dim3(chunks), dim3(256), 0, st, x, ld, coff, sg, groups, workspace);
         else hipLaunchKernelGGL(k_gn_chunk_stats, dim3(chunks), dim3(256), 0, st, x, ld, coff, sg, C, groups, workspace);
     } else {
+        ORE_CHECK_ARG(!x_bf16, "ore_groupnorm_affine_levels_bf16_fwd: built for GroupNorm(32, 128)");
         hipLaunchKernelGGL(k_gn_chunk_stats, dim3(chunks), dim3(256), 0, st, x, ld, coff, sg, C, groups, workspace);
     }
     int rc = ore_launch_status("k_gn_chunk_stats");
     if (rc) return rc;
     hipLaunchKernelGGL(k_gn_combine, dim3(n_levels * B), dim3(256), 0, st, workspace, sg, C, groups, eps, gamma, beta, mul, add);
     return ore_launch_status("k_gn_combine");
+}
+
+extern "C" int ore_groupnorm_affine_levels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
+                                               const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
+                                               const float* beta, float* mul, float* add, float* workspace, void* stream) {
+    return gn_affine_levels(x, ld, coff, B, n_levels, HW, C, groups, eps, gamma, beta, mul, add, workspace, stream, 0);
+}
+
+extern "C" int ore_groupnorm_affine_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
+                                                    const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
+                                                    const float* beta, float* mul, float* add, float* workspace, void* stream) {
+    return gn_affine_levels(x, ld, coff, B, n_levels, HW, C, groups, eps, gamma, beta, mul, add, workspace, stream, 1);
 }
 
 extern "C" int ore_groupnorm_affine_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,

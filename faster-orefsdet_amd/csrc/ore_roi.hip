@@ -34,7 +34,7 @@ __device__ __forceinline__ float ore_expf(float x) {
 }
 
 struct RoiP {
-    const float* feat[4]; int ld[4], coff[4], H[4], W[4]; float scale[4];
+    const void* feat[4]; int ld[4], coff[4], H[4], W[4]; float scale[4];
     int n_levels, min_level, C, pooled;
     float canonical_size; int canonical_level;
     const float* boxes; const int* n_ptr; int n_host; int cap;
@@ -42,7 +42,8 @@ struct RoiP {
     const int* bidx;      // optional image index per box (features are [B][H][W][ld]); NULL = one image
 };
 
-__device__ __forceinline__ f32x4 bilinear4(const float* f, int ld, int H, int W, float y, float x, int c) {
+template <typename TS>
+__device__ __forceinline__ f32x4 bilinear4(const TS* f, int ld, int H, int W, float y, float x, int c) {
     if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return f32x4{0.f, 0.f, 0.f, 0.f};
     if (y <= 0.f) y = 0.f;
     if (x <= 0.f) x = 0.f;
@@ -50,15 +51,16 @@ __device__ __forceinline__ f32x4 bilinear4(const float* f, int ld, int H, int W,
     if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
     if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
     const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_low * W + x_low) * ld + c);
-    const f32x4 v2 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_low * W + x_high) * ld + c);
-    const f32x4 v3 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_high * W + x_low) * ld + c);
-    const f32x4 v4 = *reinterpret_cast<const f32x4*>(f + (size_t)(y_high * W + x_high) * ld + c);
+    const f32x4 v1 = ld4(f + (size_t)(y_low * W + x_low) * ld + c);
+    const f32x4 v2 = ld4(f + (size_t)(y_low * W + x_high) * ld + c);
+    const f32x4 v3 = ld4(f + (size_t)(y_high * W + x_low) * ld + c);
+    const f32x4 v4 = ld4(f + (size_t)(y_high * W + x_high) * ld + c);
     return (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
 }
 
 // one block per ROI; thread = (bin, 4 channels)
 constexpr int ROI_FWD_SPLIT = 4;        // blocks per ROI: 256-320 ROIs alone do not fill 256 CUs with enough loads in flight
+template <typename TS>
 __global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
     const int r = blockIdx.x / ROI_FWD_SPLIT, part = blockIdx.x % ROI_FWD_SPLIT;
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
     const int l = (int)lv - p.min_level;
     const float sc = p.scale[l];
     const int H = p.H[l], W = p.W[l], ld = p.ld[l];
-    const float* f = p.feat[l] + p.coff[l] + (p.bidx ? (size_t)p.bidx[r] * H * W * ld : 0);
+    const TS* f = reinterpret_cast<const TS*>(p.feat[l]) + p.coff[l] + (p.bidx ? (size_t)p.bidx[r] * H * W * ld : 0);
     const float x0 = b.x * sc - 0.5f, y0 = b.y * sc - 0.5f, x1 = b.z * sc - 0.5f, y1 = b.w * sc - 0.5f;
     const float rw = x1 - x0, rh = y1 - y0;
     const float bw = rw / (float)P, bh = rh / (float)P;
@@ -611,28 +613,28 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
 extern "C" int ore_nms_device_n_fwd(const float* boxes, const float* scores, const int32_t* n_dev, int32_t cap, float thr,
                                     int64_t* keep_idx, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
 
-static int roi_align_fwd_impl(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+static int roi_align_fwd_impl(const void* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                               const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
                               const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream,
-                              const int32_t* box_image);
+                              const int32_t* box_image, int feat_bf16);
 
 extern "C" int ore_roi_align_fwd(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                                  const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
                                  const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream) {
-    return roi_align_fwd_impl(feat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, n_dev, n_host, cap, out, stream, nullptr);
+    return roi_align_fwd_impl((const void* const*)feat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, n_dev, n_host, cap, out, stream, nullptr, 0);
 }
 
 extern "C" int ore_roi_align_batched_fwd(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                                          const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
                                          const float* boxes, const int32_t* box_image, int32_t n, float* out, void* stream) {
     ORE_CHECK_ARG(box_image, "ore_roi_align_batched_fwd: null box_image");
-    return roi_align_fwd_impl(feat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, nullptr, n, n, out, stream, box_image);
+    return roi_align_fwd_impl((const void* const*)feat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, nullptr, n, n, out, stream, box_image, 0);
 }
 
-static int roi_align_fwd_impl(const float* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+static int roi_align_fwd_impl(const void* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                               const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
                               const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream,
-                              const int32_t* box_image) {
+                              const int32_t* box_image, int feat_bf16) {
     ORE_CHECK_ARG(feat && ld && coff && H && W && scales_host && boxes && out, "ore_roi_align_fwd: null pointer");
     ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && C % 4 == 0 && pooled >= 1 && pooled <= 16 && cap >= 1, "ore_roi_align_fwd: bad args");
     RoiP p{};
@@ -643,8 +645,17 @@ static int roi_align_fwd_impl(const float* const* feat, const int32_t* ld, const
     p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
     p.canonical_size = 224.0f; p.canonical_level = 4;      // ROIPooler defaults (poolers.py:96-97)
     p.boxes = boxes; p.n_ptr = n_dev; p.n_host = n_host; p.cap = cap; p.out = out; p.bidx = box_image;
-    hipLaunchKernelGGL(k_roi_align, dim3(cap * ROI_FWD_SPLIT), dim3(256), 0, (hipStream_t)stream, p);
+    if (feat_bf16) hipLaunchKernelGGL(k_roi_align<ore_bf16_t>, dim3(cap * ROI_FWD_SPLIT), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_roi_align<float>, dim3(cap * ROI_FWD_SPLIT), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_roi_align");
+}
+
+// bf16 feature maps (ORE_ST_BF16 pyramid), fp32 boxes and fp32 pooled output
+extern "C" int ore_roi_align_bf16_fwd(const uint16_t* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                                      const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                                      const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream) {
+    return roi_align_fwd_impl((const void* const*)feat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, n_dev, n_host, cap, out,
+                              stream, nullptr, 1);
 }
 
 extern "C" size_t ore_roi_predict_workspace_bytes(int32_t cap) {

@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -426,15 +426,16 @@ def groupnorm_affine(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: to
 
 
 def set_conv_precision(mode: str) -> str:
-    """"fp32" (default) or "bf16": operand precision of the MFMA conv kernels for subsequent launches (include/ore_hip.h,
-    ore_conv_set_precision); engines keep the mode in force when they were created.  Returns the previous mode."""
+    """"fp32" (default), "bf16" (operands of the MFMA conv kernels rounded to bf16, fp32 tensors) or "bf16s" (bf16 STORAGE: engines
+    created under it keep bf16 activations / weights in HBM and LDS) -- include/ore_hip.h, ore_conv_set_precision; engines keep the mode
+    in force when they were created.  Returns the previous mode."""
     prev = get_conv_precision()
-    _chk(lib().ore_conv_set_precision({"fp32": 0, "bf16": 1}[mode]), "ore_conv_set_precision")
+    _chk(lib().ore_conv_set_precision({"fp32": 0, "bf16": 1, "bf16s": 2}[mode]), "ore_conv_set_precision")
     return prev
 
 
 def get_conv_precision() -> str:
-    return ("fp32", "bf16")[int(lib().ore_conv_get_precision())]
+    return ("fp32", "bf16", "bf16s")[int(lib().ore_conv_get_precision())]
 
 
 def _detect_desc(heads: Sequence[torch.Tensor], strides, score_thresh, pre_topk, nms_thresh, post_topk, d: "DetectDesc"):
@@ -1033,6 +1034,8 @@ class Engine:
         rows, ch, ld, coff = (int(x) for x in dims)
         dt = {"pre_loc": torch.int64, "keep_idx": torch.int64, "pre_level": torch.int32, "counts": torch.int32, "det_src": torch.int64,
               "det_count": torch.int32}.get(name.split("#")[0], torch.float32)
+        if lib().ore_engine_buffer_is_bf16(self._h, name.encode()):
+            dt = torch.bfloat16                               # activation buffers of a bf16-storage engine
         flat = _from_ptr(p.value, rows * ld, dt, self.device)
         t = flat.view(rows, ld)[:, coff:coff + ch]
         if bhw is not None:
@@ -1050,9 +1053,11 @@ class Engine:
 
 class _Arr:
     def __init__(self, ptr, n, dt):
-        tstr = {torch.float32: "<f4", torch.int64: "<i8", torch.int32: "<i4"}[dt]
+        tstr = {torch.float32: "<f4", torch.int64: "<i8", torch.int32: "<i4", torch.int16: "<i2"}[dt]
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": tstr, "data": (ptr, False), "version": 2}
 
 
 def _from_ptr(ptr: int, n: int, dt, device) -> torch.Tensor:
+    if dt == torch.bfloat16:                                  # not expressible in __cuda_array_interface__: view 16-bit integers
+        return torch.as_tensor(_Arr(ptr, n, torch.int16), device=device).view(torch.bfloat16)
     return torch.as_tensor(_Arr(ptr, n, dt), device=device)

@@ -106,6 +106,13 @@ int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, int32_t WGN,
  * in force when it was created. */
 #define ORE_CONV_FP32 0
 #define ORE_CONV_BF16 1
+/* ORE_CONV_BF16S -- bf16 STORAGE (BASELINE configs[4] as a byte-saving path): an engine created under this mode keeps every activation
+ * between its layers as a bf16 tensor in HBM (the producer's epilogue rounds once, nearest even), packs bf16 weights, stages bf16
+ * tiles in LDS and multiplies with v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  fp32 stay: the image, FrozenBN / bias / eSE gate /
+ * GroupNorm statistics and their arithmetic, the (l,t,r,b | heat-map) head outputs, top-k / decode / NMS, ROIAlign's output and the
+ * second-stage GEMM and predictor.  One image per pass (max_batch = 1).  Plain ore_conv2d*_fwd calls are not affected by this mode:
+ * they choose per call through ore_conv_desc.storage. */
+#define ORE_CONV_BF16S 2
 int ore_conv_set_precision(int32_t mode);
 int32_t ore_conv_get_precision(void);
 /* The same 'same'-padded stride-1 conv over several pyramid levels in ONE launch (shared weights; CenterNet head / conv3):
@@ -422,6 +429,33 @@ int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32
 #define ORE_DET_RECORD_BYTES (ORE_DET_RECORD_ROWS * 28)
 /* ORE_DET_RECORD_ROWS as the library was built (bindings size the record from this, not from a literal). */
 int32_t ore_det_record_rows(void);
+/* 1 when the named activation buffer of this engine is a bf16 tensor (engines created under ORE_CONV_BF16S), else 0 */
+int32_t ore_engine_buffer_is_bf16(ore_engine* e, const char* name);
+/* bf16-tensor forms of the small kernels between the convs of an ORE_CONV_BF16S engine (same arguments as their fp32 namesakes, ld /
+ * coff in ELEMENTS; reductions, gates and statistics stay fp32):
+ *   stem_1 writing bf16; ceil-mode max-pool bf16 -> bf16 (eSE gate folded, rounded once); depthwise correlation bf16 -> bf16;
+ *   GroupNorm statistics from a bf16 tensor; y = act(x * mul + add) bf16 -> bf16 with the folded per-(image, channel) affine;
+ *   eSE gate + the gate-scaled lateral weight written as bf16 (source weight fp32, C % 32 == 0); ROIAlign over bf16 feature maps
+ *   (fp32 output). */
+int ore_stem1_bf16_fwd(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp, int32_t Wp, const float* mean3,
+                       const float* std3, const float* w_oihw, const float* scale, const float* shift, int32_t Cout, uint16_t* out,
+                       int32_t out_ld, int32_t out_coff, void* stream);
+int ore_maxpool3x3s2_bf16_fwd(const uint16_t* in, int32_t in_ld, int32_t in_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                              const float* in_mul, uint16_t* out, int32_t out_ld, int32_t out_coff, void* stream);
+int ore_correlation_levels_bf16_fwd(const uint16_t* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t n_levels, const int32_t* H,
+                                    const int32_t* W, int32_t C, const float* k11, const float* k13, const float* k31, uint16_t* out,
+                                    int32_t out_ld, int32_t out_coff, void* stream);
+int ore_groupnorm_affine_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels, const int32_t* HW,
+                                         int32_t C, int32_t groups, float eps, const float* gamma, const float* beta, float* mul,
+                                         float* add, float* workspace, void* stream);
+int ore_groupnorm_apply_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t images, int64_t rows_per_image, int32_t C,
+                                 const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream);
+int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
+                                        float* gate, float* mean_ws, const float* w_packed_f32, int32_t w_rows, uint16_t* w_scaled_bf16,
+                                        void* stream);
+int ore_roi_align_bf16_fwd(const uint16_t* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                           const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled, const float* boxes,
+                           const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream);
 int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
                           void* out_record, void* stream, int32_t* n_det);
 /* The same for B images of one size in ONE pass (B <= cfg.max_batch; img [B][3][H][W] contiguous): the dense stages -- backbone, FPN,

@@ -45,6 +45,11 @@ VOVNET_SPECS = {
 # every MFMA convolution -- all VoVNet/FPN convs except stem_1, conv3, the CenterNet head convs -- are rounded to bf16 (nearest
 # even) at the point where they enter the convolution; accumulation, FrozenBN, eSE, GroupNorm, the depthwise correlation and
 # everything after the head stay fp32.
+# "bf16s" restates ORE_CONV_BF16S, the bf16 STORAGE mode of an engine: every activation that travels between two kernels is a bf16 tensor
+# -- the producer rounds its fp32 result once, nearest even (`_st`) --, conv weights are bf16; stem_1's arithmetic, FrozenBN / bias, the
+# eSE pool and gate, GroupNorm statistics, the depthwise correlation's arithmetic and the head OUTPUTS stay fp32.  Two folds of the
+# product are part of the mode's definition: the eSE gate reaches the max-pool as round(max(x) * g) (= round(max(x * g)), g >= 0) and the
+# FPN lateral as a weight, round(W * g) (`_GATED`).
 _OPERANDS = "fp32"
 _LINEARS = False
 
@@ -57,7 +62,7 @@ class operand_precision:
     gradient, X and dY for the weight gradient (bias gradients and everything element-wise stay fp32)."""
 
     def __init__(self, mode: str, train: bool = False):
-        assert mode in ("fp32", "bf16")
+        assert mode in ("fp32", "bf16", "bf16s")
         self.mode, self.train = mode, train
 
     def __enter__(self):
@@ -70,7 +75,15 @@ class operand_precision:
 
 
 def _rnd(t: Tensor) -> Tensor:
-    return t.bfloat16().float() if _OPERANDS == "bf16" else t
+    return t.bfloat16().float() if _OPERANDS in ("bf16", "bf16s") else t
+
+
+def _st(t: Tensor) -> Tensor:
+    """A tensor as it is STORED between two kernels: bf16 in the storage mode, untouched otherwise."""
+    return t.bfloat16().float() if _OPERANDS == "bf16s" else t
+
+
+_GATED: Dict[int, Tuple[Tensor, Tensor]] = {}      # id(x * gate) -> (x, gate): lets fpn() fold the gate into the lateral weight (bf16s)
 
 
 class _Bf16ConvFn(torch.autograd.Function):
@@ -151,7 +164,7 @@ def conv_bn_relu(x: Tensor, sd: SD, name: str, stride: int, pad: int) -> Tensor:
         x = F.conv2d(x, sd[name + "/conv.weight"], None, stride, pad)
     else:
         x = dense_conv(x, sd[name + "/conv.weight"], None, stride, pad)
-    return F.relu(frozen_bn(x, sd, name + "/norm."))
+    return _st(F.relu(frozen_bn(x, sd, name + "/norm.")))
 
 
 # --------------------------------------------------------------------------------------
@@ -162,7 +175,10 @@ def ese(x: Tensor, sd: SD, prefix: str) -> Tensor:
     s = F.adaptive_avg_pool2d(x, 1)
     s = F.conv2d(s, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
     s = F.relu6(s + 3.0) / 6.0
-    return x * s
+    y = x * s
+    if _OPERANDS == "bf16s":
+        _GATED[id(y)] = (x, s)
+    return y
 
 
 def osa_module(x: Tensor, sd: SD, prefix: str, mod: str, n_layers: int, identity: bool) -> Tensor:
@@ -191,7 +207,7 @@ def vovnet(x: Tensor, sd: SD, prefix: str = "backbone.bottom_up.",
     for si in range(4):
         k = si + 2
         if k != 2:  # _OSA_stage (vovnet.py:349-350)
-            x = F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True)
+            x = _st(F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True))
         for b in range(spec["blocks"][si]):
             mod = f"OSA{k}_{b + 1}"
             x = osa_module(x, sd, f"{prefix}stage{k}.{mod}.", mod, spec["layers"], identity=b > 0)
@@ -208,12 +224,17 @@ def fpn(feats: Mapping[str, Tensor], sd: SD, prefix: str = "backbone.",
     res: Dict[str, Tensor] = {}
     prev = None
     for name, st in reversed(list(zip(in_features, stages))):
-        lat = dense_conv(feats[name], sd[f"{prefix}fpn_lateral{st}.weight"], sd[f"{prefix}fpn_lateral{st}.bias"])
+        if _OPERANDS == "bf16s" and id(feats[name]) in _GATED:       # the gate rides on the lateral's weight: conv(x, round(W * g))
+            xs, gs = _GATED[id(feats[name])]
+            lat = F.conv2d(xs, _rnd(sd[f"{prefix}fpn_lateral{st}.weight"] * gs.view(1, -1, 1, 1)), sd[f"{prefix}fpn_lateral{st}.bias"])
+        else:
+            lat = dense_conv(feats[name], sd[f"{prefix}fpn_lateral{st}.weight"], sd[f"{prefix}fpn_lateral{st}.bias"])
         if prev is not None:
             lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+        lat = _st(lat)
         prev = lat
-        res[f"p{st}"] = dense_conv(lat, sd[f"{prefix}fpn_output{st}.weight"],
-                                   sd[f"{prefix}fpn_output{st}.bias"], padding=1)
+        res[f"p{st}"] = _st(dense_conv(lat, sd[f"{prefix}fpn_output{st}.weight"],
+                                       sd[f"{prefix}fpn_output{st}.bias"], padding=1))
     return {k: res[k] for k in sorted(res)}
 
 
@@ -278,8 +299,8 @@ def correlation(q: Tensor, s_pool: Tensor, conv3_w: Tensor, conv3_b: Tensor) -> 
     a = F.relu(F.conv2d(a, k11, padding=(0, 0), groups=C))
     b = F.relu(F.conv2d(q, k13, padding=(0, 1), groups=C))
     b = F.relu(F.conv2d(b, k31, padding=(1, 0), groups=C))
-    attn = a + b + q
-    return F.relu(dense_conv(torch.cat((attn, q), 1), conv3_w, conv3_b))
+    attn = _st(a + b + q)
+    return _st(F.relu(dense_conv(torch.cat((attn, q), 1), conv3_w, conv3_b)))
 
 
 # --------------------------------------------------------------------------------------
@@ -290,9 +311,9 @@ def centernet_head(feats: Sequence[Tensor], sd: SD,
                    prefix: str = "proposal_generator.centernet_head.") -> Tuple[List[Tensor], List[Tensor]]:
     regs, hms = [], []
     for l, x in enumerate(feats):
-        t = dense_conv(x, sd[prefix + "bbox_tower.0.weight"], sd[prefix + "bbox_tower.0.bias"], padding=1)
+        t = _st(dense_conv(x, sd[prefix + "bbox_tower.0.weight"], sd[prefix + "bbox_tower.0.bias"], padding=1))
         t = F.group_norm(t, 32, sd[prefix + "bbox_tower.1.weight"], sd[prefix + "bbox_tower.1.bias"], eps=1e-5)
-        t = F.relu(t)
+        t = _st(F.relu(t))
         hms.append(dense_conv(t, sd[prefix + "agn_hm.weight"], sd[prefix + "agn_hm.bias"], padding=1))
         r = dense_conv(t, sd[prefix + "bbox_pred.weight"], sd[prefix + "bbox_pred.bias"], padding=1)
         r = r * sd[prefix + f"scales.{l}.scale"]

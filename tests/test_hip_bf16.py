@@ -334,3 +334,137 @@ def test_conv_bf16_storage_slices_add_colsum_levels():
         want = r[0].permute(1, 2, 0).reshape(-1, 5)
         assert float((outh[r0:r0 + h * w_, :5].cpu() - want).abs().max() / want.abs().max()) < 1e-4
         r0 += h * w_
+
+
+def _bf16s_engine(ore, sd, hw, roi=False):
+    prev = ore.set_conv_precision("bf16s")
+    try:
+        e = ore.Engine(max_batch=1, max_h=hw[0], max_w=hw[1])
+    finally:
+        ore.set_conv_precision(prev)
+    assert ore.get_conv_precision() == "fp32"
+    e.load_state_dict(sd)
+    e.set_support(R.synth_support(0))
+    e.finalize()
+    return e
+
+
+def _ulp_close(got, want, ulps=1.0):
+    """got (bf16 tensor stored by the engine) vs want (fp32 reference BEFORE rounding): within `ulps` bf16 ulps of the reference value
+    (half an ulp is the rounding itself; the rest covers a summation-order difference straddling a rounding boundary)."""
+    got, want = got.float(), want.float()
+    ulp = torch.maximum(want.abs(), torch.tensor(1e-30)) * 2.0 ** -8 + 1e-6 * float(want.abs().max())
+    return bool(((got - want).abs() <= ulps * ulp).all())
+
+
+@pytest.mark.gpu
+def test_engine_bf16_storage_every_kernel_exact_on_its_own_inputs(ore):
+    """ORE_CONV_BF16S engine, layer by layer: each kernel's bf16 OUTPUT buffer against the oracle's fp32 arithmetic applied to that
+    kernel's own bf16 INPUT buffer(s) -- one bf16 rounding (plus summation order) apart, whatever noise the layers before accumulated."""
+    sd = R.synth_state_dict(0)
+    H, W = 160, 192
+    e = _bf16s_engine(ore, sd, (H, W))
+    img = R.synth_image(5, H, W)
+    e.eval_forward(img.cuda(), use_graph=False)
+    torch.cuda.synchronize()
+    B = lambda n, h, w: e.buffer(n, (1, h, w)).cpu()                                   # noqa: E731
+    bu = "backbone.bottom_up."
+    s1, s2, s3 = B("stem1", H // 2, W // 2), B("stem2", H // 2, W // 2), B("stem3", H // 4, W // 4)
+    assert s1.dtype == torch.bfloat16 and e.buffer("head3").dtype == torch.float32
+    assert _ulp_close(s1, R.conv_bn_relu(R.preprocess(img), sd, bu + "stem.stem_1", 2, 1))
+    with R.operand_precision("bf16"):                                                # rounds the weights; the inputs are bf16 already
+        assert _ulp_close(s2, R.conv_bn_relu(s1.float(), sd, bu + "stem.stem_2", 1, 1))
+        assert _ulp_close(s3, R.conv_bn_relu(s2.float(), sd, bu + "stem.stem_3", 2, 1))
+        # stage 3: max-pool of (stage-2 output x gate), three 3x3 layers writing slices of the concat buffer, the 1x1 concat conv
+        st2, g2 = B("stage2", H // 4, W // 4).float(), e.buffer("gate2").cpu().view(1, -1, 1, 1)
+        cat3 = B("cat3", H // 8, W // 8)
+        pooled = F.max_pool2d(st2 * g2, 3, 2, ceil_mode=True)
+        assert _ulp_close(cat3[:, :112], pooled)
+        mod, pre = "OSA3_1", bu + "stage3.OSA3_1."
+        y = cat3[:, :112].float()
+        for i in range(3):
+            y_ref = R.conv_bn_relu(y, sd, f"{pre}layers.{i}.{mod}_{i}", 1, 1)
+            got = cat3[:, 112 + 80 * i: 192 + 80 * i]
+            assert _ulp_close(got, y_ref), i
+            y = got.float()
+        st3 = B("stage3", H // 8, W // 8)
+        assert _ulp_close(st3, R.conv_bn_relu(cat3.float(), sd, f"{pre}concat.{mod}_concat", 1, 0))
+        # the eSE gate: fp32, from the mean of the STORED (rounded) stage output
+        gate_ref = F.relu6(F.conv2d(st3.float().mean((2, 3), keepdim=True), sd[pre + "ese.fc.weight"], sd[pre + "ese.fc.bias"]) + 3.0) / 6.0
+        assert float((e.buffer("gate3").cpu().view(-1) - gate_ref.view(-1)).abs().max()) < 1e-5
+        # FPN level 5: lateral on round(W * g), output conv; level 4: lateral + nearest-2x add of lat5
+        st5, g5 = B("stage5", H // 32, W // 32).float(), e.buffer("gate5").cpu().view(1, -1, 1, 1)
+        lat5 = B("lat5", H // 32, W // 32)
+        w5 = (sd["backbone.fpn_lateral5.weight"] * g5).bfloat16().float()
+        assert _ulp_close(lat5, F.conv2d(st5, w5, sd["backbone.fpn_lateral5.bias"]))
+        p5 = B("p5", H // 32, W // 32)
+        assert _ulp_close(p5, R.dense_conv(lat5.float(), sd["backbone.fpn_output5.weight"], sd["backbone.fpn_output5.bias"], padding=1))
+        st4, g4 = B("stage4", H // 16, W // 16).float(), e.buffer("gate4").cpu().view(1, -1, 1, 1)
+        w4 = (sd["backbone.fpn_lateral4.weight"] * g4).bfloat16().float()
+        lat4_ref = F.conv2d(st4, w4, sd["backbone.fpn_lateral4.bias"]) + F.interpolate(lat5.float(), scale_factor=2.0, mode="nearest")
+        assert _ulp_close(B("lat4", H // 16, W // 16), lat4_ref)
+    # correlation (fp32 arithmetic on the bf16 query), conv3, tower, GroupNorm + ReLU + (reg | hm) with fp32 outputs
+    sup = R.synth_support(0)
+    for l, k in enumerate(("p3", "p4", "p5")):
+        h, w = H >> (l + 3), W >> (l + 3)
+        q = B(k, h, w).float()
+        C = q.shape[1]
+        k11 = F.adaptive_avg_pool2d(sup[k], (1, 1)).permute(1, 0, 2, 3)
+        k13 = F.adaptive_avg_pool2d(sup[k], (1, 3)).permute(1, 0, 2, 3)
+        k31 = F.adaptive_avg_pool2d(sup[k], (3, 1)).permute(1, 0, 2, 3)
+        a = F.relu(F.conv2d(F.relu(F.conv2d(q, k11, groups=C)), k11, groups=C))
+        b = F.relu(F.conv2d(F.relu(F.conv2d(q, k13, padding=(0, 1), groups=C)), k31, padding=(1, 0), groups=C))
+        attn = B(f"attn{l + 3}", h, w)
+        assert _ulp_close(attn, a + b + q), k
+        with R.operand_precision("bf16"):
+            pos = B(f"pos{l + 3}", h, w)
+            assert _ulp_close(pos, F.relu(R.dense_conv(torch.cat((attn.float(), q), 1), sd["conv3.weight"], sd["conv3.bias"]))), k
+            hp = "proposal_generator.centernet_head."
+            tw = B(f"tower{l + 3}", h, w)
+            assert _ulp_close(tw, R.dense_conv(pos.float(), sd[hp + "bbox_tower.0.weight"], sd[hp + "bbox_tower.0.bias"], padding=1)), k
+            t = F.relu(F.group_norm(tw.float(), 32, sd[hp + "bbox_tower.1.weight"], sd[hp + "bbox_tower.1.bias"], eps=1e-5)).bfloat16().float()
+            hm = R.dense_conv(t, sd[hp + "agn_hm.weight"], sd[hp + "agn_hm.bias"], padding=1)
+            rg = F.relu(R.dense_conv(t, sd[hp + "bbox_pred.weight"], sd[hp + "bbox_pred.bias"], padding=1) * sd[hp + f"scales.{l}.scale"])
+        hd = e.buffer(f"head{l + 3}", (1, h, w)).cpu()
+        # the normalised tower is itself a rounded tensor: a 1-ulp flip of one of its values moves the fp32 head output by ~1e-3 of its scale
+        assert rel_err(hd[:, 4:5].numpy(), hm.numpy()) < 2e-3 and rel_err(hd[:, :4].numpy(), rg.numpy()) < 2e-3, k
+    e.close()
+
+
+@pytest.mark.gpu
+def test_engine_bf16_storage_vs_oracle_and_fp32_tail(ore):
+    """Whole eval hot path at the BASELINE shape in the bf16 STORAGE mode: feature maps against the oracle's restatement of the mode
+    (independent bf16 rounding noise: the same bound as the operand mode), closer to it than to the fp32 network; the detection tail
+    is fp32 and stays BIT-EXACT against ref_decode.c on the engine's own head outputs; eager and graph replays agree bit for bit."""
+    sd = R.synth_state_dict(0)
+    e = _bf16s_engine(ore, sd, (640, 640))
+    img = R.synth_image(0)
+    with R.operand_precision("bf16s"):
+        ref = R.eval_dense(img, sd, R.synth_support(0))
+    ref32 = R.eval_dense(img, sd, R.synth_support(0))
+    first = None
+    for use_graph in (False, True, True):
+        e.eval_forward(img.cuda(), use_graph=use_graph)
+        torch.cuda.synchronize()
+        rms = lambda a, b: float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))      # noqa: E731
+        for l, k in enumerate(("p3", "p4", "p5")):
+            s = 640 >> (l + 3)
+            got = e.buffer(k, (1, s, s)).float().cpu().numpy()
+            assert rel_err(got, ref["features"][k].numpy()) < 3 * TOL_NET, k
+            assert 1.5 * rms(got, ref["features"][k].numpy()) < rms(got, ref32["features"][k].numpy()), k
+        hms, regs, heads = [], [], []
+        for l in range(3):
+            s = 640 >> (l + 3)
+            hd = e.buffer(f"head{l + 3}").cpu().numpy().reshape(s, s, 5)
+            heads.append(hd.copy())
+            hms.append(np.ascontiguousarray(hd[..., 4]))
+            regs.append(np.ascontiguousarray(hd[..., :4]))
+        want = odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
+        boxes, scores, keep = e.proposals()
+        assert np.array_equal(keep.cpu().numpy(), want["keep"]) and len(want["keep"]) > 0
+        assert np.array_equal(boxes.cpu().numpy(), want["boxes"]) and np.array_equal(scores.cpu().numpy(), want["scores"])
+        if first is None:
+            first = heads
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(first, heads))
+    e.close()
