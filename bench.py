@@ -293,9 +293,11 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true", help="skip the train-step measurements printed as \"train_step\"")
     ap.add_argument("--no-extras", action="store_true", help="skip engine_sequential / in_flight / folded_serving / latency legs")
     ap.add_argument("--profile-passes", type=int, default=20)
-    ap.add_argument("--conv-operands", choices=("fp32", "bf16"), default="fp32",
-                    help="fp32 = the reference's precision (the headline).  bf16 = BASELINE configs[4]: MFMA conv operands rounded to bf16, "
-                         "fp32 storage / accumulation / NMS (include/ore_hip.h ORE_CONV_BF16); reported with dtype \"bf16\", never the default")
+    ap.add_argument("--conv-operands", choices=("fp32", "bf16", "bf16s"), default="fp32",
+                    help="fp32 = the reference's precision (the headline).  bf16s = BASELINE configs[4] as a byte-saving path: bf16 activations "
+                         "and weights in HBM and LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulation / statistics / head outputs / NMS "
+                         "(include/ore_hip.h ORE_CONV_BF16S).  bf16 = the operand-rounding form (fp32 tensors, ORE_CONV_BF16).  Both are "
+                         "reported with dtype \"bf16\", never the default")
     ap.add_argument("--fold-streams", type=int, default=4, help="engine passes kept in flight in the folded-serving leg")
     ap.add_argument("--fold", type=int, default=8,
                     help="also time the same requests folded F at a time into one engine pass (\"folded_serving\" in the output); 0/1 = skip")
@@ -337,7 +339,8 @@ def main():
     device = torch.device("cuda", local_rank)
     model, cfg = build_model(device)
     model.conv_operands = args.conv_operands
-    bf16 = args.conv_operands == "bf16"
+    bf16 = args.conv_operands != "fp32"
+    bf16s = args.conv_operands == "bf16s"
     # each rank owns its shard of images (pure data parallel); a handful of distinct images is cycled
     host_imgs = [synth_image(rank * 1000 + i) for i in range(4)]
     imgs = [t.to(device) for t in host_imgs]
@@ -439,7 +442,7 @@ def main():
                                    "note": "bs=1 forwards of independent images on %d engines / HIP streams; results bit-identical to "
                                            "the sequential engine (asserted here)" % len(engines)}
         # folded serving: the SAME single-image requests, F at a time through ONE engine pass
-        if args.fold > 1:
+        if args.fold > 1 and not bf16s:                        # (a bf16-storage engine takes one image per pass)
             S = max(args.fold_streams, 1)
             efs = [model.make_engine(max_batch=args.fold) for _ in range(S)]
             fstreams = [torch.cuda.Stream(device) for _ in range(S)]
@@ -502,15 +505,25 @@ def main():
                 "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_note": "HBM-side bytes per image over the same conv launches: (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 "
                                 "--pmc passes (tools/pmc_pass.py -> profiles/%s)" % traffic_src,
-                "kernel": ("the MFMA conv kernels with bf16 operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) + the fp32 ROI fc GEMM" if bf16 else
-                           "the fp32 MFMA conv kernels (v_mfma_f32_16x16x4_f32 implicit GEMM: k_conv_kw, k_conv_gs, k_conv_igemm, "
-                           "k_conv3x3_patch / _patch_db, k_conv3x3_ws) + the second-stage GEMM"),
+                "kernel": ("the DMA-fed conv kernels on bf16 tensors (k_conv_gs / k_conv_kw, v_mfma_f32_16x16x32_bf16, fp32 accumulate) + the fp32 ROI fc GEMM" if bf16s else
+                           "the MFMA conv kernels with bf16 operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) + the fp32 ROI fc GEMM" if bf16 else
+                           "the fp32 MFMA conv kernels (v_mfma_f32_16x16x4_f32: Winograd F(2x2,3x3) k_conv3x3_wino on the large-M 3x3 layers, implicit GEMM "
+                           "k_conv_kw / k_conv_gs / k_conv_igemm on the rest) + the second-stage GEMM; FLOPs are the ALGORITHMIC (direct-convolution) "
+                           "count, so the Winograd layers, which execute 2.25x fewer multiplies, can exceed the MFMA peak"),
                 "launches_per_image": nl // npp, "gflop_per_image": round(fl / npp / 1e9, 3),
                 "kernel_ms_per_image": round(ms / npp, 4), "kernel_ms_per_image_calibrated": round(ms_cal / npp, 4),
                 "event_pair_overhead_us": round(ev_us, 3), "achieved_calibrated": round(fl / (ms_cal * 1e-3) / 1e12, 2),
                 "note": "FLOP-weighted over all conv launches of one image (different shapes), isolated one-image-at-a-time launches; "
                         "profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command"}
         roof["end_to_end_tflops"] = round(total_images / elapsed * roof["gflop_per_image"] / 1e3, 2)
+        if bf16s:
+            # bf16 storage: at 16x the fp32 MFMA rate the conv stack is bound by the bytes it moves, so the roofline is priced against
+            # HBM: algorithmic bytes = every conv layer reads its input and writes its output once in bf16 (half of the 336 MB fp32
+            # figure of SURVEY 8d / DESIGN 3) + the bf16 weights once, over the summed duration of the same conv launches
+            alg_bytes = 336e6 / 2 + 2.0 * 5.06e6
+            gbs = alg_bytes / (ms / npp * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                         "algorithmic_bytes_per_image": alg_bytes, "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / PEAK_BF16_MFMA_TFLOPS, 4)})
 
     train = {}
     if not args.no_train_leg:
@@ -531,7 +544,8 @@ def main():
             "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": W, "ms_per_step": round(elapsed / n_steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": ("bf16 MFMA conv operands + fp32 NMS (BASELINE configs[4] precision) on " if bf16 else "") +
+            "config": {"workload": ("bf16 storage (bf16 activations / weights in HBM and LDS) + bf16 MFMA + fp32 NMS (BASELINE configs[4] precision) on " if bf16s else
+                                    "bf16 MFMA conv operands + fp32 NMS (BASELINE configs[4] precision) on " if bf16 else "") +
                                    "finetune_vovnet.yaml 25-shot eval-only bs=1 640x640 (BASELINE configs[1]), the reference's FPS protocol: "
                                    "model([{image,height,width}]) + torch.cuda.synchronize() per image; preprocess+VoVNet-19-slim-eSE+FPN -> "
                                    "correlation -> CenterNet head -> top-k/NMS proposals -> ROIAlign + cascade ROI head -> NMS -> detections",

@@ -778,10 +778,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
 //   CIN = 64,  KS = 1: 4 waves = 4 groups of 16 output channels.
 //   CIN = 128, KS = 2: 8 waves; waves w and w+4 share a channel group and split the input channels (64 each); the upper half
 //                      parks its accumulators in LDS (parity double-buffered) and the lower half adds them before the epilogue.
-template <int TH, int CIN, int KS, bool BF = false>
+// SB: bf16 STORAGE build (ore_conv_desc.storage): CIN counts 4-byte units = PAIRS of bf16 channels (32 -> 64 channels, 64 -> 128), the
+// halo patch and the weights are bf16, a b128 fragment is 8 consecutive channels = the operand of v_mfma_f32_16x16x32_bf16, of which ONE
+// replaces four fp32 MFMAs; the wave keeps 16 output channels x 9 taps x all input channels in 72 / 144 VGPRs.  With the matrix time
+// gone (36-72 MFMAs of 16 clocks per 2x16 tile) the tile is made tall (TH = 8) so that the per-tile barrier, decode and halo overlap
+// (10 / 8 rows staged per 8 rows of output) amortise.
+template <int TH, int CIN, int KS, bool BF = false, bool SB = false>
 __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP p, int ntiles) {
-    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = CIN + 8, NCH = 4, NTH = 256 * KS, F4 = CIN / 4;
-    static_assert(CIN == 64 * KS, "one 64-channel weight slice per wave");
+    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = CIN + 8, NCH = SB ? CIN / 16 : 4, NTH = 256 * KS, F4 = CIN / 4;
+    static_assert(SB ? (KS == 1 && CIN % 16 == 0) : CIN == 64 * KS, "one 64-channel weight slice per wave");
     constexpr int A_IT = (NPIX * F4 + NTH - 1) / NTH;          // float4 slots per thread for one halo patch
     constexpr int BUF = NPIX * LDC;
     constexpr int PARK = KS > 1 ? 4 * TH * 256 : 0;            // floats per parity buffer of parked accumulators
@@ -878,7 +883,12 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
 #pragma unroll
                     for (int sg = 0; sg < TH; ++sg)
                         af[sg] = *reinterpret_cast<const f32x4*>(As + ((sg + dy) * PW + li + dx) * LDC + c * 16 + g4);
-                    if constexpr (BF) {
+                    if constexpr (SB) {
+#pragma unroll
+                        for (int sg = 0; sg < TH; ++sg)
+                            acc[sg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[dy * 3 + dx][c]),
+                                                                              __builtin_bit_cast(bf16x8_t, af[sg]), acc[sg], 0, 0, 0);
+                    } else if constexpr (BF) {
                         const s16x4 wh = to_bf16x4(wf[dy * 3 + dx][c]);
 #pragma unroll
                         for (int sg = 0; sg < TH; ++sg)
@@ -917,6 +927,9 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.f);
+                    if constexpr (SB) {                          // bf16 output tensor (Cout % 64 == 0 on this path: whole vectors)
+                        st4(reinterpret_cast<ore_bf16_t*>(p.out) + (size_t)(cur_g.obase + gy * cur_g.W + gx) * p.out_ld + p.out_coff + n, v);
+                    } else {
                     float* o = p.out + (size_t)(cur_g.obase + gy * cur_g.W + gx) * p.out_ld + p.out_coff + n;
                     if (n + 3 < p.Cout) {
                         *reinterpret_cast<f32x4*>(o) = v;
@@ -925,6 +938,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
                         for (int r = 0; r < 4; ++r)
                             if (n + r < p.Cout) o[r] = v[r];
                     }
+                    }
                 }
             }
         }
@@ -932,6 +946,50 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
         parity ^= 1;
         cur_g = nxt_g;
     }
+}
+
+int g_ws_sb_mode = 1;    // tuning aid (ore_conv_set_plan_override(-8, mode)): 0 = bf16-storage 3x3 layers stay on k_conv_gs / k_conv_kw, 4 / 8 = tile height, 1 = automatic
+
+// bf16 STORAGE: 3x3 stride-1 layers with 64 / 128 input channels on the weight-stationary kernel (weights in registers for the whole
+// launch, only the halo patch is staged).  c holds the input side in 4-byte units (fill_common).  1 = not covered.
+template <int TH, int CF>
+static int ws_sb_go(const PatchP& p, int tiles, dim3 pgrid, hipStream_t st) {
+    const size_t lds = (size_t)2 * ((TH + 2) * 18) * (CF + 8) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<TH, CF, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((k_conv3x3_ws<TH, CF, 1, false, true>), pgrid, dim3(256), lds, st, p, tiles);
+    return ore_launch_status("k_conv3x3_ws");
+}
+
+static int ws_sb_launch(const ConvP& c, hipStream_t st) {
+    if (!g_ws_sb_mode || !(c.sb & 1) || !(c.sb & 2)) return 1;
+    if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.in_mul || c.add || c.colsum) return 1;
+    if (c.Cin != 32 || c.Cout != c.Cout16 || c.Cout % 64 != 0) return 1;        // (128 channels: 144 VGPRs of weights leave room for 2-row tiles only -- 43 vs 21 us on k_conv_kw)
+    if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 7) != 0) return 1;
+    if (c.M < 6000) return 1;
+    // tile height: what fits the register file next to the stationary weights (72 / 144 VGPRs) and the register-staged halo patch
+    const int TH = c.Cin == 32 ? 4 : 2;
+    PatchP p{};
+    p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = c.nlev;
+    int tiles = 0;
+    for (int l = 0; l < c.nlev; ++l) {
+        p.lv[l] = c.lv[l];
+        p.tiles_x[l] = ceil_div(c.lv[l].W, 16); p.tiles_y[l] = ceil_div(c.lv[l].H, TH);
+        p.tile0[l] = tiles;
+        tiles += c.B * p.tiles_x[l] * p.tiles_y[l];
+    }
+    p.tile0[c.nlev] = tiles;
+    p.w = c.w; p.Cout = c.Cout; p.Cout16 = c.Cout16; p.K = c.K;
+    p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
+    p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
+    p.xmap = tiles >= 16 ? 1 : 0;
+    const int gy = c.Cout16 / 64;
+    int gx = 512 / gy;                                      // two resident blocks per CU
+    gx &= ~7;
+    if (gx > tiles) gx = tiles;
+    const dim3 pgrid(gx, gy);
+    if (c.Cin == 32) return ws_sb_go<4, 32>(p, tiles, pgrid, st);
+    return ws_sb_go<2, 64>(p, tiles, pgrid, st);
 }
 
 int g_conv_bf16 = 0;     // ore_conv_set_precision: 1 = bf16 MFMA operands (fp32 storage and accumulation)
@@ -1192,6 +1250,7 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
     if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
+    if (BM == -8) { g_ws_sb_mode = BN; return ORE_OK; }                                     // BM = -8: bf16-storage weight-stationary 3x3 kernel: 0 off, 1 auto, 4 / 8 tile height
     if (BM == -7) { conv_wino_mode(BN); return ORE_OK; }                                    // BM = -7: Winograd kernel 0 off / 1 automatic / 2 forced
     if (BM == -6) { conv_kw_nw_force(BN); return ORE_OK; }                                  // BM = -6: waves per block of k_conv_kw (4 / 8 / 16)                                   // BM = -5: block -> tile mapping of k_conv_kw (-1 auto, 0, 1, 2)                           // BM = -4: tile of k_conv_gs                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
     g_override = {BM, BN, WGM, WGN, WGK};
@@ -1222,6 +1281,7 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
         ConvP q{};
         q.sb = 1;
         q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (round_up(d->Cin, 32) / 32); q.kh = d->kh;
+        q.stride = d->stride;
         return ceil_div(q.M, conv_kw_tile_rows(q));
     }
     if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !d->in_mul && d->Cin % 16 == 0) {
@@ -1237,8 +1297,10 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
 }
 
 static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t workspace_floats, hipStream_t st) {
-    if (p.sb & 1) {                                           // bf16 storage: the DMA-fed kernels only (k_conv_gs / k_conv_kw, SB builds)
+    if (p.sb & 1) {                                           // bf16 storage: weight-stationary 3x3 kernel, else the DMA-fed kernels (SB builds)
         p.bf16 = 0;
+        const int wrc = ws_sb_launch(p, st);
+        if (wrc != 1) return wrc;
         const int krc = conv_kw_launch(p, workspace, workspace_floats, st);
         if (krc == 1) { ore_set_error("ore_conv2d_fwd: no bf16-storage kernel for this layer (input affine?)"); return ORE_EINVAL; }
         return krc;

@@ -648,7 +648,11 @@ int launch_gs_ns(const ConvP& p, const float* zero, hipStream_t st);
 
 template <int BM, int BN, int WGM, int WGN>
 int launch_gs(const ConvP& p, const float* zero, hipStream_t st) {
-    if (p.sb & 1) return launch_gs_ns<BM, BN, WGM, WGN, 3, true>(p, zero, st);
+    if (p.sb & 1) {
+        if (g_gs_ns == 4) return launch_gs_ns<BM, BN, WGM, WGN, 4, true>(p, zero, st);
+        if (g_gs_ns == 6) return launch_gs_ns<BM, BN, WGM, WGN, 6, true>(p, zero, st);
+        return launch_gs_ns<BM, BN, WGM, WGN, 3, true>(p, zero, st);
+    }
     if (g_gs_ns == 4) return launch_gs_ns<BM, BN, WGM, WGN, 4>(p, zero, st);
     if (g_gs_ns == 6) return launch_gs_ns<BM, BN, WGM, WGN, 6>(p, zero, st);
     return launch_gs_ns<BM, BN, WGM, WGN, 3>(p, zero, st);
@@ -771,7 +775,9 @@ int conv_kw_tile_rows(const ConvP& p) {         // rows per block of the kernel 
     if (g_kw_force[0] > 0) return g_kw_force[0];
     if (g_gs_force[0] > 0) return g_gs_force[0];
     if (p.sb & 1) {                                            // keep in step with conv_kw_launch's bf16-storage branch
-        if (p.M >= 6400 && (p.Cout16 == 64 || p.Cout16 == 112 || p.Cout16 % 128 == 0)) return 64;
+        if (p.M >= 6400 && ((p.kh == 1 && (p.Cout16 == 112 || p.Cout16 >= 256)) || (p.kh == 3 && p.stride == 2 && p.Cout16 % 128 == 0))) return 64;
+        if (p.M >= 4096 && (p.Cout16 == 128 || p.Cout16 == 64)) return 32;
+        if (p.M >= 4096 && p.Cout16 == 80) return 16;
         const int bm = kw_tile(p.M, p.Cout16, p.nchunks).BM;
         return bm ? bm : 32;
     }
@@ -801,6 +807,12 @@ static int zero_page_of(const float** out) {
 // shared-stage kernel for the large-M layers; returns 1 when the shape has no tile here
 static int conv_gs_launch(ConvP& p, hipStream_t st) {
     int bm = g_gs_force[0], bn = g_gs_force[1];
+    if (bm == 0 && (p.sb & 1)) {                              // bf16 storage (conv_kw_launch decided that this layer comes here)
+        if (p.Cout16 == 112) { bm = 64; bn = 80; }
+        else if (p.Cout16 % 128 == 0 && p.kh == 3) { bm = 64; bn = 128; }
+        else if (p.Cout16 >= 256) { bm = 64; bn = 80; }
+        else { bm = 64; bn = 64; }
+    }
     if (bm == 0) {
         // measured (profiles/r02_kw_ab.txt): 2-5 % ahead of k_conv_igemm on the 1x1 concats, 3 % behind on stem_3 (3x3 stride 2) --
         // the staging mechanism is not what bounds these layers -- so only the 1x1 layers come here automatically
@@ -843,14 +855,21 @@ void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] =
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
     if (p.sb & 1) {                                                         // bf16 storage: every layer runs on one of the two DMA-fed kernels
-        if (g_kw_force[0] == 0 && p.M >= 6400 && (p.Cout16 == 64 || p.Cout16 == 112 || p.Cout16 % 128 == 0)) {
+        // plan from tools/bf16s_sweep.py (profiles/r03_bf16s_sweep.txt): the shared-stage kernel for the two big 1x1 concats and the
+        // stride-2 stem_3, the K-split kernel with 32x64 tiles for everything else at M >= 4096 (3x3 at 128 channels: 12-21 vs 21-24 us)
+        const bool gs_pick = p.M >= 6400 && ((p.kh == 1 && (p.Cout16 == 112 || p.Cout16 >= 256)) || (p.kh == 3 && p.stride == 2 && p.Cout16 % 128 == 0));
+        if (g_kw_force[0] == 0 && (g_gs_force[0] > 0 || gs_pick)) {
             const int grc = conv_gs_launch(p, st);
             if (grc != 1) return grc;
         }
     } else
     if (g_kw_force[0] == 0 && (g_gs_force[0] > 0 || p.M >= 16384 || (p.M >= 4096 && p.Cout16 >= 256))) return p.bf16 ? 1 : conv_gs_launch(p, st);
     KwTile t = kw_tile(p.M, p.Cout16, p.nchunks);
-    if ((p.sb & 1) && t.BM == 0) t = {32, 64, 1};
+    if (p.sb & 1) {
+        if (t.BM == 0) t = {32, 64, 1};
+        if (p.M >= 4096 && (p.Cout16 == 128 || p.Cout16 == 64)) t = {32, 64, 1};
+        if (p.M >= 4096 && p.Cout16 == 80) t = {16, 80, 1};
+    }
     if (g_kw_force[0] > 0) t = {g_kw_force[0], g_kw_force[1] < p.Cout16 ? g_kw_force[1] : p.Cout16, g_kw_force[3]};
     if (t.BM == 0) return 1;
     const int gx = ceil_div(p.M, t.BM), gy = ceil_div(p.Cout16, t.BN);

@@ -283,7 +283,9 @@ def test_conv_bf16_storage_vs_oracle(B, H, W, Cin, Cout, k, stride):
     assert float((got32 - ref).abs().max() / ref.abs().max()) < 1e-4             # fp32 output: the fp32 tolerance
     y = ore.conv2d(xd, wp, Cout, k, stride, scale=sc.cuda(), shift=sh.cuda(), relu_cout=Cout)
     assert y.dtype == torch.bfloat16
-    assert torch.equal(y, y32.to(torch.bfloat16))                                 # the bf16 output is the fp32 result rounded once
+    # the bf16 output is the fp32 result rounded once (another kernel may serve the bf16-output launch -- the weight-stationary 3x3
+    # kernel at M >= 6000 --, so a different summation order can move a value across a rounding boundary: one ulp)
+    assert _ulp_close(y.cpu(), y32.cpu())
     y2 = ore.conv2d(xd, wp, Cout, k, stride, scale=sc.cuda(), shift=sh.cuda(), relu_cout=Cout)
     assert torch.equal(y, y2)
 

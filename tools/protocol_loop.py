@@ -15,6 +15,7 @@ if os.environ.get("ORE_XMAP"):                       # A/B aid: force the block 
     import orehip
     orehip.lib().ore_conv_set_plan_override(-5, int(os.environ["ORE_XMAP"]), 0, 0, 0)
 model, cfg = bench.build_model(torch.device("cuda", 0))
+model.conv_operands = os.environ.get("ORE_OPERANDS", "fp32")      # fp32 | bf16 | bf16s (bench.py --conv-operands)
 imgs = [bench.synth_image(i).cuda() for i in range(4)]
 for i in range(n):
     model([{"image": imgs[i % 4], "height": 640, "width": 640}])
