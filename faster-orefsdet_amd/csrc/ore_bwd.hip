@@ -748,6 +748,41 @@ extern "C" int ore_groupnorm_apply_fwd(const float* x, int32_t ld, int32_t coff,
     return ore_launch_status("k_gn_apply");
 }
 
+// all pyramid levels of a level-major tensor in ONE launch: segment s = level * B + image owns rows [seg_row0[s], seg_row0[s+1])
+struct GnLv { int nseg; int row0[13]; };
+__global__ __launch_bounds__(256) void k_gn_apply_levels_h(const ore_bf16_t* __restrict__ x, int ld, int coff, GnLv lv, int C,
+                                                           const float* __restrict__ mul, const float* __restrict__ add, int relu,
+                                                           ore_bf16_t* __restrict__ y) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)lv.row0[lv.nseg] * c4n) return;
+    const int row = (int)(i / c4n), c = (int)(i % c4n) * 4;
+    int sgi = 0;
+#pragma unroll
+    for (int k = 1; k < 12; ++k)
+        if (k < lv.nseg && row >= lv.row0[k]) sgi = k;
+    const f32x4 v = ld4(x + (size_t)row * ld + coff + c);
+    f32x4 o = v * *reinterpret_cast<const f32x4*>(mul + (size_t)sgi * C + c) + *reinterpret_cast<const f32x4*>(add + (size_t)sgi * C + c);
+    if (relu) o = relu4b(o);
+    st4(y + (size_t)row * C + c, o);
+}
+
+extern "C" int ore_groupnorm_apply_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels, const int32_t* HW,
+                                                   int32_t C, const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream) {
+    ORE_CHECK_ARG(x && HW && mul_c && add_c && y && B > 0 && n_levels >= 1 && n_levels * B <= 12 && C > 0 && C % 4 == 0 && ld % 4 == 0 && coff % 4 == 0,
+                  "ore_groupnorm_apply_levels_bf16_fwd: bad args (levels x images <= 12)");
+    GnLv lv{};
+    lv.nseg = n_levels * B;
+    int rows = 0;
+    for (int l = 0; l < n_levels; ++l)
+        for (int b = 0; b < B; ++b) { lv.row0[l * B + b] = rows; rows += HW[l]; }
+    lv.row0[lv.nseg] = rows;
+    const long long n = (long long)rows * (C / 4);
+    hipLaunchKernelGGL(k_gn_apply_levels_h, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const ore_bf16_t*)x, ld, coff, lv, C,
+                       mul_c, add_c, relu, (ore_bf16_t*)y);
+    return ore_launch_status("k_gn_apply_levels_h");
+}
+
 // bf16 storage: y[row][C] = act(x * mul[image] + add[image]) with the folded per-(image, channel) affine of ore_groupnorm_affine_levels_*
 // (gamma / beta already inside mul / add); `images` segments of rows_per_image rows share a (mul, add) row -- level-major head tensors
 // call it once per level.

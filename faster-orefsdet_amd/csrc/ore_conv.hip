@@ -785,8 +785,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
 // (10 / 8 rows staged per 8 rows of output) amortise.
 template <int TH, int CIN, int KS, bool BF = false, bool SB = false>
 __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP p, int ntiles) {
-    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = CIN + 8, NCH = SB ? CIN / 16 : 4, NTH = 256 * KS, F4 = CIN / 4;
-    static_assert(SB ? (KS == 1 && CIN % 16 == 0) : CIN == 64 * KS, "one 64-channel weight slice per wave");
+    constexpr int CW = CIN / KS;                                // 4-byte units of a wave's K slice: 64 (fp32 builds), 32 (bf16 storage: 64 channels)
+    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = CIN + 8, NCH = CW / 16, NTH = 256 * KS, F4 = CIN / 4;
+    static_assert(SB ? (CW == 32 || (KS == 1 && CW == 64)) : CW == 64, "one 64-channel weight slice per wave");
     constexpr int A_IT = (NPIX * F4 + NTH - 1) / NTH;          // float4 slots per thread for one halo patch
     constexpr int BUF = NPIX * LDC;
     constexpr int PARK = KS > 1 ? 4 * TH * 256 : 0;            // floats per parity buffer of parked accumulators
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
     f32x4 wf[9][NCH];
     {
         const bool okw = n0 + li < p.Cout16;
-        const float* wrow = p.w + (size_t)(okw ? n0 + li : 0) * p.K + kh * 64 + g4;
+        const float* wrow = p.w + (size_t)(okw ? n0 + li : 0) * p.K + kh * CW + g4;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
         const bool has_next = tn < t_end;
         TileGeo nxt_g = cur_g;
         if (has_next) { nxt_g = decode(tn); gload(nxt_g); }       // the next halo patch flies under this tile's MFMAs
-        const float* As = plds + cur * BUF + kh * 64;
+        const float* As = plds + cur * BUF + kh * CW;
         f32x4 acc[TH];
 #pragma unroll
         for (int sg = 0; sg < TH; ++sg) acc[sg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -952,23 +953,25 @@ int g_ws_sb_mode = 1;    // tuning aid (ore_conv_set_plan_override(-8, mode)): 0
 
 // bf16 STORAGE: 3x3 stride-1 layers with 64 / 128 input channels on the weight-stationary kernel (weights in registers for the whole
 // launch, only the halo patch is staged).  c holds the input side in 4-byte units (fill_common).  1 = not covered.
-template <int TH, int CF>
+template <int TH, int CF, int KS>
 static int ws_sb_go(const PatchP& p, int tiles, dim3 pgrid, hipStream_t st) {
-    const size_t lds = (size_t)2 * ((TH + 2) * 18) * (CF + 8) * sizeof(float);
+    const size_t lds = ((size_t)2 * ((TH + 2) * 18) * (CF + 8) + (KS > 1 ? 2 * 4 * TH * 256 : 0)) * sizeof(float);
     static bool attr = false;
-    if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<TH, CF, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL((k_conv3x3_ws<TH, CF, 1, false, true>), pgrid, dim3(256), lds, st, p, tiles);
+    if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<TH, CF, KS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((k_conv3x3_ws<TH, CF, KS, false, true>), pgrid, dim3(256 * KS), lds, st, p, tiles);
     return ore_launch_status("k_conv3x3_ws");
 }
 
 static int ws_sb_launch(const ConvP& c, hipStream_t st) {
     if (!g_ws_sb_mode || !(c.sb & 1) || !(c.sb & 2)) return 1;
     if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.in_mul || c.add || c.colsum) return 1;
-    if (c.Cin != 32 || c.Cout != c.Cout16 || c.Cout % 64 != 0) return 1;        // (128 channels: 144 VGPRs of weights leave room for 2-row tiles only -- 43 vs 21 us on k_conv_kw)
+    if ((c.Cin != 32 && c.Cin != 64) || c.Cout != c.Cout16 || c.Cout % 64 != 0) return 1;
+    if (c.Cin == 64 && g_ws_sb_mode == 3) return 1;                           // (A/B aid: 128-channel layers back on k_conv_kw)
     if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 7) != 0) return 1;
     if (c.M < 6000) return 1;
-    // tile height: what fits the register file next to the stationary weights (72 / 144 VGPRs) and the register-staged halo patch
-    const int TH = c.Cin == 32 ? 4 : 2;
+    // 64 channels: 4 waves x 16 output channels, 72 VGPRs of weights, two blocks per CU.  128 channels: 8 waves, the wave pairs (w, w+4)
+    // split the input channels (72 VGPRs each; the upper half's accumulators meet the lower half's in LDS), one block per CU.
+    const int TH = 4;
     PatchP p{};
     p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = c.nlev;
     int tiles = 0;
@@ -984,12 +987,12 @@ static int ws_sb_launch(const ConvP& c, hipStream_t st) {
     p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
     p.xmap = tiles >= 16 ? 1 : 0;
     const int gy = c.Cout16 / 64;
-    int gx = 512 / gy;                                      // two resident blocks per CU
+    int gx = (c.Cin == 32 ? 512 : 256) / gy;                // resident blocks
     gx &= ~7;
     if (gx > tiles) gx = tiles;
     const dim3 pgrid(gx, gy);
-    if (c.Cin == 32) return ws_sb_go<4, 32>(p, tiles, pgrid, st);
-    return ws_sb_go<2, 64>(p, tiles, pgrid, st);
+    if (c.Cin == 32) return ws_sb_go<4, 32, 1>(p, tiles, pgrid, st);
+    return ws_sb_go<4, 64, 2>(p, tiles, pgrid, st);
 }
 
 int g_conv_bf16 = 0;     // ore_conv_set_precision: 1 = bf16 MFMA operands (fp32 storage and accumulation)

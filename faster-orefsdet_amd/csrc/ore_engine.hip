@@ -383,11 +383,8 @@ int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
         // kernels copy their A operand verbatim), then the (l,t,r,b | hm) conv with fp32 outputs -- the detection tail is fp32 as always
         r.rc = ore_groupnorm_affine_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma,
                                                     e->gn_beta, e->gn_mul, e->gn_add, e->gn_ws, st);
-        for (int l = 0; l < 3 && !r.rc; ++l) {
-            const size_t r0 = (size_t)lvl_row0(g, l) * F;
-            r.rc = ore_groupnorm_apply_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p) + r0, F, 0, g.B, HW[l], F, e->gn_mul + (size_t)l * g.B * F,
-                                                e->gn_add + (size_t)l * g.B * F, 1, reinterpret_cast<uint16_t*>(e->tn.p) + r0, st);
-        }
+        if (!r.rc) r.rc = ore_groupnorm_apply_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, e->gn_mul, e->gn_add, 1,
+                                                              reinterpret_cast<uint16_t*>(e->tn.p), st);
         if (r.rc) return r.rc;
         r.conv_levels(e->pred, e->tn.p, F, 0, g.B, H, W, e->head.p, 8, 0, 16, nullptr, nullptr, 0, true);
         *flops = r.flops;

@@ -450,6 +450,8 @@ int ore_groupnorm_affine_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t 
                                          float* add, float* workspace, void* stream);
 int ore_groupnorm_apply_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t images, int64_t rows_per_image, int32_t C,
                                  const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream);
+int ore_groupnorm_apply_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels, const int32_t* HW, int32_t C,
+                                        const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream);
 int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
                                         float* gate, float* mean_ws, const float* w_packed_f32, int32_t w_rows, uint16_t* w_scaled_bf16,
                                         void* stream);
