@@ -783,10 +783,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch_db(PatchP p) {
 // replaces four fp32 MFMAs; the wave keeps 16 output channels x 9 taps x all input channels in 72 / 144 VGPRs.  With the matrix time
 // gone (36-72 MFMAs of 16 clocks per 2x16 tile) the tile is made tall (TH = 8) so that the per-tile barrier, decode and halo overlap
 // (10 / 8 rows staged per 8 rows of output) amortise.
-template <int TH, int CIN, int KS, bool BF = false, bool SB = false>
+// ST: conv stride (1, or 2 = stem_3: the tile is TH x 16 OUTPUT pixels, its input patch (2 TH + 1) x 33, lane li reads pixel 2 li + dx).
+template <int TH, int CIN, int KS, bool BF = false, bool SB = false, int ST = 1>
 __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP p, int ntiles) {
     constexpr int CW = CIN / KS;                                // 4-byte units of a wave's K slice: 64 (fp32 builds), 32 (bf16 storage: 64 channels)
-    constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, LDC = CIN + 8, NCH = CW / 16, NTH = 256 * KS, F4 = CIN / 4;
+    // LDS row stride: +8 floats makes the 16-lane b128 fragment reads conflict-free at stride 1; at stride 2 the lanes are two rows apart,
+    // +4 (an odd number of 16-byte units per row pair ... 2 * (CIN + 4) * 4 B) leaves a 2-way conflict instead of 4-way
+    constexpr int TW = 16, PH = (TH - 1) * ST + 3, PW = (TW - 1) * ST + 3, NPIX = PH * PW, LDC = CIN + (ST == 1 ? 8 : 4), NCH = CW / 16, NTH = 256 * KS, F4 = CIN / 4;
     static_assert(SB ? (CW == 32 || (KS == 1 && CW == 64)) : CW == 64, "one 64-channel weight slice per wave");
     constexpr int A_IT = (NPIX * F4 + NTH - 1) / NTH;          // float4 slots per thread for one halo patch
     constexpr int BUF = NPIX * LDC;
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
         s_py[i] = pi / PW; s_px[i] = pi - s_py[i] * PW;
         s_lds[i] = pi < NPIX ? pi * LDC + s_q[i] : -1;
     }
-    struct TileGeo { int lvl, ty0, tx0, ibase, obase, H, W; };
+    struct TileGeo { int lvl, ty0, tx0, ibase, obase, H, W, Ho, Wo; };
     auto decode = [&](int t) -> TileGeo {
         TileGeo g;
         g.lvl = 0;
@@ -836,14 +839,16 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
         const int tpi = p.tiles_x[g.lvl] * p.tiles_y[g.lvl];
         const int b = tl / tpi, tr = tl - b * tpi;
         g.ty0 = (tr / p.tiles_x[g.lvl]) * TH; g.tx0 = (tr % p.tiles_x[g.lvl]) * TW;
-        g.ibase = L.irow0 + b * L.H * L.W; g.obase = L.orow0 + b * L.H * L.W; g.H = L.H; g.W = L.W;
+        g.H = L.H; g.W = L.W;
+        g.Ho = ST == 1 ? L.H : L.Ho; g.Wo = ST == 1 ? L.W : L.Wo;
+        g.ibase = L.irow0 + b * L.H * L.W; g.obase = L.orow0 + b * g.Ho * g.Wo;
         return g;
     };
     f32x4 ra[A_IT];
     auto gload = [&](const TileGeo& g) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int gy = g.ty0 - 1 + s_py[i], gx = g.tx0 - 1 + s_px[i];
+            const int gy = g.ty0 * ST - 1 + s_py[i], gx = g.tx0 * ST - 1 + s_px[i];
             const bool ok = s_lds[i] >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             ra[i] = *sel(ok, p.in + (ptrdiff_t)(g.ibase + gy * g.W + gx) * p.in_ld + p.in_coff + s_q[i]);
         }
@@ -883,7 +888,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
                     f32x4 af[TH];
 #pragma unroll
                     for (int sg = 0; sg < TH; ++sg)
-                        af[sg] = *reinterpret_cast<const f32x4*>(As + ((sg + dy) * PW + li + dx) * LDC + c * 16 + g4);
+                        af[sg] = *reinterpret_cast<const f32x4*>(As + ((sg * ST + dy) * PW + li * ST + dx) * LDC + c * 16 + g4);
                     if constexpr (SB) {
 #pragma unroll
                         for (int sg = 0; sg < TH; ++sg)
@@ -923,15 +928,15 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
                 f32x4 a = acc[sg];
                 if (KS > 1) a += *reinterpret_cast<const f32x4*>(park + parity * PARK + ((cgp * TH + sg) * 64 + lane) * 4);
                 const int gy = cur_g.ty0 + sg, gx = cur_g.tx0 + li;
-                if (gy < cur_g.H && gx < cur_g.W) {
+                if (gy < cur_g.Ho && gx < cur_g.Wo) {
                     f32x4 v = a * sc4 + sh4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (n + r < p.relu_cout) v[r] = fmaxf(v[r], 0.f);
                     if constexpr (SB) {                          // bf16 output tensor (Cout % 64 == 0 on this path: whole vectors)
-                        st4(reinterpret_cast<ore_bf16_t*>(p.out) + (size_t)(cur_g.obase + gy * cur_g.W + gx) * p.out_ld + p.out_coff + n, v);
+                        st4(reinterpret_cast<ore_bf16_t*>(p.out) + (size_t)(cur_g.obase + gy * cur_g.Wo + gx) * p.out_ld + p.out_coff + n, v);
                     } else {
-                    float* o = p.out + (size_t)(cur_g.obase + gy * cur_g.W + gx) * p.out_ld + p.out_coff + n;
+                    float* o = p.out + (size_t)(cur_g.obase + gy * cur_g.Wo + gx) * p.out_ld + p.out_coff + n;
                     if (n + 3 < p.Cout) {
                         *reinterpret_cast<f32x4*>(o) = v;
                     } else {
@@ -953,13 +958,45 @@ int g_ws_sb_mode = 1;    // tuning aid (ore_conv_set_plan_override(-8, mode)): 0
 
 // bf16 STORAGE: 3x3 stride-1 layers with 64 / 128 input channels on the weight-stationary kernel (weights in registers for the whole
 // launch, only the halo patch is staged).  c holds the input side in 4-byte units (fill_common).  1 = not covered.
-template <int TH, int CF, int KS>
+template <int TH, int CF, int KS, bool SBF = true, int ST = 1>
 static int ws_sb_go(const PatchP& p, int tiles, dim3 pgrid, hipStream_t st) {
-    const size_t lds = ((size_t)2 * ((TH + 2) * 18) * (CF + 8) + (KS > 1 ? 2 * 4 * TH * 256 : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * (((TH - 1) * ST + 3) * (15 * ST + 3)) * (CF + (ST == 1 ? 8 : 4)) + (KS > 1 ? 2 * 4 * TH * 256 : 0)) * sizeof(float);
     static bool attr = false;
-    if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<TH, CF, KS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL((k_conv3x3_ws<TH, CF, KS, false, true>), pgrid, dim3(256 * KS), lds, st, p, tiles);
+    if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_ws<TH, CF, KS, false, SBF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((k_conv3x3_ws<TH, CF, KS, false, SBF, ST>), pgrid, dim3(256 * KS), lds, st, p, tiles);
     return ore_launch_status("k_conv3x3_ws");
+}
+
+int g_ws_s2_mode = 1;    // tuning aid (-9, mode): 0 = stem_3 (3x3 stride 2, 64 input channels) stays on k_conv_igemm / k_conv_gs
+
+// 3x3 STRIDE-2 layers with 64 input channels and a multiple of 64 output channels (stem_3), bf16 storage: weight-stationary too
+// (18.8 -> 16.0 us).  The fp32 build of the same kernel was measured and dropped: 144 VGPRs of weights + an 11-vector register-staged
+// 5 x 33 patch spill, and the stride-2 fragment reads are 2-way bank conflicted: 71.9 us against 50.2 on k_conv_igemm.
+static int ws_s2_launch(const ConvP& c, hipStream_t st) {
+    const bool sb = (c.sb & 1) != 0;
+    if (!sb) return 1;
+    if (!g_ws_s2_mode || c.kh != 3 || c.kw != 3 || c.stride != 2 || c.pad != 1 || c.in_mul || c.add || c.colsum || c.nlev != 1) return 1;
+    if (sb ? (c.Cin != 32 || !(c.sb & 2)) : (c.Cin != 64 || c.bf16)) return 1;
+    if (c.Cout != c.Cout16 || c.Cout % 64 != 0 || c.M < 6000) return 1;
+    if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & (sb ? 7 : 15)) != 0) return 1;
+    const int TH = 2;
+    PatchP p{};
+    p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.Cin = c.Cin; p.nlev = 1;
+    p.lv[0] = c.lv[0];
+    p.tiles_x[0] = ceil_div(c.lv[0].Wo, 16); p.tiles_y[0] = ceil_div(c.lv[0].Ho, TH);
+    p.tile0[0] = 0;
+    const int tiles = c.B * p.tiles_x[0] * p.tiles_y[0];
+    p.tile0[1] = tiles;
+    p.w = c.w; p.Cout = c.Cout; p.Cout16 = c.Cout16; p.K = c.K;
+    p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
+    p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
+    p.xmap = tiles >= 16 ? 1 : 0;
+    const int gy = c.Cout16 / 64;
+    int gx = 512 / gy;
+    gx &= ~7;
+    if (gx > tiles) gx = tiles;
+    const dim3 pgrid(gx, gy);
+    return ws_sb_go<2, 32, 1, true, 2>(p, tiles, pgrid, st);
 }
 
 static int ws_sb_launch(const ConvP& c, hipStream_t st) {
@@ -1253,6 +1290,7 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
     if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
+    if (BM == -9) { g_ws_s2_mode = BN; return ORE_OK; }                                     // BM = -9: weight-stationary stride-2 kernel (stem_3) 0 off / 1 on
     if (BM == -8) { g_ws_sb_mode = BN; return ORE_OK; }                                     // BM = -8: bf16-storage weight-stationary 3x3 kernel: 0 off, 1 auto, 4 / 8 tile height
     if (BM == -7) { conv_wino_mode(BN); return ORE_OK; }                                    // BM = -7: Winograd kernel 0 off / 1 automatic / 2 forced
     if (BM == -6) { conv_kw_nw_force(BN); return ORE_OK; }                                  // BM = -6: waves per block of k_conv_kw (4 / 8 / 16)                                   // BM = -5: block -> tile mapping of k_conv_kw (-1 auto, 0, 1, 2)                           // BM = -4: tile of k_conv_gs                 // BM = -3: (tile BM, tile BN, ring depth, split-K) of k_conv_kw      // BM = -2: BN selects the k_conv_kw mode (0 / 1 / 2)
@@ -1304,6 +1342,8 @@ static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t worksp
         p.bf16 = 0;
         const int wrc = ws_sb_launch(p, st);
         if (wrc != 1) return wrc;
+        const int src = ws_s2_launch(p, st);
+        if (src != 1) return src;
         const int krc = conv_kw_launch(p, workspace, workspace_floats, st);
         if (krc == 1) { ore_set_error("ore_conv2d_fwd: no bf16-storage kernel for this layer (input affine?)"); return ORE_EINVAL; }
         return krc;

@@ -261,7 +261,10 @@ def _bf(x):
     (1, 9, 7, 16, 5, 3, 1),         # tiny, Cout = 5
     (3, 33, 31, 64, 80, 3, 2),      # stride 2
     (1, 96, 96, 64, 64, 3, 1),      # k_conv_gs on a 3x3 layer (M = 9216)
-    (1, 80, 80, 128, 128, 3, 1),    # FPN output3 / tower class
+    (1, 80, 80, 128, 128, 3, 1),    # FPN output3 / tower class: K-split weight-stationary kernel (8 waves)
+    (1, 160, 160, 64, 128, 3, 2),   # stem_3 class: weight-stationary stride-2 kernel
+    (3, 111, 93, 64, 64, 3, 2),     # the same on odd sizes
+    (2, 70, 50, 128, 64, 3, 1),     # stage-2 layer 0 class on a size with partial tiles
 ])
 def test_conv_bf16_storage_vs_oracle(B, H, W, Cin, Cout, k, stride):
     """bf16 input / weight / output tensors.  A product of two bf16 numbers is exact in fp32 and the accumulation is fp32, so against
