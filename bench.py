@@ -487,7 +487,7 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM bytes of the conv launches of one image, from the committed PMC passes -- only if they were taken with THIS library version
         traffic, traffic_src, lib_ver = None, None, int(orehip.lib().ore_version())
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        for tf in ([] if bf16 else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)):   # (the passes are fp32-mode runs)
             try:
                 with open(tf) as f:
                     tj = json.load(f)

@@ -25,7 +25,7 @@ def load(d, counter):
 
 
 def fam(n):
-    for k in ("k_conv3x3_patch", "k_conv3x3_ws", "k_conv_igemm", "k_conv_kw", "k_conv_gs", "k_stem1", "k_maxpool", "k_correlation", "k_roi_align", "k_nms", "k_level_select"):
+    for k in ("k_conv3x3_wino", "k_conv3x3_patch", "k_conv3x3_ws", "k_conv_igemm", "k_conv_kw", "k_conv_gs", "k_stem1", "k_maxpool", "k_correlation", "k_roi_align", "k_nms", "k_level_select"):
         if k in n:
             return k
     return "other"
@@ -45,7 +45,7 @@ def main():
     for k, v in res.items():
         v["hbm_bytes"] = (2.0 * v["fetch_raw"] + v["write_raw"]) * 1024.0      # KiB -> bytes, FETCH_SIZE doubled on gfx950
         tot[k] = v
-    conv = sum(res[k]["hbm_bytes"] for k in ("k_conv_igemm", "k_conv_kw", "k_conv_gs", "k_conv3x3_patch", "k_conv3x3_ws") if k in res)
+    conv = sum(res[k]["hbm_bytes"] for k in ("k_conv3x3_wino", "k_conv_igemm", "k_conv_kw", "k_conv_gs", "k_conv3x3_patch", "k_conv3x3_ws") if k in res)
     json.dump({"per_image": tot, "conv_hbm_bytes_per_image": conv, "ore_version": ver,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over eager forwards (tools/pmc_pass.py), last "
                          "forward; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md: FETCH_SIZE halves wide reads on gfx950)"},

@@ -10,7 +10,8 @@ export TMPDIR=/tmp
 # 1. PMC traffic first (bench.py reads profiles/<tag>_pmc_traffic.json for roofline.traffic): two separate counter passes
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_pass.py > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/pmc_pass.py > $OUT/pmc_write.log 2>&1
-python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt
+VER=$(python3 -c "import sys; sys.path.insert(0, 'faster-orefsdet_amd'); import orehip; print(orehip.lib().ore_version())")
+python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json $VER > $OUT/${TAG}_pmc_traffic.txt
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 # 2. the default bench command under the kernel trace (the judged line + its rocprof summary)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
@@ -22,6 +23,11 @@ python3 tools/trace_summary.py $OUT/proto 30 > $OUT/${TAG}_bench_image_timeline.
 python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline.txt $OUT/${TAG}_conv_layers.txt
 # 4. the same without the profiler (the numbers quoted in DESIGN.md), fp32 and bf16-operand mode
 timeout -k 10 300 python3 bench.py > $OUT/${TAG}_bench_noprof.json 2> $OUT/bench_noprof.err
-timeout -k 10 300 python3 bench.py --conv-operands bf16 --no-cpu-baseline > $OUT/${TAG}_bench_bf16.json 2> $OUT/bench_bf16.err
+timeout -k 10 300 python3 bench.py --conv-operands bf16s --no-cpu-baseline --no-train-leg > $OUT/${TAG}_bench_bf16s.json 2> $OUT/bench_bf16s.err
+# 5. the bf16-storage mode kernel by kernel
+ORE_OPERANDS=bf16s timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proto_s -o proto -- python3 tools/protocol_loop.py 300 > $OUT/proto_s.log 2>&1
+python3 tools/trace_summary.py $OUT/proto_s 30 > $OUT/${TAG}_bench_image_timeline_bf16s.txt
+python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline_bf16s.txt $OUT/${TAG}_conv_layers_bf16s.txt
+rm -rf $OUT/proto $OUT/proto_s $OUT/bench $OUT/pmc_fetch $OUT/pmc_write
 tail -3 $OUT/${TAG}_conv_layers.txt
 echo "done: $OUT"
