@@ -1,4 +1,4 @@
-"""The bench line the driver parses: checked on the committed artifact of the last GPU run (profiles/r02_bench.json) so that a change
+"""The bench line the driver parses: checked on the committed artifact of the last GPU run (profiles/r03_bench.json) so that a change
 of bench.py's output format is caught on the CPU.  (The numbers themselves are produced on the MI355X.)"""
 import json
 import os
@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = _line("r02_bench.json")
+    d = _line("r03_bench.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -29,6 +29,9 @@ def test_bench_line_has_the_contract_fields():
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 157.3
     assert r["traffic"] is None or r["traffic"] > 1e8
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:      # the PMC file carries the library version it was taken with
+        assert "ore_version" in json.load(f)
+    assert d["config"]["hipgraph"] is True and "extra_legs_hipgraph" in d["config"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -53,6 +56,10 @@ def test_two_rank_rehearsal_line_carries_the_dp_train_leg():
 def test_bf16_line_is_labelled_as_such():
     d = _line("r01_bench_bf16.json")
     assert d["dtype"] == "bf16" and "bf16" in d["config"]["workload"] and d["roofline"]["peak"] == 2500.0
+    s = _line("r03_bench_bf16s.json")                     # the storage mode: priced against HBM, never the fp32 headline
+    assert s["dtype"] == "bf16" and "bf16 storage" in s["config"]["workload"]
+    r = s["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
 def test_bench_self_launches_its_ranks_dry():
