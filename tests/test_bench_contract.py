@@ -53,6 +53,14 @@ def test_two_rank_rehearsal_line_carries_the_dp_train_leg():
     assert t["global_batch"] == 32 and t["rccl_ranks_seen"] == 2 and t["exchanged_bytes_per_step"] == 16365568
 
 
+def test_self_launched_two_rank_line():
+    """`python bench.py --gpus 2` with NO launcher, GPU legs included (two ranks sharing the one card of a gpurun box, exchange over gloo):
+    the line of rank 0 carries both ranks' eval figure, the DP train leg and -- new in round 3 -- a cpu_baseline for N > 1."""
+    d = _line("r03_bench_2rank_selflaunch_gloo_rehearsal.json")
+    assert d["n_gpus"] == 2 and "dp2" in d["config"]["parallelism"] and d["train_step"]["rccl_ranks_seen"] == 2
+    assert d["train_step"]["global_batch"] == 32 and "overlap_frac" in d["train_step"] and d["cpu_baseline"]["value"] > 0
+
+
 def test_bf16_line_is_labelled_as_such():
     d = _line("r01_bench_bf16.json")
     assert d["dtype"] == "bf16" and "bf16" in d["config"]["workload"] and d["roofline"]["peak"] == 2500.0
