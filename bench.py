@@ -106,7 +106,7 @@ def cpu_baseline(model, img, budget_s=12.0):
             d = odec.decode_nms(hms, regs, (8, 16, 32), 1e-5, 1000, 0.6, 256)
             # second stage too (ROIAlign + DSA mix + fc1 + predictor + NMS 0.9 + top-100): the GPU step includes it
             feats = [o["features"][k] for k in ("p3", "p4", "p5")]
-            return R.roi_head_eval(feats, torch.from_numpy(d["boxes"]), rcnn_8, sd, (H, W), 0.0, 0.9, 100)
+            return R.roi_head_eval(feats, torch.from_numpy(d["boxes"]), rcnn_8, sd, (H, W), 0.0, 0.9, 100, compiled_roi_align=True)
 
     for _ in range(2):
         one()
@@ -118,7 +118,7 @@ def cpu_baseline(model, img, budget_s=12.0):
         if el >= budget_s or n >= 200:
             break
     return {"value": round(n / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} images of the same 640x640 bs=1 eval workload, both stages (oracle/ref_model.py + oracle/ref_decode.c, "
+            "sample": f"{n} images of the same 640x640 bs=1 eval workload, both stages (oracle/ref_model.py + oracle/ref_decode.c incl. its ROIAlign, "
                       f"torch {torch.__version__} CPU, {el:.1f} s)"}
 
 
@@ -487,7 +487,8 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM bytes of the conv launches of one image, from the committed PMC passes -- only if they were taken with THIS library version
         traffic, traffic_src, lib_ver = None, None, int(orehip.lib().ore_version())
-        for tf in ([] if bf16 else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)):   # (the passes are fp32-mode runs)
+        pmc_pat = "r*_pmc_traffic_bf16s.json" if bf16s else ("" if bf16 else "r*_pmc_traffic.json")     # one file per engine mode
+        for tf in (sorted(glob.glob(os.path.join(ROOT, "profiles", pmc_pat)), reverse=True) if pmc_pat else []):
             try:
                 with open(tf) as f:
                     tj = json.load(f)

@@ -112,6 +112,19 @@ def roi_predict(h, cls_w, cls_b, box_w, box_b, props, reg_weights, image_hw, sco
     return {"raw_boxes": raw_b[:n], "raw_scores": raw_s[:n], "boxes": det_b[:k].copy(), "scores": det_s[:k].copy(), "src": det_src[:k].copy()}
 
 
+def roi_align_c(feat_chw: np.ndarray, boxes: np.ndarray, scale: float, pooled: int) -> np.ndarray:
+    """ROIAlign (aligned, sampling_ratio 0) by oracle/ref_decode.c::oracle_roi_align -- the compiled twin of ref_model.roi_align's Python
+    loop (same published algorithm, same fp32 operation order); used by bench.py's cpu_baseline and checked against the loop in tests."""
+    f = np.ascontiguousarray(feat_chw, np.float32)
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+    Cc, H, W = f.shape
+    out = np.zeros((len(b), Cc, pooled, pooled), np.float32)
+    rc = lib().oracle_roi_align(_p(f, ctypes.c_float), ctypes.c_int32(Cc), ctypes.c_int32(H), ctypes.c_int32(W), _p(b, ctypes.c_float),
+                                ctypes.c_int64(len(b)), ctypes.c_float(scale), ctypes.c_int32(pooled), _p(out, ctypes.c_float))
+    assert rc == 0
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # Pure-numpy twin (small cases; mirrors ref_decode.c step for step, fp32 throughout).
 # ----------------------------------------------------------------------------------------------

@@ -29,6 +29,9 @@
  * Build: gcc -O2 -fPIC -shared -ffp-contract=off -fno-fast-math (oracle/Makefile).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -255,4 +258,64 @@ int oracle_roi_predict(const float* h, int64_t n, int32_t C, const float* cls_w,
     *det_count = (int32_t)nk;
     free(cb); free(cs); free(csrc); free(keep);
     return 0;
+}
+
+/* --------------------------------------------------------------------------------------------------------------------------
+ * ROIAlign (aligned = true, sampling_ratio = 0) in plain C: the same published torchvision 0.8.2 algorithm as
+ * oracle/ref_model.py::roi_align (the per-ROI Python loop that restates d2z:layers/roi_align.py:49-65 -> torchvision roi_align), same
+ * fp32 operations in the same order.  It exists so that bench.py's cpu_baseline times the second stage at the speed of compiled code
+ * (the Python loop was 130 of the oracle's 190 ms per image); tests/test_oracle_golden.py checks it against the
+ * Python loop.  ROIs are independent: an OpenMP parallel-for when built with -fopenmp (the Makefile does), serial otherwise.
+ * feat [C][H][W], boxes [R][4] (x0,y0,x1,y1 in image coordinates), out [R][C][pooled][pooled]. */
+static float bilin(const float* f, int H, int W, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.0f;
+    if (y <= 0.0f) y = 0.0f;
+    if (x <= 0.0f) x = 0.0f;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.0f - ly, hx = 1.0f - lx;
+    return (hy * hx) * f[yl * W + xl] + (hy * lx) * f[yl * W + xh] + (ly * hx) * f[yh * W + xl] + (ly * lx) * f[yh * W + xh];
+}
+
+int oracle_roi_align(const float* feat, int32_t C, int32_t H, int32_t W, const float* boxes, int64_t R, float scale, int32_t pooled,
+                     float* out) {
+    if (!feat || !boxes || !out || C <= 0 || H <= 0 || W <= 0 || pooled <= 0) return -1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int64_t r = 0; r < R; ++r) {
+        const float x0 = boxes[r * 4 + 0] * scale - 0.5f, y0 = boxes[r * 4 + 1] * scale - 0.5f;
+        const float x1 = boxes[r * 4 + 2] * scale - 0.5f, y1 = boxes[r * 4 + 3] * scale - 0.5f;
+        const float rw = x1 - x0, rh = y1 - y0;
+        const float bw = rw / (float)pooled, bh = rh / (float)pooled;
+        const int gh = (int)ceilf(rh / (float)pooled), gw = (int)ceilf(rw / (float)pooled);
+        float* o = out + (size_t)r * C * pooled * pooled;
+        if (gh <= 0 || gw <= 0) { memset(o, 0, sizeof(float) * (size_t)C * pooled * pooled); continue; }
+        const float cnt = (float)(gh * gw);
+        for (int c = 0; c < C; ++c) {
+            const float* f = feat + (size_t)c * H * W;
+            for (int ph = 0; ph < pooled; ++ph)
+                for (int pw = 0; pw < pooled; ++pw) {
+                    float acc = 0.0f;
+                    for (int iy = 0; iy < gh; ++iy) {
+                        const float y = y0 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                        for (int ix = 0; ix < gw; ++ix) {
+                            const float x = x0 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                            acc += bilin(f, H, W, y, x);
+                        }
+                    }
+                    o[(c * pooled + ph) * pooled + pw] = acc / cnt;
+                }
+        }
+    }
+    return 0;
+}
+
+int oracle_omp_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }

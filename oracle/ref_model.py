@@ -489,14 +489,19 @@ def roi_align(feat: Tensor, boxes: Tensor, scale: float, pooled: int) -> Tensor:
     return out
 
 
-def roi_pool_levels(feats: Sequence[Tensor], boxes: Tensor, pooled: int, strides=(8, 16, 32)) -> Tensor:
-    """ROIPooler.forward for one image (poolers.py:190-250).  feats[l] [1,C,H,W]."""
+def roi_pool_levels(feats: Sequence[Tensor], boxes: Tensor, pooled: int, strides=(8, 16, 32), compiled: bool = False) -> Tensor:
+    """ROIPooler.forward for one image (poolers.py:190-250).  feats[l] [1,C,H,W].
+    compiled=True: the C twin of roi_align (oracle/ref_decode.c; fp32 eval only) -- what the CPU baseline times."""
     lv = assign_levels(boxes)
     out = torch.zeros(len(boxes), feats[0].shape[1], pooled, pooled)
     for l, f in enumerate(feats):
         idx = torch.nonzero(lv == l).squeeze(1)
         if len(idx):
-            out[idx] = roi_align(f[0], boxes[idx], 1.0 / strides[l], pooled)
+            if compiled:
+                from . import decode as odec
+                out[idx] = torch.from_numpy(odec.roi_align_c(f[0].detach().numpy(), boxes[idx].detach().numpy(), 1.0 / strides[l], pooled))
+            else:
+                out[idx] = roi_align(f[0], boxes[idx], 1.0 / strides[l], pooled)
     return out
 
 
@@ -511,10 +516,10 @@ def roi_head_features(box_feat: Tensor, support_8: Tensor, sd: SD, prefix: str =
 
 
 def roi_head_eval(feats: Sequence[Tensor], proposals: Tensor, support_8: Tensor, sd: SD, image_hw: Tuple[int, int],
-                  score_thresh: float = 0.0, nms_thresh: float = 0.9, topk: int = 100, prefix: str = "roi_heads."):
+                  score_thresh: float = 0.0, nms_thresh: float = 0.9, topk: int = 100, prefix: str = "roi_heads.", compiled_roi_align: bool = False):
     """Whole second stage for one image; the predict/NMS part runs in oracle/ref_decode.c (bit-exact twin of the HIP kernel)."""
     from . import decode as odec
-    x = roi_pool_levels(feats, proposals, 8)
+    x = roi_pool_levels(feats, proposals, 8, compiled=compiled_roi_align)
     h = roi_head_features(x, support_8, sd, prefix)
     det = odec.roi_predict(h.numpy(), sd[prefix + "box_predictor.0.cls_score.weight"].numpy(),
                            sd[prefix + "box_predictor.0.cls_score.bias"].numpy(),

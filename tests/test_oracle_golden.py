@@ -344,3 +344,26 @@ def test_eval_end_to_end_matches_reference_run(golden):
             assert ok.mean() >= 0.98, (i, ok.mean())
             assert (g[f"img{i}_classes"] == 0).all()
 
+
+
+def test_compiled_roi_align_matches_the_python_loop():
+    """oracle/ref_decode.c::oracle_roi_align (what bench.py's cpu_baseline times) against ref_model.roi_align, the per-ROI Python loop
+    that restates torchvision's published algorithm: boxes inside, across and outside the map, tiny and huge, three pyramid scales."""
+    import numpy as np
+    from oracle import decode as odec
+    from oracle import ref_model as R
+    g = torch.Generator().manual_seed(9)
+    for (C, H, W, scale) in ((16, 20, 24, 1.0 / 8), (8, 10, 12, 1.0 / 16), (4, 5, 6, 1.0 / 32)):
+        feat = torch.randn(C, H, W, generator=g)
+        ctr = torch.rand(40, 2, generator=g) * torch.tensor([W / scale * 1.2, H / scale * 1.2]) - 10.0
+        wh = torch.exp(torch.rand(40, 2, generator=g) * 5.0)                    # 1 .. 148 px
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+        boxes[0] = torch.tensor([3.0, 3.0, 3.0, 3.0])                            # empty box
+        want = R.roi_align(feat, boxes, scale, 8).numpy()
+        got = odec.roi_align_c(feat.numpy(), boxes.numpy(), scale, 8)
+        assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1.0), (C, H, W)
+    feats = [torch.randn(1, 8, 40 >> l, 48 >> l, generator=g) for l in range(3)]
+    boxes = torch.tensor([[10.0, 12.0, 60.0, 90.0], [0.0, 0.0, 380.0, 300.0], [100.0, 40.0, 130.0, 70.0]])
+    a = R.roi_pool_levels(feats, boxes, 8).numpy()
+    b = R.roi_pool_levels(feats, boxes, 8, compiled=True).numpy()
+    assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()

@@ -17,6 +17,7 @@ if os.environ.get("ORE_XMAP"):                       # A/B aid: force the block 
     import orehip
     orehip.lib().ore_conv_set_plan_override(-5, int(os.environ["ORE_XMAP"]), 0, 0, 0)
 model, cfg = bench.build_model(torch.device("cuda", 0))
+model.conv_operands = os.environ.get("ORE_OPERANDS", "fp32")      # fp32 | bf16s: which engine the passes profile
 img = bench.synth_image(0).cuda()
 eng = model.engine()
 for _ in range(3):

@@ -13,6 +13,10 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 VER=$(python3 -c "import sys; sys.path.insert(0, 'faster-orefsdet_amd'); import orehip; print(orehip.lib().ore_version())")
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json $VER > $OUT/${TAG}_pmc_traffic.txt
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+ORE_OPERANDS=bf16s timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_s -- python3 tools/pmc_pass.py > $OUT/pmc_fetch_s.log 2>&1
+ORE_OPERANDS=bf16s timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_s -- python3 tools/pmc_pass.py > $OUT/pmc_write_s.log 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_fetch_s $OUT/pmc_write_s $OUT/${TAG}_pmc_traffic_bf16s.json $VER > $OUT/${TAG}_pmc_traffic_bf16s.txt
+cp $OUT/${TAG}_pmc_traffic_bf16s.json profiles/${TAG}_pmc_traffic_bf16s.json
 # 2. the default bench command under the kernel trace (the judged line + its rocprof summary)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 cp $(ls $OUT/bench/bench_kernel_stats.csv $OUT/bench/*/bench_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_bench_kernel_stats.csv
@@ -28,6 +32,6 @@ timeout -k 10 300 python3 bench.py --conv-operands bf16s --no-cpu-baseline --no-
 ORE_OPERANDS=bf16s timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proto_s -o proto -- python3 tools/protocol_loop.py 300 > $OUT/proto_s.log 2>&1
 python3 tools/trace_summary.py $OUT/proto_s 30 > $OUT/${TAG}_bench_image_timeline_bf16s.txt
 python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline_bf16s.txt $OUT/${TAG}_conv_layers_bf16s.txt
-rm -rf $OUT/proto $OUT/proto_s $OUT/bench $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/proto $OUT/proto_s $OUT/bench $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_s $OUT/pmc_write_s
 tail -3 $OUT/${TAG}_conv_layers.txt
 echo "done: $OUT"
