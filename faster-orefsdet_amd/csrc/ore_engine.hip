@@ -62,6 +62,7 @@ struct ore_engine {
     void* img_in = nullptr; size_t img_bytes = 0;
     Buf s1, s2, cat[4], sout[4], lat[3];
     Buf pcat, pos, tow, head;                    // all pyramid levels in ONE level-major matrix each ([level][b][y][x])
+    bool head_pred_valu = true;                  // k_head_pred (VALU) instead of the MFMA conv for the head's last step (A/B: ORE_HEAD_MFMA=1)
     Buf tn;                                      // bf16 storage only: GroupNorm + ReLU of the tower, materialised (the DMA-fed kernels cannot touch their A operand)
     bool sb() const { return conv_precision == ORE_CONV_BF16S; }
     // element offset into an ACTIVATION buffer (fp32, or bf16 in ORE_CONV_BF16S engines)
@@ -378,11 +379,23 @@ int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
     r.conv_levels(e->conv3, e->pcat.p, 2 * F, 0, g.B, H, W, e->pos.p, F, 0);            // relu(conv3(cat(attn, q)))
     r.conv_levels(e->tower, e->pos.p, F, 0, g.B, H, W, e->tow.p, F, 0);                 // bbox_tower conv (+bias)
     if (r.rc) return r.rc;
+    // GroupNorm statistics (fp32, from the fp32 or bf16 tower output), then GroupNorm + ReLU + the (l,t,r,b | hm) conv + per-level Scale
+    // in ONE VALU kernel (k_head_pred: N = 5 is not MFMA work; it was 20 us on the matrix cores, + a materialised bf16 tensor in the
+    // storage mode); the detection tail downstream is fp32 as always
+    r.rc = sb ? ore_groupnorm_affine_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma,
+                                                     e->gn_beta, e->gn_mul, e->gn_add, e->gn_ws, st)
+              : ore_groupnorm_affine_levels_fwd(e->tow.p, F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->gn_mul, e->gn_add,
+                                                e->gn_ws, st);
+    if (r.rc) return r.rc;
+    if (F == 128 && e->head_pred_valu) {
+        r.rc = sb ? ore_head_pred_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, g.B, 3, H, W, e->gn_mul, e->gn_add, e->pred.w,
+                                           e->pred.scale, e->pred.shift, 16, e->head.p, 8, st)
+                  : ore_head_pred_fwd(e->tow.p, F, g.B, 3, H, W, e->gn_mul, e->gn_add, e->pred.w, e->pred.scale, e->pred.shift, 16, e->head.p, 8, st);
+        r.flops += 2.0 * rows * 5.0 * F * 9.0;
+        *flops = r.flops;
+        return r.rc;
+    }
     if (sb) {
-        // bf16 storage: statistics in fp32 from the bf16 tower output, then GroupNorm + ReLU materialised as a bf16 tensor (the DMA-fed conv
-        // kernels copy their A operand verbatim), then the (l,t,r,b | hm) conv with fp32 outputs -- the detection tail is fp32 as always
-        r.rc = ore_groupnorm_affine_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma,
-                                                    e->gn_beta, e->gn_mul, e->gn_add, e->gn_ws, st);
         if (!r.rc) r.rc = ore_groupnorm_apply_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, e->gn_mul, e->gn_add, 1,
                                                               reinterpret_cast<uint16_t*>(e->tn.p), st);
         if (r.rc) return r.rc;
@@ -390,9 +403,6 @@ int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
         *flops = r.flops;
         return r.rc;
     }
-    r.rc = ore_groupnorm_affine_levels_fwd(e->tow.p, F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->gn_mul, e->gn_add,
-                                           e->gn_ws, st);
-    if (r.rc) return r.rc;
     // (l,t,r,b | hm) conv with GN affine + ReLU on its input, per-level Scale in the epilogue
     r.conv_levels(e->pred, e->tow.p, F, 0, g.B, H, W, e->head.p, 8, 0, 16, e->gn_mul, e->gn_add, 1);
     *flops = r.flops;
@@ -520,6 +530,7 @@ extern "C" int ore_engine_create(const ore_model_cfg* cfg, int32_t device, ore_e
     ore_engine* e = new ore_engine();
     e->cfg = *cfg; e->device = device;
     e->conv_precision = ore_conv_get_precision();
+    { const char* hm = getenv("ORE_HEAD_MFMA"); e->head_pred_valu = !(hm && hm[0] == '1'); }
     *out = e;
     return ORE_OK;
 }

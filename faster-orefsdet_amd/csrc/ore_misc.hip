@@ -470,7 +470,161 @@ __global__ __launch_bounds__(256) void k_gn_combine(const float* __restrict__ st
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// CenterNet head, last step (ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:150-159 on top of :141-149's GroupNorm):
+//   t = relu(GN(tower));  reg = relu(scale_l * (conv3x3_{C->4}(t) + b));  hm = conv3x3_{C->1}(t) + b      (C = 128, 5 output channels)
+// 0.1 GFLOP with N = 5: not MFMA-worthy -- on the matrix cores it ran 20 us at 3 % of peak with the GroupNorm affine costing
+// 30 VALU per MFMA.  Here it is a VALU kernel: a block owns an 8 x 8 pixel tile of one (level, image); phase 1 stages the 10 x 10 halo of
+// the tower output into LDS with the folded GroupNorm affine + ReLU applied ONCE per element (fp32 or bf16 tower), phase 2: thread
+// (4-channel quad q, tile row r) walks the 9 taps, re-using each staged f32x4 for the 5 outputs (weights broadcast from LDS), 40 scalar
+// accumulators; phase 3 sums the 32 quads per (pixel, output) through LDS in fixed order, applies bias / per-level Scale / ReLU and
+// writes the fp32 head rows [l, t, r, b, hm].
+// ------------------------------------------------------------------------------------------------
+struct HeadP {
+    const void* tow; int ld;                    // level-major rows [sum_l B*H_l*W_l][ld], C = 128 channels at offset 0
+    int B, nlev; int H[4], W[4], row0[4], tile0[5], tx[4], ty[4];
+    const float* mul; const float* add;         // [nlev*B][128] folded GroupNorm affine
+    const float* w;                             // packed [16][9][128] (rows 0..4 used)
+    const float* scale; const float* shift; int ep_stride;   // per level [16]
+    float* out; int out_ld;                     // [rows][out_ld], 5 written
+};
+
+template <typename TS>
+__global__ __launch_bounds__(256) void k_head_pred(HeadP p) {
+    constexpr int C = 128, Q = 32, NO = 5, TP = 8, HP = TP + 2;
+    __shared__ __attribute__((aligned(16))) float sX[HP * HP * C];          // 51 200 B; re-used as the partial sums [64][5][32] in phase 3
+    __shared__ __attribute__((aligned(16))) float sW[NO * 9 * C];           // 23 040 B
+    const int tid = threadIdx.x;
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+        if (l < p.nlev && (int)blockIdx.x >= p.tile0[l]) lvl = l;
+    const int H = p.H[lvl], W = p.W[lvl];
+    const int tl = blockIdx.x - p.tile0[lvl], per = p.tx[lvl] * p.ty[lvl];
+    const int b = tl / per, tr = tl - b * per;
+    const int y0 = (tr / p.tx[lvl]) * TP, x0 = (tr % p.tx[lvl]) * TP;
+    const int base = p.row0[lvl] + b * H * W;
+    const TS* tow = reinterpret_cast<const TS*>(p.tow);
+    const float* mul = p.mul + (size_t)(lvl * p.B + b) * C;
+    const float* add = p.add + (size_t)(lvl * p.B + b) * C;
+    // phase 1: all global loads of a thread are issued back to back (a load -> store loop serialises their latency)
+    constexpr int NX = (HP * HP * Q + 255) / 256;                           // 13 staged vectors per thread
+    constexpr int NWV = (NO * 9 * Q + 255) / 256;                           // 6 weight vectors per thread
+    f32x4 xv[NX], wv[NWV];
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+        const int i = tid + k * 256;
+        wv[k] = i < NO * 9 * Q ? *reinterpret_cast<const f32x4*>(p.w + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = tid + k * 256;
+        const int px = i / Q, q = i - px * Q;
+        const int gy = y0 - 1 + px / HP, gx = x0 - 1 + px % HP;
+        const bool ok = i < HP * HP * Q && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        xv[k] = ok ? ld4(tow + (size_t)(base + gy * W + gx) * p.ld + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+        const int i = tid + k * 256;
+        if (i < NO * 9 * Q) *reinterpret_cast<f32x4*>(sW + i * 4) = wv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = tid + k * 256;
+        if (i < HP * HP * Q) {
+            const int px = i / Q, q = i - px * Q;
+            const int gy = y0 - 1 + px / HP, gx = x0 - 1 + px % HP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                v = xv[k] * *reinterpret_cast<const f32x4*>(mul + q * 4) + *reinterpret_cast<const f32x4*>(add + q * 4);
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(sX + i * 4) = v;
+        }
+    }
+    __syncthreads();
+    const int q = tid & 31, r = tid >> 5;                                   // quad of 4 input channels, tile row
+    float acc[TP][NO];
+#pragma unroll
+    for (int x = 0; x < TP; ++x)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[x][o] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        f32x4 xr[HP];                                                       // the 10 staged pixels of halo row r + dy, this quad
+#pragma unroll
+        for (int x = 0; x < HP; ++x) xr[x] = *reinterpret_cast<const f32x4*>(sX + (((r + dy) * HP + x) * Q + q) * 4);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(sW + ((o * 9 + dy * 3 + dx) * Q + q) * 4);
+#pragma unroll
+                for (int x = 0; x < TP; ++x) {
+                    const f32x4 v = xr[x + dx];
+                    acc[x][o] = fmaf(v.x, w4.x, fmaf(v.y, w4.y, fmaf(v.z, w4.z, fmaf(v.w, w4.w, acc[x][o]))));
+                }
+            }
+    }
+    __syncthreads();                                                        // everybody is done with sX
+    float* part = sX;                                                       // [64 px][5][32 quads]
+#pragma unroll
+    for (int x = 0; x < TP; ++x)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) part[((r * TP + x) * NO + o) * Q + q] = acc[x][o];
+    __syncthreads();
+    for (int i = tid; i < TP * TP * NO; i += 256) {                         // 320 (pixel, output) sums of 32 partials, fixed order
+        const int px = i / NO, o = i - px * NO;
+        const float* pp = part + i * Q;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < Q; k += 4) { s0 += pp[k]; s1 += pp[k + 1]; s2 += pp[k + 2]; s3 += pp[k + 3]; }
+        float v = (s0 + s1) + (s2 + s3);
+        const int gy = y0 + px / TP, gx = x0 + px % TP;
+        if (gy < H && gx < W) {
+            v = v * p.scale[lvl * p.ep_stride + o] + p.shift[lvl * p.ep_stride + o];
+            if (o < 4) v = fmaxf(v, 0.f);
+            p.out[(size_t)(base + gy * W + gx) * p.out_ld + o] = v;
+        }
+    }
+}
+
 }  // namespace
+
+static int head_pred_launch(const void* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W, const float* mul,
+                            const float* add, const float* w_packed16, const float* scale, const float* shift, int32_t ep_stride,
+                            float* out, int32_t out_ld, void* stream, int bf16) {
+    ORE_CHECK_ARG(tower && H && W && mul && add && w_packed16 && scale && shift && out, "ore_head_pred_fwd: null pointer");
+    ORE_CHECK_ARG(B > 0 && n_levels >= 1 && n_levels <= 4 && ld >= 128 && ld % 4 == 0 && out_ld >= 5, "ore_head_pred_fwd: bad args");
+    HeadP p{};
+    p.tow = tower; p.ld = ld; p.B = B; p.nlev = n_levels;
+    int rows = 0, tiles = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        ORE_CHECK_ARG(H[l] > 0 && W[l] > 0, "ore_head_pred_fwd: level %d geometry", l);
+        p.H[l] = H[l]; p.W[l] = W[l]; p.row0[l] = rows; p.tile0[l] = tiles;
+        p.tx[l] = ceil_div(W[l], 8); p.ty[l] = ceil_div(H[l], 8);
+        rows += B * H[l] * W[l]; tiles += B * p.tx[l] * p.ty[l];
+    }
+    p.tile0[n_levels] = tiles;
+    p.mul = mul; p.add = add; p.w = w_packed16; p.scale = scale; p.shift = shift; p.ep_stride = ep_stride; p.out = out; p.out_ld = out_ld;
+    if (bf16) hipLaunchKernelGGL(k_head_pred<ore_bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_head_pred<float>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return ore_launch_status("k_head_pred");
+}
+
+extern "C" int ore_head_pred_fwd(const float* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W,
+                                 const float* gn_mul, const float* gn_add, const float* w_packed16, const float* scale, const float* shift,
+                                 int32_t ep_stride, float* out, int32_t out_ld, void* stream) {
+    return head_pred_launch(tower, ld, B, n_levels, H, W, gn_mul, gn_add, w_packed16, scale, shift, ep_stride, out, out_ld, stream, 0);
+}
+
+extern "C" int ore_head_pred_bf16_fwd(const uint16_t* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W,
+                                      const float* gn_mul, const float* gn_add, const float* w_packed16, const float* scale,
+                                      const float* shift, int32_t ep_stride, float* out, int32_t out_ld, void* stream) {
+    return head_pred_launch(tower, ld, B, n_levels, H, W, gn_mul, gn_add, w_packed16, scale, shift, ep_stride, out, out_ld, stream, 1);
+}
 
 static int stem1_launch(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp,
                              int32_t Wp, const float* mean3, const float* std3, const float* w_oihw,

@@ -450,6 +450,17 @@ int ore_groupnorm_affine_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t 
                                          float* add, float* workspace, void* stream);
 int ore_groupnorm_apply_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t images, int64_t rows_per_image, int32_t C,
                                  const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream);
+/* CenterNet head, last step, as ONE VALU kernel over all pyramid levels (level-major rows): t = relu(tower * gn_mul + gn_add) with the
+ * folded GroupNorm affine of ore_groupnorm_affine_levels_*_fwd ([level*B + image][128]); (l,t,r,b | hm) = conv3x3_{128->5}(t) with the
+ * packed [16][9][128] weight, y = conv * scale[level][o] + shift[level][o], ReLU on the four box outputs; out rows [.., out_ld >= 5] fp32.
+ * Replaces ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:146-159 (GN + ReLU + bbox_pred / agn_hm + Scale + ReLU).
+ * The tower may be fp32 or bf16 (bf16-storage engines). */
+int ore_head_pred_fwd(const float* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W, const float* gn_mul,
+                      const float* gn_add, const float* w_packed16, const float* scale, const float* shift, int32_t ep_stride, float* out,
+                      int32_t out_ld, void* stream);
+int ore_head_pred_bf16_fwd(const uint16_t* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W,
+                           const float* gn_mul, const float* gn_add, const float* w_packed16, const float* scale, const float* shift,
+                           int32_t ep_stride, float* out, int32_t out_ld, void* stream);
 int ore_groupnorm_apply_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels, const int32_t* HW, int32_t C,
                                         const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream);
 int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,

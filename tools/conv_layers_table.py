@@ -18,7 +18,8 @@ PEAK = 157.3
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02_bench_image_timeline.txt"
     dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_conv_layers.txt"
-    tl = [l for l in open(src) if l.startswith("k_conv")]
+    # the head's (reg|hm) step is a VALU kernel since round 3 (k_head_pred): it is listed with the conv launches it replaced
+    tl = [l for l in open(src) if l.startswith("k_conv") or l.startswith("k_head_pred")]
     assert len(tl) == 28, len(tl)
     out = ["# per-conv-launch efficiency of ONE image, strictly sequential mode (rocprofv3 --kernel-trace of the headline protocol, tools/protocol_loop.py,",
            "# %s); algorithmic FLOPs = 2*M*Cout*Cin*k*k; peak = %.1f TFLOP/s (fp32 MFMA, gfx950)" % (src, PEAK),
