@@ -149,61 +149,83 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     }
 }
 
-// pass 2a: mean[b][c] = sum_p part[b][p][c] / HW.  One block per 16 channels: 4 float4 groups x 64 row slices, so a thread
-// has at most ceil(P/64) independent loads in flight and the whole reduction is one memory round trip.
-__global__ __launch_bounds__(256) void k_colmean(const float* __restrict__ part, int P, int HW, int C, float* __restrict__ mean) {
-    __shared__ __attribute__((aligned(16))) float red[256 * 4];
-    const int b = blockIdx.y;
-    const int cg = threadIdx.x & 3, sl = threadIdx.x >> 2;
-    const int c = blockIdx.x * 16 + cg * 4;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (c < C)
-        for (int p = sl; p < P; p += 64) a += *reinterpret_cast<const f32x4*>(part + ((size_t)b * P + p) * C + c);
-    *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = a;
-    __syncthreads();
-    for (int h = 32; h > 0; h >>= 1) {      // fixed-order tree over the 64 slices: deterministic
-        if (sl < h) {
-            a = *reinterpret_cast<const f32x4*>(red + threadIdx.x * 4) + *reinterpret_cast<const f32x4*>(red + (threadIdx.x + h * 4) * 4);
-            *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = a;
-        }
-        __syncthreads();
+// pass 2: gate = relu6(fc(mean) + 3) / 6 straight from the partial column sums, ONE launch (it was k_colmean + k_ese_gate: two ~5 us
+// launch floors per stage).  Every block (16 waves, one output channel each) first reduces part[b][0..P)[C] to the mean vector in LDS
+// -- redundantly, in the same fixed order in every block, so all blocks hold the same bits and nothing crosses blocks -- while its
+// fc weight row is already on its way to registers; then one wave per output (coalesced row, shuffle reduction).
+// Optional (bs = 1 engine): the block also writes the sixteen gate-scaled COLUMNS of a consumer's packed 1x1 weight, lws[n][o] =
+// lw[n][o] * gate[o] (n < lrows) -- the FPN lateral of this stage then reads x * (g W) instead of (x * g) W: the same product with
+// the per-channel multiplier moved onto the weights, so the lateral runs on the DMA-fed conv kernel (which cannot touch its A
+// operand) instead of k_conv_igemm's input-affine path.
+constexpr int ESE_T = 1024, ESE_FP = 8;
+__global__ __launch_bounds__(ESE_T) void k_ese_gate_fused(const float* __restrict__ part, int P, int HW, int C, const float* __restrict__ fw,
+                                                          const float* __restrict__ fb, float* __restrict__ gate,
+                                                          const float* __restrict__ lw, float* __restrict__ lws, int lrows, int lws_bf16) {
+    __shared__ __attribute__((aligned(16))) float red[4096];     // [NSL][C], NSL * C <= 4096
+    __shared__ __attribute__((aligned(16))) float mean_s[4096];
+    __shared__ float g16[16];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int o = blockIdx.x * 16 + wave;
+    float fwv[ESE_FP];                                           // the first 512 weights of this wave's row: in flight under the reduction
+#pragma unroll
+    for (int j = 0; j < ESE_FP; ++j) {
+        const int k = lane + 64 * j;
+        fwv[j] = (o < C && k < C) ? fw[(size_t)o * C + k] : 0.f;
     }
-    if (sl == 0 && c < C) *reinterpret_cast<f32x4*>(mean + (size_t)b * C + c) = a * (1.0f / (float)HW);
-}
-
-// pass 2b: gate = relu6(fc(mean) + 3) / 6; one wave per output channel (coalesced weight row), 4 outputs per block.
-// Optional (bs = 1 engine): the block also writes the four gate-scaled COLUMNS of a consumer's packed 1x1 weight, lws[n][o] =
-// lw[n][o] * gate[o] (n < lrows, 16 bytes per row and block) -- the FPN lateral of this stage then reads x * (g W) instead of
-// (x * g) W: the same product with the per-channel multiplier moved onto the weights, so the lateral runs on the DMA-fed conv kernel
-// (which cannot touch its A operand) instead of k_conv_igemm's input-affine path.
-__global__ __launch_bounds__(256) void k_ese_gate(const float* __restrict__ mean, int C, const float* __restrict__ fw,
-                                                  const float* __restrict__ fb, float* __restrict__ gate,
-                                                  const float* __restrict__ lw, float* __restrict__ lws, int lrows, int lws_bf16 = 0) {
-    __shared__ float g4[4];
-    const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int o = blockIdx.x * 4 + wave;
+    const int Q4 = C >> 2, NSL = ESE_T / Q4;                     // C <= 4096: NSL >= 1
+    {
+        const int q = tid % Q4, sl = tid / Q4;
+        if (sl < NSL) {
+            const float* pb = part + (size_t)b * P * C + q * 4;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            int p = sl;
+            for (; p + 7 * NSL < P; p += 8 * NSL) {              // 8 independent loads in flight, summed in a fixed order
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(pb + (size_t)(p + u * NSL) * C);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+            for (; p < P; p += NSL) a += *reinterpret_cast<const f32x4*>(pb + (size_t)p * C);
+            *reinterpret_cast<f32x4*>(red + sl * C + q * 4) = a;
+        }
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)HW;
+    for (int c = tid; c < C; c += ESE_T) {
+        float m = red[c];
+        for (int sl = 1; sl < NSL; ++sl) m += red[sl * C + c];
+        mean_s[c] = m * inv;
+    }
+    __syncthreads();
     if (o < C) {
-        const float* m = mean + (size_t)b * C;
         float s = 0.f;
-        for (int k = lane; k < C; k += 64) s += fw[(size_t)o * C + k] * m[k];
+#pragma unroll
+        for (int j = 0; j < ESE_FP; ++j) {
+            const int k = lane + 64 * j;
+            if (k < C) s += fwv[j] * mean_s[k];
+        }
+        for (int k = lane + 64 * ESE_FP; k < C; k += 64) s += fw[(size_t)o * C + k] * mean_s[k];
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
         if (lane == 0) {
             const float v = s + fb[o] + 3.0f;
             const float gv = fminf(fmaxf(v, 0.f), 6.0f) / 6.0f;
             gate[b * C + o] = gv;
-            g4[wave] = gv;
+            g16[wave] = gv;
         }
     }
     if (!lws) return;                                   // (uniform)
     __syncthreads();
-    const int o0 = blockIdx.x * 4;                      // C % 4 == 0: the four columns of this block are all real
-    for (int n = threadIdx.x; n < lrows; n += 256) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(lw + (size_t)n * C + o0);
-        const f32x4 ws4 = f32x4{w.x * g4[0], w.y * g4[1], w.z * g4[2], w.w * g4[3]};
-        if (lws_bf16) st4(reinterpret_cast<ore_bf16_t*>(lws) + (size_t)n * C + o0, ws4);      // bf16 storage: the scaled weight is a bf16 tensor
-        else *reinterpret_cast<f32x4*>(lws + (size_t)n * C + o0) = ws4;
+    const int o0 = blockIdx.x * 16;                     // C % 4 == 0: a column quad of this block is all real or all beyond C
+    for (int it = tid; it < lrows * 4; it += ESE_T) {
+        const int n = it >> 2, j = it & 3;
+        if (o0 + j * 4 >= C) continue;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lw + (size_t)n * C + o0 + j * 4);
+        const f32x4 ws4 = f32x4{w.x * g16[j * 4], w.y * g16[j * 4 + 1], w.z * g16[j * 4 + 2], w.w * g16[j * 4 + 3]};
+        if (lws_bf16) st4(reinterpret_cast<ore_bf16_t*>(lws) + (size_t)n * C + o0 + j * 4, ws4);   // bf16 storage: the scaled weight is a bf16 tensor
+        else *reinterpret_cast<f32x4*>(lws + (size_t)n * C + o0 + j * 4) = ws4;
     }
 }
 
@@ -706,11 +728,9 @@ extern "C" int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_
     hipLaunchKernelGGL(k_colsum_partial, dim3(P, B), dim3(256), 0, st, x, ld, coff, HW, C, workspace);
     int rc = ore_launch_status("k_colsum_partial");
     if (rc) return rc;
-    float* mean = workspace + (size_t)B * P * C;
-    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), B), dim3(256), 0, st, workspace, P, HW, C, mean);
-    if ((rc = ore_launch_status("k_colmean"))) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean, C, fc_w, fc_b, gate, (const float*)nullptr, (float*)nullptr, 0);
-    return ore_launch_status("k_ese_gate");
+    hipLaunchKernelGGL(k_ese_gate_fused, dim3(ceil_div(C, 16), B), dim3(ESE_T), 0, st, workspace, P, HW, C, fc_w, fc_b, gate,
+                       (const float*)nullptr, (float*)nullptr, 0, 0);
+    return ore_launch_status("k_ese_gate_fused");
 }
 
 extern "C" int ore_ese_gate_from_colsum_fwd(const float* part, int32_t P, int32_t B, int32_t HW, int32_t C, const float* fc_w,
@@ -718,11 +738,9 @@ extern "C" int ore_ese_gate_from_colsum_fwd(const float* part, int32_t P, int32_
     ORE_CHECK_ARG(part && fc_w && fc_b && gate && mean_ws && P > 0 && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096,
                   "ore_ese_gate_from_colsum_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), B), dim3(256), 0, st, part, P, HW, C, mean_ws);
-    int rc = ore_launch_status("k_colmean");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), B), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, (const float*)nullptr, (float*)nullptr, 0);
-    return ore_launch_status("k_ese_gate");
+    hipLaunchKernelGGL(k_ese_gate_fused, dim3(ceil_div(C, 16), B), dim3(ESE_T), 0, st, part, P, HW, C, fc_w, fc_b, gate,
+                       (const float*)nullptr, (float*)nullptr, 0, 0);
+    return ore_launch_status("k_ese_gate_fused");
 }
 
 extern "C" int ore_ese_gate_scaled_weight_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
@@ -731,11 +749,9 @@ extern "C" int ore_ese_gate_scaled_weight_fwd(const float* part, int32_t P, int3
     ORE_CHECK_ARG(part && fc_w && fc_b && gate && mean_ws && w_packed && w_scaled && P > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096 &&
                       w_rows > 0, "ore_ese_gate_scaled_weight_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), 1), dim3(256), 0, st, part, P, HW, C, mean_ws);
-    int rc = ore_launch_status("k_colmean");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), 1), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, w_packed, w_scaled, (int)w_rows, 0);
-    return ore_launch_status("k_ese_gate");
+    hipLaunchKernelGGL(k_ese_gate_fused, dim3(ceil_div(C, 16), 1), dim3(ESE_T), 0, st, part, P, HW, C, fc_w, fc_b, gate, w_packed, w_scaled,
+                       (int)w_rows, 0);
+    return ore_launch_status("k_ese_gate_fused");
 }
 
 extern "C" int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
@@ -744,12 +760,9 @@ extern "C" int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P,
     ORE_CHECK_ARG(part && fc_w && fc_b && gate && mean_ws && w_packed_f32 && w_scaled_bf16 && P > 0 && HW > 0 && C > 0 && C % 32 == 0 &&
                       C <= 4096 && w_rows > 0, "ore_ese_gate_scaled_weight_bf16_fwd: bad args (C must be a multiple of 32)");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(C, 16), 1), dim3(256), 0, st, part, P, HW, C, mean_ws);
-    int rc = ore_launch_status("k_colmean");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_ese_gate, dim3(ceil_div(C, 4), 1), dim3(256), 0, st, mean_ws, C, fc_w, fc_b, gate, w_packed_f32,
+    hipLaunchKernelGGL(k_ese_gate_fused, dim3(ceil_div(C, 16), 1), dim3(ESE_T), 0, st, part, P, HW, C, fc_w, fc_b, gate, w_packed_f32,
                        reinterpret_cast<float*>(w_scaled_bf16), (int)w_rows, 1);
-    return ore_launch_status("k_ese_gate");
+    return ore_launch_status("k_ese_gate_fused");
 }
 
 extern "C" int ore_scale_channels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
