@@ -240,6 +240,147 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_conv3x3_wino_nu -- the same arithmetic for the input widths that are not 64 / 128: 80, 96 and 112 channels (the 3x3 layers of
+// stages 3-5: stage 3 of a single image, all three at training batch sizes, and their dgrads).  What differs from k_conv3x3_wino:
+//   roles   wave w: xi = w & 3, and the second wave of an xi takes the positions nu = 2, 3 (the first nu = 0, 1) -- the split is over
+//           NU, not over output or input channels, so a wave multiplies 2 positions x NCGB*16 output channels x CIN input channels
+//           (96-120 VGPRs of weights) and the two waves' halves of the nu transform meet in P3 exactly like the K halves of the
+//           128-channel build.  A block covers NCGB * 16 output channels (48 at 80 input channels, else 32); channels past Cout in
+//           the last block column multiply zero weights (a block owns its CU for the whole launch, skipping them would free nothing).
+//   LDS     rows padded by 4 floats instead of XOR-swizzled (the strides 84 / 100 / 116 and 52 / 36 floats are odd multiples of 16
+//           bytes: the 16 tiles x 4 quads of a fragment read fall on all banks evenly).
+//   P1      thread = (tile, 4 channels) for all four xi: the 4 x 4 patch in 16 loads issued together (one round trip), 16 LDS stores.
+template <int CIN, int NCGB>
+__global__ __launch_bounds__(512, 2) void k_conv3x3_wino_nu(WinoP p) {
+    constexpr int NC = CIN / 16, COUTB = NCGB * 16;
+    constexpr int QV = CIN / 4, QZ = COUTB / 4;
+    constexpr int VS = CIN + 4, ZS = COUTB + 4;     // row strides in floats
+    constexpr int VF = 16 * 16 * VS;
+    static_assert(CIN % 16 == 0 && 16 * QV <= 512 && 32 * QZ <= 512, "one P1 / P3 item per thread");
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    float* V = wl;                                  // [16 pos][16 tiles][VS]
+    float* Z = wl + VF;                             // [4 xi][2 nu half][2 j][16 tiles][ZS]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int xi = w & 3, hi = w >> 2;
+    const int n16_0 = blockIdx.y * NCGB, ncg_real = min(NCGB, (p.Cout16 >> 4) - n16_0);
+
+    f32x4 wf[2][NCGB][NC];
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+        for (int cg = 0; cg < NCGB; ++cg)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                wf[n2][cg][c] = cg < ncg_real ? wino_u_frag(p.U, xi * 4 + hi * 2 + n2, n16_0 + cg, c, p.Cout16, CIN, lane)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool p1_on = tid < 16 * QV;
+    const int q1 = tid % QV, t1 = (tid / QV) & 15;
+    const int ty1 = t1 >> 3, tx1 = t1 & 7;
+    const int cq3 = tid % QZ, j3 = (tid / QZ) & 1, t3 = tid / (2 * QZ);
+    const int n3 = blockIdx.y * COUTB + cq3 * 4;
+    const bool p3_on = t3 < 16 && n3 < p.Cout;
+    const int ty3 = (t3 & 15) >> 3, tx3 = t3 & 7;
+    const float* zero = g_zero_wino;
+
+    for (int bat = blockIdx.x; bat < p.nbat; bat += gridDim.x) {
+        int lvl = 0;
+#pragma unroll
+        for (int l = 1; l < 4; ++l)
+            if (l < p.nlev && bat >= p.bat0[l]) lvl = l;
+        const Lvl L = p.lv[lvl];
+        const int r0 = bat - p.bat0[lvl], per = p.nbx[lvl] * p.nby[lvl];
+        const int b = r0 / per, r1 = r0 - b * per;
+        const int byi = r1 / p.nbx[lvl], bxi = r1 - byi * p.nbx[lvl];
+        const int H = L.H, W = L.W;
+        // ---------------- P1: input transform -> V
+        if (p1_on) {
+            const int iy0 = (byi * 2 + ty1) * 2 - 1, ix0 = (bxi * 8 + tx1) * 2 - 1;
+            const float* base = p.in + (ptrdiff_t)(L.irow0 + b * H * W) * p.in_ld + p.in_coff + q1 * 4;
+            f32x4 d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    d[r][c] = *reinterpret_cast<const f32x4*>(ok ? base + (ptrdiff_t)(iy * W + ix) * p.in_ld : zero);
+                }
+            float* vrow = V + t1 * VS + q1 * 4;
+#pragma unroll
+            for (int x1 = 0; x1 < 4; ++x1) {
+                f32x4 X[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    X[c] = x1 == 0 ? d[0][c] - d[2][c] : x1 == 1 ? d[1][c] + d[2][c] : x1 == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c];
+                float* vr = vrow + (x1 * 4) * 16 * VS;
+                *reinterpret_cast<f32x4*>(vr) = X[0] - X[2];
+                *reinterpret_cast<f32x4*>(vr + 16 * VS) = X[1] + X[2];
+                *reinterpret_cast<f32x4*>(vr + 32 * VS) = X[2] - X[1];
+                *reinterpret_cast<f32x4*>(vr + 48 * VS) = X[1] - X[3];
+            }
+        }
+        lds_barrier();
+        // ---------------- P2: this wave's two positions x all block channels
+        {
+            f32x4 acc[2][NCGB];
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int cg = 0; cg < NCGB; ++cg) acc[n2][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* vb = V + ((xi * 4 + hi * 2) * 16 + li) * VS + g * 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f32x4 bf[2];
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) bf[n2] = *reinterpret_cast<const f32x4*>(vb + n2 * 16 * VS + c * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                        for (int cg = 0; cg < NCGB; ++cg)
+                            acc[n2][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n2][cg][c][k], bf[n2][k], acc[n2][cg], 0, 0, 0);
+            }
+            // this wave's half of the nu transform: Z_0 = (M0 + M1) + M2, Z_1 = M1 - (M2 + M3)
+            float* zb = Z + (((xi * 2 + hi) * 2) * 16 + li) * ZS + g * 4;
+#pragma unroll
+            for (int cg = 0; cg < NCGB; ++cg) {
+                const f32x4 z0 = hi == 0 ? acc[0][cg] + acc[1][cg] : acc[0][cg];
+                const f32x4 z1 = hi == 0 ? acc[1][cg] : -(acc[0][cg] + acc[1][cg]);
+                *reinterpret_cast<f32x4*>(zb + cg * 16) = z0;
+                *reinterpret_cast<f32x4*>(zb + 16 * ZS + cg * 16) = z1;
+            }
+        }
+        lds_barrier();
+        // ---------------- P3: the halves meet, xi half of the output transform, epilogue, store
+        if (p3_on) {
+            f32x4 z[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float* zr = Z + (((x * 2) * 2 + j3) * 16 + t3) * ZS + cq3 * 4;
+                z[x] = *reinterpret_cast<const f32x4*>(zr) + *reinterpret_cast<const f32x4*>(zr + 2 * 16 * ZS);
+            }
+            const f32x4 y0 = (z[0] + z[1]) + z[2], y1 = (z[1] - z[2]) - z[3];
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + lvl * p.ep_stride + n3);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + lvl * p.ep_stride + n3);
+            f32x4 v0 = y0 * sc + sh, v1 = y1 * sc + sh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n3 + r < p.relu_cout) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
+            const int oy = (byi * 2 + ty3) * 2, ox = (bxi * 8 + tx3) * 2 + j3;
+            if (ox < W && oy < H) {
+                float* o = p.out + (size_t)(L.orow0 + b * H * W + oy * W + ox) * p.out_ld + p.out_coff + n3;
+                *reinterpret_cast<f32x4*>(o) = v0;
+                if (oy + 1 < H) *reinterpret_cast<f32x4*>(o + (size_t)W * p.out_ld) = v1;
+            }
+        }
+    }
+}
+
 int g_wino_mode = 1;          // ore_conv_set_plan_override(-7, mode): 0 off, 1 automatic (M >= 6000), 2 wherever it applies
 
 }  // namespace
@@ -248,13 +389,35 @@ namespace oreconv {
 
 void conv_wino_mode(int mode) { g_wino_mode = mode; }
 
+// the (Cin, Cout) pairs of 3x3 stride-1 layers a Winograd build exists for
+bool conv_wino_covers(int Cout, int Cin) {
+    if (Cout <= 0 || Cout % 16 != 0) return false;
+    if (Cin == 64) return Cout % 64 == 0;
+    if (Cin == 128) return Cout % 32 == 0;
+    return Cin == 80 || Cin == 96 || Cin == 112;
+}
+
+template <int CIN, int NCGB>
+static int wino_nu_go(const WinoP& p, int nb, hipStream_t st) {
+    const int gy = ceil_div(p.Cout16 / 16, NCGB);
+    int gx = 256 / gy;                                  // one resident block per CU
+    if (gx > nb) gx = nb;
+    if (gx < 1) gx = 1;
+    const size_t lds = ((size_t)16 * 16 * (CIN + 4) + 4 * 2 * 2 * 16 * (NCGB * 16 + 4)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        ORE_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wino_nu<CIN, NCGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3_wino_nu<CIN, NCGB>), dim3(gx, gy), dim3(512), lds, st, p);
+    return ore_launch_status("k_conv3x3_wino_nu");
+}
+
 // ORE_OK if launched, 1 if the layer is not covered (the caller goes on to the direct kernels)
 int conv_wino_launch(const ConvP& c, hipStream_t st) {
     if (!g_wino_mode || !c.wino || c.bf16) return 1;
     if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.in_mul || c.add || c.colsum) return 1;
-    if (c.Cin != 64 && c.Cin != 128) return 1;
-    const int coutb = c.Cin == 64 ? 64 : 32;
-    if (c.Cout != c.Cout16 || c.Cout % coutb != 0) return 1;
+    if (c.Cout != c.Cout16 || !conv_wino_covers(c.Cout, c.Cin)) return 1;
     if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 15) != 0 || c.in_ld % 4 != 0 || c.in_coff % 4 != 0) return 1;
     if (c.ep_stride % 4 != 0 || ((uintptr_t)c.scale & 15) != 0 || ((uintptr_t)c.shift & 15) != 0) return 1;
     if (g_wino_mode != 2 && c.M < 6000) return 1;      // the small-M layers are latency-bound, not multiply-bound
@@ -271,6 +434,10 @@ int conv_wino_launch(const ConvP& c, hipStream_t st) {
     p.U = c.wino; p.Cout = c.Cout; p.Cout16 = c.Cout16;
     p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
     p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
+    if (c.Cin == 80) return wino_nu_go<80, 3>(p, nb, st);
+    if (c.Cin == 96) return wino_nu_go<96, 2>(p, nb, st);
+    if (c.Cin == 112) return wino_nu_go<112, 2>(p, nb, st);
+    const int coutb = c.Cin == 64 ? 64 : 32;
     const int gy = c.Cout / coutb;
     int gx = 256 / gy;                                  // one resident block per CU
     if (gx > nb) gx = nb;
@@ -288,6 +455,8 @@ int conv_wino_launch(const ConvP& c, hipStream_t st) {
 }
 
 }  // namespace oreconv
+
+extern "C" int32_t ore_winograd_covers(int32_t Cout, int32_t Cin) { return oreconv::conv_wino_covers(Cout, Cin) ? 1 : 0; }
 
 extern "C" size_t ore_winograd_weight_floats(int32_t Cout, int32_t Cin) { return (size_t)16 * round_up(Cout, 16) * Cin; }
 

@@ -25,7 +25,7 @@ struct HostTensor { std::vector<float> v; std::vector<int64_t> shape; };
 struct Conv {
     float* w = nullptr; float* scale = nullptr; float* shift = nullptr;
     uint16_t* wh = nullptr;              // bf16 packed weights (engines created in ORE_CONV_BF16S mode)
-    float* wino = nullptr;               // Winograd F(2x2,3x3) form of w for the 3x3 stride-1 layers with Cin 64 / 128 (else null)
+    float* wino = nullptr;               // Winograd F(2x2,3x3) form of w where ore_winograd_covers() (else null)
     int Cin = 0, Cout = 0, k = 1, stride = 1, pad = 0, relu_cout = 0;
 };
 
@@ -159,7 +159,7 @@ int make_bf16_w(ore_engine* e, Conv* c, const float* w_oihw) {
 
 int make_wino(ore_engine* e, Conv* c) {
     if (e->sb()) return ORE_OK;
-    if (c->k != 3 || c->stride != 1 || (c->Cin != 64 && c->Cin != 128) || c->Cout % 64 != 0) return ORE_OK;
+    if (c->k != 3 || c->stride != 1 || !ore_winograd_covers(c->Cout, c->Cin)) return ORE_OK;
     int rc = e->dalloc(&c->wino, ore_winograd_weight_floats(c->Cout, c->Cin));
     if (rc) return rc;
     if ((rc = ore_winograd_weight_fwd(c->w, c->Cout, c->Cin, c->wino, nullptr))) return rc;

@@ -54,7 +54,7 @@ class _Unit(nn.Sequential):
             w = orehip.pack_conv_weight(conv.weight)
             # 3x3 stride-1 layers with 64 / 128 input channels also get the Winograd form of their weights: the library then runs the
             # large-M launches (stem_2, stage 2; every frozen layer of a training step) on k_conv3x3_wino
-            wino_ok = conv.kernel_size[0] == 3 and conv.stride[0] == 1 and conv.in_channels in (64, 128) and conv.out_channels % 64 == 0
+            wino_ok = conv.kernel_size[0] == 3 and conv.stride[0] == 1 and orehip.winograd_covers(conv.out_channels, conv.in_channels)
             U = orehip.winograd_weight(w, conv.out_channels, conv.in_channels) if wino_ok and w.is_cuda else None
             self._cache = (key, w, sc.contiguous(), sh.contiguous(), U)
         _, w, sc, sh, U = self._cache

@@ -59,12 +59,12 @@ def _c16(n: int) -> int:
 
 
 def packed_wino(w: torch.Tensor, dgrad: bool):
-    """Winograd F(2x2,3x3) form of packed(w, dgrad) for the 3x3 layers k_conv3x3_wino covers (64 / 128 channels on the conv's input
-    side, a multiple of 64 on its output side), else None.  Cached next to the packed copy, same tag."""
+    """Winograd F(2x2,3x3) form of packed(w, dgrad) for the 3x3 layers the Winograd kernels cover (ore_winograd_covers), else None.
+    Cached next to the packed copy, same tag."""
     if w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
         return None
     cout, cin = (w.shape[1], _c16(w.shape[0])) if dgrad else (w.shape[0], w.shape[1])     # of the conv that will be launched
-    if cin not in (64, 128) or cout % 64 != 0:
+    if not orehip.winograd_covers(cout, cin):
         return None
     pw = packed(w, dgrad)
     base = _base_param(w)

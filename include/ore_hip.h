@@ -81,7 +81,10 @@ int ore_pack_conv_weight_bf16_host(const float* w_oihw, int32_t Cout, int32_t Ci
 
 /* Winograd F(2x2,3x3) form of packed 3x3 weights: U_p = G g G^T per (Cout, Cin) pair for the 16 positions p, computed on the device in
  * fp32 (the halves in G are exact), stored in the kernel's MFMA-fragment order [16][Cout16/16][Cin/16][64 lanes][4] (opaque to callers).  `packed_w` is ore_pack_conv_weight_host's layout for kh = kw = 3; U needs
- * ore_winograd_weight_floats(Cout, Cin) floats.  Call again whenever the weights change. */
+ * ore_winograd_weight_floats(Cout, Cin) floats.  Call again whenever the weights change.  ore_winograd_covers: 1 if a Winograd build
+ * exists for a 3x3 stride-1 pad-1 layer of these widths (Cin 64 with Cout % 64 == 0, Cin 128 with Cout % 32 == 0, Cin 80 / 96 / 112 with
+ * Cout % 16 == 0); for other layers ore_conv_desc.w_wino is ignored. */
+int32_t ore_winograd_covers(int32_t Cout, int32_t Cin);
 size_t ore_winograd_weight_floats(int32_t Cout, int32_t Cin);
 int ore_winograd_weight_fwd(const float* packed_w, int32_t Cout, int32_t Cin, float* U, void* stream);
 

@@ -123,6 +123,12 @@ def wino_forced(ore):
     (2, 13, 11, 64, 128),     # odd sizes: tiles hanging over the right and bottom edge, two images, two channel blocks
     (1, 10, 40, 128, 128),    # FPN output / head tower class
     (1, 3, 5, 64, 64),        # smaller than one batch
+    (1, 24, 40, 80, 80),      # nu-split build (k_conv3x3_wino_nu): stage-3 class, 48 channels per block, second block 32 real
+    (2, 13, 19, 112, 80),     # stage-3 layer 0 class: 32 channels per block, third block half empty; odd sizes, two images
+    (1, 20, 20, 96, 96),      # stage-4 class, three full channel blocks
+    (1, 9, 33, 112, 112),     # stage-5 class
+    (1, 12, 16, 96, 256),     # dgrad of stage-4 layer 0: eight channel blocks
+    (1, 7, 9, 80, 16),        # a single channel group
 ])
 def test_conv_winograd_kernel_vs_oracle(ore, wino_forced, B, H, W, Cin, Cout):
     """k_conv3x3_wino against F.conv2d at the fp32 tolerance, with FrozenBN scale / shift + ReLU, and bit-reproducible."""
@@ -181,6 +187,18 @@ def test_conv_winograd_slices_levels_bias(ore, wino_forced):
         ref_l = F.conv2d(t, w2, b2, 1, 1)[0].permute(1, 2, 0).reshape(-1, 128)
         assert rel_err(y[r0:r0 + h * w_].numpy(), ref_l.numpy()) < TOL
         r0 += h * w_
+    # nu-split build: slice of the stage-3 concat buffer in, slice out
+    buf3 = torch.randn(1, 352, 12, 20, generator=g)
+    w3 = torch.randn(80, 80, 3, 3, generator=g) * 0.04
+    sh3 = torch.randn(80, generator=g) * 0.1
+    out3 = torch.full((1, 12, 20, 352), 7.0).cuda()
+    wp3 = ore.pack_conv_weight(w3).cuda()
+    ore.conv2d(nhwc(buf3), wp3, 80, 3, 1, in_coff=112, Cin=80, shift=dev(sh3), relu_cout=80, out=out3, out_coff=192,
+               w_wino=ore.winograd_weight(wp3, 80, 80))
+    ref3 = F.relu(F.conv2d(buf3[:, 112:192], w3, sh3, 1, 1))
+    assert rel_err(nchw(out3[..., 192:272].contiguous()).numpy(), ref3.numpy()) < TOL
+    assert float(out3[..., :192].min()) == 7.0 and float(out3[..., 272:].max()) == 7.0
+    assert ore.winograd_covers(80, 80) and ore.winograd_covers(384, 112) and not ore.winograd_covers(96, 256) and not ore.winograd_covers(40, 80)
     ore.lib().ore_conv_set_plan_override(-7, 1, 0, 0, 0)                              # automatic: M = 6400 qualifies
     x3 = torch.randn(1, 64, 80, 80, generator=g)
     y3 = ore.conv2d(nhwc(x3), wp, 64, 3, 1, shift=dev(sh), w_wino=U)
@@ -847,7 +865,16 @@ def test_detector_inference_many_equals_one_at_a_time(model, sd):
         gi = got["instances"]
         assert gi.image_size == one.image_size and len(gi) == len(one) and len(one) > 0
         np.testing.assert_allclose(gi.scores.cpu().numpy(), one.scores.cpu().numpy(), rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(gi.pred_boxes.tensor.cpu().numpy(), one.pred_boxes.tensor.cpu().numpy(), rtol=1e-4, atol=0.05)
+        # the folded pass reduces the eSE pools in another order (1e-7 on the gates): detections whose scores agree to 1e-4 may swap
+        # places in the score-sorted list, so the boxes are matched as a set among rows of (nearly) equal score
+        gb, ob = gi.pred_boxes.tensor.cpu().numpy(), one.pred_boxes.tensor.cpu().numpy()
+        gs, os_ = gi.scores.cpu().numpy(), one.scores.cpu().numpy()
+        used = np.zeros(len(gb), dtype=bool)
+        for i in range(len(ob)):
+            cand = np.nonzero(~used & (np.abs(gs - os_[i]) <= 1e-4 * abs(os_[i]) + 1e-6))[0]
+            hit = [j for j in cand if np.allclose(gb[j], ob[i], rtol=1e-4, atol=0.05)]
+            assert hit, "detection %d of the one-at-a-time pass (score %.6f) has no partner in the folded pass" % (i, os_[i])
+            used[hit[0]] = True
 
 
 # ------------------------------------------------------------------------------------------ batched-level / fused entry points

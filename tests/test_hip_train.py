@@ -741,21 +741,52 @@ def test_train_forward_batch_and_empty_gt(oh):
         assert abs(float(l_raw[k]) - float(l_gen[k])) <= 2e-5 * max(abs(float(l_gen[k])), 1e-3), k
     # the batched pass (two batched backbone passes, ONE second-stage pass over the ROIs of both images) against the two
     # single-image passes, with a deterministic fg/bg subsample so that all five losses and the gradients are comparable
-    c = item(3, 3)
     det = lambda n: torch.arange(n - 1, -1, -1)                                                 # noqa: E731
-    m.zero_grad(set_to_none=True)
-    l2, aux = TF.train_forward(m, [a, c], perm=det, return_aux=True)
-    assert len(aux["rois_per_image"]) == 2 and int(aux["valid"].sum()) == sum(aux["rois_per_image"])
-    sum(l2.values()).backward()
-    batch_grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
-    navg = (aux["cn_counts"] / 2).clamp(min=1.0)
-    singles, grads = [], []
-    for it in (a, c):
+    # The two kinds of pass run different conv kernels on the frozen stages (the batch crosses the Winograd row threshold): features
+    # differ by ~1e-6, harmless everywhere except AT the two kinks of the trainable eSE gates' hsigmoid, where d gate / d z jumps
+    # between 0 and 1/6 (seed 3 puts a stage-5 pre-activation 2.4e-6 from z = 3, and its derivative flips between the passes).  The
+    # comparison is defined where both passes sit on the same linear piece, so a candidate second image whose masks differ is skipped.
+    zs = []
+    real_addmm = torch.addmm
+
+    def spy(*args, **kw):                                                                       # EseFn.forward: z = addmm(fc_b, mean, W^T)
+        zs.append(real_addmm(*args, **kw).detach())
+        return real_addmm(*args, **kw)
+
+    def spied(fn):
+        del zs[:]
+        torch.addmm = spy
+        try:
+            out = fn()
+        finally:
+            torch.addmm = real_addmm
+        return out, [((z > -3.0) & (z < 3.0)) for z in zs]
+    for seed_c in (3, 4, 5, 6):
+        c = item(seed_c, 3)
         m.zero_grad(set_to_none=True)
-        l1 = TF.train_forward(m, [it], perm=det, cn_norm_avg=navg)
-        sum(l1.values()).backward()
-        singles.append({k: float(v) for k, v in l1.items()})
-        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        (l2, aux), mask_b = spied(lambda: TF.train_forward(m, [a, c], perm=det, return_aux=True))
+        assert len(mask_b) >= 2                                                                 # the trainable stages' gates were seen
+        assert len(aux["rois_per_image"]) == 2 and int(aux["valid"].sum()) == sum(aux["rois_per_image"])
+        sum(l2.values()).backward()
+        batch_grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        navg = (aux["cn_counts"] / 2).clamp(min=1.0)
+        singles, grads, same_piece = [], [], True
+        for i, it in enumerate((a, c)):
+            m.zero_grad(set_to_none=True)
+            # the single pass trains on the batch's ROI sample of this image (a 1e-6 heatmap difference may swap two proposals of
+            # nearly equal score)
+            over_i = {"boxes": aux["roi_boxes"][i], "labels": aux["roi_labels"][i], "gt": aux["roi_gt"][i]}
+            l1, mask_1 = spied(lambda: TF.train_forward(m, [it], roi_override=over_i, cn_norm_avg=navg))
+            # (query pass: one row per image; support pass: `shots` rows per image)
+            same_piece = same_piece and len(mask_1) == len(mask_b) and all(
+                torch.equal(mb[i * m1.shape[0]:(i + 1) * m1.shape[0]], m1) for mb, m1 in zip(mask_b, mask_1))
+            sum(l1.values()).backward()
+            singles.append({k: float(v) for k, v in l1.items()})
+            grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        if same_piece:
+            break
+    else:
+        pytest.fail("every candidate image flips an eSE hsigmoid derivative between the batched and the single pass")
     for k in singles[0]:
         want = 0.5 * (singles[0][k] + singles[1][k])
         assert abs(float(l2[k]) - want) <= 2e-4 * max(abs(want), 1e-3), (k, float(l2[k]), want)
@@ -765,9 +796,9 @@ def test_train_forward_batch_and_empty_gt(oh):
             assert n not in grads[0]
             continue
         want = 0.5 * (grads[0][n] + grads[1][n])
-        errs.append(float((batch_grads[n] - want).abs().max() / want.abs().max().clamp_min(1e-12)))
+        errs.append((float((batch_grads[n] - want).abs().max() / want.abs().max().clamp_min(1e-12)), n))
     errs.sort()
-    assert errs[len(errs) // 2] <= 1e-4 and errs[int(len(errs) * 0.85)] <= 1e-3 and errs[-1] <= 2e-2, errs[-5:]
+    assert errs[len(errs) // 2][0] <= 1e-4 and errs[int(len(errs) * 0.85)][0] <= 1e-3 and errs[-1][0] <= 2e-2, errs[-12:]
 
 
 def test_colsum_segments_and_scaled_gate_weight(oh):
