@@ -161,7 +161,7 @@ class OSAFn(Function):
         src, cin, dst = 0, in_ch, in_ch
         for i in range(n):
             orehip.conv2d(cat, packed(ws[i], False), stage_ch, 3, 1, 1, in_coff=src, Cin=cin, scale=scs[i], shift=shs[i],
-                          relu_cout=stage_ch, out=cat, out_coff=dst)
+                          relu_cout=stage_ch, out=cat, out_coff=dst, w_wino=packed_wino(ws[i], False))
             src, cin, dst = dst, stage_ch, dst + stage_ch
         y = orehip.conv2d(cat, packed(ws[n], False), ws[n].shape[0], 1, 1, 0, scale=scs[n], shift=shs[n], relu_cout=ws[n].shape[0])
         ctx.save_for_backward(cat, y, *ws, *scs)
@@ -186,7 +186,7 @@ class OSAFn(Function):
             if ctx.needs_input_grad[1 + 3 * i]:
                 grads[3 * i] = orehip.conv2d_wgrad(cat, dzi, 3, x_coff=src, Cin=cin)
             if i > 0 or ctx.needs_input_grad[0]:
-                dcat[..., src:src + cin] += orehip.conv2d(dzi, packed(ws[i], True), cin, 3, 1, 1)
+                dcat[..., src:src + cin] += orehip.conv2d(dzi, packed(ws[i], True), cin, 3, 1, 1, w_wino=packed_wino(ws[i], True))
         gx = dcat[..., :in_ch].contiguous() if ctx.needs_input_grad[0] else None
         return (gx, *grads)
 
