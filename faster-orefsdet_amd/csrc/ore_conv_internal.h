@@ -56,7 +56,7 @@ void conv_xmap_force(int mode);
 int conv_xmap_forced();                          // -1 when automatic                  // (-5, mode): -1 automatic, 0 / 1 / 2 force the block -> tile mapping of k_conv_kw
 // ore_conv_wino.hip: Winograd F(2x2,3x3) kernel for the large-M 3x3 stride-1 layers.  1 = not covered.
 int conv_wino_launch(const ConvP& p, hipStream_t st);
-void conv_wino_mode(int mode);                             // (-7, mode): 0 off, 1 automatic (M >= 6000), 2 wherever it applies
+void conv_wino_mode(int mode);                             // (-7, mode): 0 off, 1 automatic (by row count), 2 wherever it applies
 bool conv_wino_covers(int Cout, int Cin);                  // a Winograd build exists for this 3x3 stride-1 layer
 void conv_gs_force(int bm, int bn, int ns);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic
 

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_nu(WinoP p) {
     }
 }
 
-int g_wino_mode = 1;          // ore_conv_set_plan_override(-7, mode): 0 off, 1 automatic (M >= 6000), 2 wherever it applies
+int g_wino_mode = 1;          // ore_conv_set_plan_override(-7, mode): 0 off, 1 automatic (by row count), 2 wherever it applies
 
 }  // namespace
 
@@ -420,7 +420,9 @@ int conv_wino_launch(const ConvP& c, hipStream_t st) {
     if (c.Cout != c.Cout16 || !conv_wino_covers(c.Cout, c.Cin)) return 1;
     if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 15) != 0 || c.in_ld % 4 != 0 || c.in_coff % 4 != 0) return 1;
     if (c.ep_stride % 4 != 0 || ((uintptr_t)c.scale & 15) != 0 || ((uintptr_t)c.shift & 15) != 0) return 1;
-    if (g_wino_mode != 2 && c.M < 6000) return 1;      // the small-M layers are latency-bound, not multiply-bound
+    // below these row counts a launch is latency-bound, not multiply-bound (tools/wino_time.py: 128 -> 128 at 1600 rows 13.4 -> 10.3 us,
+    // 96 -> 96 at 1600-1900 rows and everything at 400 rows a tie)
+    if (g_wino_mode != 2 && c.M < ((c.Cin == 64 || c.Cin == 128) ? 1500 : 3000)) return 1;
     WinoP p{};
     p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.nlev = c.nlev;
     int nb = 0;

@@ -64,8 +64,9 @@ typedef struct ore_conv_desc {
     float* workspace;  size_t workspace_floats;
     float* colsum;        /* optional [ore_conv_colsum_rows()][Cout16]: per-row-tile column sums of y (eSE average pool) */
     const float* w_wino;  /* optional: the same weights in Winograd F(2x2,3x3) form (ore_winograd_weight_fwd).  When given, 3x3
-                           * stride-1 pad-1 layers with Cin 64 / 128, Cout % 64 == 0 and M >= 6000 rows run on the Winograd kernel
-                           * (2.25x fewer multiplies, fp32 throughout); NULL = direct kernels only */
+                           * stride-1 pad-1 layers that ore_winograd_covers() and that have enough rows (>= 1500 at Cin 64 / 128, >= 3000 at
+                           * Cin 80 / 96 / 112) run on the Winograd kernels (2.25x fewer multiplies, fp32 throughout); NULL = direct
+                           * kernels only */
     int32_t storage;      /* ORE_ST_F32 (0): every tensor is fp32.  ORE_ST_BF16: `in`, `w` (ore_pack_conv_weight_bf16_host), `add` and `out`
                            * are bf16 tensors (ld / coff count ELEMENTS), accumulation, scale / shift and colsum stay fp32, the output is
                            * rounded once (nearest even) when it is stored and colsum sums the ROUNDED values.  ORE_ST_BF16_F32OUT: the

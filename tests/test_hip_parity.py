@@ -111,7 +111,7 @@ def test_conv_slices_inmul_add_partial_relu(ore):
 
 @pytest.fixture
 def wino_forced(ore):
-    """Winograd F(2x2,3x3) kernel (csrc/ore_conv_wino.hip) wherever it applies -- the automatic plan only takes it from 6000 rows."""
+    """Winograd F(2x2,3x3) kernel (csrc/ore_conv_wino.hip) wherever it applies -- the automatic plan only takes it from 1500 / 3000 rows."""
     ore.lib().ore_conv_set_plan_override(-7, 2, 0, 0, 0)
     yield
     ore.lib().ore_conv_set_plan_override(-7, 1, 0, 0, 0)

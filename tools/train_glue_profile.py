@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where do the ATen element-wise / copy / fill kernels of a bs = 16 training step come from?  torch.profiler with stacks, grouped by
-the innermost frame inside this repository.  usage: python tools/train_glue_profile.py [batch]"""
+the innermost frame inside this repository (or, where the profiler has no Python frames, by operand shapes).  usage: python tools/train_glue_profile.py [batch]"""
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "faster-orefsdet_amd"))
@@ -35,7 +35,7 @@ def step():
     losses = model(items); opt.zero_grad(); sum(losses.values()).backward(); opt.step(); sched.step()
 for _ in range(3): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0.0, 0])
 for ev in prof.events():
@@ -46,9 +46,11 @@ for ev in prof.events():
         continue
     site = "?"
     for fr in (ev.stack or []):
-        if "faster-orefsdet_amd" in fr or "/bench.py" in fr:
+        if ("faster-orefsdet_amd" in fr or "/bench.py" in fr) and "orehip/__init__" not in fr:
             site = fr.split("faster-orefsdet_amd/")[-1][:90]
             break
+    if site == "?":                                       # no Python frames (this torch build): the operand shapes tell the call site
+        site = str([tuple(x) for x in (ev.input_shapes or []) if x])[:110]
     k = (ev.name, site)
     agg[k][0] += t; agg[k][1] += 1
 tot = sum(v[0] for v in agg.values())

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "faster-orefsdet_amd"))
 import torch, orehip
 LAYERS = [("stem2", 1, 320, 320, 64, 64), ("s2l0", 1, 160, 160, 128, 64), ("s2l1", 1, 160, 160, 64, 64), ("out3", 1, 80, 80, 128, 128),
-          ("s3l0", 1, 80, 80, 112, 80), ("s3l1", 1, 80, 80, 80, 80), ("out4", 1, 40, 40, 128, 128), ("s4l1", 1, 40, 40, 96, 96), ("s4l1x16", 16, 40, 40, 96, 96), ("s5l1x16", 16, 20, 20, 112, 112),
+          ("s3l0", 1, 80, 80, 112, 80), ("s3l1", 1, 80, 80, 80, 80), ("out4", 1, 40, 40, 128, 128), ("s4l1", 1, 40, 40, 96, 96), ("out5", 1, 20, 20, 128, 128), ("s5l1", 1, 20, 20, 112, 112),
+          ("s3l1_480", 1, 60, 80, 80, 80), ("s4l1_800", 1, 38, 50, 96, 96), ("s4l1x16", 16, 40, 40, 96, 96), ("s5l1x16", 16, 20, 20, 112, 112),
           ("stem2x16", 16, 320, 320, 64, 64), ("s2l0x16", 16, 160, 160, 128, 64), ("s3l1x16", 16, 80, 80, 80, 80)]
 modes = [int(a) for a in sys.argv[1:]] or [0, 1, 3]
 dev = torch.device("cuda")
