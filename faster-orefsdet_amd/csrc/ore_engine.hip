@@ -303,11 +303,12 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
     r.conv(e->stem2, e->s1.p, e->s1.ld, 0, g.B, g.h[1], g.w[1], e->s2.p, e->s2.ld, 0);
     r.conv(e->stem3, e->s2.p, e->s2.ld, 0, g.B, g.h[1], g.w[1], e->cat[0].p, e->cat[0].ld, 0);
     bool lat_scaled_ok[3] = {false, false, false};         // this forward wrote lat_scaled[l] (bs = 1 with the fused column sums)
+    bool pooled_next = false;                              // the gate kernel of the previous stage already pooled into this stage's buffer
     for (int s = 0; s < 4 && !r.rc; ++s) {
         auto& S = e->stage[s];
         const int k = s + 2;
         Buf& cat = e->cat[s];
-        if (s > 0) {
+        if (s > 0 && !pooled_next) {
             r.rc = sb ? ore_maxpool3x3s2_bf16_fwd(reinterpret_cast<const uint16_t*>(e->sout[s - 1].p), e->sout[s - 1].ld, 0, g.B, g.h[k - 1],
                                                   g.w[k - 1], S.in_ch, e->gate[s - 1], reinterpret_cast<uint16_t*>(cat.p), cat.ld, 0, st)
                       : ore_maxpool3x3s2_fwd(e->sout[s - 1].p, e->sout[s - 1].ld, 0, g.B, g.h[k - 1], g.w[k - 1], S.in_ch,
@@ -323,7 +324,23 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
         r.conv(S.concat, cat.p, cat.ld, 0, g.B, g.h[k], g.w[k], e->sout[s].p, e->sout[s].ld, 0, nullptr, nullptr, 0, nullptr, 0, 0,
                g.B == 1 ? e->colsum : nullptr, &cs_rows);   // eSE average pool fused into the concat conv's epilogue
         if (r.rc) break;
-        if (cs_rows > 0 && s >= 1 && e->lat_scaled[s - 1]) { // bs = 1: gate + the gate-scaled lateral weight of this stage in one launch
+        pooled_next = false;
+        if (cs_rows > 0 && s < 3 && (s == 0 || e->lat_scaled[s - 1])) {
+            // bs = 1, a stage followed by the max-pool: gate + the gate-scaled lateral weight of this stage + the pooled, gated input of
+            // the next stage (written into its concat buffer) in one launch
+            Buf& nx = e->cat[s + 1];
+            const float* lw = s >= 1 ? e->lateral[s - 1].w : nullptr;
+            const int lrows = s >= 1 ? round_up(e->lateral[s - 1].Cout, 16) : 0;
+            if (s >= 1) lat_scaled_ok[s - 1] = true;
+            r.rc = sb ? ore_ese_gate_pool_bf16_fwd(e->colsum, cs_rows, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], lw, lrows,
+                                                   s >= 1 ? reinterpret_cast<uint16_t*>(e->lat_scaled[s - 1]) : nullptr,
+                                                   reinterpret_cast<const uint16_t*>(e->sout[s].p), e->sout[s].ld, 0, g.h[k], g.w[k],
+                                                   reinterpret_cast<uint16_t*>(nx.p), nx.ld, 0, st)
+                      : ore_ese_gate_pool_fwd(e->colsum, cs_rows, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], lw, lrows,
+                                              s >= 1 ? e->lat_scaled[s - 1] : nullptr, e->sout[s].p, e->sout[s].ld, 0, g.h[k], g.w[k], nx.p,
+                                              nx.ld, 0, st);
+            pooled_next = true;
+        } else if (cs_rows > 0 && s >= 1 && e->lat_scaled[s - 1]) { // bs = 1, last stage: gate + the gate-scaled lateral weight in one launch
             lat_scaled_ok[s - 1] = true;
             r.rc = sb ? ore_ese_gate_scaled_weight_bf16_fwd(e->colsum, cs_rows, g.h[k] * g.w[k], S.out_ch, S.fc_w, S.fc_b, e->gate[s], e->ese_ws,
                                                             e->lateral[s - 1].w, round_up(e->lateral[s - 1].Cout, 16),

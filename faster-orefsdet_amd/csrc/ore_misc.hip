@@ -2,6 +2,7 @@
 // ceil-mode max-pool, eSE gate, depthwise query<->support correlation, support kernel pooling,
 // GroupNorm statistics.  All NHWC fp32, 16-byte vector accesses, 64-wide wavefronts.
 #include "ore_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -158,13 +159,15 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
 // the per-channel multiplier moved onto the weights, so the lateral runs on the DMA-fed conv kernel (which cannot touch its A
 // operand) instead of k_conv_igemm's input-affine path.
 constexpr int ESE_T = 1024, ESE_FP = 8;
-__global__ __launch_bounds__(ESE_T) void k_ese_gate_fused(const float* __restrict__ part, int P, int HW, int C, const float* __restrict__ fw,
-                                                          const float* __restrict__ fb, float* __restrict__ gate,
-                                                          const float* __restrict__ lw, float* __restrict__ lws, int lrows, int lws_bf16) {
-    __shared__ __attribute__((aligned(16))) float red[4096];     // [NSL][C], NSL * C <= 4096
-    __shared__ __attribute__((aligned(16))) float mean_s[4096];
-    __shared__ float g16[16];
-    const int b = blockIdx.y, tid = threadIdx.x;
+struct EseSm {
+    __attribute__((aligned(16))) float red[4096];      // [NSL][C], NSL * C <= 4096
+    __attribute__((aligned(16))) float mean_s[4096];
+    float g16[16];
+};
+// the block's sixteen gates (channels 16 blockIdx.x ..) of image b -> sm.g16 and gate[]; ends with a barrier
+__device__ __forceinline__ void ese_gate16(EseSm& sm, const float* __restrict__ part, int P, int HW, int C, const float* __restrict__ fw,
+                                           const float* __restrict__ fb, float* __restrict__ gate, int b, bool write_gate) {
+    const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int o = blockIdx.x * 16 + wave;
     float fwv[ESE_FP];                                           // the first 512 weights of this wave's row: in flight under the reduction
@@ -188,15 +191,15 @@ __global__ __launch_bounds__(ESE_T) void k_ese_gate_fused(const float* __restric
                 for (int u = 0; u < 8; ++u) a += v[u];
             }
             for (; p < P; p += NSL) a += *reinterpret_cast<const f32x4*>(pb + (size_t)p * C);
-            *reinterpret_cast<f32x4*>(red + sl * C + q * 4) = a;
+            *reinterpret_cast<f32x4*>(sm.red + sl * C + q * 4) = a;
         }
     }
     __syncthreads();
     const float inv = 1.0f / (float)HW;
     for (int c = tid; c < C; c += ESE_T) {
-        float m = red[c];
-        for (int sl = 1; sl < NSL; ++sl) m += red[sl * C + c];
-        mean_s[c] = m * inv;
+        float m = sm.red[c];
+        for (int sl = 1; sl < NSL; ++sl) m += sm.red[sl * C + c];
+        sm.mean_s[c] = m * inv;
     }
     __syncthreads();
     if (o < C) {
@@ -204,28 +207,76 @@ __global__ __launch_bounds__(ESE_T) void k_ese_gate_fused(const float* __restric
 #pragma unroll
         for (int j = 0; j < ESE_FP; ++j) {
             const int k = lane + 64 * j;
-            if (k < C) s += fwv[j] * mean_s[k];
+            if (k < C) s += fwv[j] * sm.mean_s[k];
         }
-        for (int k = lane + 64 * ESE_FP; k < C; k += 64) s += fw[(size_t)o * C + k] * mean_s[k];
+        for (int k = lane + 64 * ESE_FP; k < C; k += 64) s += fw[(size_t)o * C + k] * sm.mean_s[k];
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
         if (lane == 0) {
             const float v = s + fb[o] + 3.0f;
             const float gv = fminf(fmaxf(v, 0.f), 6.0f) / 6.0f;
-            gate[b * C + o] = gv;
-            g16[wave] = gv;
+            if (write_gate) gate[b * C + o] = gv;
+            sm.g16[wave] = gv;
         }
     }
-    if (!lws) return;                                   // (uniform)
     __syncthreads();
+}
+// the block's sixteen gate-scaled columns of the consumer's packed 1x1 weight
+__device__ __forceinline__ void ese_scale_columns(const EseSm& sm, int C, const float* __restrict__ lw, float* __restrict__ lws, int lrows,
+                                                  int lws_bf16) {
     const int o0 = blockIdx.x * 16;                     // C % 4 == 0: a column quad of this block is all real or all beyond C
-    for (int it = tid; it < lrows * 4; it += ESE_T) {
+    for (int it = threadIdx.x; it < lrows * 4; it += ESE_T) {
         const int n = it >> 2, j = it & 3;
         if (o0 + j * 4 >= C) continue;
         const f32x4 w = *reinterpret_cast<const f32x4*>(lw + (size_t)n * C + o0 + j * 4);
-        const f32x4 ws4 = f32x4{w.x * g16[j * 4], w.y * g16[j * 4 + 1], w.z * g16[j * 4 + 2], w.w * g16[j * 4 + 3]};
+        const f32x4 ws4 = f32x4{w.x * sm.g16[j * 4], w.y * sm.g16[j * 4 + 1], w.z * sm.g16[j * 4 + 2], w.w * sm.g16[j * 4 + 3]};
         if (lws_bf16) st4(reinterpret_cast<ore_bf16_t*>(lws) + (size_t)n * C + o0 + j * 4, ws4);   // bf16 storage: the scaled weight is a bf16 tensor
         else *reinterpret_cast<f32x4*>(lws + (size_t)n * C + o0 + j * 4) = ws4;
+    }
+}
+
+__global__ __launch_bounds__(ESE_T) void k_ese_gate_fused(const float* __restrict__ part, int P, int HW, int C, const float* __restrict__ fw,
+                                                          const float* __restrict__ fb, float* __restrict__ gate,
+                                                          const float* __restrict__ lw, float* __restrict__ lws, int lrows, int lws_bf16) {
+    __shared__ EseSm sm;
+    ese_gate16(sm, part, P, HW, C, fw, fb, gate, blockIdx.y, true);
+    if (lws) ese_scale_columns(sm, C, lw, lws, lrows, lws_bf16);
+}
+
+// bs = 1 engine, stages followed by a max-pool: gate + scaled lateral columns + the 3x3 / stride-2 ceil-mode max-pool of
+// x * gate in ONE launch (it was k_ese_gate_fused + k_maxpool: a ~5 us launch floor per stage).  Block (cg, pb) computes the sixteen
+// gates of channel group cg like k_ese_gate_fused -- every pb redundantly -- and pools exactly those sixteen channels over its share
+// of the output pixels (max(x) * g == max(x * g): g >= 0), so nothing crosses blocks.  The pb == 0 blocks publish gate[] and the
+// scaled weight columns.
+template <typename TS>
+__global__ __launch_bounds__(ESE_T) void k_ese_gate_pool(const float* __restrict__ part, int P, int HW, int C, const float* __restrict__ fw,
+                                                         const float* __restrict__ fb, float* __restrict__ gate,
+                                                         const float* __restrict__ lw, float* __restrict__ lws, int lrows, int lws_bf16,
+                                                         const TS* __restrict__ in, int in_ld, int in_coff, int H, int W, int Ho, int Wo,
+                                                         TS* __restrict__ out, int out_ld, int out_coff) {
+    __shared__ EseSm sm;
+    const int pb = blockIdx.y;
+    ese_gate16(sm, part, P, HW, C, fw, fb, gate, 0, pb == 0);
+    if (lws && pb == 0) ese_scale_columns(sm, C, lw, lws, lrows, lws_bf16);
+    const int npx = Ho * Wo, per = (npx + gridDim.y - 1) / gridDim.y;
+    const int p1 = min((pb + 1) * per, npx);
+    const int j = threadIdx.x & 3, c = blockIdx.x * 16 + j * 4;
+    if (c >= C) return;
+    const f32x4 g4 = {sm.g16[j * 4], sm.g16[j * 4 + 1], sm.g16[j * 4 + 2], sm.g16[j * 4 + 3]};
+    for (int px = pb * per + (threadIdx.x >> 2); px < p1; px += ESE_T / 4) {
+        const int oy = px / Wo, ox = px - oy * Wo;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * 2 + ky, ix = ox * 2 + kx;
+                if (iy < H && ix < W) {
+                    const f32x4 v = ld4(in + (size_t)(iy * W + ix) * in_ld + in_coff + c);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+        st4(out + (size_t)px * out_ld + out_coff + c, m * g4);
     }
 }
 
@@ -763,6 +814,44 @@ extern "C" int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P,
     hipLaunchKernelGGL(k_ese_gate_fused, dim3(ceil_div(C, 16), 1), dim3(ESE_T), 0, st, part, P, HW, C, fc_w, fc_b, gate, w_packed_f32,
                        reinterpret_cast<float*>(w_scaled_bf16), (int)w_rows, 1);
     return ore_launch_status("k_ese_gate_fused");
+}
+
+// gate + gate-scaled consumer weight (optional) + max-pool of x * gate, one launch (bs = 1; see k_ese_gate_pool)
+static int ese_gate_pool_launch(const float* part, int P, int HW, int C, const float* fc_w, const float* fc_b, float* gate, const float* lw,
+                                int lrows, void* lws, int lws_bf16, const void* x, int x_ld, int x_coff, int H, int W, void* out,
+                                int out_ld, int out_coff, int bf16, hipStream_t st) {
+    ORE_CHECK_ARG(part && fc_w && fc_b && gate && x && out && P > 0 && HW == H * W && C > 0 && C % 4 == 0 && C <= 4096,
+                  "ore_ese_gate_pool_fwd: bad args");
+    ORE_CHECK_ARG((lws == nullptr) == (lw == nullptr) && (!lws || lrows > 0), "ore_ese_gate_pool_fwd: scaled weight needs source, rows and destination");
+    ORE_CHECK_ARG(x_ld % 4 == 0 && x_coff % 4 == 0 && out_ld % 4 == 0 && out_coff % 4 == 0, "ore_ese_gate_pool_fwd: align");
+    auto osz = [](int n) { int o = (n - 3 + 1) / 2 + 1; if (n < 3) o = 1; if ((o - 1) * 2 >= n) --o; return o < 1 ? 1 : o; };
+    const int Ho = osz(H), Wo = osz(W);
+    const int gx = ceil_div(C, 16);
+    int gy = ceil_div(224, gx);                                       // ~ one block per CU, at least 64 output pixels per block
+    gy = std::max(1, std::min(gy, ceil_div(Ho * Wo, 64)));
+    if (bf16)
+        hipLaunchKernelGGL(k_ese_gate_pool<ore_bf16_t>, dim3(gx, gy), dim3(ESE_T), 0, st, part, P, HW, C, fc_w, fc_b, gate, lw, (float*)lws, lrows,
+                           lws_bf16, (const ore_bf16_t*)x, x_ld, x_coff, H, W, Ho, Wo, (ore_bf16_t*)out, out_ld, out_coff);
+    else
+        hipLaunchKernelGGL(k_ese_gate_pool<float>, dim3(gx, gy), dim3(ESE_T), 0, st, part, P, HW, C, fc_w, fc_b, gate, lw, (float*)lws, lrows,
+                           lws_bf16, (const float*)x, x_ld, x_coff, H, W, Ho, Wo, (float*)out, out_ld, out_coff);
+    return ore_launch_status("k_ese_gate_pool");
+}
+
+extern "C" int ore_ese_gate_pool_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b, float* gate,
+                                     const float* w_packed, int32_t w_rows, float* w_scaled, const float* x, int32_t x_ld, int32_t x_coff,
+                                     int32_t H, int32_t W, float* out, int32_t out_ld, int32_t out_coff, void* stream) {
+    return ese_gate_pool_launch(part, P, HW, C, fc_w, fc_b, gate, w_packed, w_rows, w_scaled, 0, x, x_ld, x_coff, H, W, out, out_ld, out_coff, 0,
+                                (hipStream_t)stream);
+}
+
+extern "C" int ore_ese_gate_pool_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
+                                          float* gate, const float* w_packed_f32, int32_t w_rows, uint16_t* w_scaled_bf16, const uint16_t* x,
+                                          int32_t x_ld, int32_t x_coff, int32_t H, int32_t W, uint16_t* out, int32_t out_ld, int32_t out_coff,
+                                          void* stream) {
+    ORE_CHECK_ARG(!w_scaled_bf16 || C % 32 == 0, "ore_ese_gate_pool_bf16_fwd: C must be a multiple of 32 for the bf16 scaled weight");
+    return ese_gate_pool_launch(part, P, HW, C, fc_w, fc_b, gate, w_packed_f32, w_rows, w_scaled_bf16, 1, x, x_ld, x_coff, H, W, out, out_ld,
+                                out_coff, 1, (hipStream_t)stream);
 }
 
 extern "C" int ore_scale_channels_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,

@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -382,6 +382,28 @@ def ese_gate(x: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.T
                                 C.c_void_p(_ptr(_f32(fc_b))), C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(ws)), _stream()),
          "ore_ese_gate_fwd")
     return gate
+
+
+def ese_gate_pool(part: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor, x: torch.Tensor, w_packed: Optional[torch.Tensor] = None):
+    """One image: gate from the concat conv's fused column sums `part` [P, C], the gate-scaled copy of `w_packed` [rows, C] (or None)
+    and maxpool3x3s2(x * gate) in one launch (ore_ese_gate_pool_fwd).  x [1,H,W,C] fp32 or bf16.  Returns (gate [1,C], pooled, scaled)."""
+    _f32(part)
+    P, Cc = part.shape
+    _, H, W, Cx = x.shape
+    assert x.shape[0] == 1 and Cx == Cc and x.is_contiguous()
+    Ho, Wo = maxpool3x3s2_out_hw(H, W)
+    gate = torch.empty(1, Cc, device=x.device, dtype=torch.float32)
+    out = torch.empty(1, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
+    bf = x.dtype == torch.bfloat16
+    ws = None
+    if w_packed is not None:
+        _f32(w_packed)
+        ws = torch.empty(w_packed.shape, device=x.device, dtype=x.dtype)
+    fn = lib().ore_ese_gate_pool_bf16_fwd if bf else lib().ore_ese_gate_pool_fwd
+    _chk(fn(C.c_void_p(_ptr(part)), P, H * W, Cc, C.c_void_p(_ptr(_f32(fc_w.reshape(Cc, Cc)))), C.c_void_p(_ptr(_f32(fc_b))),
+            C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(w_packed)), 0 if w_packed is None else w_packed.shape[0], C.c_void_p(_ptr(ws)),
+            C.c_void_p(_ptr(x)), Cc, 0, H, W, C.c_void_p(_ptr(out)), Cc, 0, _stream()), "ore_ese_gate_pool_fwd")
+    return gate, out, ws
 
 
 def scale_channels(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:

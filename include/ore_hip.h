@@ -470,6 +470,16 @@ int ore_groupnorm_apply_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t c
 int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
                                         float* gate, float* mean_ws, const float* w_packed_f32, int32_t w_rows, uint16_t* w_scaled_bf16,
                                         void* stream);
+/* bs = 1 engine, a stage that is followed by the max-pool: gate (as ore_ese_gate_from_colsum_fwd for one image), optionally the
+ * gate-scaled copy of a consumer's packed 1x1 weight (as ore_ese_gate_scaled_weight_fwd; w_packed / w_scaled NULL = none), and
+ * out[oy][ox][out_coff + c] = max over the 3x3 / stride-2 ceil-mode window of x[..][x_coff + c] * gate[c], all in ONE launch.
+ * Replaces eSE + the next stage's MaxPool2d(3, 2, ceil_mode=True) of d2z:modeling/backbone/vovnet.py:238-260,359-361. */
+int ore_ese_gate_pool_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b, float* gate,
+                          const float* w_packed, int32_t w_rows, float* w_scaled, const float* x, int32_t x_ld, int32_t x_coff,
+                          int32_t H, int32_t W, float* out, int32_t out_ld, int32_t out_coff, void* stream);
+int ore_ese_gate_pool_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b, float* gate,
+                               const float* w_packed_f32, int32_t w_rows, uint16_t* w_scaled_bf16, const uint16_t* x, int32_t x_ld,
+                               int32_t x_coff, int32_t H, int32_t W, uint16_t* out, int32_t out_ld, int32_t out_coff, void* stream);
 int ore_roi_align_bf16_fwd(const uint16_t* const* feat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                            const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled, const float* boxes,
                            const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream);

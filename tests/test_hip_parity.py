@@ -336,6 +336,37 @@ def test_maxpool_ceil(ore, H, W, C):
     assert torch.equal(nchw(y), ref)  # exact: positive scaling commutes with max
 
 
+@pytest.mark.parametrize("H,W,C,rows", [(160, 160, 112, 0), (80, 80, 256, 128), (40, 40, 384, 128), (21, 13, 48, 16)])
+def test_ese_gate_pool_one_launch(ore, H, W, C, rows):
+    """ore_ese_gate_pool_fwd (gate + gate-scaled consumer weight + max-pool of x * gate in one launch, the bs = 1 engine's form) against
+    the separate entry points: same gate bits, same scaled weight, pooled output exactly max-pool(x) * gate."""
+    g = torch.Generator().manual_seed(H + C)
+    x = torch.relu(torch.randn(1, C, H, W, generator=g))
+    fw = torch.randn(C, C, 1, 1, generator=g) / C ** 0.5
+    fb = torch.randn(C, generator=g)
+    P = 37
+    xr = nhwc(x).reshape(-1, C)
+    part = torch.stack([c.sum(0) for c in xr.chunk(P, 0)])                              # any split of the rows into partial sums
+    P = part.shape[0]
+    wp = (torch.randn(rows, C, generator=g).cuda() if rows else None)
+    gate, pooled, ws = ore.ese_gate_pool(part.contiguous(), dev(fw), dev(fb), nhwc(x), wp)
+    ref = F.relu6(F.conv2d(F.adaptive_avg_pool2d(x, 1), fw, fb) + 3.0) / 6.0
+    assert rel_err(gate.cpu().numpy().reshape(-1), ref.numpy().reshape(-1)) < TOL
+    if rows:
+        g2, ws2 = ore.ese_gate_scaled_weight(part.contiguous(), H * W, dev(fw), dev(fb), wp)
+        assert torch.equal(g2, gate) and torch.equal(ws2, ws)
+    else:
+        assert ws is None and torch.equal(ore.ese_gate_from_colsum(part.contiguous(), H * W, dev(fw), dev(fb)), gate)
+    assert torch.equal(pooled, ore.maxpool3x3s2(nhwc(x), gate))
+    xb = nhwc(x).to(torch.bfloat16)
+    gb, pb, wsb = ore.ese_gate_pool(part.contiguous(), dev(fw), dev(fb), xb, wp if rows and C % 32 == 0 else None)
+    assert torch.equal(gb, gate) and pb.dtype == torch.bfloat16
+    want = (F.max_pool2d(xb.float().permute(0, 3, 1, 2), 3, 2, ceil_mode=True) * gate.view(1, -1, 1, 1)).to(torch.bfloat16)
+    assert torch.equal(pb.permute(0, 3, 1, 2), want)
+    if wsb is not None:
+        assert wsb.dtype == torch.bfloat16 and torch.equal(wsb, ws.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("HW,C", [((160, 160), 112), ((20, 20), 512), ((3, 5), 256), ((80, 80), 256)])
 def test_ese_gate(ore, HW, C):
     g = torch.Generator().manual_seed(C)
