@@ -1420,6 +1420,7 @@ static void fill_common(ConvP& p, const ore_conv_desc* d) {
     p.nchunks = d->kh * d->kw * (d->Cin / 16);
     p.colsum = d->colsum;
     p.wino = d->w_wino;
+    p.wino_lstride = 0;
     p.sb = 0;
     if (d->storage == ORE_ST_BF16 || d->storage == ORE_ST_BF16_F32OUT) {
         // bf16 tensors: the input side is handed to the kernels in 4-byte units (pairs of channels); the packed weights hold
@@ -1472,5 +1473,15 @@ extern "C" int ore_conv2d_levels_fwd(const ore_conv_desc* d, int32_t n_levels, c
     }
     p.M = rows;
     p.ep_stride = ep_stride;
+    if (d->w_wino_level_stride) {                             // per-level layers: the Winograd kernel or nothing
+        ORE_CHECK_ARG(d->w_wino && d->w_wino_level_stride > 0 && d->kh == 3 && d->storage == ORE_ST_F32 && !d->in_mul && !d->colsum &&
+                          oreconv::conv_wino_covers(d->Cout, d->Cin) && (d->Cin == 64 || d->Cin == 128),
+                      "ore_conv2d_levels_fwd: per-level weights need the Winograd form of a 3x3 layer with 64 / 128 input channels, fp32 storage");
+        p.wino_lstride = (size_t)d->w_wino_level_stride;
+        p.bf16 = 0;
+        const int wrc = conv_wino_launch(p, (hipStream_t)stream);
+        if (wrc == 1) { ore_set_error("ore_conv2d_levels_fwd: the Winograd kernel does not cover this per-level launch (alignment / mode)"); return ORE_EINVAL; }
+        return wrc;
+    }
     return conv_launch(p, d->splitk, d->workspace, d->workspace_floats, (hipStream_t)stream);
 }

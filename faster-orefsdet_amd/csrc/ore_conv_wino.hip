@@ -35,6 +35,7 @@
 // Replaces F.conv2d(3x3, pad 1) + FrozenBatchNorm2d + ReLU of d2z:modeling/backbone/vovnet.py:205-219,408-412 (stem_2, OSA2 layers),
 // fpn.py:139-145 (fpn_output3) and conv3x3 + bias of ref:CenterNet2/centernet/modeling/dense_heads/centernet_head.py:141-150 (tower).
 #include "ore_conv_internal.h"
+#include <algorithm>
 
 namespace {
 using namespace oreconv;
@@ -43,6 +44,8 @@ struct WinoP {
     const float* in; int in_ld, in_coff;
     int B, nlev; Lvl lv[4]; int bat0[5]; int nbx[4], nby[4];      // batches of level l: [bat0[l], bat0[l+1]), nbx x nby per image
     const float* U; int Cout, Cout16;
+    size_t u_lstride; int blk0[5];                                // per-level weights (u_lstride != 0): level l's U is u_lstride floats
+                                                                  // further and blocks [blk0[l], blk0[l+1]) of a block row work on level l only
     const float* scale; const float* shift; int ep_stride, relu_cout;
     float* out; int out_ld, out_coff;
     int nbat;
@@ -115,6 +118,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
     const int cin_w0 = KH == 2 ? hi * 64 : 0;
     auto zs = [](int t) -> int { return QZ == 16 ? (t & 7) : ((t >> 1) & 3); };
 
+    // ---- which batches this block walks: all levels with one set of weights, or (per-level weights: the three FPN output convs
+    // in one launch) the batches of ITS level only, since the weights never leave the registers
+    int bat_first = blockIdx.x, bat_step = gridDim.x, bat_end = p.nbat;
+    const float* Ub = p.U;
+    if (p.u_lstride) {
+        int lb = 0;
+#pragma unroll
+        for (int l = 1; l < 4; ++l)
+            if (l < p.nlev && (int)blockIdx.x >= p.blk0[l]) lb = l;
+        Ub += lb * p.u_lstride;
+        bat_first = p.bat0[lb] + ((int)blockIdx.x - p.blk0[lb]); bat_step = p.blk0[lb + 1] - p.blk0[lb]; bat_end = p.bat0[lb + 1];
+    }
     // ---- transformed weights -> registers (MFMA A operand: row = output channel, 4 consecutive k per lane)
     f32x4 wf[4][2][4];
 #pragma unroll
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
         for (int cg = 0; cg < 2; ++cg) {
             const int n16 = (blockIdx.y * COUTB + cb) / 16 + cg;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) wf[nu][cg][c] = wino_u_frag(p.U, xi * 4 + nu, n16, (cin_w0 >> 4) + c, p.Cout16, CIN, lane);
+            for (int c = 0; c < 4; ++c) wf[nu][cg][c] = wino_u_frag(Ub, xi * 4 + nu, n16, (cin_w0 >> 4) + c, p.Cout16, CIN, lane);
         }
 
     // ---- P1 items of this thread: (tile t1, row combination xi1, quad q1), the same tile / quad for all its items
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
     const int ty3 = (t3 & 15) >> 3, tx3 = t3 & 7;
     const float* zero = g_zero_wino;
 
-    for (int bat = blockIdx.x; bat < p.nbat; bat += gridDim.x) {
+    for (int bat = bat_first; bat < bat_end; bat += bat_step) {
         int lvl = 0;
 #pragma unroll
         for (int l = 1; l < 4; ++l)
@@ -415,14 +430,14 @@ static int wino_nu_go(const WinoP& p, int nb, hipStream_t st) {
 
 // ORE_OK if launched, 1 if the layer is not covered (the caller goes on to the direct kernels)
 int conv_wino_launch(const ConvP& c, hipStream_t st) {
-    if (!g_wino_mode || !c.wino || c.bf16) return 1;
+    if ((!g_wino_mode && !c.wino_lstride) || !c.wino || c.bf16) return 1;   // (per-level launches have no direct twin: mode 0 does not apply)
     if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.in_mul || c.add || c.colsum) return 1;
     if (c.Cout != c.Cout16 || !conv_wino_covers(c.Cout, c.Cin)) return 1;
     if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 15) != 0 || c.in_ld % 4 != 0 || c.in_coff % 4 != 0) return 1;
     if (c.ep_stride % 4 != 0 || ((uintptr_t)c.scale & 15) != 0 || ((uintptr_t)c.shift & 15) != 0) return 1;
     // below these row counts a launch is latency-bound, not multiply-bound (tools/wino_time.py: 128 -> 128 at 1600 rows 13.4 -> 10.3 us,
     // 96 -> 96 at 1600-1900 rows and everything at 400 rows a tie)
-    if (g_wino_mode != 2 && c.M < ((c.Cin == 64 || c.Cin == 128) ? 1500 : 3000)) return 1;
+    if (g_wino_mode != 2 && !c.wino_lstride && c.M < ((c.Cin == 64 || c.Cin == 128) ? 1500 : 3000)) return 1;
     WinoP p{};
     p.in = c.in; p.in_ld = c.in_ld; p.in_coff = c.in_coff; p.B = c.B; p.nlev = c.nlev;
     int nb = 0;
@@ -436,6 +451,10 @@ int conv_wino_launch(const ConvP& c, hipStream_t st) {
     p.U = c.wino; p.Cout = c.Cout; p.Cout16 = c.Cout16;
     p.scale = c.scale; p.shift = c.shift; p.ep_stride = c.ep_stride; p.relu_cout = c.relu_cout;
     p.out = c.out; p.out_ld = c.out_ld; p.out_coff = c.out_coff;
+    if (c.wino_lstride && c.Cin != 64 && c.Cin != 128) {
+        ore_set_error("ore_conv2d_levels_fwd: per-level Winograd weights exist for 64 / 128 input channels only");
+        return ORE_EINVAL;
+    }
     if (c.Cin == 80) return wino_nu_go<80, 3>(p, nb, st);
     if (c.Cin == 96) return wino_nu_go<96, 2>(p, nb, st);
     if (c.Cin == 112) return wino_nu_go<112, 2>(p, nb, st);
@@ -444,6 +463,20 @@ int conv_wino_launch(const ConvP& c, hipStream_t st) {
     int gx = 256 / gy;                                  // one resident block per CU
     if (gx > nb) gx = nb;
     if (gx < 1) gx = 1;
+    if (c.wino_lstride) {
+        // per-level weights: a block serves one level.  The fewest rounds R for which sum_l ceil(batches_l / R) blocks fit a block row
+        p.u_lstride = c.wino_lstride;
+        const int G = std::max(256 / gy, c.nlev);
+        int R = 1;
+        for (;; ++R) {
+            int need = 0;
+            for (int l = 0; l < c.nlev; ++l) need += ceil_div(p.bat0[l + 1] - p.bat0[l], R);
+            if (need <= G) break;
+        }
+        gx = 0;
+        for (int l = 0; l < c.nlev; ++l) { p.blk0[l] = gx; gx += ceil_div(p.bat0[l + 1] - p.bat0[l], R); }
+        p.blk0[c.nlev] = gx;
+    }
     const size_t lds = ((size_t)16 * 16 * c.Cin + 4 * 2 * 16 * 64) * sizeof(float);      // V + Z (32 KB for both builds)
     static bool attr = false;
     if (!attr) {

@@ -54,13 +54,14 @@ struct ore_engine {
     Conv stem2, stem3;
     struct Stage { Conv layer[8]; Conv concat; float* fc_w = nullptr; float* fc_b = nullptr; int in_ch, conv_ch, out_ch, cat_ch; } stage[4];
     Conv lateral[3], output[3], conv3, tower, pred;      // pred.scale/shift are [3 levels][16]
+    float* out_wino3 = nullptr; float* out_shift3 = nullptr; size_t out_wino_stride = 0;   // the three FPN output convs as ONE per-level Winograd launch: [3][U], [3][F] bias
     float* gn_gamma = nullptr; float* gn_beta = nullptr;
     float* k11 = nullptr, *k13 = nullptr, *k31 = nullptr; // level-major [3][C], [3][C][3], [3][C][3]
     HostTensor support[3];
     bool support_set[3] = {false, false, false};
     // buffers
     void* img_in = nullptr; size_t img_bytes = 0;
-    Buf s1, s2, cat[4], sout[4], lat[3];
+    Buf s1, s2, cat[4], sout[4], lat_all;                 // lat_all: the three inner (top-down) FPN maps, level-major rows
     Buf pcat, pos, tow, head;                    // all pyramid levels in ONE level-major matrix each ([level][b][y][x])
     bool head_pred_valu = true;                  // k_head_pred (VALU) instead of the MFMA conv for the head's last step (A/B: ORE_HEAD_MFMA=1)
     Buf tn;                                      // bf16 storage only: GroupNorm + ReLU of the tower, materialised (the DMA-fed kernels cannot touch their A operand)
@@ -233,7 +234,7 @@ struct Run {
     // one launch over all pyramid levels (level-major rows)
     void conv_levels(const Conv& c, const float* in, int in_ld, int in_coff, int B, const int* H, const int* W, float* out,
                      int out_ld, int out_coff, int ep_stride = 0, const float* in_mul = nullptr, const float* in_add = nullptr,
-                     int in_relu = 0, bool out_f32 = false) {
+                     int in_relu = 0, bool out_f32 = false, size_t wino_level_stride = 0) {
         if (rc) return;
         ore_conv_desc d{};
         d.in = in; d.in_ld = in_ld; d.in_coff = in_coff; d.B = B; d.Cin = c.Cin;
@@ -242,7 +243,7 @@ struct Run {
         d.in_mul = in_mul; d.in_add = in_add; d.in_relu = in_relu;
         d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
         d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
-        d.w_wino = c.wino;
+        d.w_wino = c.wino; d.w_wino_level_stride = (int64_t)wino_level_stride;
         if (e->sb()) { d.storage = out_f32 ? ORE_ST_BF16_F32OUT : ORE_ST_BF16; d.w = reinterpret_cast<const float*>(c.wh); }
         double rows = 0;
         for (int l = 0; l < 3; ++l) rows += (double)B * H[l] * W[l];
@@ -356,21 +357,33 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
     }
     // FPN top-down: level index 2 = p5, 1 = p4, 0 = p3; outputs land in the q half of pcat
     const int F = c.fpn_ch;
+    float* lat[3];
+    for (int l = 0; l < 3; ++l) lat[l] = e->at(e->lat_all.p, (size_t)lvl_row0(g, l) * F);
+    const bool grouped = e->out_wino3 != nullptr;          // fp32: the three output convs run as one launch behind the lateral chain
     for (int l = 2; l >= 0 && !r.rc; --l) {
         const int k = l + 3, s = l + 1;
-        const float* add = l < 2 ? e->lat[l + 1].p : nullptr;
+        const float* add = l < 2 ? lat[l + 1] : nullptr;
         if (lat_scaled_ok[l]) {                             // x * (g W): plain conv on the gate-scaled weights (k_conv_kw)
             Conv lc = e->lateral[l];
             lc.w = e->lat_scaled[l];
             lc.wh = reinterpret_cast<uint16_t*>(e->lat_scaled[l]);
-            r.conv(lc, e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, nullptr, nullptr, 0, add, F, 0);
+            r.conv(lc, e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], lat[l], F, 0, nullptr, nullptr, 0, add, F, 0);
         } else if (sb) {
             ore_set_error("bf16-storage engine: the lateral needs the gate-scaled weights (one image per pass)"); r.rc = ORE_EINVAL;
         } else {
-            r.conv(e->lateral[l], e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], e->lat[l].p, F, 0, e->gate[s], nullptr, 0,
+            r.conv(e->lateral[l], e->sout[s].p, e->sout[s].ld, 0, g.B, g.h[k], g.w[k], lat[l], F, 0, e->gate[s], nullptr, 0,
                    add, F, 0);
         }
-        r.conv(e->output[l], e->lat[l].p, F, 0, g.B, g.h[k], g.w[k], e->at(e->pcat.p, (size_t)lvl_row0(g, l) * 2 * F), 2 * F, F);
+        if (!grouped)
+            r.conv(e->output[l], lat[l], F, 0, g.B, g.h[k], g.w[k], e->at(e->pcat.p, (size_t)lvl_row0(g, l) * 2 * F), 2 * F, F);
+    }
+    if (grouped && !r.rc) {
+        // fpn_output3/4/5 (d2z:modeling/backbone/fpn.py:139-145): three layers of one shape -> ONE Winograd launch, every block keeps the
+        // weights of its level in registers (the levels' 100 / 25 / 7 batches of a 640 x 640 image in 3 rounds instead of 3 launches)
+        const int H[3] = {g.h[3], g.h[4], g.h[5]}, W[3] = {g.w[3], g.w[4], g.w[5]};
+        Conv oc = e->output[0];
+        oc.wino = e->out_wino3; oc.shift = e->out_shift3;
+        r.conv_levels(oc, e->lat_all.p, F, 0, g.B, H, W, e->pcat.p, 2 * F, F, F, nullptr, nullptr, 0, false, e->out_wino_stride);
     }
     *flops = r.flops;
     return r.rc;
@@ -642,6 +655,16 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
         if ((rc = make_conv_bias(e, "backbone.fpn_lateral" + st, c.stage_out_ch[l + 1], F, 1, 0, &e->lateral[l]))) return rc;
         if ((rc = make_conv_bias(e, "backbone.fpn_output" + st, F, F, 3, 0, &e->output[l]))) return rc;
     }
+    if (!e->sb() && (F == 64 || F == 128) && ore_winograd_covers(F, F)) {
+        // the three output convs are one shape: their Winograd weights and biases side by side, one launch over the three levels
+        e->out_wino_stride = ore_winograd_weight_floats(F, F);
+        if ((rc = e->dalloc(&e->out_wino3, 3 * e->out_wino_stride)) || (rc = e->dalloc(&e->out_shift3, (size_t)3 * F))) return rc;
+        for (int l = 0; l < 3; ++l) {
+            if ((rc = ore_winograd_weight_fwd(e->output[l].w, F, F, e->out_wino3 + l * e->out_wino_stride, nullptr))) return rc;
+            ORE_HIP(hipMemcpy(e->out_shift3 + (size_t)l * F, e->output[l].shift, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+        ORE_HIP(hipDeviceSynchronize());
+    }
     if ((rc = make_conv_bias(e, "conv3", 2 * F, F, 1, 1, &e->conv3))) return rc;
     const std::string hp = "proposal_generator.centernet_head.";
     if ((rc = make_conv_bias(e, hp + "bbox_tower.0", F, F, 3, 0, &e->tower))) return rc;
@@ -691,12 +714,8 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
         if (cs > cs_need) cs_need = cs;
     }
     size_t rows_all = 0;
-    for (int l = 0; l < 3; ++l) {
-        const int k = l + 3;
-        const size_t M = B * g.h[k] * g.w[k];
-        rows_all += M;
-        if ((rc = alloc_buf(e, &e->lat[l], M, F))) return rc;
-    }
+    for (int l = 0; l < 3; ++l) rows_all += (size_t)B * g.h[l + 3] * g.w[l + 3];
+    if ((rc = alloc_buf(e, &e->lat_all, rows_all, F))) return rc;        // the three inner (top-down) maps, level-major rows like pcat
     if ((rc = alloc_buf(e, &e->pcat, rows_all, 2 * F)) || (rc = alloc_buf(e, &e->pos, rows_all, F)) ||
         (rc = alloc_buf(e, &e->tow, rows_all, F)) || (rc = alloc_buf(e, &e->head, rows_all, 8, false))) return rc;
     if (e->sb() && (rc = alloc_buf(e, &e->tn, rows_all, F))) return rc;
@@ -929,7 +948,7 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
         const size_t r0 = (size_t)lvl_row0(g, l);
         if (n == "p" + k) return set(e->at(e->pcat.p, r0 * 2 * F), rows, F, 2 * F, F);
         if (n == "attn" + k) return set(e->at(e->pcat.p, r0 * 2 * F), rows, F, 2 * F, 0);
-        if (n == "lat" + k) return set(e->lat[l].p, rows, F, F, 0);
+        if (n == "lat" + k) return set(e->at(e->lat_all.p, r0 * F), rows, F, F, 0);
         if (n == "pos" + k) return set(e->at(e->pos.p, r0 * F), rows, F, F, 0);
         if (n == "tower" + k) return set(e->at(e->tow.p, r0 * F), rows, F, F, 0);
         if (n == "head" + k) return set(e->head.p + r0 * 8, rows, 5, 8, 0);

@@ -72,6 +72,10 @@ typedef struct ore_conv_desc {
                            * rounded once (nearest even) when it is stored and colsum sums the ROUNDED values.  ORE_ST_BF16_F32OUT: the
                            * same with an fp32 `out` (the detection head's outputs).  The input buffer must extend 32 bytes past its
                            * last row when Cin % 32 == 16 (the last K chunk of a row reads 16 channels further, against zero weights). */
+    int64_t w_wino_level_stride; /* ore_conv2d_levels_fwd only.  0: all levels share the weights.  Otherwise the levels are DIFFERENT layers of
+                           * one shape (the three FPN output convs, d2z:modeling/backbone/fpn.py:139-145): level l's Winograd weights start
+                           * l * w_wino_level_stride floats after w_wino, its scale / shift l * ep_stride floats after scale / shift; `w` is
+                           * not read.  Winograd kernels only (3x3, Cin 64 / 128, fp32 storage), any row count; else ORE_EINVAL. */
 } ore_conv_desc;
 #define ORE_ST_F32 0
 #define ORE_ST_BF16 1

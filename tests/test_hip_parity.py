@@ -206,6 +206,32 @@ def test_conv_winograd_slices_levels_bias(ore, wino_forced):
     assert not torch.equal(y3, d3) and rel_err(nchw(y3).numpy(), F.conv2d(x3, w, sh, 1, 1).numpy()) < TOL
 
 
+@pytest.mark.parametrize("HW,B", [([(80, 80), (40, 40), (20, 20)], 1), ([(12, 20), (6, 10), (3, 5)], 2), ([(5, 7), (3, 4), (2, 2)], 1)])
+def test_conv_winograd_per_level_weights(ore, HW, B):
+    """Three layers of one shape over three pyramid levels in ONE launch (the FPN output convs): level l multiplies its own Winograd
+    weights and adds its own bias; every block of the kernel serves one level."""
+    g = torch.Generator().manual_seed(HW[0][0] + B)
+    Cc = 128
+    xs = [torch.randn(B, Cc, h, w_, generator=g) for h, w_ in HW]
+    ws = [torch.randn(Cc, Cc, 3, 3, generator=g) * 0.03 for _ in HW]
+    bs = [torch.randn(Cc, generator=g) * 0.1 for _ in HW]
+    rows = torch.cat([nhwc(t).reshape(-1, Cc) for t in xs], 0).contiguous()
+    wps = [ore.pack_conv_weight(w).cuda() for w in ws]
+    U = torch.stack([ore.winograd_weight(wp, Cc, Cc) for wp in wps]).contiguous()
+    out = torch.full((rows.shape[0], 2 * Cc), 7.0).cuda()
+    ore.conv2d_levels(rows, HW, B, wps[0], Cc, 3, shift=dev(torch.stack(bs).contiguous()), ep_stride=Cc, w_wino=U, w_wino_level_stride=U.shape[1],
+                      out=out, out_coff=Cc)
+    assert float(out[:, :Cc].min()) == 7.0 and float(out[:, :Cc].max()) == 7.0
+    y = out[:, Cc:].cpu()
+    r0 = 0
+    for (h, w_), t, w, b in zip(HW, xs, ws, bs):
+        ref_l = F.conv2d(t, w, b, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cc)
+        assert rel_err(y[r0:r0 + B * h * w_].numpy(), ref_l.numpy()) < TOL
+        r0 += B * h * w_
+    with pytest.raises(ore.OreError):                                                # 1x1 layers have no per-level form
+        ore.conv2d_levels(rows, HW, B, ore.pack_conv_weight(torch.randn(Cc, Cc, 1, 1)).cuda(), Cc, 1, w_wino=U, w_wino_level_stride=U.shape[1])
+
+
 @pytest.fixture
 def kw_forced(ore):
     """Force the wave-private K-split LDS-DMA kernel (k_conv_kw, csrc/ore_conv_kw.hip) wherever it applies, then restore the plan."""

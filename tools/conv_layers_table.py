@@ -20,24 +20,30 @@ def main():
     dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_conv_layers.txt"
     # the head's (reg|hm) step is a VALU kernel since round 3 (k_head_pred): it is listed with the conv launches it replaced
     tl = [l for l in open(src) if l.startswith("k_conv") or l.startswith("k_head_pred")]
-    assert len(tl) == 28, len(tl)
+    # 28 launches: one per FPN output conv (round 2, and the bf16-storage engine); 26: the fp32 engine of round 3 runs the three output
+    # convs as ONE per-level Winograd launch behind the lateral chain
+    assert len(tl) in (26, 28), len(tl)
+    layers, extra = LAYERS, EXTRA
+    if len(tl) == 26:
+        layers = LAYERS[:18] + [LAYERS[18], LAYERS[20], LAYERS[22]]
+        extra = [("FPN output3/4/5 (one launch)", 8400, 128, 128, 3)] + EXTRA
     out = ["# per-conv-launch efficiency of ONE image, strictly sequential mode (rocprofv3 --kernel-trace of the headline protocol, tools/protocol_loop.py,",
            "# %s); algorithmic FLOPs = 2*M*Cout*Cin*k*k; peak = %.1f TFLOP/s (fp32 MFMA, gfx950)" % (src, PEAK),
-           "%-26s %-44s %9s %8s %8s %7s" % ("layer", "kernel / grid", "us", "GFLOP", "TFLOP/s", "% peak")]
+           "%-28s %-44s %9s %8s %8s %7s" % ("layer", "kernel / grid", "us", "GFLOP", "TFLOP/s", "% peak")]
     tu = tg = 0.0
     for i, l in enumerate(tl):
         m = re.match(r"(\S+.*?)\s+grid=(\([^)]*\))\s+dur=\s*([\d.]+)", l)
         kn, grid, us = m.group(1).strip(), m.group(2), float(m.group(3))
-        if i < 24:
-            n, H, W, ci, co, k, s = LAYERS[i]
+        if i < len(layers):
+            n, H, W, ci, co, k, s = layers[i]
             gf = 2.0 * (H // s) * (W // s) * co * ci * k * k / 1e9
         else:
-            n, M, ci, co, k = EXTRA[i - 24]
+            n, M, ci, co, k = extra[i - len(layers)]
             gf = 2.0 * M * co * ci * k * k / 1e9
         tu += us
         tg += gf
-        out.append("%-26s %-44s %9.2f %8.3f %8.1f %7.1f" % (n, (kn + " " + grid)[:44], us, gf, gf / us * 1e3, gf / us * 1e3 / PEAK * 100))
-    out.append("%-26s %-44s %9.2f %8.3f %8.1f %7.1f" % ("all 28 conv launches", "", tu, tg, tg / tu * 1e3, tg / tu * 1e3 / PEAK * 100))
+        out.append("%-28s %-44s %9.2f %8.3f %8.1f %7.1f" % (n, (kn + " " + grid)[:44], us, gf, gf / us * 1e3, gf / us * 1e3 / PEAK * 100))
+    out.append("%-28s %-44s %9.2f %8.3f %8.1f %7.1f" % ("all %d conv launches" % len(tl), "", tu, tg, tg / tu * 1e3, tg / tu * 1e3 / PEAK * 100))
     open(dst, "w").write("\n".join(out) + "\n")
     print(out[-1])
 
