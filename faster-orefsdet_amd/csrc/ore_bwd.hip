@@ -8,6 +8,7 @@
 // What they replace: torch.autograd of F.conv2d / F.linear / F.relu / FrozenBatchNorm2d
 //   (d2z:layers/wrappers.py:48-91, d2z:layers/batch_norm.py:44-66) inside d2z:engine/train_loop.py:279 `losses.backward()`.
 #include "ore_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -58,7 +59,13 @@ constexpr int WG_LD = 80;
 #ifndef ORE_WG_BLOCKS
 #define ORE_WG_BLOCKS 1536
 #endif
-constexpr int WG_BLOCKS = ORE_WG_BLOCKS;   // blocks aimed at per weight-gradient launch (rows are split until the grid has this many)    // LDS row stride: the 4 k-rows of an MFMA operand land 16 banks apart -> conflict-free ds_read_b32
+static int wg_blocks() {                   // env ORE_WG_BLOCKS overrides the build-time target (A/B runs)
+    static int v = 0;
+    if (!v) { const char* e = getenv("ORE_WG_BLOCKS"); v = e ? atoi(e) : 0; if (v < 64) v = ORE_WG_BLOCKS; }
+    return v;
+}
+#define WG_BLOCKS wg_blocks()
+constexpr int WG_BLOCKS_UNUSED = ORE_WG_BLOCKS;   // blocks aimed at per weight-gradient launch (rows are split until the grid has this many)    // LDS row stride: the 4 k-rows of an MFMA operand land 16 banks apart -> conflict-free ds_read_b32
 
 __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     __shared__ float sA[2][WG_K][WG_LD];   // dZ rows x co
@@ -241,21 +248,29 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     }
 }
 
-// dw_oihw[co][ci][tap] = beta * dw + sum_z slab[z][co][tap][ci]  (fixed summation order: even and odd slabs ascending, then their sum).
-// One thread = 4 consecutive ci (Cin % 4 == 0): 16-byte slab loads, two independent accumulator chains.
+// dw_oihw[co][ci][tap] = beta * dw + sum_z slab[z][co][tap][ci].  Fixed summation order: slab z belongs to group z % G, every group is
+// summed ascending by one thread, the G partial sums are added ascending (deterministic for a given S).  One thread = (4 consecutive
+// ci, one group): 16-byte slab loads, G x as many loads in flight as one thread per output has -- the 1x1 layers split their rows 192-745
+// ways (few tiles), and a single chain per output made their reductions 26-96 us of pure latency.
+template <int G>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cout, int taps, int Cin, float beta,
                                                       float* __restrict__ dw) {
+    __shared__ __attribute__((aligned(16))) float part[256 * 4];
+    constexpr int PER = 256 / G;                                  // outputs quads per block
     const long long n = (long long)Cout * taps * Cin;
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    int z = 0;
-    for (; z + 1 < S; z += 2) {
-        s0 += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n + i);
-        s1 += *reinterpret_cast<const f32x4*>(slab + (size_t)(z + 1) * n + i);
+    const int q = threadIdx.x % PER, g = threadIdx.x / PER;
+    const long long i = ((long long)blockIdx.x * PER + q) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n)
+        for (int z = g; z < S; z += G) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n + i);
+    if (G > 1) {
+        *reinterpret_cast<f32x4*>(part + threadIdx.x * 4) = s;
+        __syncthreads();
+        if (g != 0) return;
+#pragma unroll
+        for (int k = 1; k < G; ++k) s += *reinterpret_cast<const f32x4*>(part + (k * PER + q) * 4);
     }
-    if (z < S) s0 += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n + i);
-    const f32x4 s = s0 + s1;
+    if (i >= n) return;
     const int ci = (int)(i % Cin), tap = (int)((i / Cin) % taps), co = (int)(i / ((long long)Cin * taps));
     float* o = dw + ((size_t)co * Cin + ci) * taps + tap;
     if (taps == 1) {
@@ -659,7 +674,14 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     else hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
     int rc = ore_launch_status("k_wgrad");
     if (rc || S == 1) return rc;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+    // slab groups per output: enough threads to fill the chip and enough independent loads per output to hide the latency
+    const long long quads = per / 4;
+    if (S >= 64 && quads <= 65536)
+        hipLaunchKernelGGL(k_wgrad_reduce<16>, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+    else if (S >= 16)
+        hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
     return ore_launch_status("k_wgrad_reduce");
 }
 
