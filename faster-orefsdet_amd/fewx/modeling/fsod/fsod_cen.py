@@ -5,6 +5,7 @@ stem_1 with fused BGR normalisation -> VoVNet OSA stages -> FPN -> query<->suppo
 conv3 -> CenterNet head -> sigmoid/top-k/decode/NMS.  The support prototypes are loaded ONCE (the reference re-reads
 support_feature.pkl on every forward) and the engine is rebuilt only when parameters change."""
 import logging
+import operator
 import os
 
 import numpy as np
@@ -21,6 +22,8 @@ from detectron2.structures import ImageList
 
 from .fsod_roi_heads import build_roi_heads
 from .fsod_rpn import make_proposals
+
+_TENSOR_VERSION = operator.attrgetter("_version")
 
 
 class MLP(nn.Module):
@@ -243,7 +246,7 @@ class CenterNet2Detector(nn.Module):
         ts = self.__dict__.get("_key_tensors")
         if ts is None:
             ts = self.__dict__["_key_tensors"] = list(self.parameters()) + list(self.buffers())
-        return (self.__dict__.get("_key_epoch", 0), sum([t._version for t in ts]))
+        return (self.__dict__.get("_key_epoch", 0), sum(map(_TENSOR_VERSION, ts)))      # (a C-level loop: ~200 tensors per forward)
 
     def _invalidate_state_key(self):
         self.__dict__.pop("_key_tensors", None)
