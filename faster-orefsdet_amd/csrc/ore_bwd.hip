@@ -41,7 +41,31 @@ struct WgradP {
     float* slab;             // [S][Cout][taps][Cin]
     float* dw; float beta;   // S == 1: write OIHW directly (no slab, no reduce launch)
     int bf16;                // ore_conv_set_precision(ORE_CONV_BF16): both operands rounded to bf16 (nearest even) as they are staged
+    float* db; float beta_b; // optional bias gradient = column sums of dZ, accumulated by the blocks that stage dZ anyway (blockIdx.y == 0):
+                             // slab z holds them behind its weight part (slab_stride = weight floats + Cout), S == 1 writes db directly
+    long long slab_stride;
 };
+
+// column sums of the dZ rows a block staged: every thread kept the running sum of its own (row lr, columns lc..lc+3) loads; the 16 rows
+// meet in LDS (one barrier, only when a bias gradient was asked for) and go to the slab's bias part, or straight to db when S == 1
+__device__ __forceinline__ void wgrad_bias_out(const WgradP& p, float (*sA)[80], f32x4 bsum, int co0, float* slab) {
+    const int tid = threadIdx.x, lr = tid >> 4, lc = (tid & 15) * 4;
+    __syncthreads();                                             // the K loop's last reads of sA are done
+    *reinterpret_cast<f32x4*>(&sA[lr][lc]) = bsum;
+    __syncthreads();
+    if (tid < 16 && co0 + lc < p.Cout) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(&sA[0][lc]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) s += *reinterpret_cast<const f32x4*>(&sA[r][lc]);
+        if (p.dw) {
+            float* o = p.db + co0 + lc;
+            if (p.beta_b != 0.0f) s += p.beta_b * *reinterpret_cast<const f32x4*>(o);
+            *reinterpret_cast<f32x4*>(o) = s;
+        } else {
+            *reinterpret_cast<f32x4*>(slab + (size_t)p.Cout * p.kh * p.kw * p.Cin + co0 + lc) = s;
+        }
+    }
+}
 
 // bf16-operand mode of the weight gradient: dZ and X are rounded to bf16 on their way into LDS and multiplied on the fp32 MFMA --
 // a product of two bf16 values is exact in fp32 and the accumulation is fp32 either way, so the result is that of a bf16 MFMA up to
@@ -56,6 +80,7 @@ __device__ __forceinline__ f32x4 bf16_rne4(f32x4 v) { return f32x4{bf16_rne(v.x)
 constexpr int WG_T = 64;     // block tile: 64 output channels x 64 input channels of one tap
 constexpr int WG_K = 16;     // rows per step
 constexpr int WG_LD = 80;
+static_assert(WG_LD == 80, "wgrad_bias_out reuses a staging buffer with this row stride");
 #ifndef ORE_WG_BLOCKS
 #define ORE_WG_BLOCKS 1536
 #endif
@@ -100,8 +125,11 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     };
     f32x4 va, vb;
     load(m_begin, va, vb);
+    const bool do_b = p.db != nullptr && blockIdx.y == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     int buf = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+        if (do_b) bsum += va;                                    // (fp32 dZ: the bias gradient is not an MFMA operand)
         if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); }
         *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
         *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
@@ -125,7 +153,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     }
     // D: column = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
     const int taps = p.kh * p.kw;
-    float* slab = p.slab + (size_t)blockIdx.z * p.Cout * taps * p.Cin;
+    float* slab = p.slab + (size_t)blockIdx.z * p.slab_stride;
+    if (do_b) wgrad_bias_out(p, sA[0], bsum, co0, slab);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -191,8 +220,11 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     f32x4 va, vb, vb2;
     int msk;
     load(m_begin, va, vb, vb2, msk);
+    const bool do_b = p.db != nullptr && blockIdx.y == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     int buf = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+        if (do_b) bsum += va;
         if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); vb2 = bf16_rne4(vb2); }
         *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
         *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
@@ -223,7 +255,8 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
         }
         buf ^= 1;
     }
-    float* slab = p.slab + (size_t)blockIdx.z * p.Cout * 9 * p.Cin;
+    float* slab = p.slab + (size_t)blockIdx.z * p.slab_stride;
+    if (do_b) wgrad_bias_out(p, sA[0], bsum, co0, slab);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int tap = dyi * 3 + d;
@@ -254,15 +287,16 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
 // ways (few tiles), and a single chain per output made their reductions 26-96 us of pure latency.
 template <int G>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int Cout, int taps, int Cin, float beta,
-                                                      float* __restrict__ dw) {
+                                                      float* __restrict__ dw, long long stride, float* __restrict__ db, float beta_b) {
     __shared__ __attribute__((aligned(16))) float part[256 * 4];
     constexpr int PER = 256 / G;                                  // outputs quads per block
-    const long long n = (long long)Cout * taps * Cin;
+    const long long nw = (long long)Cout * taps * Cin;
+    const long long n = nw + (db ? Cout : 0);                     // the slabs' bias part follows their weight part
     const int q = threadIdx.x % PER, g = threadIdx.x / PER;
     const long long i = ((long long)blockIdx.x * PER + q) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n)
-        for (int z = g; z < S; z += G) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n + i);
+        for (int z = g; z < S; z += G) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * stride + i);
     if (G > 1) {
         *reinterpret_cast<f32x4*>(part + threadIdx.x * 4) = s;
         __syncthreads();
@@ -271,6 +305,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
         for (int k = 1; k < G; ++k) s += *reinterpret_cast<const f32x4*>(part + (k * PER + q) * 4);
     }
     if (i >= n) return;
+    if (i >= nw) {                                               // bias gradient
+        float* o = db + (i - nw);
+        if (beta_b != 0.0f) s += beta_b * *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = s;
+        return;
+    }
     const int ci = (int)(i % Cin), tap = (int)((i / Cin) % taps), co = (int)(i / ((long long)Cin * taps));
     float* o = dw + ((size_t)co * Cin + ci) * taps + tap;
     if (taps == 1) {
@@ -640,15 +680,16 @@ static int wgrad_tiles(int Cin, int Cout, int kh, int kw) {
 }
 
 extern "C" size_t ore_conv_wgrad_workspace_floats(int32_t rows, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw) {
-    const long long per = (long long)Cout * kh * kw * Cin;
+    const long long per = (long long)Cout * kh * kw * Cin + Cout;      // (+ the bias part of a slab, whether or not it is asked for)
     const int tiles = wgrad_tiles(Cin, Cout, kh, kw);
     int S = max(1, min(ceil_div(WG_BLOCKS, tiles), ceil_div(rows, 128)));
     return (size_t)(per * S);
 }
 
-extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff, const float* dz, int32_t dz_ld, int32_t dz_coff,
-                                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t pad,
-                                    float* dw_oihw, float beta, float* workspace, size_t workspace_floats, void* stream) {
+extern "C" int ore_conv2d_wgrad_bias_fwd(const float* x, int32_t x_ld, int32_t x_coff, const float* dz, int32_t dz_ld, int32_t dz_coff,
+                                         int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t pad,
+                                         float* dw_oihw, float beta, float* db, float beta_b, float* workspace, size_t workspace_floats,
+                                         void* stream) {
     ORE_CHECK_ARG(x && dz && dw_oihw && workspace, "ore_conv2d_wgrad_fwd: null pointer");
     ORE_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && kh > 0 && kw > 0 && kh == 2 * pad + 1 && kw == 2 * pad + 1,
                   "ore_conv2d_wgrad_fwd: stride-1 'same' convolutions only (k = 2*pad+1)");
@@ -656,7 +697,8 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
                   x_coff + Cin <= x_ld && dz_coff + Cout <= dz_ld, "ore_conv2d_wgrad_fwd: channel counts/offsets must be multiples of 4 and fit ld");
     const long long M = (long long)B * H * W;
     ORE_CHECK_ARG(M < (1ll << 31), "ore_conv2d_wgrad_fwd: too many rows");
-    const long long per = (long long)Cout * kh * kw * Cin;
+    const long long pw = (long long)Cout * kh * kw * Cin;
+    const long long per = pw + Cout;                                   // slab = weight part + bias part
     const int tiles = wgrad_tiles(Cin, Cout, kh, kw);
     int S = max(1, min(ceil_div(WG_BLOCKS, tiles), ceil_div((int)M, 128)));
     { const long long cap = (long long)(workspace_floats / (size_t)per); if (cap < S) S = (int)cap; }
@@ -666,7 +708,8 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.kh = kh; p.kw = kw; p.pad = pad;
     p.M = (int)M; p.chunk = round_up(ceil_div((int)M, S), WG_K);
     S = ceil_div((int)M, p.chunk);
-    p.slab = workspace;
+    p.slab = workspace; p.slab_stride = per;
+    p.db = db; p.beta_b = beta_b;
     if (S == 1) { p.dw = dw_oihw; p.beta = beta; }
     p.bf16 = ore_conv_get_precision();
     hipStream_t st = (hipStream_t)stream;
@@ -675,14 +718,24 @@ extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff
     int rc = ore_launch_status("k_wgrad");
     if (rc || S == 1) return rc;
     // slab groups per output: enough threads to fill the chip and enough independent loads per output to hide the latency
-    const long long quads = per / 4;
+    const long long quads = (pw + (db ? Cout : 0)) / 4;
     if (S >= 64 && quads <= 65536)
-        hipLaunchKernelGGL(k_wgrad_reduce<16>, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+        hipLaunchKernelGGL(k_wgrad_reduce<16>, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw,
+                           per, db, beta_b);
     else if (S >= 16)
-        hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+        hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw,
+                           per, db, beta_b);
     else
-        hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw);
+        hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace, S, Cout, kh * kw, Cin, beta, dw_oihw,
+                           per, db, beta_b);
     return ore_launch_status("k_wgrad_reduce");
+}
+
+extern "C" int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff, const float* dz, int32_t dz_ld, int32_t dz_coff,
+                                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t pad,
+                                    float* dw_oihw, float beta, float* workspace, size_t workspace_floats, void* stream) {
+    return ore_conv2d_wgrad_bias_fwd(x, x_ld, x_coff, dz, dz_ld, dz_coff, B, H, W, Cin, Cout, kh, kw, pad, dw_oihw, beta, nullptr, 0.0f, workspace,
+                                     workspace_floats, stream);
 }
 
 extern "C" int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_coff, const float* y, int32_t y_ld, int32_t y_coff,

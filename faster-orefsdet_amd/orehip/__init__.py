@@ -70,7 +70,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
-           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
+           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_conv2d_wgrad_bias_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_roi_predict_post_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
@@ -727,8 +727,9 @@ def _wgrad_ws(device, n: int) -> torch.Tensor:
 
 
 def conv2d_wgrad(x: torch.Tensor, dz: torch.Tensor, k: int, *, x_coff: int = 0, Cin: Optional[int] = None, dz_coff: int = 0,
-                 Cout: Optional[int] = None, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
-    """x [B,H,W,x_ld], dz [B,H,W,dz_ld] NHWC -> dW [Cout,Cin,k,k] (OIHW); stride 1, pad k//2."""
+                 Cout: Optional[int] = None, out: Optional[torch.Tensor] = None, beta: float = 0.0, want_bias: bool = False):
+    """x [B,H,W,x_ld], dz [B,H,W,dz_ld] NHWC -> dW [Cout,Cin,k,k] (OIHW); stride 1, pad k//2.  want_bias: also the bias gradient
+    (column sums of dz) from the same launch -> (dW, db)."""
     _f32(x); _f32(dz)
     B, H, W, xld = x.shape
     dld = dz.shape[-1]
@@ -741,10 +742,11 @@ def conv2d_wgrad(x: torch.Tensor, dz: torch.Tensor, k: int, *, x_coff: int = 0, 
     assert out.shape == (Cout, Cin, k, k) and out.is_contiguous()
     n = lib().ore_conv_wgrad_workspace_floats(B * H * W, Cin, Cout, k, k)
     ws = _wgrad_ws(x.device, n)
-    _chk(lib().ore_conv2d_wgrad_fwd(C.c_void_p(_ptr(x)), xld, x_coff, C.c_void_p(_ptr(dz)), dld, dz_coff, B, H, W, Cin, Cout, k, k,
-                                    k // 2, C.c_void_p(_ptr(out)), C.c_float(beta), C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()),
-                                    _stream()), "ore_conv2d_wgrad_fwd")
-    return out
+    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None
+    _chk(lib().ore_conv2d_wgrad_bias_fwd(C.c_void_p(_ptr(x)), xld, x_coff, C.c_void_p(_ptr(dz)), dld, dz_coff, B, H, W, Cin, Cout, k, k,
+                                         k // 2, C.c_void_p(_ptr(out)), C.c_float(beta), C.c_void_p(_ptr(db)), C.c_float(0.0),
+                                         C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_conv2d_wgrad_bias_fwd")
+    return (out, db) if want_bias else out
 
 
 def relu_affine_bwd(dy: torch.Tensor, y: torch.Tensor, scale: Optional[torch.Tensor] = None, *, dy_coff: int = 0, y_coff: int = 0,

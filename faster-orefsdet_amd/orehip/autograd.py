@@ -85,9 +85,12 @@ def _conv_backward(x, x_coff, Cin, weight, dz, k, need_x: bool, need_w: bool, ne
     gx = gw = gb = None
     if need_x:
         gx = orehip.conv2d(dz, packed(weight, True), Cin, k, 1, k // 2, w_wino=packed_wino(weight, True) if k == 3 else None)
-    if need_w:
+    if need_w and need_b:                                    # the weight-gradient launch sums the dZ rows it stages anyway
+        gw, gb = orehip.conv2d_wgrad(x, dz, k, x_coff=x_coff, Cin=Cin, want_bias=True)
+        gw, gb = gw[:Cout], gb[:Cout]
+    elif need_w:
         gw = orehip.conv2d_wgrad(x, dz, k, x_coff=x_coff, Cin=Cin)[:Cout]
-    if need_b:
+    elif need_b:
         gb = orehip.colsum(dz)[:Cout]
     return gx, gw, gb
 

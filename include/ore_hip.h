@@ -334,6 +334,12 @@ size_t ore_conv_wgrad_workspace_floats(int32_t rows, int32_t Cin, int32_t Cout, 
 int ore_conv2d_wgrad_fwd(const float* x, int32_t x_ld, int32_t x_coff, const float* dz, int32_t dz_ld, int32_t dz_coff,
                          int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t pad,
                          float* dw_oihw, float beta, float* workspace, size_t workspace_floats, void* stream);
+/* The same launch also returns the bias gradient db[Cout] = beta_b * db + column sums of dZ (NULL = not wanted): the blocks that stage
+ * the dZ rows for the matrix cores add them up on the side, so no separate reduction pass over dZ is needed
+ * (torch.autograd of the bias of F.conv2d / F.linear). */
+int ore_conv2d_wgrad_bias_fwd(const float* x, int32_t x_ld, int32_t x_coff, const float* dz, int32_t dz_ld, int32_t dz_coff, int32_t B,
+                              int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t pad, float* dw_oihw,
+                              float beta, float* db, float beta_b, float* workspace, size_t workspace_floats, void* stream);
 int ore_relu_affine_bwd(const float* dy, int32_t dy_ld, int32_t dy_coff, const float* y, int32_t y_ld, int32_t y_coff,
                         const float* scale, int64_t rows, int32_t C, float* dz, int32_t dz_ld, int32_t dz_coff, void* stream);
 /* out[c] = beta * out[c] + sum_rows x[row][coff + c]; workspace >= ceil(rows/64) * C floats. */

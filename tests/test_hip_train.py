@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import ref_model as R
 
@@ -142,6 +143,25 @@ def _close(got, ref, tol=2e-5):
 
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(1, 6, 9, 32, 16, 3), (2, 40, 44, 96, 96, 3), (1, 64, 64, 128, 128, 1), (4, 30, 30, 256, 112, 1),
+                                              (1, 20, 20, 128, 16, 3)])
+def test_wgrad_with_fused_bias_gradient(oh, B, H, W, Cin, Cout, k):
+    """ore_conv2d_wgrad_bias_fwd: weight gradient and bias gradient (column sums of dZ) from ONE launch, with and without a row split
+    (the first shape runs unsplit and writes both outputs directly), against torch.autograd of F.conv2d."""
+    g = torch.Generator().manual_seed(B * 7 + H + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    dz = torch.randn(B, Cout, H, W, generator=g)
+    (F.conv2d(x, w, b, 1, k // 2) * dz).sum().backward()
+    gw, gb = oh.conv2d_wgrad(_nhwc(x).cuda(), _nhwc(dz).cuda(), k, want_bias=True)
+    _close(gw, w.grad, tol=3e-5)
+    _close(gb, b.grad, tol=3e-5)
+    gw2 = oh.conv2d_wgrad(_nhwc(x).cuda(), _nhwc(dz).cuda(), k)
+    assert torch.equal(gw2, gw)                                                  # the bias side does not disturb the weight gradient
+    _close(oh.colsum(_nhwc(dz).cuda()), b.grad, tol=3e-5)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,mode", [(2, 13, 17, 32, 48, 3, "bn_relu"), (1, 20, 24, 128, 128, 3, "bias"),
