@@ -896,6 +896,88 @@ extern "C" int ore_groupnorm_bwd(const float* dy, const float* y, const float* x
     return ore_launch_status("k_gn_bwd_dx");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// SM_Block glue (ref:fewx/modeling/fsod/fsod_cen.py:584-630, training): the H- and W-mixing Linears see the map with (segment, the
+// other axis) as rows and (mixed axis, S channels) as K.  In memory that is a transpose of 16-byte granules -- for a fixed (image,
+// other-axis index) an [A x Bc] matrix of S-float granules becomes [Bc x A] -- which ATen runs element by element at ~1.3 TB/s.
+// One block moves one such matrix through LDS: reads and writes are both whole granule rows (512 B at 128 channels).
+__global__ __launch_bounds__(256) void k_granule_transpose(const float* __restrict__ in, float* __restrict__ out, int nb2, int A, int Bc,
+                                                           int S4, long long in_b1, long long in_b2, long long in_rs, long long out_b1,
+                                                           long long out_b2, long long out_rs) {
+    extern __shared__ __attribute__((aligned(16))) float gt[];    // [A][Bc * S4 + 1] granules of 4 floats (odd pitch: column reads spread)
+    const int b1 = blockIdx.x / nb2, b2 = blockIdx.x - b1 * nb2;
+    const int row = Bc * S4, pitch = row + 1, n = A * row;
+    const float* src = in + b1 * in_b1 + b2 * in_b2;
+    float* dst = out + b1 * out_b1 + b2 * out_b2;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / row, cs = i - r * row;
+        *reinterpret_cast<f32x4*>(gt + (size_t)(r * pitch + cs) * 4) = *reinterpret_cast<const f32x4*>(src + r * in_rs + cs * 4);
+    }
+    __syncthreads();
+    const int orow = A * S4;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / orow, rs = i - c * orow;
+        const int r = rs / S4, s4 = rs - r * S4;
+        *reinterpret_cast<f32x4*>(dst + c * out_rs + rs * 4) = *reinterpret_cast<const f32x4*>(gt + (size_t)(r * pitch + c * S4 + s4) * 4);
+    }
+}
+
+// y = w * a0[b][c] + h * a1[b][c]  (the re-weighted sum of the two mixed maps); backward: dw = dy * a0 + v, dh = dy * a1 + v with the
+// optional per-(image, channel) constant v (the gradient of the mean pool that fed the re-weighting MLP)
+__global__ __launch_bounds__(256) void k_combine2(const float* __restrict__ w, const float* __restrict__ h, const float* __restrict__ a0,
+                                                  const float* __restrict__ a1, int B, int rows, int C, float* __restrict__ y) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * rows * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    const int b = (int)(i / ((long long)rows * c4n));
+    reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(w)[i] * *reinterpret_cast<const f32x4*>(a0 + (size_t)b * C + c) +
+                                     reinterpret_cast<const f32x4*>(h)[i] * *reinterpret_cast<const f32x4*>(a1 + (size_t)b * C + c);
+}
+__global__ __launch_bounds__(256) void k_combine2_bwd(const float* __restrict__ dy, const float* __restrict__ a0, const float* __restrict__ a1,
+                                                      const float* __restrict__ v, int B, int rows, int C, float* __restrict__ dw,
+                                                      float* __restrict__ dh) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * rows * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    const int b = (int)(i / ((long long)rows * c4n));
+    const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    f32x4 ow = g * *reinterpret_cast<const f32x4*>(a0 + (size_t)b * C + c), oh = g * *reinterpret_cast<const f32x4*>(a1 + (size_t)b * C + c);
+    if (v) { const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (size_t)b * C + c); ow += vv; oh += vv; }
+    reinterpret_cast<f32x4*>(dw)[i] = ow;
+    reinterpret_cast<f32x4*>(dh)[i] = oh;
+}
+
+extern "C" int ore_granule_transpose_fwd(const float* in, float* out, int32_t nb1, int32_t nb2, int32_t A, int32_t Bc, int32_t S, int64_t in_b1,
+                                         int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, void* stream) {
+    ORE_CHECK_ARG(in && out && in != out && nb1 > 0 && nb2 > 0 && A > 0 && Bc > 0 && S > 0 && S % 4 == 0, "ore_granule_transpose_fwd: bad args");
+    ORE_CHECK_ARG(in_b1 % 4 == 0 && in_b2 % 4 == 0 && in_rs % 4 == 0 && out_b1 % 4 == 0 && out_b2 % 4 == 0 && out_rs % 4 == 0,
+                  "ore_granule_transpose_fwd: strides must be multiples of 4 floats");
+    const size_t lds = (size_t)A * (Bc * (S / 4) + 1) * 16;
+    ORE_CHECK_ARG(lds <= 64 * 1024, "ore_granule_transpose_fwd: one [A x Bc] granule matrix must fit 64 KB of LDS (A=%d Bc=%d S=%d)", A, Bc, S);
+    hipLaunchKernelGGL(k_granule_transpose, dim3((unsigned)nb1 * nb2), dim3(256), lds, (hipStream_t)stream, in, out, nb2, A, Bc, S / 4,
+                       (long long)in_b1, (long long)in_b2, (long long)in_rs, (long long)out_b1, (long long)out_b2, (long long)out_rs);
+    return ore_launch_status("k_granule_transpose");
+}
+
+extern "C" int ore_combine2_fwd(const float* w, const float* h, const float* a0_bc, const float* a1_bc, int32_t B, int32_t rows, int32_t C,
+                                float* y, void* stream) {
+    ORE_CHECK_ARG(w && h && a0_bc && a1_bc && y && B > 0 && rows > 0 && C > 0 && C % 4 == 0, "ore_combine2_fwd: bad args");
+    const long long n = (long long)B * rows * (C / 4);
+    hipLaunchKernelGGL(k_combine2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, h, a0_bc, a1_bc, B, rows, C, y);
+    return ore_launch_status("k_combine2");
+}
+
+extern "C" int ore_combine2_bwd(const float* dy, const float* a0_bc, const float* a1_bc, const float* add_bc, int32_t B, int32_t rows, int32_t C,
+                                float* dw, float* dh, void* stream) {
+    ORE_CHECK_ARG(dy && a0_bc && a1_bc && dw && dh && B > 0 && rows > 0 && C > 0 && C % 4 == 0, "ore_combine2_bwd: bad args");
+    const long long n = (long long)B * rows * (C / 4);
+    hipLaunchKernelGGL(k_combine2_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, a0_bc, a1_bc, add_bc, B, rows, C,
+                       dw, dh);
+    return ore_launch_status("k_combine2_bwd");
+}
+
 extern "C" int ore_prod_colsum_fwd(const float* p, const float* q, int32_t B, int32_t rows, int32_t C, float scale, float* out_bc,
                                    float* workspace, size_t workspace_floats, void* stream) {
     ORE_CHECK_ARG(p && out_bc && workspace && B > 0 && rows > 0 && C > 0 && C % 4 == 0, "ore_prod_colsum_fwd: bad args");

@@ -70,7 +70,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
-           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_conv2d_wgrad_bias_fwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
+           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_conv2d_wgrad_bias_fwd", "ore_granule_transpose_fwd", "ore_combine2_fwd", "ore_combine2_bwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_roi_predict_post_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
@@ -876,6 +876,49 @@ def scale_add_channels(x: torch.Tensor, scale_bc: torch.Tensor, add_bc: Optional
                                           C.c_void_p(_ptr(_f32(add_bc)) if add_bc is not None else None), B, rows, Cc, C.c_void_p(_ptr(out)),
                                           _stream()), "ore_scale_add_channels_fwd")
     return out
+
+
+def sm_permute(x: torch.Tensor, B: int, H: int, W: int, G: int, S: int, axis: str, inverse: bool) -> torch.Tensor:
+    """The SM_Block's mixing layouts as one coalesced pass (ore_granule_transpose_fwd).  axis 'h': [B,H,W,G,S] <-> [B,G,W,H,S]
+    (= .permute(0,3,2,1,4)); axis 'w': [B,H,W,G,S] <-> [B,G,H,W,S] (= .permute(0,3,1,2,4) and back).  x contiguous with B*H*W*G*S elements;
+    returns a contiguous tensor in the other layout (forward: the mixing layout, inverse: NHWC)."""
+    _f32(x)
+    assert x.numel() == B * H * W * G * S and axis in ("h", "w")
+    Cc, img = G * S, H * W * G * S
+    if axis == "h":
+        nb2, mix = W, (B, G, W, H, S)
+        fwd = (H, G, img, Cc, W * Cc, img, H * S, W * H * S)          # A, Bc, in_b1, in_b2, in_rs, out_b1, out_b2, out_rs
+        inv = (G, H, img, H * S, W * H * S, img, Cc, W * Cc)
+    else:
+        nb2, mix = H, (B, G, H, W, S)
+        fwd = (W, G, img, W * Cc, Cc, img, W * S, H * W * S)
+        inv = (G, W, img, W * S, H * W * S, img, W * Cc, Cc)
+    A_, Bc, ib1, ib2, irs, ob1, ob2, ors = inv if inverse else fwd
+    out = torch.empty((B, H, W, G * S) if inverse else mix, device=x.device, dtype=torch.float32)
+    _chk(lib().ore_granule_transpose_fwd(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), B, nb2, A_, Bc, S, C.c_int64(ib1), C.c_int64(ib2),
+                                         C.c_int64(irs), C.c_int64(ob1), C.c_int64(ob2), C.c_int64(ors), _stream()), "ore_granule_transpose_fwd")
+    return out
+
+
+def combine2(w: torch.Tensor, h: torch.Tensor, a0: torch.Tensor, a1: torch.Tensor) -> torch.Tensor:
+    """y = w * a0[b, c] + h * a1[b, c];  w, h [B, ..., C], a0, a1 [B, C]."""
+    _f32(w); _f32(h)
+    B, Cc = w.shape[0], w.shape[-1]
+    y = torch.empty_like(w)
+    _chk(lib().ore_combine2_fwd(C.c_void_p(_ptr(w)), C.c_void_p(_ptr(h)), C.c_void_p(_ptr(_f32(a0))), C.c_void_p(_ptr(_f32(a1))), B,
+                                w.numel() // (B * Cc), Cc, C.c_void_p(_ptr(y)), _stream()), "ore_combine2_fwd")
+    return y
+
+
+def combine2_bwd(dy: torch.Tensor, a0: torch.Tensor, a1: torch.Tensor, add_bc: Optional[torch.Tensor] = None):
+    """(dw, dh) = (dy * a0 + v, dy * a1 + v) with the optional per-(image, channel) constant v."""
+    _f32(dy)
+    B, Cc = dy.shape[0], dy.shape[-1]
+    dw, dh = torch.empty_like(dy), torch.empty_like(dy)
+    _chk(lib().ore_combine2_bwd(C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(_f32(a0))), C.c_void_p(_ptr(_f32(a1))),
+                                C.c_void_p(_ptr(_f32(add_bc)) if add_bc is not None else None), B, dy.numel() // (B * Cc), Cc,
+                                C.c_void_p(_ptr(dw)), C.c_void_p(_ptr(dh)), _stream()), "ore_combine2_bwd")
+    return dw, dh
 
 
 def maxpool3x3s2_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:

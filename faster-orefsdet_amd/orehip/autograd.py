@@ -275,6 +275,69 @@ def ese(x, fc_w, fc_b):
     return EseFn.apply(x, fc_w, fc_b)
 
 
+class SmPermuteFn(Function):
+    """SM_Block mixing layouts (ref fsod_cen.py:602-611): the permute + reshape pairs around mlp_h / mlp_w as one coalesced granule
+    transpose each way; the backward of a layout change is the opposite layout change."""
+
+    @staticmethod
+    def forward(ctx, x, dims, axis: str, inverse: bool):
+        ctx.meta = (dims, axis, inverse, tuple(x.shape))
+        return orehip.sm_permute(x.contiguous(), *dims, axis, inverse)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dims, axis, inverse, shape = ctx.meta
+        return orehip.sm_permute(dy.contiguous(), *dims, axis, not inverse).reshape(shape), None, None, None
+
+
+def sm_permute(x, dims, axis, inverse=False):
+    return SmPermuteFn.apply(x, dims, axis, inverse)
+
+
+class MeanPairFn(Function):
+    """m[b, c] = mean over pixels of (h + w) without the sum tensor (ref fsod_cen.py:612); backward: the same constant for every pixel
+    of both maps (returned as an expanded view: autograd adds it to the other gradient of h / w in one pass)."""
+
+    @staticmethod
+    def forward(ctx, h, w):
+        B, Cc = h.shape[0], h.shape[-1]
+        n = h.numel() // (B * Cc)
+        ctx.meta = (tuple(h.shape), n)
+        return orehip.prod_colsum(h.contiguous(), None, 1.0 / n) + orehip.prod_colsum(w.contiguous(), None, 1.0 / n)
+
+    @staticmethod
+    def backward(ctx, dm):
+        shape, n = ctx.meta
+        g = (dm / n).reshape(shape[0], *([1] * (len(shape) - 2)), shape[-1]).expand(shape)
+        return g, g
+
+
+def mean_pair(h, w):
+    return MeanPairFn.apply(h, w)
+
+
+class Combine2Fn(Function):
+    """y = w * a0 + h * a1 with per-(image, channel) weights a0, a1 [B, C] (ref fsod_cen.py:614-615) in one pass; backward: both map
+    gradients from one pass over dy, the weight gradients as per-image column sums of dy * w and dy * h."""
+
+    @staticmethod
+    def forward(ctx, w, h, a0, a1):
+        w, h, a0, a1 = w.contiguous(), h.contiguous(), a0.contiguous(), a1.contiguous()
+        ctx.save_for_backward(w, h, a0, a1)
+        return orehip.combine2(w, h, a0, a1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, h, a0, a1 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dw, dh = orehip.combine2_bwd(dy, a0, a1)
+        return dw, dh, orehip.prod_colsum(dy, w, 1.0), orehip.prod_colsum(dy, h, 1.0)
+
+
+def combine2(w, h, a0, a1):
+    return Combine2Fn.apply(w, h, a0, a1)
+
+
 class MaxPoolFn(Function):
     """MaxPool2d(3, 2, ceil_mode=True) on NHWC: ore_maxpool3x3s2_fwd | ore_maxpool3x3s2_bwd."""
 

@@ -385,6 +385,18 @@ int ore_prod_colsum_fwd(const float* p, const float* q, int32_t B, int32_t rows,
                         float* workspace, size_t workspace_floats, void* stream);
 int ore_scale_add_channels_fwd(const float* x, const float* scale_bc, const float* add_bc, int32_t B, int32_t rows, int32_t C,
                                float* out, void* stream);
+/* SM_Block glue (ref:fewx/modeling/fsod/fsod_cen.py:584-630, training side).
+ * ore_granule_transpose_fwd: for every (i1 < nb1, i2 < nb2) the [A][Bc] matrix of S-float granules at in + i1*in_b1 + i2*in_b2 (row stride
+ *   in_rs, a row = Bc*S contiguous floats) is written transposed, [Bc][A] granules, at out + i1*out_b1 + i2*out_b2 (row stride out_rs, a
+ *   row = A*S contiguous floats).  All strides in floats, multiples of 4; in != out.  This is x.reshape(B,H,W,seg,S).permute(0,3,2,1,4)
+ *   / .permute(0,3,1,2,4) and their inverses as one coalesced pass.
+ * ore_combine2_fwd: y = w * a0[b][c] + h * a1[b][c];  ore_combine2_bwd: dw = dy * a0 + v, dh = dy * a1 + v (v [B][C] optional). */
+int ore_granule_transpose_fwd(const float* in, float* out, int32_t nb1, int32_t nb2, int32_t A, int32_t Bc, int32_t S, int64_t in_b1,
+                              int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, void* stream);
+int ore_combine2_fwd(const float* w, const float* h, const float* a0_bc, const float* a1_bc, int32_t B, int32_t rows, int32_t C, float* y,
+                     void* stream);
+int ore_combine2_bwd(const float* dy, const float* a0_bc, const float* a1_bc, const float* add_bc, int32_t B, int32_t rows, int32_t C,
+                     float* dw, float* dh, void* stream);
 int ore_maxpool3x3s2_bwd(const float* x, const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
 int ore_sumpool2x2_fwd(const float* in, int32_t ld, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* stream);
 

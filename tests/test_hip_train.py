@@ -145,6 +145,43 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize("B,H,W,G,S", [(3, 32, 32, 32, 4), (2, 16, 16, 16, 8), (5, 8, 8, 8, 16), (1, 6, 10, 4, 4)])
+def test_sm_block_glue_kernels(oh, B, H, W, G, S):
+    """The SM_Block's training-side glue as HIP kernels: the two mixing layouts and their inverses (granule transposes) are exactly the
+    reference's permutes; mean-pair and the re-weighted sum match the torch expressions, values and gradients."""
+    from orehip import autograd as A
+    g = torch.Generator().manual_seed(B + H + G)
+    C = G * S
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    dims = (B, H, W, G, S)
+    x5 = x.reshape(B, H, W, G, S)
+    ph = oh.sm_permute(x, *dims, "h", False)
+    pw = oh.sm_permute(x, *dims, "w", False)
+    assert torch.equal(ph, x5.permute(0, 3, 2, 1, 4).contiguous()) and torch.equal(pw, x5.permute(0, 3, 1, 2, 4).contiguous())
+    assert torch.equal(oh.sm_permute(ph, *dims, "h", True), x) and torch.equal(oh.sm_permute(pw, *dims, "w", True), x)
+    # autograd of the layout change
+    xr = x.clone().requires_grad_(True)
+    up = torch.randn(ph.shape, generator=g).cuda()
+    (A.sm_permute(xr, dims, "h") * up).sum().backward()
+    assert torch.equal(xr.grad, up.permute(0, 3, 2, 1, 4).reshape(B, H, W, C))
+    # mean-pair + combine against torch, forward and backward
+    h0, w0 = torch.randn(B, H, W, C, generator=g).cuda(), torch.randn(B, H, W, C, generator=g).cuda()
+    a0_, a1_ = torch.rand(B, C, generator=g).cuda(), torch.rand(B, C, generator=g).cuda()
+    uy, um = torch.randn(B, H, W, C, generator=g).cuda(), torch.randn(B, C, generator=g).cuda()
+    outs = []
+    for hip in (False, True):
+        h, w, a0, a1 = (t.clone().requires_grad_(True) for t in (h0, w0, a0_, a1_))
+        if hip:
+            m, y = A.mean_pair(h, w), A.combine2(w, h, a0, a1)
+        else:
+            m = (h + w).permute(0, 3, 1, 2).flatten(2).mean(2)
+            y = w * a0[:, None, None, :] + h * a1[:, None, None, :]
+        ((y * uy).sum() + (m * um).sum()).backward()
+        outs.append((m, y, h.grad, w.grad, a0.grad, a1.grad))
+    for got, ref in zip(outs[1], outs[0]):
+        _close(got, ref.cpu(), tol=2e-5)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(1, 6, 9, 32, 16, 3), (2, 40, 44, 96, 96, 3), (1, 64, 64, 128, 128, 1), (4, 30, 30, 256, 112, 1),
                                               (1, 20, 20, 128, 16, 3)])
 def test_wgrad_with_fused_bias_gradient(oh, B, H, W, Cin, Cout, k):
