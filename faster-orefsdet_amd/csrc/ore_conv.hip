@@ -483,6 +483,7 @@ struct PatchP {
     const float* scale; const float* shift; int ep_stride, relu_cout;
     float* out; int out_ld, out_coff;
     int xmap;                               // tile_of_block mode (1: an XCD owns a contiguous band of tiles -> halo rows re-read inside its L2)
+    size_t w_lstride;                       // k_conv3x3_ws, per-level weights: level l's packed weights start w_lstride floats further (one tile per block)
 };
 
 template <int TH, bool BF = false>
@@ -804,7 +805,13 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void k_conv3x3_ws(PatchP
     f32x4 wf[9][NCH];
     {
         const bool okw = n0 + li < p.Cout16;
-        const float* wrow = p.w + (size_t)(okw ? n0 + li : 0) * p.K + kh * CW + g4;
+        int wl = 0;                                             // per-level weights (the three FPN output convs in one launch): this block's
+        if (p.w_lstride) {                                      // only tile is tile blockIdx.x (the launcher sizes the grid that way)
+#pragma unroll
+            for (int l = 1; l < 4; ++l)
+                if (l < p.nlev && (int)blockIdx.x >= p.tile0[l]) wl = l;
+        }
+        const float* wrow = p.w + wl * p.w_lstride + (size_t)(okw ? n0 + li : 0) * p.K + kh * CW + g4;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -1005,7 +1012,7 @@ static int ws_sb_launch(const ConvP& c, hipStream_t st) {
     if ((c.Cin != 32 && c.Cin != 64) || c.Cout != c.Cout16 || c.Cout % 64 != 0) return 1;
     if (c.Cin == 64 && g_ws_sb_mode == 3) return 1;                           // (A/B aid: 128-channel layers back on k_conv_kw)
     if (c.out_ld % 4 != 0 || c.out_coff % 4 != 0 || ((uintptr_t)c.out & 7) != 0) return 1;
-    if (c.M < 6000) return 1;
+    if (c.M < 6000 && !c.w_lstride) return 1;
     // 64 channels: 4 waves x 16 output channels, 72 VGPRs of weights, two blocks per CU.  128 channels: 8 waves, the wave pairs (w, w+4)
     // split the input channels (72 VGPRs each; the upper half's accumulators meet the lower half's in LDS), one block per CU.
     const int TH = 4;
@@ -1027,6 +1034,7 @@ static int ws_sb_launch(const ConvP& c, hipStream_t st) {
     int gx = (c.Cin == 32 ? 512 : 256) / gy;                // resident blocks
     gx &= ~7;
     if (gx > tiles) gx = tiles;
+    if (c.w_lstride) { gx = tiles; p.xmap = 0; p.w_lstride = c.w_lstride; }   // per-level weights: one tile per block, in tile order
     const dim3 pgrid(gx, gy);
     if (c.Cin == 32) return ws_sb_go<4, 32, 1>(p, tiles, pgrid, st);
     return ws_sb_go<4, 64, 2>(p, tiles, pgrid, st);
@@ -1421,6 +1429,7 @@ static void fill_common(ConvP& p, const ore_conv_desc* d) {
     p.colsum = d->colsum;
     p.wino = d->w_wino;
     p.wino_lstride = 0;
+    p.w_lstride = 0;
     p.sb = 0;
     if (d->storage == ORE_ST_BF16 || d->storage == ORE_ST_BF16_F32OUT) {
         // bf16 tensors: the input side is handed to the kernels in 4-byte units (pairs of channels); the packed weights hold
@@ -1473,6 +1482,16 @@ extern "C" int ore_conv2d_levels_fwd(const ore_conv_desc* d, int32_t n_levels, c
     }
     p.M = rows;
     p.ep_stride = ep_stride;
+    if (d->w_level_stride) {                                  // per-level layers, bf16 storage: the weight-stationary 3x3 kernel or nothing
+        ORE_CHECK_ARG(d->w_level_stride > 0 && d->w_level_stride % 2 == 0 && d->kh == 3 && d->storage == ORE_ST_BF16 && !d->in_mul && !d->colsum &&
+                          !d->w_wino_level_stride,
+                      "ore_conv2d_levels_fwd: w_level_stride is for 3x3 layers in bf16 storage (ORE_ST_BF16)");
+        p.w_lstride = (size_t)d->w_level_stride / 2;              // the kernels count the bf16 side in 4-byte units
+        p.bf16 = 0;
+        const int wrc = ws_sb_launch(p, (hipStream_t)stream);
+        if (wrc == 1) { ore_set_error("ore_conv2d_levels_fwd: the weight-stationary bf16 kernel does not cover this per-level launch (64 / 128 channels, Cout %% 64 == 0)"); return ORE_EINVAL; }
+        return wrc;
+    }
     if (d->w_wino_level_stride) {                             // per-level layers: the Winograd kernel or nothing
         ORE_CHECK_ARG(d->w_wino && d->w_wino_level_stride > 0 && d->kh == 3 && d->storage == ORE_ST_F32 && !d->in_mul && !d->colsum &&
                           oreconv::conv_wino_covers(d->Cout, d->Cin) && (d->Cin == 64 || d->Cin == 128),

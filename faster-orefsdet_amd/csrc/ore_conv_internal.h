@@ -24,6 +24,7 @@ struct ConvP {
     int sb;                              // bf16 STORAGE mode (ore_conv_desc.storage): bit 0 = in / w are bf16 (in_ld, in_coff, Cin, K then count
                                          // PAIRS of bf16 = 4-byte units, a K chunk is 32 channels), bit 1 = out is bf16, bit 2 = add is bf16
     const float* wino;                   // Winograd F(2x2,3x3) transformed weights [16][Cout16][Cin] (ore_winograd_weight_fwd) or null
+    size_t w_lstride;                    // bf16 storage, per-level weights for k_conv3x3_ws: level l's packed weights start w_lstride 4-byte units further
     size_t wino_lstride;                 // several levels, one set of weights each: level l's transformed weights start wino_lstride floats further (0 = shared)
 };
 

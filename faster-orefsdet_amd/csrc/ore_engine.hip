@@ -55,6 +55,7 @@ struct ore_engine {
     struct Stage { Conv layer[8]; Conv concat; float* fc_w = nullptr; float* fc_b = nullptr; int in_ch, conv_ch, out_ch, cat_ch; } stage[4];
     Conv lateral[3], output[3], conv3, tower, pred;      // pred.scale/shift are [3 levels][16]
     float* out_wino3 = nullptr; float* out_shift3 = nullptr; size_t out_wino_stride = 0;   // the three FPN output convs as ONE per-level Winograd launch: [3][U], [3][F] bias
+    uint16_t* out_wh3 = nullptr; size_t out_wh_stride = 0;                                 // bf16 storage: [3][packed bf16 weights] for the weight-stationary kernel
     float* gn_gamma = nullptr; float* gn_beta = nullptr;
     float* k11 = nullptr, *k13 = nullptr, *k31 = nullptr; // level-major [3][C], [3][C][3], [3][C][3]
     HostTensor support[3];
@@ -234,7 +235,7 @@ struct Run {
     // one launch over all pyramid levels (level-major rows)
     void conv_levels(const Conv& c, const float* in, int in_ld, int in_coff, int B, const int* H, const int* W, float* out,
                      int out_ld, int out_coff, int ep_stride = 0, const float* in_mul = nullptr, const float* in_add = nullptr,
-                     int in_relu = 0, bool out_f32 = false, size_t wino_level_stride = 0) {
+                     int in_relu = 0, bool out_f32 = false, size_t wino_level_stride = 0, size_t w_level_stride = 0) {
         if (rc) return;
         ore_conv_desc d{};
         d.in = in; d.in_ld = in_ld; d.in_coff = in_coff; d.B = B; d.Cin = c.Cin;
@@ -243,7 +244,7 @@ struct Run {
         d.in_mul = in_mul; d.in_add = in_add; d.in_relu = in_relu;
         d.out = out; d.out_ld = out_ld; d.out_coff = out_coff;
         d.splitk = 0; d.workspace = e->ws; d.workspace_floats = e->ws_floats;
-        d.w_wino = c.wino; d.w_wino_level_stride = (int64_t)wino_level_stride;
+        d.w_wino = c.wino; d.w_wino_level_stride = (int64_t)wino_level_stride; d.w_level_stride = (int64_t)w_level_stride;
         if (e->sb()) { d.storage = out_f32 ? ORE_ST_BF16_F32OUT : ORE_ST_BF16; d.w = reinterpret_cast<const float*>(c.wh); }
         double rows = 0;
         for (int l = 0; l < 3; ++l) rows += (double)B * H[l] * W[l];
@@ -359,7 +360,7 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
     const int F = c.fpn_ch;
     float* lat[3];
     for (int l = 0; l < 3; ++l) lat[l] = e->at(e->lat_all.p, (size_t)lvl_row0(g, l) * F);
-    const bool grouped = e->out_wino3 != nullptr;          // fp32: the three output convs run as one launch behind the lateral chain
+    const bool grouped = e->out_wino3 != nullptr || e->out_wh3 != nullptr;   // the three output convs run as one launch behind the lateral chain
     for (int l = 2; l >= 0 && !r.rc; --l) {
         const int k = l + 3, s = l + 1;
         const float* add = l < 2 ? lat[l + 1] : nullptr;
@@ -383,7 +384,9 @@ int run_backbone(ore_engine* e, const void* img, int is_u8, const Geo& g, hipStr
         const int H[3] = {g.h[3], g.h[4], g.h[5]}, W[3] = {g.w[3], g.w[4], g.w[5]};
         Conv oc = e->output[0];
         oc.wino = e->out_wino3; oc.shift = e->out_shift3;
-        r.conv_levels(oc, e->lat_all.p, F, 0, g.B, H, W, e->pcat.p, 2 * F, F, F, nullptr, nullptr, 0, false, e->out_wino_stride);
+        if (sb) oc.wh = e->out_wh3;
+        r.conv_levels(oc, e->lat_all.p, F, 0, g.B, H, W, e->pcat.p, 2 * F, F, F, nullptr, nullptr, 0, false, sb ? 0 : e->out_wino_stride,
+                      sb ? e->out_wh_stride : 0);
     }
     *flops = r.flops;
     return r.rc;
@@ -664,6 +667,14 @@ extern "C" int ore_engine_finalize(ore_engine* e) {
             ORE_HIP(hipMemcpy(e->out_shift3 + (size_t)l * F, e->output[l].shift, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice));
         }
         ORE_HIP(hipDeviceSynchronize());
+    } else if (e->sb() && (F == 64 || F == 128)) {
+        // bf16 storage: the same grouping on the weight-stationary kernel (one tile per block, the block loads its level's weights)
+        e->out_wh_stride = ore_packed_weight_bf16_elems(F, F, 3, 3);
+        if ((rc = e->dalloc(&e->out_wh3, 3 * e->out_wh_stride)) || (rc = e->dalloc(&e->out_shift3, (size_t)3 * F))) return rc;
+        for (int l = 0; l < 3; ++l) {
+            ORE_HIP(hipMemcpy(e->out_wh3 + l * e->out_wh_stride, e->output[l].wh, e->out_wh_stride * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+            ORE_HIP(hipMemcpy(e->out_shift3 + (size_t)l * F, e->output[l].shift, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice));
+        }
     }
     if ((rc = make_conv_bias(e, "conv3", 2 * F, F, 1, 1, &e->conv3))) return rc;
     const std::string hp = "proposal_generator.centernet_head.";

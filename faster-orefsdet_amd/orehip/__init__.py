@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
                 ("add", C.c_void_p), ("add_ld", C.c_int32), ("add_coff", C.c_int32),
                 ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_coff", C.c_int32),
                 ("splitk", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t), ("colsum", C.c_void_p),
-                ("w_wino", C.c_void_p), ("storage", C.c_int32), ("w_wino_level_stride", C.c_int64)]
+                ("w_wino", C.c_void_p), ("storage", C.c_int32), ("w_wino_level_stride", C.c_int64), ("w_level_stride", C.c_int64)]
 
 
 class DetectDesc(C.Structure):
@@ -231,7 +231,8 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
 def conv2d_levels(x_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, w_packed: torch.Tensor, Cout: int, k: int, *,
                   in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, ep_stride: int = 0, relu_cout: int = 0,
                   in_mul=None, in_add=None, in_relu: bool = False, out: Optional[torch.Tensor] = None, out_coff: int = 0,
-                  splitk: int = 0, w_wino: Optional[torch.Tensor] = None, out_f32: bool = False, w_wino_level_stride: int = 0) -> torch.Tensor:
+                  splitk: int = 0, w_wino: Optional[torch.Tensor] = None, out_f32: bool = False, w_wino_level_stride: int = 0,
+                  w_level_stride: int = 0) -> torch.Tensor:
     """One launch over several pyramid levels: x_rows [sum_l B*H_l*W_l, ld] level-major (fp32, or bf16 = ORE_ST_BF16 storage)."""
     st_bf16 = x_rows.dtype == torch.bfloat16
     if not st_bf16:
@@ -256,6 +257,7 @@ def conv2d_levels(x_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, w
     d.splitk, d.workspace, d.workspace_floats = splitk, _ptr(ws), ws.numel()
     d.w_wino = _ptr(w_wino)
     d.w_wino_level_stride = int(w_wino_level_stride)   # != 0: the levels are different layers of one shape, w_wino = [L][stride] (Winograd only)
+    d.w_level_stride = int(w_level_stride)             # the same for bf16 storage: w_packed = [L][stride] bf16 (weight-stationary 3x3 kernel)
     L = len(HW)
     Hs = (C.c_int32 * L)(*[h for h, _ in HW])
     Ws = (C.c_int32 * L)(*[w for _, w in HW])

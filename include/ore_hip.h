@@ -76,6 +76,8 @@ typedef struct ore_conv_desc {
                            * one shape (the three FPN output convs, d2z:modeling/backbone/fpn.py:139-145): level l's Winograd weights start
                            * l * w_wino_level_stride floats after w_wino, its scale / shift l * ep_stride floats after scale / shift; `w` is
                            * not read.  Winograd kernels only (3x3, Cin 64 / 128, fp32 storage), any row count; else ORE_EINVAL. */
+    int64_t w_level_stride; /* the same for ORE_ST_BF16 storage: level l's packed bf16 weights start l * w_level_stride ELEMENTS after `w`
+                           * (3x3, 64 / 128 input channels, Cout % 64 == 0: the weight-stationary kernel, one tile per block); else ORE_EINVAL. */
 } ore_conv_desc;
 #define ORE_ST_F32 0
 #define ORE_ST_BF16 1

@@ -341,6 +341,34 @@ def test_conv_bf16_storage_slices_add_colsum_levels():
         r0 += h * w_
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("HW,B", [([(80, 80), (40, 40), (20, 20)], 1), ([(12, 20), (6, 10), (3, 5)], 2)])
+def test_conv_bf16_storage_per_level_weights(HW, B):
+    """bf16 storage twin of test_conv_winograd_per_level_weights: three 3x3 128 -> 128 layers over three pyramid levels in ONE launch
+    of the weight-stationary kernel (ore_conv_desc.w_level_stride: every block loads its level's weights), bf16 in, bf16 out."""
+    import orehip as ore
+    g = torch.Generator().manual_seed(HW[0][0] + B)
+    Cc = 128
+    xs = [_bf(torch.randn(B, Cc, h, w_, generator=g)) for h, w_ in HW]
+    ws = [_bf(torch.randn(Cc, Cc, 3, 3, generator=g) * 0.03) for _ in HW]
+    bs = [torch.randn(Cc, generator=g) * 0.1 for _ in HW]
+    rows = torch.cat([t.permute(0, 2, 3, 1).reshape(-1, Cc) for t in xs] + [torch.zeros(1, Cc, dtype=torch.bfloat16)], 0).contiguous().cuda()
+    nrow = rows.shape[0] - 1
+    wp = torch.stack([ore.pack_conv_weight_bf16(w.float()) for w in ws]).contiguous().cuda()
+    out = torch.full((nrow, 2 * Cc), 7.0, dtype=torch.bfloat16).cuda()
+    ore.conv2d_levels(rows[:nrow], HW, B, wp, Cc, 3, shift=torch.stack(bs).contiguous().cuda(), ep_stride=Cc, out=out, out_coff=Cc,
+                      w_level_stride=wp.shape[1])
+    assert float(out[:, :Cc].float().min()) == 7.0 and float(out[:, :Cc].float().max()) == 7.0
+    r0 = 0
+    for (h, w_), t, w, b in zip(HW, xs, ws, bs):
+        ref_l = F.conv2d(t.float(), w.float(), b, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cc)
+        got = out[r0:r0 + B * h * w_, Cc:].float().cpu()
+        assert float((got - ref_l).abs().max() / ref_l.abs().max()) < 1e-2           # one bf16 rounding of the output
+        r0 += B * h * w_
+    with pytest.raises(ore.OreError):                                                # 1x1 layers have no per-level form
+        ore.conv2d_levels(rows[:nrow], HW, B, ore.pack_conv_weight_bf16(torch.randn(Cc, Cc, 1, 1)).cuda(), Cc, 1, w_level_stride=wp.shape[1])
+
+
 def _bf16s_engine(ore, sd, hw, roi=False):
     prev = ore.set_conv_precision("bf16s")
     try:
