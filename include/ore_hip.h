@@ -157,8 +157,9 @@ int ore_maxpool3x3s2_fwd(const float* in, int32_t in_ld, int32_t in_coff, int32_
 int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
                      const float* fc_w, const float* fc_b, float* gate, float* workspace, void* stream);
 
-/* Same gate from partial column sums part[B][P][C] (e.g. the fused ore_conv_desc.colsum of the concat conv).
- * mean_ws >= B*C floats. */
+/* Same gate from partial column sums part[B][P][C] (e.g. the fused ore_conv_desc.colsum of the concat conv), one launch: every block
+ * reduces the partial sums itself (same fixed order everywhere).  mean_ws: >= B*C floats, must be non-NULL (kept for callers of
+ * round 2; not written since round 3). */
 int ore_ese_gate_from_colsum_fwd(const float* part, int32_t P, int32_t B, int32_t HW, int32_t C,
                                  const float* fc_w, const float* fc_b, float* gate, float* mean_ws, void* stream);
 /* The same for ONE image, and in the same launch the gate-scaled copy of a consumer's packed 1x1 weight: w_scaled[n][c] = w_packed[n][c] *
