@@ -949,6 +949,97 @@ __global__ __launch_bounds__(256) void k_combine2_bwd(const float* __restrict__ 
     reinterpret_cast<f32x4*>(dh)[i] = oh;
 }
 
+// adaptive_avg_pool2d on NHWC maps (F.adaptive_avg_pool2d semantics: bin i of an axis of length L pooled to S covers
+// [floor(i L / S), ceil((i + 1) L / S)) ), forward and backward, 4 channels per thread.  The support maps reach the SM_Block through it
+// (30x30 -> 32x32, ref fsod_cen.py:214-227) and the support kernels are three of them (1x1, 1x3, 3x1, :229-231); ATen's path costs an
+// NCHW <-> NHWC copy of the map and an atomic backward.
+__device__ __forceinline__ int apool_lo(int i, int L, int S) { return (i * L) / S; }
+__device__ __forceinline__ int apool_hi(int i, int L, int S) { return ((i + 1) * L + S - 1) / S; }
+__global__ __launch_bounds__(256) void k_apool_fwd(const float* __restrict__ x, int B, int H, int W, int C, int OH, int OW, float* __restrict__ y) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * OH * OW * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    long long t = i / c4n;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const int y0 = apool_lo(oy, H, OH), y1 = apool_hi(oy, H, OH), x0 = apool_lo(ox, W, OW), x1 = apool_hi(ox, W, OW);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) a += *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + yy) * W + xx) * C + c);
+    reinterpret_cast<f32x4*>(y)[i] = a / (float)((y1 - y0) * (x1 - x0));
+}
+// gather form of the backward: input pixel (yy, xx) collects dy / |bin| from every bin that covers it (no atomics, deterministic)
+__global__ __launch_bounds__(256) void k_apool_bwd(const float* __restrict__ dy, int B, int H, int W, int C, int OH, int OW, float* __restrict__ dx) {
+    const int c4n = C / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * H * W * c4n) return;
+    const int c = (int)(i % c4n) * 4;
+    long long t = i / c4n;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const int b = (int)(t / H);
+    // bins that can cover yy: i with floor(i H / OH) <= yy < ceil((i + 1) H / OH)  ->  i in [yy OH / H - 1, (yy + 1) OH / H]
+    const int oy0 = max(0, (yy * OH) / H - 1), oy1 = min(OH - 1, ((yy + 1) * OH) / H);
+    const int ox0 = max(0, (xx * OW) / W - 1), ox1 = min(OW - 1, ((xx + 1) * OW) / W);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const int y0 = apool_lo(oy, H, OH), y1 = apool_hi(oy, H, OH);
+        if (yy < y0 || yy >= y1) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const int x0 = apool_lo(ox, W, OW), x1 = apool_hi(ox, W, OW);
+            if (xx < x0 || xx >= x1) continue;
+            a += *reinterpret_cast<const f32x4*>(dy + ((size_t)(b * OH + oy) * OW + ox) * C + c) / (float)((y1 - y0) * (x1 - x0));
+        }
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = a;
+}
+// y[g][m] = scale * sum_{n < N} x[g*N + n][m]  (the prototype = mean over an image's shots, fsod_cen.py:228);  backward: every member gets
+// scale * dy[g][m]
+__global__ __launch_bounds__(256) void k_group_sum(const float* __restrict__ x, int G, int N, long long M4, float scale, float* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)G * M4) return;
+    const long long g = i / M4, m = i - g * M4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(x) + (size_t)g * N * M4 + m;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) a += src[(size_t)n * M4];
+    reinterpret_cast<f32x4*>(y)[i] = a * scale;
+}
+__global__ __launch_bounds__(256) void k_group_bcast(const float* __restrict__ dy, int G, int N, long long M4, float scale, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)G * N * M4) return;
+    const long long g = i / (N * M4), m = i % M4;
+    reinterpret_cast<f32x4*>(dx)[i] = reinterpret_cast<const f32x4*>(dy)[g * M4 + m] * scale;
+}
+
+extern "C" int ore_adaptive_avgpool_nhwc_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, float* y,
+                                             void* stream) {
+    ORE_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "ore_adaptive_avgpool_nhwc_fwd: bad args");
+    const long long n = (long long)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(k_apool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, OH, OW, y);
+    return ore_launch_status("k_apool_fwd");
+}
+extern "C" int ore_adaptive_avgpool_nhwc_bwd(const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, float* dx,
+                                             void* stream) {
+    ORE_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "ore_adaptive_avgpool_nhwc_bwd: bad args");
+    const long long n = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(k_apool_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, B, H, W, C, OH, OW, dx);
+    return ore_launch_status("k_apool_bwd");
+}
+extern "C" int ore_group_mean_fwd(const float* x, int32_t G, int32_t N, int64_t M, float* y, void* stream) {
+    ORE_CHECK_ARG(x && y && G > 0 && N > 0 && M > 0 && M % 4 == 0, "ore_group_mean_fwd: bad args");
+    const long long n = (long long)G * (M / 4);
+    hipLaunchKernelGGL(k_group_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, G, N, (long long)(M / 4), 1.0f / (float)N, y);
+    return ore_launch_status("k_group_sum");
+}
+extern "C" int ore_group_mean_bwd(const float* dy, int32_t G, int32_t N, int64_t M, float* dx, void* stream) {
+    ORE_CHECK_ARG(dy && dx && G > 0 && N > 0 && M > 0 && M % 4 == 0, "ore_group_mean_bwd: bad args");
+    const long long n = (long long)G * N * (M / 4);
+    hipLaunchKernelGGL(k_group_bcast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, G, N, (long long)(M / 4), 1.0f / (float)N, dx);
+    return ore_launch_status("k_group_bcast");
+}
+
 extern "C" int ore_granule_transpose_fwd(const float* in, float* out, int32_t nb1, int32_t nb2, int32_t A, int32_t Bc, int32_t S, int64_t in_b1,
                                          int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, void* stream) {
     ORE_CHECK_ARG(in && out && in != out && nb1 > 0 && nb2 > 0 && A > 0 && Bc > 0 && S > 0 && S % 4 == 0, "ore_granule_transpose_fwd: bad args");

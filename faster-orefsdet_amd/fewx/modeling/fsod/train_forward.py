@@ -98,15 +98,16 @@ def dense_part(model, xq: torch.Tensor, xs: torch.Tensor, raw: bool = False):
     pos = []
     for i, k in enumerate(LEVELS):
         size = (32, 16, 8)[i]
-        sf = sfeats[k]
-        if sf.shape[-2:] != (size, size):
-            sf = F.adaptive_avg_pool2d(sf, (size, size))
-        # support prototypes: avg-pool to 32/16/8, SM_Block, the reference's H<->W swapping permute, mean over the image's shots
-        v = getattr(model, f"vip_p{3 + i}")(nhwc_view(sf)).permute(0, 3, 2, 1)
-        proto = v.mean(0, True) if B == 1 else v.reshape(B, N, *v.shape[1:]).mean(1)
-        k11 = F.adaptive_avg_pool2d(proto, (1, 1))[:, :, 0, 0]                  # support kernels (fsod_cen.py:229-231), [B,C]
-        k13 = F.adaptive_avg_pool2d(proto, (1, 3))[:, :, 0, :]                  # [B,C,3]
-        k31 = F.adaptive_avg_pool2d(proto, (3, 1))[:, :, :, 0]
+        # support prototypes: avg-pool to 32/16/8, SM_Block, mean over the image's shots -- all on the NHWC maps (HIP pooling kernels,
+        # no NCHW round trip).  The reference pools `proto = v.permute(0, 3, 2, 1)` = [B,C,W,H] to (1,1) / (1,3) / (3,1)
+        # (fsod_cen.py:226-231): in NHWC terms the (1,3) kernel is 3 bins over H and one over W, the (3,1) kernel the other way round.
+        sf = nhwc_view(sfeats[k])
+        if tuple(sf.shape[1:3]) != (size, size):
+            sf = A.adaptive_avg_pool(sf, size, size)
+        pn = A.group_mean(getattr(model, f"vip_p{3 + i}")(sf), B)               # [B,S,S,C]
+        k11 = A.adaptive_avg_pool(pn, 1, 1)[:, 0, 0, :]                          # support kernels, [B,C]
+        k13 = A.adaptive_avg_pool(pn, 3, 1)[:, :, 0, :].permute(0, 2, 1)         # [B,C,3]
+        k31 = A.adaptive_avg_pool(pn, 1, 3)[:, 0, :, :].permute(0, 2, 1)
         # [B,H,W,2C] = [attn | q], every image correlated with its own support kernels in one launch
         cat = A.correlation_cat(nhwc_view(feats[k]), k11, k13, k31)
         pos.append(A.conv(cat, model.conv3.weight, model.conv3.bias, None, None, True))

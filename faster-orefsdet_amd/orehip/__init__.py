@@ -70,7 +70,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
            "ore_nms_workspace_bytes", "ore_nms_fwd", "ore_nms_device_n_fwd", "ore_roi_align_fwd", "ore_roi_predict_workspace_bytes",
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
-           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_conv2d_wgrad_bias_fwd", "ore_granule_transpose_fwd", "ore_combine2_fwd", "ore_combine2_bwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
+           "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_conv2d_wgrad_bias_fwd", "ore_granule_transpose_fwd", "ore_combine2_fwd", "ore_combine2_bwd", "ore_adaptive_avgpool_nhwc_fwd", "ore_adaptive_avgpool_nhwc_bwd", "ore_group_mean_fwd", "ore_group_mean_bwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_roi_predict_post_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
@@ -878,6 +878,40 @@ def scale_add_channels(x: torch.Tensor, scale_bc: torch.Tensor, add_bc: Optional
                                           C.c_void_p(_ptr(_f32(add_bc)) if add_bc is not None else None), B, rows, Cc, C.c_void_p(_ptr(out)),
                                           _stream()), "ore_scale_add_channels_fwd")
     return out
+
+
+def adaptive_avgpool_nhwc(x: torch.Tensor, OH: int, OW: int, grad_of: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """F.adaptive_avg_pool2d on an NHWC map: x [B,H,W,C] -> [B,OH,OW,C].  grad_of=(H, W): x is the gradient w.r.t. the pooled map
+    [B,OH,OW,C] and the result is the gradient w.r.t. the [B,H,W,C] input."""
+    _f32(x)
+    B, Cc = x.shape[0], x.shape[-1]
+    if grad_of is None:
+        H, W = x.shape[1:3]
+        y = torch.empty(B, OH, OW, Cc, device=x.device, dtype=torch.float32)
+        _chk(lib().ore_adaptive_avgpool_nhwc_fwd(C.c_void_p(_ptr(x)), B, H, W, Cc, OH, OW, C.c_void_p(_ptr(y)), _stream()), "ore_adaptive_avgpool_nhwc_fwd")
+        return y
+    H, W = grad_of
+    assert tuple(x.shape[1:3]) == (OH, OW)
+    dx = torch.empty(B, H, W, Cc, device=x.device, dtype=torch.float32)
+    _chk(lib().ore_adaptive_avgpool_nhwc_bwd(C.c_void_p(_ptr(x)), B, H, W, Cc, OH, OW, C.c_void_p(_ptr(dx)), _stream()), "ore_adaptive_avgpool_nhwc_bwd")
+    return dx
+
+
+def group_mean(x: torch.Tensor, groups: int, backward: bool = False, members: int = 0) -> torch.Tensor:
+    """x [groups*N, ...] -> [groups, ...]: mean over the N consecutive members of each group (the prototype over an image's shots);
+    backward=True: x [groups, ...] is the gradient of that mean -> [groups*members, ...]."""
+    _f32(x)
+    if not backward:
+        N = x.shape[0] // groups
+        assert N * groups == x.shape[0]
+        M = x.numel() // x.shape[0]
+        y = torch.empty(groups, *x.shape[1:], device=x.device, dtype=torch.float32)
+        _chk(lib().ore_group_mean_fwd(C.c_void_p(_ptr(x)), groups, N, C.c_int64(M), C.c_void_p(_ptr(y)), _stream()), "ore_group_mean_fwd")
+        return y
+    M = x.numel() // groups
+    dx = torch.empty(groups * members, *x.shape[1:], device=x.device, dtype=torch.float32)
+    _chk(lib().ore_group_mean_bwd(C.c_void_p(_ptr(x)), groups, members, C.c_int64(M), C.c_void_p(_ptr(dx)), _stream()), "ore_group_mean_bwd")
+    return dx
 
 
 def sm_permute(x: torch.Tensor, B: int, H: int, W: int, G: int, S: int, axis: str, inverse: bool) -> torch.Tensor:

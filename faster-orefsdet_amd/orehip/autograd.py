@@ -275,6 +275,44 @@ def ese(x, fc_w, fc_b):
     return EseFn.apply(x, fc_w, fc_b)
 
 
+class AdaptiveAvgPoolFn(Function):
+    """F.adaptive_avg_pool2d on NHWC maps (ref fsod_cen.py:214-231): x [B,H,W,C] -> [B,OH,OW,C]; deterministic gather backward."""
+
+    @staticmethod
+    def forward(ctx, x, OH: int, OW: int):
+        x = x.contiguous()
+        ctx.meta = (x.shape[1], x.shape[2], OH, OW)
+        return orehip.adaptive_avgpool_nhwc(x, OH, OW)
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, W, OH, OW = ctx.meta
+        return orehip.adaptive_avgpool_nhwc(dy.contiguous(), OH, OW, grad_of=(H, W)), None, None
+
+
+def adaptive_avg_pool(x_nhwc, OH, OW):
+    return AdaptiveAvgPoolFn.apply(x_nhwc, OH, OW)
+
+
+class GroupMeanFn(Function):
+    """[groups*N, ...] -> [groups, ...]: mean over each group's N consecutive members (the support prototype over an image's shots)."""
+
+    @staticmethod
+    def forward(ctx, x, groups: int):
+        x = x.contiguous()
+        ctx.meta = (groups, x.shape[0] // groups)
+        return orehip.group_mean(x, groups)
+
+    @staticmethod
+    def backward(ctx, dy):
+        groups, N = ctx.meta
+        return orehip.group_mean(dy.contiguous(), groups, backward=True, members=N), None
+
+
+def group_mean(x, groups):
+    return GroupMeanFn.apply(x, groups)
+
+
 class SmPermuteFn(Function):
     """SM_Block mixing layouts (ref fsod_cen.py:602-611): the permute + reshape pairs around mlp_h / mlp_w as one coalesced granule
     transpose each way; the backward of a layout change is the opposite layout change."""

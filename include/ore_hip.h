@@ -394,6 +394,13 @@ int ore_scale_add_channels_fwd(const float* x, const float* scale_bc, const floa
  *   row = A*S contiguous floats).  All strides in floats, multiples of 4; in != out.  This is x.reshape(B,H,W,seg,S).permute(0,3,2,1,4)
  *   / .permute(0,3,1,2,4) and their inverses as one coalesced pass.
  * ore_combine2_fwd: y = w * a0[b][c] + h * a1[b][c];  ore_combine2_bwd: dw = dy * a0 + v, dh = dy * a1 + v (v [B][C] optional). */
+/* F.adaptive_avg_pool2d on NHWC maps, forward and (gather-form, deterministic) backward: x [B][H][W][C] -> y [B][OH][OW][C]
+ * (ref:fewx/modeling/fsod/fsod_cen.py:214-231: the support maps pooled to 32 / 16 / 8 and the 1x1 / 1x3 / 3x1 support kernels).
+ * ore_group_mean_fwd: y[g][m] = mean over n < N of x[g*N + n][m] (the prototype = mean over an image's shots, :228), _bwd its gradient. */
+int ore_adaptive_avgpool_nhwc_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, float* y, void* stream);
+int ore_adaptive_avgpool_nhwc_bwd(const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, float* dx, void* stream);
+int ore_group_mean_fwd(const float* x, int32_t G, int32_t N, int64_t M, float* y, void* stream);
+int ore_group_mean_bwd(const float* dy, int32_t G, int32_t N, int64_t M, float* dx, void* stream);
 int ore_granule_transpose_fwd(const float* in, float* out, int32_t nb1, int32_t nb2, int32_t A, int32_t Bc, int32_t S, int64_t in_b1,
                               int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, void* stream);
 int ore_combine2_fwd(const float* w, const float* h, const float* a0_bc, const float* a1_bc, int32_t B, int32_t rows, int32_t C, float* y,

@@ -145,6 +145,36 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize("B,H,W,OH,OW,C", [(3, 30, 30, 32, 32, 16), (2, 15, 15, 16, 16, 8), (2, 32, 32, 1, 3, 128), (2, 16, 16, 3, 1, 128),
+                                           (1, 8, 8, 1, 1, 128), (2, 7, 11, 3, 5, 4), (1, 5, 5, 9, 12, 4)])
+def test_adaptive_avg_pool_nhwc_and_group_mean(oh, B, H, W, OH, OW, C):
+    """ore_adaptive_avgpool_nhwc_fwd / _bwd against F.adaptive_avg_pool2d (value and gradient, up- and down-sampling bins), and the
+    mean over an image's shots (ore_group_mean_*)."""
+    from orehip import autograd as A
+    g = torch.Generator().manual_seed(H + OH + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    up = torch.randn(B, C, OH, OW, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xr, (OH, OW))
+    (ref * up).sum().backward()
+    xg = _nhwc(x).cuda().requires_grad_(True)
+    y = A.adaptive_avg_pool(xg, OH, OW)
+    _close(y.permute(0, 3, 1, 2), ref)
+    (y * _nhwc(up).cuda()).sum().backward()
+    _close(xg.grad.permute(0, 3, 1, 2), xr.grad)
+    # group mean: 3 groups of B members
+    z = torch.randn(3 * B, H, W, C, generator=g)
+    zr = z.clone().requires_grad_(True)
+    mref = zr.reshape(3, B, H, W, C).mean(1)
+    um = torch.randn(3, H, W, C, generator=g)
+    (mref * um).sum().backward()
+    zg = z.cuda().requires_grad_(True)
+    m = A.group_mean(zg, 3)
+    _close(m, mref)
+    (m * um.cuda()).sum().backward()
+    _close(zg.grad, zr.grad)
+
+
 @pytest.mark.parametrize("B,H,W,G,S", [(3, 32, 32, 32, 4), (2, 16, 16, 16, 8), (5, 8, 8, 8, 16), (1, 6, 10, 4, 4)])
 def test_sm_block_glue_kernels(oh, B, H, W, G, S):
     """The SM_Block's training-side glue as HIP kernels: the two mixing layouts and their inverses (granule transposes) are exactly the
