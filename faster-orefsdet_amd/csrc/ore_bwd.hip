@@ -970,6 +970,28 @@ __global__ __launch_bounds__(256) void k_apool_fwd(const float* __restrict__ x, 
         for (int xx = x0; xx < x1; ++xx) a += *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + yy) * W + xx) * C + c);
     reinterpret_cast<f32x4*>(y)[i] = a / (float)((y1 - y0) * (x1 - x0));
 }
+// large bins (the 1x1 / 1x3 / 3x1 support kernels pool 11-32 rows x 32 columns each): one block per output pixel, the bin's pixels dealt
+// to 256 / (C/4) slices of threads and combined through LDS in a fixed order -- a thread per output would walk ~1000 pixels alone
+__global__ __launch_bounds__(256) void k_apool_fwd_big(const float* __restrict__ x, int H, int W, int C, int OH, int OW, float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int c4n = C / 4, nsl = 256 / c4n;                     // C <= 1024
+    const int q = threadIdx.x % c4n, sl = threadIdx.x / c4n;
+    const int ox = blockIdx.x % OW, oy = (blockIdx.x / OW) % OH, b = blockIdx.x / (OW * OH);
+    const int y0 = apool_lo(oy, H, OH), y1 = apool_hi(oy, H, OH), x0 = apool_lo(ox, W, OW), x1 = apool_hi(ox, W, OW);
+    const int bw = x1 - x0, n = (y1 - y0) * bw;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (sl < nsl)
+        for (int i = sl; i < n; i += nsl) {
+            const int yy = y0 + i / bw, xx = x0 + i % bw;
+            a += *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + yy) * W + xx) * C + q * 4);
+        }
+    *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = a;
+    __syncthreads();
+    if (sl == 0) {
+        for (int k = 1; k < nsl; ++k) a += *reinterpret_cast<const f32x4*>(red + (k * c4n + q) * 4);
+        *reinterpret_cast<f32x4*>(y + (size_t)blockIdx.x * C + q * 4) = a / (float)n;
+    }
+}
 // gather form of the backward: input pixel (yy, xx) collects dy / |bin| from every bin that covers it (no atomics, deterministic)
 __global__ __launch_bounds__(256) void k_apool_bwd(const float* __restrict__ dy, int B, int H, int W, int C, int OH, int OW, float* __restrict__ dx) {
     const int c4n = C / 4;
@@ -1017,6 +1039,11 @@ extern "C" int ore_adaptive_avgpool_nhwc_fwd(const float* x, int32_t B, int32_t 
                                              void* stream) {
     ORE_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "ore_adaptive_avgpool_nhwc_fwd: bad args");
     const long long n = (long long)B * OH * OW * (C / 4);
+    const int bin = ((H + OH - 1) / OH + 1) * ((W + OW - 1) / OW + 1);
+    if (bin >= 64 && C <= 1024) {                               // few outputs, large bins: a block per output pixel
+        hipLaunchKernelGGL(k_apool_fwd_big, dim3((unsigned)(B * OH * OW)), dim3(256), 0, (hipStream_t)stream, x, H, W, C, OH, OW, y);
+        return ore_launch_status("k_apool_fwd_big");
+    }
     hipLaunchKernelGGL(k_apool_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, OH, OW, y);
     return ore_launch_status("k_apool_fwd");
 }
