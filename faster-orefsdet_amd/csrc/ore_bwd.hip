@@ -84,13 +84,14 @@ static_assert(WG_LD == 80, "wgrad_bias_out reuses a staging buffer with this row
 #ifndef ORE_WG_BLOCKS
 #define ORE_WG_BLOCKS 1536
 #endif
-static int wg_blocks() {                   // env ORE_WG_BLOCKS overrides the build-time target (A/B runs)
+// blocks aimed at per weight-gradient launch (rows are split until the grid has this many); env ORE_WG_BLOCKS overrides the build-time
+// target for A/B runs (1024 ... 3072 measured: no difference beyond noise, EXPERIMENTS.md)
+static int wg_blocks() {
     static int v = 0;
     if (!v) { const char* e = getenv("ORE_WG_BLOCKS"); v = e ? atoi(e) : 0; if (v < 64) v = ORE_WG_BLOCKS; }
     return v;
 }
 #define WG_BLOCKS wg_blocks()
-constexpr int WG_BLOCKS_UNUSED = ORE_WG_BLOCKS;   // blocks aimed at per weight-gradient launch (rows are split until the grid has this many)    // LDS row stride: the 4 k-rows of an MFMA operand land 16 banks apart -> conflict-free ds_read_b32
 
 __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     __shared__ float sA[2][WG_K][WG_LD];   // dZ rows x co

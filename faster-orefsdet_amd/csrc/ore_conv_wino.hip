@@ -1,5 +1,6 @@
-// k_conv3x3_wino -- Winograd F(2x2, 3x3) NHWC convolution for the LARGE-M 3x3 stride-1 layers of the path (stem_2, the three
-// 3x3 layers of stage 2, FPN output3, the CenterNet head tower: 19.5 of the 33.7 GFLOP of an image), fp32 on the gfx950 matrix cores.
+// k_conv3x3_wino / k_conv3x3_wino_nu -- Winograd F(2x2, 3x3) NHWC convolution for the 3x3 stride-1 layers of the path with enough rows
+// (stem_2, the 3x3 layers of stages 2 and 3, the three FPN output convs as ONE per-level launch, the CenterNet head tower: 22.6 of the
+// 33.7 GFLOP of an image; stages 4-5 and the data gradients at training batch sizes), fp32 on the gfx950 matrix cores.
 //
 // Why.  The fp32 MFMA rate is the fp32 VECTOR rate (157.3 TFLOP/s), so the direct implicit-GEMM kernels of these layers are bound by
 // the number of multiplies they issue, and rounds 1-2 established that their non-MFMA overhead (staging, LDS traffic, addressing)

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Every weight-gradient launch of the last traced training step with its grid and duration.
+usage: rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 tools/bench_train.py --batch 16 ; python tools/wgrad_rows.py DIR"""
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
