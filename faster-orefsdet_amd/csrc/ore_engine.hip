@@ -415,19 +415,22 @@ int run_heads(ore_engine* e, const Geo& g, hipStream_t st, double* flops) {
     // GroupNorm statistics (fp32, from the fp32 or bf16 tower output), then GroupNorm + ReLU + the (l,t,r,b | hm) conv + per-level Scale
     // in ONE VALU kernel (k_head_pred: N = 5 is not MFMA work; it was 20 us on the matrix cores, + a materialised bf16 tensor in the
     // storage mode); the detection tail downstream is fp32 as always
+    if (F == 128 && e->head_pred_valu) {
+        // statistics, then ONE kernel for GroupNorm fold + ReLU + the (l,t,r,b | hm) conv + per-level Scale: its blocks combine the chunk
+        // statistics of their own (level, image) under their tower loads
+        r.rc = sb ? ore_head_pred_gn_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, g.B, 3, H, W, 32, 1e-5f, e->gn_gamma, e->gn_beta,
+                                              e->pred.w, e->pred.scale, e->pred.shift, 16, e->head.p, 8, e->gn_ws, st)
+                  : ore_head_pred_gn_fwd(e->tow.p, F, g.B, 3, H, W, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->pred.w, e->pred.scale,
+                                         e->pred.shift, 16, e->head.p, 8, e->gn_ws, st);
+        r.flops += 2.0 * rows * 5.0 * F * 9.0;
+        *flops = r.flops;
+        return r.rc;
+    }
     r.rc = sb ? ore_groupnorm_affine_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma,
                                                      e->gn_beta, e->gn_mul, e->gn_add, e->gn_ws, st)
               : ore_groupnorm_affine_levels_fwd(e->tow.p, F, 0, g.B, 3, HW, F, 32, 1e-5f, e->gn_gamma, e->gn_beta, e->gn_mul, e->gn_add,
                                                 e->gn_ws, st);
     if (r.rc) return r.rc;
-    if (F == 128 && e->head_pred_valu) {
-        r.rc = sb ? ore_head_pred_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, g.B, 3, H, W, e->gn_mul, e->gn_add, e->pred.w,
-                                           e->pred.scale, e->pred.shift, 16, e->head.p, 8, st)
-                  : ore_head_pred_fwd(e->tow.p, F, g.B, 3, H, W, e->gn_mul, e->gn_add, e->pred.w, e->pred.scale, e->pred.shift, 16, e->head.p, 8, st);
-        r.flops += 2.0 * rows * 5.0 * F * 9.0;
-        *flops = r.flops;
-        return r.rc;
-    }
     if (sb) {
         if (!r.rc) r.rc = ore_groupnorm_apply_levels_bf16_fwd(reinterpret_cast<const uint16_t*>(e->tow.p), F, 0, g.B, 3, HW, F, e->gn_mul, e->gn_add, 1,
                                                               reinterpret_cast<uint16_t*>(e->tn.p), st);

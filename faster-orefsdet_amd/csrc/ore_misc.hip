@@ -485,12 +485,11 @@ __global__ __launch_bounds__(256) void k_gn_chunk_stats4(const TS* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_gn_combine(const float* __restrict__ stats, GnSeg sg, int C, int G, float eps,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float* __restrict__ mul, float* __restrict__ add) {
-    __shared__ float sn[8][64], sm[8][64], sq[8][64];
-    __shared__ float fmean[64], frstd[64];
-    const int b = blockIdx.x;                     // segment id = level*B + image
+// chunk records of segment b (= level * B + image) -> the folded affine of its C channels, written to omul / oadd (global or LDS).
+// 256 threads, two barriers; every caller runs the same fixed order, so copies computed by several blocks are bit-identical.
+struct GnCombineSm { float sn[8][64], sm[8][64], sq[8][64], fmean[64], frstd[64]; };
+__device__ __forceinline__ void gn_combine_block(GnCombineSm& S, const float* __restrict__ stats, const GnSeg& sg, int b, int C, int G, float eps,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* omul, float* oadd) {
     const int lvl = b / sg.B, img = b - lvl * sg.B;
     const int nchunks = sg.nchunk[lvl], HW = sg.HW[lvl];
     stats += (size_t)(sg.chunk0[lvl] + img * nchunks) * G * 2;
@@ -519,28 +518,36 @@ __global__ __launch_bounds__(256) void k_gn_combine(const float* __restrict__ st
                 }
             }
         }
-    sn[sl][g] = n; sm[sl][g] = mean; sq[sl][g] = m2;
+    S.sn[sl][g] = n; S.sm[sl][g] = mean; S.sq[sl][g] = m2;
     __syncthreads();
     if (threadIdx.x < G) {
-        float N = sn[0][g], M = sm[0][g], Q = sq[0][g];
+        float N = S.sn[0][g], M = S.sm[0][g], Q = S.sq[0][g];
         for (int k = 1; k < nsl; ++k) {
-            const float nb = sn[k][g];
+            const float nb = S.sn[k][g];
             if (nb > 0.f) {
-                const float nt = N + nb, d = sm[k][g] - M;
+                const float nt = N + nb, d = S.sm[k][g] - M;
                 M += d * (nb / nt);
-                Q += sq[k][g] + d * d * (N * nb / nt);
+                Q += S.sq[k][g] + d * d * (N * nb / nt);
                 N = nt;
             }
         }
-        fmean[g] = M;
-        frstd[g] = 1.0f / sqrtf(Q / N + eps);
+        S.fmean[g] = M;
+        S.frstd[g] = 1.0f / sqrtf(Q / N + eps);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        const float m = frstd[c / cpg] * gamma[c];
-        mul[b * C + c] = m;
-        add[b * C + c] = beta[c] - fmean[c / cpg] * m;
+        const float m = S.frstd[c / cpg] * gamma[c];
+        omul[c] = m;
+        oadd[c] = beta[c] - S.fmean[c / cpg] * m;
     }
+}
+
+__global__ __launch_bounds__(256) void k_gn_combine(const float* __restrict__ stats, GnSeg sg, int C, int G, float eps,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ mul, float* __restrict__ add) {
+    __shared__ GnCombineSm S;
+    const int b = blockIdx.x;                     // segment id = level*B + image
+    gn_combine_block(S, stats, sg, b, C, G, eps, gamma, beta, mul + (size_t)b * C, add + (size_t)b * C);
 }
 
 
@@ -561,6 +568,8 @@ struct HeadP {
     const float* w;                             // packed [16][9][128] (rows 0..4 used)
     const float* scale; const float* shift; int ep_stride;   // per level [16]
     float* out; int out_ld;                     // [rows][out_ld], 5 written
+    const float* stats; GnSeg sg; const float* gamma; const float* beta; float eps; int G;   // stats != NULL: mul / add are not read, the
+                                                // block folds the GroupNorm chunk statistics of its (level, image) itself (k_gn_combine's work)
 };
 
 template <typename TS>
@@ -579,8 +588,8 @@ __global__ __launch_bounds__(256) void k_head_pred(HeadP p) {
     const int y0 = (tr / p.tx[lvl]) * TP, x0 = (tr % p.tx[lvl]) * TP;
     const int base = p.row0[lvl] + b * H * W;
     const TS* tow = reinterpret_cast<const TS*>(p.tow);
-    const float* mul = p.mul + (size_t)(lvl * p.B + b) * C;
-    const float* add = p.add + (size_t)(lvl * p.B + b) * C;
+    __shared__ __attribute__((aligned(16))) float s_mul[C], s_add[C];
+    __shared__ GnCombineSm S;
     // phase 1: all global loads of a thread are issued back to back (a load -> store loop serialises their latency)
     constexpr int NX = (HP * HP * Q + 255) / 256;                           // 13 staged vectors per thread
     constexpr int NWV = (NO * 9 * Q + 255) / 256;                           // 6 weight vectors per thread
@@ -598,6 +607,12 @@ __global__ __launch_bounds__(256) void k_head_pred(HeadP p) {
         const bool ok = i < HP * HP * Q && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         xv[k] = ok ? ld4(tow + (size_t)(base + gy * W + gx) * p.ld + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // the folded GroupNorm affine of this (level, image): from the chunk statistics (under the loads just issued), or precomputed
+    if (p.stats) gn_combine_block(S, p.stats, p.sg, lvl * p.B + b, C, p.G, p.eps, p.gamma, p.beta, s_mul, s_add);
+    else if (tid < C) { s_mul[tid] = p.mul[(size_t)(lvl * p.B + b) * C + tid]; s_add[tid] = p.add[(size_t)(lvl * p.B + b) * C + tid]; }
+    __syncthreads();
+    const float* mul = s_mul;
+    const float* add = s_add;
 #pragma unroll
     for (int k = 0; k < NWV; ++k) {
         const int i = tid + k * 256;
@@ -666,10 +681,11 @@ __global__ __launch_bounds__(256) void k_head_pred(HeadP p) {
 
 }  // namespace
 
+struct HeadGn { const float* stats; GnSeg sg; const float* gamma; const float* beta; float eps; int G; };
 static int head_pred_launch(const void* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W, const float* mul,
                             const float* add, const float* w_packed16, const float* scale, const float* shift, int32_t ep_stride,
-                            float* out, int32_t out_ld, void* stream, int bf16) {
-    ORE_CHECK_ARG(tower && H && W && mul && add && w_packed16 && scale && shift && out, "ore_head_pred_fwd: null pointer");
+                            float* out, int32_t out_ld, void* stream, int bf16, const HeadGn* gn = nullptr) {
+    ORE_CHECK_ARG(tower && H && W && (gn || (mul && add)) && w_packed16 && scale && shift && out, "ore_head_pred_fwd: null pointer");
     ORE_CHECK_ARG(B > 0 && n_levels >= 1 && n_levels <= 4 && ld >= 128 && ld % 4 == 0 && out_ld >= 5, "ore_head_pred_fwd: bad args");
     HeadP p{};
     p.tow = tower; p.ld = ld; p.B = B; p.nlev = n_levels;
@@ -682,6 +698,7 @@ static int head_pred_launch(const void* tower, int32_t ld, int32_t B, int32_t n_
     }
     p.tile0[n_levels] = tiles;
     p.mul = mul; p.add = add; p.w = w_packed16; p.scale = scale; p.shift = shift; p.ep_stride = ep_stride; p.out = out; p.out_ld = out_ld;
+    if (gn) { p.stats = gn->stats; p.sg = gn->sg; p.gamma = gn->gamma; p.beta = gn->beta; p.eps = gn->eps; p.G = gn->G; }
     if (bf16) hipLaunchKernelGGL(k_head_pred<ore_bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(k_head_pred<float>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_head_pred");
@@ -916,12 +933,12 @@ extern "C" int ore_support_kernels_fwd(const float* proto_chw, int32_t C, int32_
     return ore_launch_status("k_support_kernels");
 }
 
-static int gn_affine_levels(const void* xv, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
-                                               const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
-                                               const float* beta, float* mul, float* add, float* workspace, void* stream, int x_bf16) {
+// GroupNorm chunk statistics of all levels in one launch -> workspace, *sg = the segment table the consumers need
+static int gn_stats_levels(const void* xv, int32_t ld, int32_t coff, int32_t B, int32_t n_levels, const int32_t* HW, int32_t C, int32_t groups,
+                           float* workspace, hipStream_t st, int x_bf16, GnSeg* out_sg) {
     const float* x = (const float*)xv;
-    ORE_CHECK_ARG(x && HW && gamma && beta && mul && add && workspace && n_levels >= 1 && n_levels <= 4 && groups > 0 && groups <= 64 &&
-                      C % groups == 0 && C <= 256 && 256 % C == 0, "ore_groupnorm_affine_levels_fwd: bad args (need C | 256, groups <= 64)");
+    ORE_CHECK_ARG(x && HW && workspace && n_levels >= 1 && n_levels <= 4 && groups > 0 && groups <= 64 && C % groups == 0 && C <= 256 &&
+                      256 % C == 0, "ore_groupnorm_affine_levels_fwd: bad args (need C | 256, groups <= 64)");
     GnSeg sg{};
     sg.nlev = n_levels; sg.B = B;
     int rows = 0, chunks = 0;
@@ -929,7 +946,6 @@ static int gn_affine_levels(const void* xv, int32_t ld, int32_t coff, int32_t B,
         sg.HW[l] = HW[l]; sg.row0[l] = rows; sg.chunk0[l] = chunks; sg.nchunk[l] = ceil_div(HW[l], GN_ROWS);
         rows += B * HW[l]; chunks += B * sg.nchunk[l];
     }
-    hipStream_t st = (hipStream_t)stream;
     if (C == groups * 4 && 256 % groups == 0 && GN_ROWS * groups / 256 >= 1 && GN_ROWS * groups % 256 == 0 && ld % 4 == 0 && coff % 4 == 0 &&
         ((uintptr_t)x & 15) == 0) {
         const int rpt = GN_ROWS * groups / 256;
@@ -944,7 +960,17 @@ static int gn_affine_levels(const void* xv, int32_t ld, int32_t coff, int32_t B,
         ORE_CHECK_ARG(!x_bf16, "ore_groupnorm_affine_levels_bf16_fwd: built for GroupNorm(32, 128)");
         hipLaunchKernelGGL(k_gn_chunk_stats, dim3(chunks), dim3(256), 0, st, x, ld, coff, sg, C, groups, workspace);
     }
-    int rc = ore_launch_status("k_gn_chunk_stats");
+    *out_sg = sg;
+    return ore_launch_status("k_gn_chunk_stats");
+}
+
+static int gn_affine_levels(const void* xv, int32_t ld, int32_t coff, int32_t B, int32_t n_levels,
+                                               const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
+                                               const float* beta, float* mul, float* add, float* workspace, void* stream, int x_bf16) {
+    ORE_CHECK_ARG(gamma && beta && mul && add, "ore_groupnorm_affine_levels_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    GnSeg sg{};
+    int rc = gn_stats_levels(xv, ld, coff, B, n_levels, HW, C, groups, workspace, st, x_bf16, &sg);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gn_combine, dim3(n_levels * B), dim3(256), 0, st, workspace, sg, C, groups, eps, gamma, beta, mul, add);
     return ore_launch_status("k_gn_combine");
@@ -960,6 +986,35 @@ extern "C" int ore_groupnorm_affine_levels_bf16_fwd(const uint16_t* x, int32_t l
                                                     const int32_t* HW, int32_t C, int32_t groups, float eps, const float* gamma,
                                                     const float* beta, float* mul, float* add, float* workspace, void* stream) {
     return gn_affine_levels(x, ld, coff, B, n_levels, HW, C, groups, eps, gamma, beta, mul, add, workspace, stream, 1);
+}
+
+// GroupNorm statistics + the head's last step in two launches: the k_head_pred blocks fold the chunk statistics of their own (level,
+// image) -- k_gn_combine's work, ~1 us under their tower loads -- instead of waiting for a third launch (5.5 us on 3 blocks).
+static int head_pred_gn(const void* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W, int32_t groups, float eps,
+                        const float* gamma, const float* beta, const float* w_packed16, const float* scale, const float* shift,
+                        int32_t ep_stride, float* out, int32_t out_ld, float* workspace, void* stream, int bf16) {
+    ORE_CHECK_ARG(H && W && gamma && beta && n_levels >= 1 && n_levels <= 4, "ore_head_pred_gn_fwd: bad args");
+    int32_t HW[4];
+    for (int l = 0; l < n_levels; ++l) HW[l] = H[l] * W[l];
+    HeadGn gn{};
+    int rc = gn_stats_levels(tower, ld, 0, B, n_levels, HW, 128, groups, workspace, (hipStream_t)stream, bf16, &gn.sg);
+    if (rc) return rc;
+    gn.stats = workspace; gn.gamma = gamma; gn.beta = beta; gn.eps = eps; gn.G = groups;
+    return head_pred_launch(tower, ld, B, n_levels, H, W, nullptr, nullptr, w_packed16, scale, shift, ep_stride, out, out_ld, stream, bf16, &gn);
+}
+
+extern "C" int ore_head_pred_gn_fwd(const float* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W,
+                                    int32_t groups, float eps, const float* gamma, const float* beta, const float* w_packed16,
+                                    const float* scale, const float* shift, int32_t ep_stride, float* out, int32_t out_ld, float* workspace,
+                                    void* stream) {
+    return head_pred_gn(tower, ld, B, n_levels, H, W, groups, eps, gamma, beta, w_packed16, scale, shift, ep_stride, out, out_ld, workspace, stream, 0);
+}
+
+extern "C" int ore_head_pred_gn_bf16_fwd(const uint16_t* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W,
+                                         int32_t groups, float eps, const float* gamma, const float* beta, const float* w_packed16,
+                                         const float* scale, const float* shift, int32_t ep_stride, float* out, int32_t out_ld,
+                                         float* workspace, void* stream) {
+    return head_pred_gn(tower, ld, B, n_levels, H, W, groups, eps, gamma, beta, w_packed16, scale, shift, ep_stride, out, out_ld, workspace, stream, 1);
 }
 
 extern "C" int ore_groupnorm_affine_fwd(const float* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,

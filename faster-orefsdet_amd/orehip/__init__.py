@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",

@@ -497,6 +497,14 @@ int ore_head_pred_fwd(const float* tower, int32_t ld, int32_t B, int32_t n_level
 int ore_head_pred_bf16_fwd(const uint16_t* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W,
                            const float* gn_mul, const float* gn_add, const float* w_packed16, const float* scale, const float* shift,
                            int32_t ep_stride, float* out, int32_t out_ld, void* stream);
+/* GroupNorm statistics + ore_head_pred in TWO launches: the blocks of the head kernel fold the chunk statistics of their own (level,
+ * image) themselves (groups must divide 128; workspace as ore_groupnorm_affine_levels_fwd). */
+int ore_head_pred_gn_fwd(const float* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W, int32_t groups,
+                         float eps, const float* gamma, const float* beta, const float* w_packed16, const float* scale, const float* shift,
+                         int32_t ep_stride, float* out, int32_t out_ld, float* workspace, void* stream);
+int ore_head_pred_gn_bf16_fwd(const uint16_t* tower, int32_t ld, int32_t B, int32_t n_levels, const int32_t* H, const int32_t* W,
+                              int32_t groups, float eps, const float* gamma, const float* beta, const float* w_packed16, const float* scale,
+                              const float* shift, int32_t ep_stride, float* out, int32_t out_ld, float* workspace, void* stream);
 int ore_groupnorm_apply_levels_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t n_levels, const int32_t* HW, int32_t C,
                                         const float* mul_c, const float* add_c, int32_t relu, uint16_t* y, void* stream);
 int ore_ese_gate_scaled_weight_bf16_fwd(const float* part, int32_t P, int32_t HW, int32_t C, const float* fc_w, const float* fc_b,
