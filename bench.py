@@ -14,7 +14,8 @@ the same protocol fed a host uint8 image (H2D copy inside the step, what a datal
 "protocol_host_image".  The K steps are repeated until the timed region is >= --min-time seconds (default 1 s) so a small --steps
 still gives a stable figure; `value` = images of all repeats / their time.
 Beside it, never as `value`: "engine_sequential" (the C-ABI engine call alone, no per-image sync), "in_flight" (4 bs=1 forwards in
-flight on 4 streams), "folded_serving", "train_step" / "train_step_bs16".
+flight on 4 streams), "folded_serving", "train_step" / "train_step_bs16", and "gpu_idle_us_per_image" (a protocol step minus the same
+graph replayed back to back = what the per-image sync leaves idle on the GPU).
 N>1: pure data parallel.  Eval: every rank runs the protocol on its own images, no data-path collective (weak scaling); RCCL
 (backend "nccl") carries the barrier and the max-over-ranks.  Training (BASELINE configs[3]): 16 query images per GPU per step under
 FlatDataParallel, the gradient bucket all-reduced over RCCL from backward hooks -- "train_step" then carries the global rate, the
@@ -414,6 +415,9 @@ def main():
         lat.sort()
         extras["engine_latency_ms_host_sync"] = {"p50": round(lat[len(lat) // 2] * 1e3, 4), "min": round(lat[0] * 1e3, 4)}
         extras["protocol_overhead_us"] = round((elapsed / n_steps - lat[len(lat) // 2]) * 1e6, 1)
+        # what the per-image sync of the protocol leaves idle on the GPU: a protocol step against the same graph replayed back to back
+        # (sync wake-up + Python + graph launch + input copy)
+        extras["gpu_idle_us_per_image"] = round((elapsed / n_steps - el_e / n_e) * 1e6, 1)
         # several bs=1 forwards in flight per GPU, each on its own engine + HIP stream
         if args.inflight > 1:
             engines = [eng] + [model.make_engine() for _ in range(args.inflight - 1)]
