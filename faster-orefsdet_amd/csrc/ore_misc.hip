@@ -2,6 +2,7 @@
 // ceil-mode max-pool, eSE gate, depthwise query<->support correlation, support kernel pooling,
 // GroupNorm statistics.  All NHWC fp32, 16-byte vector accesses, 64-wide wavefronts.
 #include "ore_common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -844,7 +845,9 @@ static int ese_gate_pool_launch(const float* part, int P, int HW, int C, const f
     auto osz = [](int n) { int o = (n - 3 + 1) / 2 + 1; if (n < 3) o = 1; if ((o - 1) * 2 >= n) --o; return o < 1 ? 1 : o; };
     const int Ho = osz(H), Wo = osz(W);
     const int gx = ceil_div(C, 16);
-    int gy = ceil_div(224, gx);                                       // ~ one block per CU, at least 64 output pixels per block
+    static int tb = 0;                                                // blocks aimed at (env ORE_GATE_POOL_BLOCKS for A/B)
+    if (!tb) { const char* e = getenv("ORE_GATE_POOL_BLOCKS"); tb = e ? atoi(e) : 224; if (tb < 8) tb = 224; }
+    int gy = ceil_div(tb, gx);                                        // ~ one block per CU, at least 64 output pixels per block
     gy = std::max(1, std::min(gy, ceil_div(Ho * Wo, 64)));
     if (bf16)
         hipLaunchKernelGGL(k_ese_gate_pool<ore_bf16_t>, dim3(gx, gy), dim3(ESE_T), 0, st, part, P, HW, C, fc_w, fc_b, gate, lw, (float*)lws, lrows,
