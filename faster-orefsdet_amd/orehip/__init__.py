@@ -1107,7 +1107,7 @@ class Engine:
         Returns (boxes [n,4], scores [n], classes [n] int64) -- the caller's own tensors, nothing of the engine aliases them."""
         assert img.is_contiguous() and img.dim() == 3
         _, H, W = img.shape
-        R = int(lib().ore_det_record_rows())                           # ORE_DET_RECORD_ROWS of the loaded library (= the engine's roi_cap)
+        R = self.__dict__.get("_rec_rows") or self.__dict__.setdefault("_rec_rows", int(lib().ore_det_record_rows()))   # ORE_DET_RECORD_ROWS of the loaded library (= the engine's roi_cap)
         rec = torch.empty(R * 7, dtype=torch.float32, device=self.device)  # [R][4] f32 | [R] f32 | [R] i64, written by the last kernel
         n = C.c_int32(0)
         _chk(lib().ore_engine_detect_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W, int(out_h), int(out_w),
