@@ -904,7 +904,7 @@ extern "C" int ore_groupnorm_bwd(const float* dy, const float* y, const float* x
 // One block moves one such matrix through LDS: reads and writes are both whole granule rows (512 B at 128 channels).
 __global__ __launch_bounds__(256) void k_granule_transpose(const float* __restrict__ in, float* __restrict__ out, int nb2, int A, int Bc,
                                                            int S4, long long in_b1, long long in_b2, long long in_rs, long long out_b1,
-                                                           long long out_b2, long long out_rs) {
+                                                           long long out_b2, long long out_rs, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float gt[];    // [A][Bc * S4 + 1] granules of 4 floats (odd pitch: column reads spread)
     const int b1 = blockIdx.x / nb2, b2 = blockIdx.x - b1 * nb2;
     const int row = Bc * S4, pitch = row + 1, n = A * row;
@@ -919,7 +919,9 @@ __global__ __launch_bounds__(256) void k_granule_transpose(const float* __restri
     for (int i = threadIdx.x; i < n; i += 256) {
         const int c = i / orow, rs = i - c * orow;
         const int r = rs / S4, s4 = rs - r * S4;
-        *reinterpret_cast<f32x4*>(dst + c * out_rs + rs * 4) = *reinterpret_cast<const f32x4*>(gt + (size_t)(r * pitch + c * S4 + s4) * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(gt + (size_t)(r * pitch + c * S4 + s4) * 4);
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(dst + c * out_rs + rs * 4);   // out += transposed(in): the second of two gradients
+        *reinterpret_cast<f32x4*>(dst + c * out_rs + rs * 4) = v;
     }
 }
 
@@ -1069,14 +1071,15 @@ extern "C" int ore_group_mean_bwd(const float* dy, int32_t G, int32_t N, int64_t
 }
 
 extern "C" int ore_granule_transpose_fwd(const float* in, float* out, int32_t nb1, int32_t nb2, int32_t A, int32_t Bc, int32_t S, int64_t in_b1,
-                                         int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, void* stream) {
+                                         int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, int32_t accumulate,
+                                         void* stream) {
     ORE_CHECK_ARG(in && out && in != out && nb1 > 0 && nb2 > 0 && A > 0 && Bc > 0 && S > 0 && S % 4 == 0, "ore_granule_transpose_fwd: bad args");
     ORE_CHECK_ARG(in_b1 % 4 == 0 && in_b2 % 4 == 0 && in_rs % 4 == 0 && out_b1 % 4 == 0 && out_b2 % 4 == 0 && out_rs % 4 == 0,
                   "ore_granule_transpose_fwd: strides must be multiples of 4 floats");
     const size_t lds = (size_t)A * (Bc * (S / 4) + 1) * 16;
     ORE_CHECK_ARG(lds <= 64 * 1024, "ore_granule_transpose_fwd: one [A x Bc] granule matrix must fit 64 KB of LDS (A=%d Bc=%d S=%d)", A, Bc, S);
     hipLaunchKernelGGL(k_granule_transpose, dim3((unsigned)nb1 * nb2), dim3(256), lds, (hipStream_t)stream, in, out, nb2, A, Bc, S / 4,
-                       (long long)in_b1, (long long)in_b2, (long long)in_rs, (long long)out_b1, (long long)out_b2, (long long)out_rs);
+                       (long long)in_b1, (long long)in_b2, (long long)in_rs, (long long)out_b1, (long long)out_b2, (long long)out_rs, (int)accumulate);
     return ore_launch_status("k_granule_transpose");
 }
 

@@ -84,18 +84,16 @@ class SM_Block(nn.Module):
 
 def _sm_block_train(self, x):
     """Same arithmetic as the eval forward with the Linears going through orehip.autograd (forward, data- and weight-gradient
-    kernels), the mixing layouts as granule transposes (SmPermuteFn), the pooled mean without the (h + w) tensor and the re-weighted sum
-    in one pass (MeanPairFn, Combine2Fn); the [B, C]-sized re-weighting MLP / softmax / dropout stay torch ops (ref fsod_cen.py:584-630)."""
+    kernels), the mixing layouts as granule transposes (SmDualPermuteFn / SmPermuteFn), the pooled mean without the (h + w) tensor and the
+    re-weighted sum in one pass (MeanPairFn, Combine2Fn); the [B, C]-sized re-weighting MLP / softmax / dropout stay torch ops (ref fsod_cen.py:584-630)."""
     from orehip import autograd as A
     B, H, W, C = x.shape
     S = C // self.seg_dim
     dims = (B, H, W, self.seg_dim, S)
-    h = A.sm_permute(x, dims, "h").reshape(-1, H * S)
-    h = A.sm_permute(A.linear(h, self.mlp_h.weight, self.mlp_h.bias), dims, "h", True)
-    w = A.sm_permute(x, dims, "w").reshape(-1, W * S)
-    w = A.sm_permute(A.linear(w, self.mlp_w.weight, self.mlp_w.bias), dims, "w", True)
-    a = A.mean_pair(h, w)
-    a = self.reweighting(a).reshape(B, C, 2).permute(2, 0, 1).softmax(0)
+    xh, xw = A.sm_dual_permute(x, dims)
+    h = A.sm_permute(A.linear(xh.reshape(-1, H * S), self.mlp_h.weight, self.mlp_h.bias), dims, "h", True)
+    w = A.sm_permute(A.linear(xw.reshape(-1, W * S), self.mlp_w.weight, self.mlp_w.bias), dims, "w", True)
+    a = self.reweighting(A.mean_pair(h, w)).reshape(B, C, 2).permute(2, 0, 1).softmax(0)
     y = A.combine2(w, h, a[0], a[1])
     return self.proj_drop(A.linear(y.reshape(-1, C), self.proj.weight, self.proj.bias).reshape(B, H, W, C))
 

@@ -914,10 +914,11 @@ def group_mean(x: torch.Tensor, groups: int, backward: bool = False, members: in
     return dx
 
 
-def sm_permute(x: torch.Tensor, B: int, H: int, W: int, G: int, S: int, axis: str, inverse: bool) -> torch.Tensor:
+def sm_permute(x: torch.Tensor, B: int, H: int, W: int, G: int, S: int, axis: str, inverse: bool, out: Optional[torch.Tensor] = None,
+               accumulate: bool = False) -> torch.Tensor:
     """The SM_Block's mixing layouts as one coalesced pass (ore_granule_transpose_fwd).  axis 'h': [B,H,W,G,S] <-> [B,G,W,H,S]
     (= .permute(0,3,2,1,4)); axis 'w': [B,H,W,G,S] <-> [B,G,H,W,S] (= .permute(0,3,1,2,4) and back).  x contiguous with B*H*W*G*S elements;
-    returns a contiguous tensor in the other layout (forward: the mixing layout, inverse: NHWC)."""
+    returns a contiguous tensor in the other layout (forward: the mixing layout, inverse: NHWC).  out + accumulate: out += the result."""
     _f32(x)
     assert x.numel() == B * H * W * G * S and axis in ("h", "w")
     Cc, img = G * S, H * W * G * S
@@ -930,9 +931,15 @@ def sm_permute(x: torch.Tensor, B: int, H: int, W: int, G: int, S: int, axis: st
         fwd = (W, G, img, W * Cc, Cc, img, W * S, H * W * S)
         inv = (G, W, img, W * S, H * W * S, img, W * Cc, Cc)
     A_, Bc, ib1, ib2, irs, ob1, ob2, ors = inv if inverse else fwd
-    out = torch.empty((B, H, W, G * S) if inverse else mix, device=x.device, dtype=torch.float32)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, H, W, G * S) if inverse else mix, device=x.device, dtype=torch.float32)
+    else:
+        _f32(out)
+        assert out.numel() == x.numel()
     _chk(lib().ore_granule_transpose_fwd(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), B, nb2, A_, Bc, S, C.c_int64(ib1), C.c_int64(ib2),
-                                         C.c_int64(irs), C.c_int64(ob1), C.c_int64(ob2), C.c_int64(ors), _stream()), "ore_granule_transpose_fwd")
+                                         C.c_int64(irs), C.c_int64(ob1), C.c_int64(ob2), C.c_int64(ors), int(accumulate), _stream()),
+         "ore_granule_transpose_fwd")
     return out
 
 

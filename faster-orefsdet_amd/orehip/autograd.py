@@ -332,6 +332,69 @@ def sm_permute(x, dims, axis, inverse=False):
     return SmPermuteFn.apply(x, dims, axis, inverse)
 
 
+class SmDualPermuteFn(Function):
+    """Both mixing layouts of one map, (x in the 'h' layout, x in the 'w' layout); backward: the two gradients come back through the
+    inverse layouts into ONE tensor (the second transpose accumulates), instead of two tensors and an add."""
+
+    @staticmethod
+    def forward(ctx, x, dims):
+        x = x.contiguous()
+        ctx.meta = (dims, tuple(x.shape))
+        return orehip.sm_permute(x, *dims, "h", False), orehip.sm_permute(x, *dims, "w", False)
+
+    @staticmethod
+    def backward(ctx, dh, dw):
+        dims, shape = ctx.meta
+        dx = orehip.sm_permute(dh.contiguous(), *dims, "h", True)
+        orehip.sm_permute(dw.contiguous(), *dims, "w", True, out=dx, accumulate=True)
+        return dx.reshape(shape), None
+
+
+def sm_dual_permute(x, dims):
+    return SmDualPermuteFn.apply(x, dims)
+
+
+class SMTailFn(Function):
+    """The tail of the SM_Block (ref fsod_cen.py:612-615) as one node: m = mean_hw(h + w); a = softmax(reweighting(m)); y = w a0 + h a1.
+    The [B, C]-sized MLP + softmax stay torch ops, differentiated by an inner autograd graph kept in the node; the map-sized work is
+    three HIP passes forward (two pooled sums, the re-weighted sum) and three backward (two per-image column sums of dy * map, and ONE
+    pass that writes dw = dy a0 + dm / HW and dh = dy a1 + dm / HW -- the mean's gradient rides along instead of two broadcast adds).
+    NOT used by the model: the inner torch.autograd.grad makes the backward re-entrant, and the re-entrant engine stalls the launch
+    thread (kernel time of a bs16 step 45.1 -> 44.7 ms, wall time 44.4 -> 49-53 ms; profiles/EXPERIMENTS.md).  Kept as a tested
+    reference of the fused arithmetic (tests/test_hip_train.py)."""
+
+    @staticmethod
+    def forward(ctx, w, h, mod, *params):
+        w, h = w.contiguous(), h.contiguous()
+        B, Cc = w.shape[0], w.shape[-1]
+        n = w.numel() // (B * Cc)
+        m = orehip.prod_colsum(h, None, 1.0 / n) + orehip.prod_colsum(w, None, 1.0 / n)
+        with torch.enable_grad():
+            m_ = m.detach().requires_grad_(True)
+            a = mod(m_).reshape(B, Cc, 2).permute(2, 0, 1).softmax(0)             # [2, B, C]
+        a0, a1 = a[0].detach().contiguous(), a[1].detach().contiguous()
+        ctx.save_for_backward(w, h, a0, a1)
+        ctx.inner = (m_, a, params)
+        ctx.n = n
+        return orehip.combine2(w, h, a0, a1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, h, a0, a1 = ctx.saved_tensors
+        m_, a, params = ctx.inner
+        dy = dy.contiguous()
+        da = torch.stack([orehip.prod_colsum(dy, w, 1.0), orehip.prod_colsum(dy, h, 1.0)])
+        need = [p for p in params if p.requires_grad]
+        grads = torch.autograd.grad([a], [m_] + need, [da], allow_unused=True)
+        dw, dh = orehip.combine2_bwd(dy, a0, a1, (grads[0] / ctx.n).contiguous())
+        it = iter(grads[1:])
+        return (dw, dh, None) + tuple(next(it) if p.requires_grad else None for p in params)
+
+
+def sm_tail(w, h, mod):
+    return SMTailFn.apply(w, h, mod, *tuple(mod.parameters()))
+
+
 class MeanPairFn(Function):
     """m[b, c] = mean over pixels of (h + w) without the sum tensor (ref fsod_cen.py:612); backward: the same constant for every pixel
     of both maps (returned as an expanded view: autograd adds it to the other gradient of h / w in one pass)."""

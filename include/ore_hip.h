@@ -392,7 +392,7 @@ int ore_scale_add_channels_fwd(const float* x, const float* scale_bc, const floa
  * ore_granule_transpose_fwd: for every (i1 < nb1, i2 < nb2) the [A][Bc] matrix of S-float granules at in + i1*in_b1 + i2*in_b2 (row stride
  *   in_rs, a row = Bc*S contiguous floats) is written transposed, [Bc][A] granules, at out + i1*out_b1 + i2*out_b2 (row stride out_rs, a
  *   row = A*S contiguous floats).  All strides in floats, multiples of 4; in != out.  This is x.reshape(B,H,W,seg,S).permute(0,3,2,1,4)
- *   / .permute(0,3,1,2,4) and their inverses as one coalesced pass.
+ *   / .permute(0,3,1,2,4) and their inverses as one coalesced pass; accumulate != 0: out += (the second of two gradients of one map).
  * ore_combine2_fwd: y = w * a0[b][c] + h * a1[b][c];  ore_combine2_bwd: dw = dy * a0 + v, dh = dy * a1 + v (v [B][C] optional). */
 /* F.adaptive_avg_pool2d on NHWC maps, forward and (gather-form, deterministic) backward: x [B][H][W][C] -> y [B][OH][OW][C]
  * (ref:fewx/modeling/fsod/fsod_cen.py:214-231: the support maps pooled to 32 / 16 / 8 and the 1x1 / 1x3 / 3x1 support kernels).
@@ -402,7 +402,7 @@ int ore_adaptive_avgpool_nhwc_bwd(const float* dy, int32_t B, int32_t H, int32_t
 int ore_group_mean_fwd(const float* x, int32_t G, int32_t N, int64_t M, float* y, void* stream);
 int ore_group_mean_bwd(const float* dy, int32_t G, int32_t N, int64_t M, float* dx, void* stream);
 int ore_granule_transpose_fwd(const float* in, float* out, int32_t nb1, int32_t nb2, int32_t A, int32_t Bc, int32_t S, int64_t in_b1,
-                              int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, void* stream);
+                              int64_t in_b2, int64_t in_rs, int64_t out_b1, int64_t out_b2, int64_t out_rs, int32_t accumulate, void* stream);
 int ore_combine2_fwd(const float* w, const float* h, const float* a0_bc, const float* a1_bc, int32_t B, int32_t rows, int32_t C, float* y,
                      void* stream);
 int ore_combine2_bwd(const float* dy, const float* a0_bc, const float* a1_bc, const float* add_bc, int32_t B, int32_t rows, int32_t C,

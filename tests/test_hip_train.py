@@ -210,6 +210,30 @@ def test_sm_block_glue_kernels(oh, B, H, W, G, S):
         outs.append((m, y, h.grad, w.grad, a0.grad, a1.grad))
     for got, ref in zip(outs[1], outs[0]):
         _close(got, ref.cpu(), tol=2e-5)
+    # both layouts from one node, the two gradients back into one tensor (the second transpose accumulates)
+    xr2 = x.clone().requires_grad_(True)
+    uh, uw = torch.randn(ph.shape, generator=g).cuda(), torch.randn(pw.shape, generator=g).cuda()
+    qh, qw = A.sm_dual_permute(xr2, dims)
+    assert torch.equal(qh, ph) and torch.equal(qw, pw)
+    ((qh * uh).sum() + (qw * uw).sum()).backward()
+    want = uh.permute(0, 3, 2, 1, 4).reshape(B, H, W, C) + uw.permute(0, 2, 3, 1, 4).reshape(B, H, W, C)
+    _close(xr2.grad, want.cpu(), tol=1e-6)
+    # the tail node (pooled mean -> re-weighting MLP -> softmax -> re-weighted sum) against the same expression in torch ops
+    torch.manual_seed(3)
+    mlp = torch.nn.Sequential(torch.nn.Linear(C, C // 2), torch.nn.GELU(), torch.nn.Linear(C // 2, 2 * C)).cuda()
+    outs = []
+    for hip in (False, True):
+        mlp.zero_grad(set_to_none=True)
+        h, w = (t.clone().requires_grad_(True) for t in (h0, w0))
+        if hip:
+            y = A.sm_tail(w, h, mlp)
+        else:
+            a = mlp((h + w).permute(0, 3, 1, 2).flatten(2).mean(2)).reshape(B, C, 2).permute(2, 0, 1).softmax(0)
+            y = w * a[0][:, None, None, :] + h * a[1][:, None, None, :]
+        (y * uy).sum().backward()
+        outs.append([y.detach(), h.grad, w.grad] + [p.grad.clone() for p in mlp.parameters()])
+    for got, ref in zip(outs[1], outs[0]):
+        _close(got, ref.cpu(), tol=5e-5)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(1, 6, 9, 32, 16, 3), (2, 40, 44, 96, 96, 3), (1, 64, 64, 128, 128, 1), (4, 30, 30, 256, 112, 1),
