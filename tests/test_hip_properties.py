@@ -96,6 +96,40 @@ def test_roi_align_and_conv_linearity_full_size(oh):
         assert torch.equal(oh.conv2d(x1, w, Cout, 3), y1)                   # and bit-reproducible
 
 
+def test_winograd_kernels_linearity_full_size(oh):
+    """The Winograd kernels at the path's full sizes without an oracle: linear in the input, bit-reproducible, and equal to the direct
+    kernels within the fp32 rounding of the transforms -- stem_2 (64 ch), stage-2 layer 0 (128 ch), stage 3 (80 / 112 ch: the nu-split
+    build), and the three FPN output convs as one per-level launch against three single-level launches."""
+    g = torch.Generator().manual_seed(18)
+    a, b = 0.75, -1.5
+    for (H, W, Cin, Cout) in ((320, 320, 64, 64), (160, 160, 128, 64), (80, 80, 80, 80), (80, 80, 112, 80)):
+        x1, x2 = torch.randn(1, H, W, Cin, generator=g).cuda(), torch.randn(1, H, W, Cin, generator=g).cuda()
+        w = oh.pack_conv_weight(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+        U = oh.winograd_weight(w, Cout, Cin)
+        y1, y2 = oh.conv2d(x1, w, Cout, 3, w_wino=U), oh.conv2d(x2, w, Cout, 3, w_wino=U)
+        y12 = oh.conv2d(a * x1 + b * x2, w, Cout, 3, w_wino=U)
+        d1 = oh.conv2d(x1, w, Cout, 3)
+        assert not torch.equal(y1, d1), "the Winograd kernel did not run"
+        assert float((y12 - (a * y1 + b * y2)).abs().max()) <= 3e-5 * float(y12.abs().max())
+        assert float((y1 - d1).abs().max()) <= 2e-5 * float(d1.abs().max())
+        assert torch.equal(oh.conv2d(x1, w, Cout, 3, w_wino=U), y1)
+    HW = [(80, 80), (40, 40), (20, 20)]
+    rows = torch.randn(sum(h * w_ for h, w_ in HW), 128, generator=g).cuda()
+    ws = [oh.pack_conv_weight(torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda() for _ in HW]
+    Us = torch.stack([oh.winograd_weight(w, 128, 128) for w in ws]).contiguous()
+    bias = (torch.randn(3, 128, generator=g) * 0.1).cuda()
+    y = oh.conv2d_levels(rows, HW, 1, ws[0], 128, 3, shift=bias, ep_stride=128, w_wino=Us, w_wino_level_stride=Us.shape[1])
+    r0 = 0
+    oh.lib().ore_conv_set_plan_override(-7, 2, 0, 0, 0)            # single-level reference launches on the Winograd kernel whatever the row count
+    try:
+        for l, (h, w_) in enumerate(HW):
+            yl = oh.conv2d(rows[r0:r0 + h * w_].reshape(1, h, w_, 128), ws[l], 128, 3, shift=bias[l].contiguous(), w_wino=Us[l].contiguous())
+            assert torch.equal(y[r0:r0 + h * w_], yl.reshape(-1, 128)), "level %d of the grouped launch differs from its own launch" % l
+            r0 += h * w_
+    finally:
+        oh.lib().ore_conv_set_plan_override(-7, 1, 0, 0, 0)
+
+
 def test_centernet_targets_properties_full_size(oh):
     """640x640, 128 boxes: every positive index addresses the cell containing its box centre on a level that cares for the box size;
     a location with a regression target lies inside that box; heat-map in [0, 1] and exactly 1 at positive cells."""
