@@ -243,24 +243,43 @@ def self_launch(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst = 0
     try:
-        for p in procs:
-            rc = p.wait()
-            if rc != 0 and worst == 0:
-                worst = rc
-                for q in procs:                                 # one rank died: the others would wait in a collective forever
-                    if q.poll() is None:
-                        q.terminate()
+        # poll ALL ranks: whichever dies first (bad device, OOM, rendezvous error) is seen at once, the others -- which would sit in
+        # init_process_group or a collective until the backend's timeout -- are terminated, killed after a grace period, and the
+        # first failing exit code is returned
+        live = list(procs)
+        while live and worst == 0:
+            for q in list(live):
+                rc = q.poll()
+                if rc is None:
+                    continue
+                live.remove(q)
+                if rc != 0:
+                    worst = rc
+                    break
+            else:
+                time.sleep(0.05)
+        if worst != 0:
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+            deadline = time.time() + 5.0
+            while time.time() < deadline and any(q.poll() is None for q in procs):
+                time.sleep(0.05)
     finally:
         for q in procs:
             if q.poll() is None:
                 q.kill()
-    return worst if 0 <= worst < 256 else 1
+        for q in procs:
+            q.wait()
+    return worst if 0 < worst < 256 else (1 if worst != 0 else 0)
 
 
 def dry_run(args, world, rank):
     """--dry: everything around the GPU legs (rendezvous, barrier, max-over-ranks, the one JSON line from rank 0) on gloo / CPU."""
     import torch.distributed as dist
     from detectron2.utils import comm
+    if os.environ.get("ORE_BENCH_DRY_FAIL_RANK") == str(rank):       # test hook: a rank that dies before the rendezvous
+        sys.exit(7)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("ORE_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)

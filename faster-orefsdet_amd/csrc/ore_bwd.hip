@@ -712,7 +712,7 @@ extern "C" int ore_conv2d_wgrad_bias_fwd(const float* x, int32_t x_ld, int32_t x
     p.slab = workspace; p.slab_stride = per;
     p.db = db; p.beta_b = beta_b;
     if (S == 1) { p.dw = dw_oihw; p.beta = beta; }
-    p.bf16 = ore_conv_get_precision();
+    p.bf16 = ore_conv_get_precision() == ORE_CONV_BF16;   // the STORAGE mode (2) is an engine property, plain calls stay fp32 (ore_hip.h)
     hipStream_t st = (hipStream_t)stream;
     if (kh == 3 && kw == 3) hipLaunchKernelGGL(k_wgrad3, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * 3, S), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);

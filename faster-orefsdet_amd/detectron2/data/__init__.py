@@ -2,6 +2,7 @@
 ref:fewx/data/datasets/builtin.py).  Dataset decoding / augmentation is outside the hot path: the catalogs and
 the batching helper are real, image I/O is not provided."""
 import itertools
+import operator
 
 import torch
 import torch.utils.data as torchdata
@@ -62,10 +63,31 @@ def build_batch_data_loader(dataset, sampler, total_batch_size, *, aspect_ratio_
     from detectron2.utils.comm import get_world_size
     world = get_world_size()
     assert total_batch_size > 0 and total_batch_size % world == 0, "Total batch size ({}) must be divisible by the number of gpus ({}).".format(total_batch_size, world)
+    batch = total_batch_size // world
     if aspect_ratio_grouping:
-        raise NotImplementedError("aspect-ratio grouping belongs to the data pipeline (SURVEY 8f row 3)")
-    return torchdata.DataLoader(dataset, sampler=sampler, num_workers=num_workers, batch_size=total_batch_size // world, drop_last=True,
+        # one mapped dict at a time, then two buckets by orientation (d2z:data/build.py:286-295, data/common.py:152-186)
+        one = torchdata.DataLoader(dataset, sampler=sampler, num_workers=num_workers, batch_sampler=None, collate_fn=operator.itemgetter(0))
+        return AspectRatioGroupedDataset(one, batch)
+    return torchdata.DataLoader(dataset, sampler=sampler, num_workers=num_workers, batch_size=batch, drop_last=True,
                                 collate_fn=trivial_batch_collator)
+
+
+class AspectRatioGroupedDataset(torchdata.IterableDataset):
+    """d2z:data/common.py:152-186: records whose width > height and the rest are batched separately (less padding inside a
+    batch); a bucket is emitted when it holds `batch_size` records, so a batch never mixes orientations and the order inside a
+    bucket is the sampler's."""
+
+    def __init__(self, dataset, batch_size):
+        self.dataset, self.batch_size = dataset, batch_size
+        self._buckets = ([], [])
+
+    def __iter__(self):
+        for d in self.dataset:
+            bucket = self._buckets[0 if d["width"] > d["height"] else 1]
+            bucket.append(d)
+            if len(bucket) == self.batch_size:
+                yield bucket[:]
+                del bucket[:]
 
 
 class InferenceSampler(torchdata.Sampler):
@@ -100,6 +122,54 @@ class TrainingSampler(torchdata.Sampler):
         g.manual_seed(self._seed)
         while True:
             yield from (torch.randperm(self._size, generator=g) if self._shuffle else torch.arange(self._size)).tolist()
+
+
+def get_detection_dataset_dicts(names, filter_empty=True, min_keypoints=0, proposal_files=None):
+    """d2z:data/build.py:207-257 for box-only datasets: the registered records of every name, concatenated; records whose
+    annotations are all crowd are dropped when filter_empty."""
+    if isinstance(names, str):
+        names = [names]
+    assert len(names), names
+    assert proposal_files is None and min_keypoints == 0, "precomputed proposals / keypoints are outside the fsod configs"
+    per_name = [DatasetCatalog.get(n) for n in names]
+    for n, d in zip(names, per_name):
+        assert len(d), "Dataset '{}' is empty!".format(n)
+    dicts = list(itertools.chain.from_iterable(per_name))
+    if filter_empty and "annotations" in dicts[0]:
+        dicts = [d for d in dicts if any(a.get("iscrowd", 0) == 0 for a in d["annotations"])]
+    assert len(dicts), "No valid data found in {}.".format(",".join(names))
+    return dicts
+
+
+class MapDataset(torchdata.Dataset):
+    def __init__(self, dicts, mapper):
+        self.dicts, self.mapper = dicts, mapper
+
+    def __len__(self):
+        return len(self.dicts)
+
+    def __getitem__(self, i):
+        return self.mapper(self.dicts[i])
+
+
+def build_detection_train_loader(cfg, mapper=None):
+    """d2z:data/build.py:302-386 (what the base DefaultTrainer.build_train_loader calls): plain records, TrainingSampler,
+    orientation-grouped batches per cfg.DATALOADER.ASPECT_RATIO_GROUPING."""
+    dicts = get_detection_dataset_dicts(cfg.DATASETS.TRAIN, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)
+    if cfg.DATALOADER.SAMPLER_TRAIN != "TrainingSampler":
+        raise ValueError("Unknown training sampler: {}".format(cfg.DATALOADER.SAMPLER_TRAIN))
+    ds = MapDataset(dicts, mapper if mapper is not None else DatasetMapper(cfg, True))
+    return build_batch_data_loader(ds, TrainingSampler(len(ds)), cfg.SOLVER.IMS_PER_BATCH,
+                                   aspect_ratio_grouping=cfg.DATALOADER.ASPECT_RATIO_GROUPING, num_workers=cfg.DATALOADER.NUM_WORKERS)
+
+
+def build_detection_test_loader(cfg, dataset_name, mapper=None):
+    """d2z:data/build.py:389-440: the named dataset unfiltered, one image per batch, contiguous shard per rank."""
+    dicts = get_detection_dataset_dicts([dataset_name], filter_empty=False)
+    ds = MapDataset(dicts, mapper if mapper is not None else DatasetMapper(cfg, False))
+    return torchdata.DataLoader(ds, num_workers=cfg.DATALOADER.NUM_WORKERS,
+                                batch_sampler=torchdata.sampler.BatchSampler(InferenceSampler(len(ds)), 1, drop_last=False),
+                                collate_fn=trivial_batch_collator)
 
 
 def DatasetMapper(cfg, is_train=True, **kw):

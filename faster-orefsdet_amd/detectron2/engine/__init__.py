@@ -30,6 +30,14 @@ def create_ddp_model(model, cfg=None, **kwargs):
 
 
 class SimpleTrainer:
+    """d2z:engine/train_loop.py:213-341.  The reference's `_write_metrics` reads every loss on the host in every step
+    (`v.detach().cpu().item()`), i.e. one device synchronisation per iteration, and raises FloatingPointError when their sum is not
+    finite.  Here the step stays free of host syncs: the loss vector of step i travels to pinned host memory behind step i's kernels
+    and is looked at once step i+1's forward has been enqueued (`metrics_lag` = 1; 0 = the reference's blocking form).  The guard is
+    the reference's: the same exception type and message, naming the iteration whose loss was not finite, raised on every rank for
+    its own losses (the reference checks the mean over ranks on the main process)."""
+    metrics_lag = 1
+
     def __init__(self, model, data_loader, optimizer):
         model.train()
         self.model, self.data_loader, self.optimizer = model, data_loader, optimizer
@@ -37,6 +45,7 @@ class SimpleTrainer:
         self.iter = 0
         self.storage = None
         self.last_losses = None
+        self._pending = []                                       # [(iteration, names, pinned host vector, event, data_time)]
 
     def run_step(self):
         assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
@@ -44,12 +53,51 @@ class SimpleTrainer:
         data = next(self._data_loader_iter)
         data_time = time.perf_counter() - start
         loss_dict = self.model(data)
-        losses = loss_dict if isinstance(loss_dict, torch.Tensor) else sum(loss_dict.values())
+        self.flush_metrics(keep=self.metrics_lag - 1)            # step i-1's losses, behind step i's forward launches
+        if isinstance(loss_dict, torch.Tensor):
+            losses, loss_dict = loss_dict, {"total_loss": loss_dict}
+        else:
+            losses = sum(loss_dict.values())
         self.optimizer.zero_grad()
         losses.backward()
-        self.last_losses = {k: v.detach() for k, v in loss_dict.items()} if not isinstance(loss_dict, torch.Tensor) else {"total_loss": losses.detach()}
+        self.last_losses = {k: v.detach() for k, v in loss_dict.items()}
         self.last_data_time = data_time
+        self._write_metrics(self.last_losses, data_time)
         self.optimizer.step()
+
+    def _write_metrics(self, loss_dict, data_time, prefix=""):
+        names = list(loss_dict)
+        vec = torch.stack([loss_dict[k].reshape(()).float() for k in names])
+        if vec.is_cuda:
+            host = torch.empty(len(names), dtype=torch.float32, pin_memory=True)
+            host.copy_(vec, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = vec.clone(), None
+        self._pending.append((self.iter, names, host, ev, data_time, prefix))
+        if self.metrics_lag <= 0:
+            self.flush_metrics()
+
+    def flush_metrics(self, keep=0):
+        """Look at the stashed loss vectors, oldest first, until `keep` are left: scalars into the current EventStorage, and the
+        reference's NaN / Inf guard (d2z:engine/train_loop.py:336-341)."""
+        while len(self._pending) > max(keep, 0):
+            it, names, host, ev, data_time, prefix = self._pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            metrics = {k: float(v) for k, v in zip(names, host.tolist())}
+            total = sum(metrics.values())
+            if not (total == total and abs(total) != float("inf")):
+                self._pending.clear()
+                raise FloatingPointError("Loss became infinite or NaN at iteration={}!\nloss_dict = {}".format(it, metrics))
+            from detectron2.utils.events import get_event_storage, has_event_storage
+            if has_event_storage() and comm.is_main_process():
+                st = get_event_storage()
+                st.put_scalar("data_time", data_time, cur_iter=it)
+                st.put_scalar("{}total_loss".format(prefix), total, cur_iter=it)
+                if len(metrics) > 1:
+                    st.put_scalars(cur_iter=it, **metrics)
 
 
 class DefaultTrainer(SimpleTrainer):
@@ -84,12 +132,16 @@ class DefaultTrainer(SimpleTrainer):
 
     @classmethod
     def build_train_loader(cls, cfg):
-        raise NotImplementedError("dataset loading (fewx.data.build / DatasetMapperWithSupport) is SURVEY 8f row 3; override "
-                                  "build_train_loader, e.g. with an iterator of synthetic batches (tools/bench_train.py)")
+        """d2z:engine/defaults.py:523-533: the plain detection loader (records as registered, plain DatasetMapper); the reference's
+        script overrides it with fewx.data.build + DatasetMapperWithSupport (ref:fsod_train_net.py:38-47)."""
+        from detectron2.data import build_detection_train_loader
+        return build_detection_train_loader(cfg)
 
     @classmethod
     def build_test_loader(cls, cfg, dataset_name):
-        raise NotImplementedError("dataset loading is SURVEY 8f row 3")
+        """d2z:engine/defaults.py:535-544."""
+        from detectron2.data import build_detection_test_loader
+        return build_detection_test_loader(cfg, dataset_name)
 
     @classmethod
     def build_evaluator(cls, cfg, dataset_name, output_folder=None):
@@ -103,11 +155,15 @@ class DefaultTrainer(SimpleTrainer):
     def train(self):
         with EventStorage(self.start_iter) as self.storage:
             for self.iter in range(self.start_iter, self.max_iter):
+                self.storage.iter = self.iter
                 self.run_step()
                 self.scheduler.step()
                 period = self.cfg.SOLVER.CHECKPOINT_PERIOD
-                if comm.is_main_process() and period > 0 and (self.iter + 1) % period == 0:
-                    self.checkpointer.save("model_{:07d}".format(self.iter), iteration=self.iter)
+                if period > 0 and (self.iter + 1) % period == 0:
+                    self.flush_metrics()                         # never checkpoint behind an unexamined loss
+                    if comm.is_main_process():
+                        self.checkpointer.save("model_{:07d}".format(self.iter), iteration=self.iter)
+            self.flush_metrics()
             if comm.is_main_process():
                 self.checkpointer.save("model_final", iteration=self.max_iter - 1)
 

@@ -10,14 +10,14 @@ class EventStorage:
         self._latest = {}
         self._history = defaultdict(list)
 
-    def put_scalar(self, name, value, smoothing_hint=True):
-        v = float(value)
-        self._latest[name] = (v, self.iter)
-        self._history[name].append((v, self.iter))
+    def put_scalar(self, name, value, smoothing_hint=True, cur_iter=None):
+        v, it = float(value), self.iter if cur_iter is None else cur_iter
+        self._latest[name] = (v, it)
+        self._history[name].append((v, it))
 
-    def put_scalars(self, *, smoothing_hint=True, **kw):
+    def put_scalars(self, *, smoothing_hint=True, cur_iter=None, **kw):
         for k, v in kw.items():
-            self.put_scalar(k, v)
+            self.put_scalar(k, v, cur_iter=cur_iter)
 
     def put_image(self, name, img):
         pass

@@ -60,8 +60,9 @@ def _default_mapper(cfg, is_train):
 
 
 def build_detection_train_loader(cfg, mapper=None):
-    """ref:fewx/data/build.py:108-160 (TrainingSampler; RepeatFactorTrainingSampler and aspect-ratio grouping are not used by the
-    fsod configs and raise)."""
+    """ref:fewx/data/build.py:108-160: TrainingSampler over the per-category records, batches grouped by orientation when
+    cfg.DATALOADER.ASPECT_RATIO_GROUPING (detectron2's default True, which the fsod configs keep -- ref:fewx/data/build.py:158).
+    RepeatFactorTrainingSampler is not used by the fsod configs and raises."""
     dicts = fsod_get_detection_dataset_dicts(cfg.DATASETS.TRAIN, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)
     if mapper is None:
         mapper = _default_mapper(cfg, True)
@@ -70,7 +71,7 @@ def build_detection_train_loader(cfg, mapper=None):
     if name != "TrainingSampler":
         raise ValueError("Unknown training sampler: {}".format(name))
     return build_batch_data_loader(ds, TrainingSampler(len(ds)), cfg.SOLVER.IMS_PER_BATCH,
-                                   aspect_ratio_grouping=False, num_workers=cfg.DATALOADER.NUM_WORKERS)
+                                   aspect_ratio_grouping=cfg.DATALOADER.ASPECT_RATIO_GROUPING, num_workers=cfg.DATALOADER.NUM_WORKERS)
 
 
 def build_detection_test_loader(cfg, dataset_name, mapper=None):

@@ -178,6 +178,22 @@ def winograd_weight(w_packed: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor
     return U
 
 
+def _bf16_in_with_slack(x: torch.Tensor, Cin: int, in_coff: int, ld: int) -> torch.Tensor:
+    """ore_hip.h (ORE_ST_BF16): when Cin % 32 == 16 and the slice ends at the row end, the last K chunk of the LAST row reads 16
+    channels (32 bytes) past the tensor against zero weights -- the bytes must exist and be finite (0 * NaN = NaN).  A tensor whose
+    storage already extends that far (a view into a wider buffer: the caller owns what lies there, as the header says) is taken as
+    it is; a plain tensor, whose storage ends with its last element, is copied once into a buffer with 16 zeroed elements of slack."""
+    if Cin % 32 == 0 or in_coff + Cin != ld:
+        return x
+    end = x.storage_offset() + x.numel()
+    if x.untyped_storage().nbytes() // 2 - end >= 16:
+        return x
+    buf = torch.empty(x.numel() + 16, device=x.device, dtype=torch.bfloat16)
+    buf[x.numel():].zero_()
+    buf[:x.numel()].copy_(x.reshape(-1))
+    return buf[:x.numel()].view(x.shape)
+
+
 def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: int = 1, pad: Optional[int] = None, *,
            in_coff: int = 0, Cin: Optional[int] = None, scale=None, shift=None, relu_cout: int = 0, in_mul=None,
            in_add=None, in_relu: bool = False, add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -193,6 +209,8 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, Cout: int, k: int, stride: i
         _f32(x)
     B, H, W, ld = x.shape
     Cin = Cin if Cin is not None else ld - in_coff
+    if st_bf16:
+        x = _bf16_in_with_slack(x, Cin, in_coff, ld)
     pad = k // 2 if pad is None else pad
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out_dt = torch.bfloat16 if (st_bf16 and not out_f32) else torch.float32
@@ -240,6 +258,8 @@ def conv2d_levels(x_rows: torch.Tensor, HW: Sequence[Tuple[int, int]], B: int, w
     rows, ld = x_rows.shape
     assert rows == sum(B * h * w for h, w in HW)
     Cin = Cin if Cin is not None else ld - in_coff
+    if st_bf16:
+        x_rows = _bf16_in_with_slack(x_rows, Cin, in_coff, ld)
     out_dt = torch.bfloat16 if (st_bf16 and not out_f32) else torch.float32
     if out is None:
         out = torch.empty(rows, Cout, device=x_rows.device, dtype=out_dt)

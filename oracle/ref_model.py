@@ -49,7 +49,7 @@ VOVNET_SPECS = {
 # -- the producer rounds its fp32 result once, nearest even (`_st`) --, conv weights are bf16; stem_1's arithmetic, FrozenBN / bias, the
 # eSE pool and gate, GroupNorm statistics, the depthwise correlation's arithmetic and the head OUTPUTS stay fp32.  Two folds of the
 # product are part of the mode's definition: the eSE gate reaches the max-pool as round(max(x) * g) (= round(max(x * g)), g >= 0) and the
-# FPN lateral as a weight, round(W * g) (`_GATED`).
+# FPN lateral as a weight, round(W * g) (the pair rides on the gated tensor: `_ore_gated`).
 _OPERANDS = "fp32"
 _LINEARS = False
 
@@ -83,7 +83,6 @@ def _st(t: Tensor) -> Tensor:
     return t.bfloat16().float() if _OPERANDS == "bf16s" else t
 
 
-_GATED: Dict[int, Tuple[Tensor, Tensor]] = {}      # id(x * gate) -> (x, gate): lets fpn() fold the gate into the lateral weight (bf16s)
 
 
 class _Bf16ConvFn(torch.autograd.Function):
@@ -177,7 +176,7 @@ def ese(x: Tensor, sd: SD, prefix: str) -> Tensor:
     s = F.relu6(s + 3.0) / 6.0
     y = x * s
     if _OPERANDS == "bf16s":
-        _GATED[id(y)] = (x, s)
+        y._ore_gated = (x, s)          # lets fpn() fold the gate into the lateral weight; lives and dies with y (no global table)
     return y
 
 
@@ -224,8 +223,8 @@ def fpn(feats: Mapping[str, Tensor], sd: SD, prefix: str = "backbone.",
     res: Dict[str, Tensor] = {}
     prev = None
     for name, st in reversed(list(zip(in_features, stages))):
-        if _OPERANDS == "bf16s" and id(feats[name]) in _GATED:       # the gate rides on the lateral's weight: conv(x, round(W * g))
-            xs, gs = _GATED[id(feats[name])]
+        if _OPERANDS == "bf16s" and hasattr(feats[name], "_ore_gated"):   # the gate rides on the lateral's weight: conv(x, round(W * g))
+            xs, gs = feats[name]._ore_gated
             lat = F.conv2d(xs, _rnd(sd[f"{prefix}fpn_lateral{st}.weight"] * gs.view(1, -1, 1, 1)), sd[f"{prefix}fpn_lateral{st}.bias"])
         else:
             lat = dense_conv(feats[name], sd[f"{prefix}fpn_lateral{st}.weight"], sd[f"{prefix}fpn_lateral{st}.bias"])

@@ -103,3 +103,19 @@ def test_bench_under_an_external_launcher_dry():
     assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
     lines = [l for o in outs for l in o[0].splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_bench_self_launch_returns_promptly_when_a_rank_dies():
+    """rank 1 exits before the rendezvous while rank 0 blocks in init_process_group.  The parent must notice the dead
+    rank whatever its position, stop the others and return ITS exit code within seconds, not after the backend's timeout."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ORE_BENCH_BACKEND="gloo", ORE_BENCH_DRY_FAIL_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--dry"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 60
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -280,3 +280,104 @@ def test_loader_builders_accept_the_reference_call_forms(tmp_path):
     finally:
         DatasetCatalog.remove("ore_unit_train")
         DatasetCatalog.remove("ore_unit_val")
+
+
+def test_nan_loss_guard_of_the_train_loop():
+    """d2z:engine/train_loop.py:336-341: a loss that is not finite stops training with FloatingPointError naming the iteration.
+    The product looks at step i's losses behind step i+1's forward (no host sync inside a step); metrics_lag = 0 is the
+    reference's blocking form.  Both raise for the same iteration; finite losses land in the EventStorage under their own
+    iteration."""
+    from detectron2.engine import SimpleTrainer
+    from detectron2.utils.events import EventStorage
+
+    class M(torch.nn.Module):
+        def __init__(self, bad_at):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(()))
+            self.calls, self.bad_at = 0, bad_at
+
+        def forward(self, batch):
+            v = self.w * (float("nan") if self.calls == self.bad_at else 1.0 + self.calls)
+            self.calls += 1
+            return {"loss_a": v, "loss_b": self.w * 0.5}
+
+    def loader():
+        while True:
+            yield [{}]
+
+    for lag, raised_in_call in ((1, 3), (0, 2)):
+        m = M(bad_at=2)
+        tr = SimpleTrainer(m, loader(), torch.optim.SGD(m.parameters(), lr=0.0))
+        tr.metrics_lag = lag
+        with EventStorage(0) as st:
+            done = 0
+            with pytest.raises(FloatingPointError, match=r"Loss became infinite or NaN at iteration=2!"):
+                for tr.iter in range(5):
+                    st.iter = tr.iter
+                    tr.run_step()
+                    done += 1
+            assert done == raised_in_call
+            assert st.history("total_loss") == [(1.5, 0), (2.5, 1)] and st.history("loss_a") == [(1.0, 0), (2.0, 1)]
+    # the end-of-training flush sees the last step too
+    m = M(bad_at=1)
+    tr = SimpleTrainer(m, loader(), torch.optim.SGD(m.parameters(), lr=0.0))
+    with EventStorage(0):
+        tr.iter = 0
+        tr.run_step()
+        tr.iter = 1
+        tr.run_step()
+        with pytest.raises(FloatingPointError, match="iteration=1"):
+            tr.flush_metrics()
+
+
+def test_aspect_ratio_grouping_and_base_trainer_loaders(tmp_path):
+    """d2z:data/build.py:286-295 + data/common.py:152-186: with cfg.DATALOADER.ASPECT_RATIO_GROUPING (detectron2's default, kept by
+    the fsod configs -- ref:fewx/data/build.py:158) a batch never mixes landscape and portrait records and keeps the sampler's order
+    inside an orientation; DefaultTrainer.build_train_loader / build_test_loader delegate to detectron2.data like
+    d2z:engine/defaults.py:523-544."""
+    from detectron2.data import (AspectRatioGroupedDataset, DatasetCatalog, TrainingSampler, build_batch_data_loader)
+    from detectron2.engine import DefaultTrainer
+    from fewx.config import get_cfg
+    recs = [{"width": 4 if i % 3 else 2, "height": 3, "i": i} for i in range(12)]
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(recs)
+
+        def __getitem__(self, i):
+            return recs[i]
+
+    order = list(range(12))
+    got = []
+    for b in build_batch_data_loader(DS(), order, 2, aspect_ratio_grouping=True):
+        assert len(b) == 2 and len({d["width"] > d["height"] for d in b}) == 1
+        got.append([d["i"] for d in b])
+    assert got == [[1, 2], [0, 3], [4, 5], [7, 8], [6, 9], [10, 11]]
+    assert isinstance(build_batch_data_loader(DS(), TrainingSampler(12), 2, aspect_ratio_grouping=True), AspectRatioGroupedDataset)
+    plain = build_batch_data_loader(DS(), order, 3, aspect_ratio_grouping=False)
+    assert [[d["i"] for d in b] for b in plain] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]]
+
+    from PIL import Image
+    f = str(tmp_path / "im.png")
+    Image.fromarray(np.zeros((120, 160, 3), dtype=np.uint8)).save(f)
+    rec = {"file_name": f, "height": 120, "width": 160, "image_id": 1,
+           "annotations": [{"bbox": [10.0, 20.0, 50.0, 40.0], "bbox_mode": 1, "category_id": 0, "iscrowd": 0}]}
+    crowd = dict(rec, annotations=[dict(rec["annotations"][0], iscrowd=1)])
+    import copy
+    for n in ("ore_base_train", "ore_base_val"):
+        if n in DatasetCatalog:
+            DatasetCatalog.remove(n)
+        DatasetCatalog.register(n, lambda: copy.deepcopy([rec, crowd]))
+    cfg = get_cfg()
+    cfg.merge_from_list(["DATASETS.TRAIN", ("ore_base_train",), "DATASETS.TEST", ("ore_base_val",), "DATALOADER.NUM_WORKERS", 0,
+                         "SOLVER.IMS_PER_BATCH", 1, "INPUT.MIN_SIZE_TEST", 96, "INPUT.MAX_SIZE_TEST", 160,
+                         "INPUT.MIN_SIZE_TRAIN", (96,), "INPUT.MAX_SIZE_TRAIN", 160])
+    try:
+        assert cfg.DATALOADER.ASPECT_RATIO_GROUPING is True
+        b = next(iter(DefaultTrainer.build_train_loader(cfg)))
+        assert len(b) == 1 and tuple(b[0]["image"].shape) == (3, 96, 128) and len(b[0]["instances"]) == 1
+        batches = list(DefaultTrainer.build_test_loader(cfg, "ore_base_val"))
+        assert len(batches) == 2 and batches[0][0]["width"] == 160                  # test side: unfiltered (crowd-only record kept)
+    finally:
+        DatasetCatalog.remove("ore_base_train")
+        DatasetCatalog.remove("ore_base_val")
