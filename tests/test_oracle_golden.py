@@ -4,7 +4,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+import os
+
+from conftest import ROOT, rel_err
 from oracle import decode as odec
 from oracle import ref_model as R
 
@@ -367,3 +369,14 @@ def test_compiled_roi_align_matches_the_python_loop():
     a = R.roi_pool_levels(feats, boxes, 8).numpy()
     b = R.roi_pool_levels(feats, boxes, 8, compiled=True).numpy()
     assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+
+
+def test_c_oracle_under_asan_ubsan():
+    """SURVEY 5 (CPU sanitizer build; GPU sanitizers are not available on this pool): oracle/ref_decode.c and the product library's
+    host-only translation unit, built with -fsanitize=address,undefined -fno-sanitize-recover and driven over the edge cases of the
+    path (no / few / all candidates, score ties, nms_thresh <= 0, zero-area boxes, ROIs outside the map, 0 ROIs).  Any memory error,
+    leak or undefined behaviour makes the driver exit non-zero."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "asan ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
