@@ -268,6 +268,141 @@ def main():
     gen_generate_support()
     gen_dataset_split()
     gen_eval_end_to_end(sd)
+    gen_cn_indices()
+
+
+def gen_cn_indices():
+    """SURVEY Appendix E (`cn_infer_640_*`: "per-level selected flat indices ... NMS keep indices int64"), VERDICT r03 missing #4.
+
+        python -m oracle.refrun.gen_golden indices        # writes tests/golden/cn_infer_640_{sparse,dense,train}_idx.npz only
+
+    The reference's predict_instances / predict_single_level / nms_and_topK (ref:fewx/modeling/fsod/fsod_rpn.py:1101-1210) executed on
+    the head outputs the existing cn_infer_640_* fixtures hold, in eval mode (1e-5 / 1000 / 0.6 / 256) and -- on the dense maps -- with
+    the TRAINING thresholds (4000 / 0.9 / 2000; the call CenterNet.forward makes in its training branch, :674-679).  The index tensors
+    never leave predict_single_level, so torch.Tensor.nonzero / topk and the module's batched NMS are watched while it runs: per level
+    `per_candidate_inds.nonzero()[:, 0]` (the flat locations above the threshold) and, where a level holds more than pre_topk, the
+    `top_k_indices` into them.  Stored:
+      sel{l}            int64, SORTED flat indices the reference selected at level l (topk(sorted=False) order is implementation-defined);
+      pre_level/pre_loc the reference's own pre-NMS order (level, flat index) -- row r of the stored pre_boxes / pre_scores;
+      nms_keep          int64 keep list of ml_nms in the CANONICAL pre order (levels concatenated, ascending flat index inside a level;
+                        what oracle/ref_decode.c and the HIP path emit), in the reference's order (descending score);
+      post_keep         the same after the post-NMS `score >= kth` filter = rows of the returned proposals.
+    The NMS arithmetic itself is the restated torchvision nms (un-vendored); everything else is the reference's code."""
+    ns = shims.setup()
+    rpn = ns.fsod_rpn
+
+    class _FakeHead(torch.nn.Module):
+        def forward(self, feats):
+            raise RuntimeError("head outputs are injected")
+
+    def build():
+        return rpn.CenterNet(in_channels=128, num_classes=1, in_features=("p3", "p4", "p5"), strides=(8, 16, 32),
+                             score_thresh=1e-5, with_agn_hm=True, only_proposal=True, not_norm_reg=True,
+                             pre_nms_topk_train=4000, pre_nms_topk_test=1000, post_nms_topk_train=2000,
+                             post_nms_topk_test=256, nms_thresh_train=0.9, nms_thresh_test=0.6,
+                             pos_weight=0.5, neg_weight=0.5, ignore_high_fp=0.85, reg_weight=1.0,
+                             sizes_of_interest=[[0, 64], [48, 192], [128, 1000000]], centernet_head=_FakeHead())
+
+    def run(hm_l, reg_l, training):
+        cn = build()
+        cn.train(training)
+        log = []                                                    # ("nonzero", tensor) / ("topk", indices) in call order
+        o_nz, o_tk, o_nms = torch.Tensor.nonzero, torch.Tensor.topk, rpn.ml_nms
+        cap = {}
+
+        def nz(self, *a, **k):
+            r = o_nz(self, *a, **k)
+            if self.dtype == torch.bool and r.dim() == 2 and r.shape[1] == 2:
+                log.append(("nonzero", r.clone()))
+            return r
+
+        def tk(self, *a, **k):
+            r = o_tk(self, *a, **k)
+            log.append(("topk", r[1].clone()))
+            return r
+
+        def spy_nms(boxlist, thr, *a, **k):
+            cap["pre_boxes"], cap["pre_scores"] = boxlist.pred_boxes.tensor.clone(), boxlist.scores.clone()
+            ob = o_nms.__globals__["batched_nms"]
+
+            def bn(boxes, scores, labels, t):
+                kp = ob(boxes, scores, labels, t)
+                cap["keep"] = kp.clone()
+                return kp
+            o_nms.__globals__["batched_nms"] = bn
+            try:
+                return o_nms(boxlist, thr, *a, **k)
+            finally:
+                o_nms.__globals__["batched_nms"] = ob
+
+        torch.Tensor.nonzero, torch.Tensor.topk = nz, tk
+        rpn.ml_nms = spy_nms
+        try:
+            feats = [torch.zeros(1, 128, s, s) for s in (80, 40, 20)]
+            grids = cn.compute_grids(feats)
+            with torch.no_grad():
+                props = cn.predict_instances(grids, [x.sigmoid() for x in hm_l], reg_l, [(640, 640)], [None, None, None])
+        finally:
+            torch.Tensor.nonzero, torch.Tensor.topk = o_nz, o_tk
+            rpn.ml_nms = o_nms
+        # replay the log: one nonzero per level, followed by a topk when the level was cut
+        sel, i = [], 0
+        for l in range(3):
+            assert log[i][0] == "nonzero", [e[0] for e in log]
+            loc = log[i][1][:, 0]
+            i += 1
+            if i < len(log) and log[i][0] == "topk":
+                loc = loc[log[i][1]]
+                i += 1
+            sel.append(loc)
+        # the `cls_scores >= image_thresh` filter calls torch.nonzero (the function), not Tensor.nonzero on a 2-d mask: nothing else logged
+        assert i == len(log), [e[0] for e in log]
+        pre_level = torch.cat([torch.full((len(s_),), l, dtype=torch.int64) for l, s_ in enumerate(sel)])
+        pre_loc = torch.cat(sel)
+        assert len(pre_loc) == len(cap["pre_scores"])
+        # canonical pre order: (level, flat index) ascending
+        key = pre_level * (1 << 20) + pre_loc
+        order = torch.argsort(key)
+        canon_of_ref = torch.empty_like(order)
+        canon_of_ref[order] = torch.arange(len(order))
+        keep_ref = cap["keep"]
+        nms_keep = canon_of_ref[keep_ref]
+        p = props[0]
+        boxes_out = p.pred_boxes.tensor if p.has("pred_boxes") else p.proposal_boxes.tensor
+        scores_out = p.scores
+        # rows of the returned proposals among the NMS survivors: the reference filters result[keep] with a mask, order preserved
+        kept_scores = cap["pre_scores"][keep_ref]
+        if len(keep_ref) > (cn.post_nms_topk_train if training else cn.post_nms_topk_test):
+            k_ = cn.post_nms_topk_train if training else cn.post_nms_topk_test
+            thr = torch.kthvalue(kept_scores.float(), len(keep_ref) - k_ + 1)[0]
+            post_keep = nms_keep[kept_scores >= thr]
+        else:
+            post_keep = nms_keep
+        assert len(post_keep) == len(scores_out) and torch.equal(cap["pre_scores"][order][post_keep], scores_out)
+        return dict(**{f"sel{l}": np_(torch.sort(sel[l])[0]) for l in range(3)}, pre_level=np_(pre_level), pre_loc=np_(pre_loc),
+                    pre_boxes=np_(cap["pre_boxes"]), pre_scores=np_(cap["pre_scores"]), nms_keep=np_(nms_keep), post_keep=np_(post_keep),
+                    boxes=np_(boxes_out), scores=np_(scores_out))
+
+    for tag in ("sparse", "dense"):
+        f = dict(np.load(os.path.join(OUT, f"cn_infer_640_{tag}.npz")))
+        hm_l = [torch.from_numpy(f[f"hm{l}"])[None, None] for l in range(3)]
+        reg_l = [torch.from_numpy(f[f"reg{l}"]).permute(2, 0, 1)[None].contiguous() for l in range(3)]
+        out = run(hm_l, reg_l, training=False)
+        # the same run the box fixture came from: identical pre lists and outputs, bit for bit
+        assert np.array_equal(out["pre_boxes"], f["pre_boxes"]) and np.array_equal(out["pre_scores"], f["pre_scores"])
+        assert np.array_equal(out["boxes"], f["boxes"]) and np.array_equal(out["scores"], f["scores"])
+        save(f"cn_infer_640_{tag}_idx", **{k: v for k, v in out.items() if k not in ("pre_boxes", "pre_scores", "boxes", "scores")})
+    # training thresholds (4000 / 0.9 / 2000) on maps of their own: large smooth boxes so that neighbours overlap by more than 0.9
+    g = torch.Generator().manual_seed(4321)
+    hm_l, reg_l = [], []
+    for s_ in (80, 40, 20):
+        base = torch.nn.functional.interpolate(torch.randn(1, 1, s_ // 4, s_ // 4, generator=g), size=(s_, s_), mode="bilinear", align_corners=False)
+        hm_l.append(base * 2.5 + torch.randn(1, 1, s_, s_, generator=g) * 0.7 + 2.0)
+        rb = torch.nn.functional.interpolate(torch.randn(1, 4, s_ // 8, s_ // 8, generator=g), size=(s_, s_), mode="bilinear", align_corners=False)
+        reg_l.append(torch.relu(rb * 2.0 + 9.0 + torch.randn(1, 4, s_, s_, generator=g) * 0.15))
+    out_t = run(hm_l, reg_l, training=True)
+    save("cn_infer_640_train_idx", **{f"hm{l}": np_(hm_l[l][0, 0]) for l in range(3)},
+         **{f"reg{l}": np_(reg_l[l][0].permute(1, 2, 0).contiguous()) for l in range(3)}, **out_t)
 
 
 def reference_detector(sd, shots, device_cfg="cpu"):
@@ -634,5 +769,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "eval":
         torch.manual_seed(0)
         gen_eval_end_to_end(R.synth_state_dict(SEED))
+    elif len(sys.argv) > 1 and sys.argv[1] == "indices":
+        gen_cn_indices()
     else:
         main()

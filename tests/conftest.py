@@ -33,3 +33,18 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def chan_err(a, b, axis=1, floor=1e-2):
+    """Per-channel companion of rel_err (under the max-norm measure a channel -- or a pyramid level -- whose
+    magnitude is 1 % of the tensor's maximum could be 1 % wrong and pass "1e-4 rel").  For every channel c along `axis`:
+    rms(a_c - b_c) / max(rms(b_c), floor * rms(b)); the maximum over channels is returned.  The floor (1 % of the whole tensor's rms)
+    only keeps channels that are dead after a ReLU from dividing by zero."""
+    import numpy as np
+
+    a = np.moveaxis(np.asarray(a, dtype=np.float64), axis, 0)
+    b = np.moveaxis(np.asarray(b, dtype=np.float64), axis, 0)
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    num = np.sqrt(((a - b) ** 2).mean(1))
+    den = np.maximum(np.sqrt((b ** 2).mean(1)), floor * np.sqrt((b ** 2).mean()) + 1e-30)
+    return float((num / den).max())

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import chan_err, rel_err
 from oracle import decode as odec
 from oracle import ref_model as R
 
@@ -59,10 +59,12 @@ def test_conv_golden_blocks(ore, sd, golden):
     g = golden("conv_stem2")
     y = conv_bn(ore, nhwc(torch.from_numpy(g["x"])), sd, p + "stem_2", 3, 1)
     assert rel_err(nchw(y).numpy(), g["y"]) < TOL
+    assert chan_err(nchw(y).numpy(), g["y"]) < TOL
     g = golden("conv_stem3_odd")
     y = conv_bn(ore, nhwc(torch.from_numpy(g["x"])), sd, p + "stem_3", 3, 2)
     assert y.shape[1:3] == g["y"].shape[2:]
     assert rel_err(nchw(y).numpy(), g["y"]) < TOL
+    assert chan_err(nchw(y).numpy(), g["y"]) < TOL
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,splitk", [
@@ -426,6 +428,7 @@ def test_osa_stage_golden(ore, sd, golden, name, k):
     gate = ore.ese_gate(y, dev(sd[p + "ese.fc.weight"]), dev(sd[p + "ese.fc.bias"]))
     y = ore.scale_channels(y, gate)
     assert rel_err(nchw(y).numpy(), g["y"]) < TOL
+    assert chan_err(nchw(y).numpy(), g["y"]) < TOL
 
 
 # ------------------------------------------------------------------------------------------ correlation / head
@@ -446,6 +449,7 @@ def test_correlation_golden(ore, sd, golden):
         ore.correlation(pcat, k11, k13, k31, out=pcat, q_coff=C, out_coff=0, Cc=C)
         y = ore.conv2d(pcat, w3, C, 1, shift=dev(sd["conv3.bias"]), relu_cout=C)
         assert rel_err(nchw(y).numpy(), g["out_" + k]) < TOL, k
+        assert chan_err(nchw(y).numpy(), g["out_" + k]) < TOL, k
 
 
 def head_level(ore, sd, x_nhwc, l):
@@ -514,6 +518,26 @@ def test_detect_vs_reference_run(ore, golden, tag):
     np.testing.assert_allclose(got["boxes"], g["boxes"], rtol=2e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag,pre_topk,nms_thr,post_topk", [("sparse", 1000, 0.6, 256), ("dense", 1000, 0.6, 256), ("train", 4000, 0.9, 2000)])
+def test_detect_indices_vs_reference_run(ore, golden, tag, pre_topk, nms_thr, post_topk):
+    """north_star: bit-exact box indices / NMS keep masks vs the reference CPU path.  tests/golden/cn_infer_640_*_idx.npz hold the
+    int64 index tensors of the EXECUTED reference (oracle/refrun/gen_golden.py::gen_cn_indices): per-level selected flat
+    locations, the rows left by the post-NMS filter in the canonical pre order; eval thresholds on two maps, the training
+    thresholds (4000 / 0.9 / 2000) on a third.  The HIP path must reproduce them with np.array_equal (keep lists up to the order
+    inside a run of exactly tied scores, which the reference's topk(sorted=False) leaves undefined -- same_keep_list)."""
+    from test_oracle_golden import same_keep_list
+    gi = golden(f"cn_infer_640_{tag}_idx")
+    g = gi if tag == "train" else golden(f"cn_infer_640_{tag}")
+    got = run_detect(ore, [g[f"hm{l}"] for l in range(3)], [g[f"reg{l}"] for l in range(3)], pre_topk, nms_thr, post_topk)
+    base = np.cumsum([0] + [g[f"hm{l}"].size for l in range(3)])
+    for l in range(3):
+        mine = got["pre_loc"][got["pre_level"] == l].astype(np.int64) - base[l]
+        assert np.array_equal(mine, gi[f"sel{l}"]), l
+    same_keep_list(got["keep"].astype(np.int64), gi["post_keep"], got["pre_scores"])
+    full = ore.nms(torch.from_numpy(got["pre_boxes"]).cuda(), torch.from_numpy(got["pre_scores"]).cuda(), nms_thr)
+    same_keep_list(full.cpu().numpy().astype(np.int64), gi["nms_keep"], got["pre_scores"])
+
+
 def test_detect_ties_and_edge_cases(ore):
     rng = np.random.default_rng(3)
     # heavy score ties (quantised logits) + identical boxes: exercises tie-breaking in top-k, sort and post-top-k
@@ -566,6 +590,7 @@ def test_engine_backbone_golden(engine, golden):
     for k in ("p3", "p4", "p5"):
         assert tuple(out[k].shape) == g[k].shape
         assert rel_err(out[k].cpu().numpy(), g[k]) < TOL, k
+        assert chan_err(out[k].cpu().numpy(), g[k]) < TOL, k
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -580,6 +605,8 @@ def test_engine_eval_640_vs_oracle(engine, sd, use_graph):
         s = 640 >> (l + 3)
         assert rel_err(engine.buffer(k, (1, s, s)).cpu().numpy(), ref["features"][k].numpy()) < TOL, k
         assert rel_err(engine.buffer(f"pos{l + 3}", (1, s, s)).cpu().numpy(), ref["pos_features"][l].numpy()) < TOL
+        assert chan_err(engine.buffer(k, (1, s, s)).cpu().numpy(), ref["features"][k].numpy()) < TOL, k
+        assert chan_err(engine.buffer(f"pos{l + 3}", (1, s, s)).cpu().numpy(), ref["pos_features"][l].numpy()) < TOL
         hd = engine.buffer(f"head{l + 3}", (1, s, s)).cpu()
         assert rel_err(hd[:, :4].numpy(), ref["reg"][l].numpy()) < TOL
         assert rel_err(hd[:, 4:5].numpy(), ref["hm"][l].numpy()) < TOL
@@ -621,6 +648,7 @@ def test_engine_on_reference_demo_images(ore, sd, golden):
             hd = e.buffer(f"head{l + 3}", (1, s, s)).cpu()
             assert rel_err(hd[:, :4].numpy(), ref["reg"][l].numpy()) < TOL
             assert rel_err(hd[:, 4:5].numpy(), ref["hm"][l].numpy()) < TOL
+            assert chan_err(e.buffer(k, (1, s, s)).cpu().numpy(), ref["features"][k].numpy()) < TOL, k
             raw = e.buffer(f"head{l + 3}").cpu().numpy().reshape(s, s, 5)
             hms.append(np.ascontiguousarray(raw[..., 4]))
             regs.append(np.ascontiguousarray(raw[..., :4]))
@@ -703,6 +731,7 @@ def test_module_backbone_forward_golden(model, golden):
     for k in ("p3", "p4", "p5"):
         assert tuple(out[k].shape) == g[k].shape
         assert rel_err(out[k].cpu().numpy(), g[k]) < TOL, k
+        assert chan_err(out[k].cpu().numpy(), g[k]) < TOL, k
 
 
 def test_module_sm_block_golden(model, golden):
