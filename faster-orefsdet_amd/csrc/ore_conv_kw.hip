@@ -31,6 +31,17 @@ using namespace oreconv;
 __device__ __attribute__((aligned(256))) float g_zero_kw[64] = {};
 
 
+#ifdef ORE_TRACE
+// Phase-timeline build (make trace; tools/kw_phase_trace.py): thread 0 of every block stamps s_memtime (shader clocks) -- and
+// s_memrealtime (100 MHz, comparable across blocks) at entry and exit -- into g_trace_kw[block][16].  Never in the product library.
+__device__ unsigned long long* g_trace_kw = nullptr;
+#define KW_TR(i) do { if (g_trace_kw && threadIdx.x == 0) g_trace_kw[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KW_TRR(i) do { if (g_trace_kw && threadIdx.x == 0) g_trace_kw[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define KW_TR(i) do { } while (0)
+#define KW_TRR(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void decode_row(const ConvP& p, int m, int& lvl, int& b, int& oy, int& ox) {
     lvl = 0;
 #pragma unroll
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
     extern __shared__ __attribute__((aligned(16))) float lds[];    // LDS_F + 8 floats; ONE LDS object (a second one de-pipelines the DMA waits)
     int* sh_flag = reinterpret_cast<int*>(lds + LDS_F);
 
+    KW_TR(0); KW_TRR(1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
@@ -270,8 +282,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
     const int frow = lane & 15;
     const int foff = frow * 16 + (((lane >> 4) ^ swz(frow)) << 2);
     // ---- prologue: NS-1 stages in flight
+    KW_TR(2);
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue(s);
+    KW_TR(3);
     int slot = 0;
     for (int t = 0; t < nst; ++t) {
         int nslot = slot + NS - 1;
@@ -279,6 +293,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
         asm volatile("" ::: "memory");
         issue(nslot);                                             // the slot read at step t-1: its fragment reads have retired (own wave)
         wait_vmcnt<(NS - 1) * G>();                               // stage t has landed (all but the NS-1 youngest stages)
+        if (t == 0) KW_TR(4);
         const float* st = ring + slot * STAGE_F;
         f32x4 af[GA], bf[GB];
 #pragma unroll
@@ -313,8 +328,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this step's fragment reads are done before the slot is refilled
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
+    KW_TR(5);
     wait_vmcnt<0>();                                              // drain the zero-page tail loads before the ring is reused
     __syncthreads();
+    KW_TR(6);
 
     // ---- sum the four K slices in wave order through LDS; all 256 threads share the epilogue (one 16-byte item each)
     constexpr int NT = GA * GB;
@@ -324,6 +341,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
         for (int j = 0; j < GB; ++j)
             *reinterpret_cast<f32x4*>(lds + ((wave * NT) + i * GB + j) * 256 + lane * 4) = acc[i][j];
     __syncthreads();
+    KW_TR(7);
     const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & ((p.sb & 2) ? 7 : 15)) == 0;
     const int ntile = by * gridDim.x + bx;
     if (p.splitk <= 1) {
@@ -359,6 +377,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kw(ConvP p, const float* __res
                 if (n < p.Cout16) p.colsum[(size_t)bx * p.Cout16 + n] = sacc;
             }
         }
+        KW_TR(8);
+#ifdef ORE_TRACE
+        wait_vmcnt<0>();
+        KW_TR(9); KW_TRR(10);
+#endif
         return;
     }
     // ---- split-K and/or fused column sums: wave 0 carries the block's tile
@@ -902,3 +925,10 @@ int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStrea
 }
 
 }  // namespace oreconv
+
+#ifdef ORE_TRACE
+extern "C" int ore_debug_set_trace_kw(unsigned long long* buf) {
+    ORE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_kw), &buf, sizeof(buf)));
+    return ORE_OK;
+}
+#endif

@@ -138,6 +138,16 @@ def graphed_dense_part(model, xq, xs):
     if key not in cache:
         try:
             mod = _DensePart(model)
+            # The capture runs on side streams and keeps its autograd graph: AccumulateGrad nodes of the parameters that exist
+            # already (an eager step ran before) meet the capture's stream now, the ones the capture creates meet the training
+            # stream in every later step.  Either way the engine orders the two streams with events -- gradient accumulation, the
+            # post-accumulate hooks that issue the RCCL slices and the end-of-backward join run correctly
+            # (tests/test_hip_train.py::test_rccl_one_rank_rehearsal pins a wrapped step to the plain one) -- so the mismatch is
+            # intentional and torch's once-per-process warning about it is switched off.  (Creating the nodes up front on the
+            # training stream instead would make the CAPTURE depend on the legacy default stream, which a capture may not.)
+            _w = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if _w is not None:
+                _w(False)
             cache[key] = torch.cuda.make_graphed_callables(mod, (xq.clone(), xs.clone()), num_warmup_iters=3, allow_unused_input=True)
         except Exception as ex:                                   # noqa: BLE001 -- capture is an optimisation, never a requirement
             cache[key] = None

@@ -141,29 +141,82 @@ class FlatDataParallel(torch.nn.Module):
 
     forward = the wrapped model.  During backward, the moment the last gradient of an exchange slice has been accumulated its
     all-reduce(SUM) is issued asynchronously; `finish()` (called by the optimizer) waits for all of them.  The 1/world_size
-    average is folded into the SGD kernel (grad_scale).  Ranks start from rank 0's parameters (one broadcast of the bucket)."""
+    average is folded into the SGD kernel (grad_scale).  Ranks start from rank 0's parameters (one broadcast of the bucket).
 
-    def __init__(self, module: torch.nn.Module, cfg=None, process_group=None, entries=None, overlap: bool = True):
+    transport:
+      "torch"  dist.all_reduce(async_op=True) on the process group (RCCL under backend "nccl", gloo in the CPU tests);
+      "rccl"   the C-ABI exchange of include/ore_hip.h (ore_rccl_* / ore_allreduce_grads): a communicator of this wrapper's own,
+               created from a unique id that travels through the process group's store, reduced on a HIP stream of its own that
+               is ordered against the backward kernels' stream with events -- no torch collective on the gradient path.
+    force_exchange: run the exchange machinery (hooks, all-reduce, wait) for world_size 1 too; a one-rank SUM is the identity, so
+    the step must equal the unwrapped step bit for bit (tests/test_hip_train.py: the RCCL rehearsal on one GPU)."""
+
+    def __init__(self, module: torch.nn.Module, cfg=None, process_group=None, entries=None, overlap: bool = True,
+                 transport: str = "torch", force_exchange: bool = False):
         super().__init__()
+        assert transport in ("torch", "rccl"), transport
         self.module = module
         self.group = process_group
         self.bucket = get_bucket(module, cfg, entries)
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.exchange = self.world > 1 or bool(force_exchange)
+        self.transport = transport
         self.overlap = overlap
         self._pending = [0] * len(self.bucket.slices)
         self._works: List = []
         self._issued = [False] * len(self.bucket.slices)
+        self.issue_log: List[Tuple[int, bool]] = []            # (slice, issued from a backward hook?) of the step in progress
+        self.last_issue_log: List[Tuple[int, bool]] = []       # ... of the last finished step
+        self._in_backward_hook = False
         self.bucket.grad_scale = 1.0 / self.world
         self.bucket.finish = self.finish
+        self._comm = None
+        self._xstream = None
         if self.world > 1:
             dist.broadcast(self.bucket.params, src=0, group=process_group)
             inb = {id(p) for p in self.bucket.tensors}
             for t in list(module.parameters()) + list(module.buffers()):     # DDP syncs the whole module state once at construction
                 if id(t) not in inb:
                     dist.broadcast(t.data, src=0, group=process_group)
+        if self.exchange:
+            if transport == "rccl":
+                self._init_rccl()
             for i, p in enumerate(self.bucket.tensors):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
         self._reset()
+
+    # ---- the C-ABI transport -------------------------------------------------------------------------------------------------
+    def _init_rccl(self):
+        import ctypes as C
+        import os
+        import orehip
+        assert self.bucket.grads.is_cuda, "the RCCL transport exchanges device memory"
+        L = orehip.lib()
+        # inside a torch process reuse torch's RCCL (one copy per process)
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        orehip._chk(L.ore_rccl_load(cand.encode() if os.path.exists(cand) else None), "ore_rccl_load")
+        rank = dist.get_rank(self.group) if self.world > 1 else 0
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            orehip._chk(L.ore_rccl_unique_id(buf), "ore_rccl_unique_id")
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.world > 1:
+            obj = [ident.tolist()]
+            dist.broadcast_object_list(obj, src=0, group=self.group)   # through the group's store / side channel, any backend
+            ident = torch.tensor(obj[0], dtype=torch.uint8)
+        comm = C.c_void_p()
+        raw = (C.c_char * 128).from_buffer_copy(bytes(ident.tolist()))
+        orehip._chk(L.ore_rccl_comm_create(raw, self.world, rank, C.byref(comm)), "ore_rccl_comm_create")
+        self._comm = comm
+        self._xstream = torch.cuda.Stream(device=self.bucket.grads.device, priority=-1)
+
+    def close(self):
+        if self._comm is not None:
+            import orehip
+            torch.cuda.synchronize()
+            orehip._chk(orehip.lib().ore_rccl_comm_destroy(self._comm), "ore_rccl_comm_destroy")
+            self._comm = None
 
     def _reset(self):
         for s, (_, _, f, l) in enumerate(self.bucket.slices):
@@ -175,14 +228,18 @@ class FlatDataParallel(torch.nn.Module):
         s = self.bucket.param_slice[i]
 
         def hook(_p):
-            if self._issued[s] and self.world > 1:
+            if self._issued[s] and self.exchange:
                 # this slice was already all-reduced for the current step: a second backward() before optimizer.step() would add
                 # un-exchanged local gradients to it and the ranks would diverge silently (DDP's no_sync() case; not built)
                 raise RuntimeError("FlatDataParallel: backward() ran twice before optimizer.step(); gradient accumulation is not "
                                    "supported (one backward per step, as d2z:engine/train_loop.py:258-294 runs it)")
             self._pending[s] -= 1
             if self._pending[s] == 0 and self.overlap:
-                self._issue(s)
+                self._in_backward_hook = True
+                try:
+                    self._issue(s)
+                finally:
+                    self._in_backward_hook = False
         return hook
 
     def _issue(self, s: int):
@@ -190,15 +247,29 @@ class FlatDataParallel(torch.nn.Module):
             return
         b, e, _, _ = self.bucket.slices[s]
         self._issued[s] = True
+        self.issue_log.append((s, self._in_backward_hook))
+        if self.transport == "rccl":
+            import ctypes as C
+            import orehip
+            # everything enqueued so far on the stream the gradients were accumulated on (the hook runs under it) happens before
+            # the reduction; the reduction runs on the exchange stream beside the rest of backward
+            self._xstream.wait_stream(torch.cuda.current_stream())
+            g = self.bucket.grads
+            orehip._chk(orehip.lib().ore_allreduce_grads(self._comm, C.c_void_p(g.data_ptr() + 4 * b), C.c_size_t(e - b),
+                                                         C.c_void_p(self._xstream.cuda_stream)), "ore_allreduce_grads")
+            return
         self._works.append(dist.all_reduce(self.bucket.grads[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Complete the exchange: issue whatever a skipped hook left behind (a parameter unused this iteration), wait for all."""
-        if self.world > 1:
+        if self.exchange:
             for s in range(len(self.bucket.slices)):
                 self._issue(s)
+            if self.transport == "rccl":
+                torch.cuda.current_stream().wait_stream(self._xstream)     # the optimizer kernel is ordered behind every slice
             for w in self._works:
                 w.wait()
+        self.last_issue_log, self.issue_log = self.issue_log, []
         self._reset()
 
     def forward(self, *a, **k):

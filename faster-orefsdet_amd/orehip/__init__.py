@@ -73,7 +73,8 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd
            "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_conv2d_wgrad_bias_fwd", "ore_granule_transpose_fwd", "ore_combine2_fwd", "ore_combine2_bwd", "ore_adaptive_avgpool_nhwc_fwd", "ore_adaptive_avgpool_nhwc_bwd", "ore_group_mean_fwd", "ore_group_mean_bwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
            "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_roi_predict_post_fwd",
-           "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us"]
+           "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us",
+           "ore_rccl_load", "ore_rccl_unique_id", "ore_rccl_comm_create", "ore_rccl_comm_destroy", "ore_allreduce_grads"]
 
 _lib = None
 

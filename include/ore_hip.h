@@ -547,6 +547,22 @@ int ore_engine_read_profile(ore_engine* e, double* conv_ms, double* conv_flops, 
  * launches, event) on `stream`; subtracting launches x this value makes the event-based kernel time agree with rocprofv3's. */
 int ore_event_pair_overhead_us(void* stream, int32_t reps, double* median_us);
 
+/* ------------------------------------------------------------------ gradient exchange (RCCL) -- */
+/* The data-parallel train step's ONE exchange: replaces DistributedDataParallel's bucketed gradient all-reduce
+ * (d2z:engine/defaults.py:60-79 create_ddp_model, :383; behind losses.backward() in d2z:engine/train_loop.py:258-294).  The flat fp32
+ * gradient bucket is reduced in place, slice by slice, on a HIP stream of the caller's choice; 1 / world is folded into
+ * ore_sgd_step_fwd (grad_scale).  RCCL is resolved at run time (no link-time dependency; path NULL = the copy already mapped into the
+ * process, else librccl.so by the loader's search path).
+ *   rank 0:      ore_rccl_unique_id(id)            -> hand the 128 bytes to every rank (any side channel)
+ *   every rank:  ore_rccl_comm_create(id, world, rank, &comm)      collective; call with the exchanging device current
+ *   per slice:   ore_allreduce_grads(comm, grads + begin, count, stream)   returns at once; order it with events
+ *   at the end:  ore_rccl_comm_destroy(comm) */
+int32_t ore_rccl_load(const char* path);
+int32_t ore_rccl_unique_id(void* id128);
+int32_t ore_rccl_comm_create(const void* id128, int32_t world, int32_t rank, void** comm);
+int32_t ore_rccl_comm_destroy(void* comm);
+int32_t ore_allreduce_grads(void* comm, float* grads, size_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,4 +47,11 @@ def chan_err(a, b, axis=1, floor=1e-2):
     a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
     num = np.sqrt(((a - b) ** 2).mean(1))
     den = np.maximum(np.sqrt((b ** 2).mean(1)), floor * np.sqrt((b ** 2).mean()) + 1e-30)
-    return float((num / den).max())
+    v = float((num / den).max())
+    log = os.environ.get("ORE_CHAN_LOG")
+    if log:                                                   # measurement aid: what the per-channel figure actually is, per call site
+        import inspect
+        fr = inspect.stack()[1]
+        with open(log, "a") as f:
+            f.write("%s:%d %s chan_err %.3e rel_err %.3e\n" % (os.path.basename(fr.filename), fr.lineno, fr.function, v, rel_err(a, b)))
+    return v

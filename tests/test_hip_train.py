@@ -685,6 +685,102 @@ def test_two_rank_detector_train_step_flat_bucket(oh):
     assert d0 > 0 and e0 <= 2e-3 * d0 + 1e-7 and e1 <= 2e-3 * d1 + 1e-7, (e0, d0, e1, d1)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# RCCL readiness on the ONE GPU a round has: backend "nccl" (= RCCL) with world_size 1, the exchange machinery
+# forced on.  A one-rank SUM is the identity, so a wrapped step must equal the unwrapped step bit for bit; what the test adds is
+# that the RCCL code path RUNS: init_process_group("nccl"), the slice all-reduces issued from the backward hooks on RCCL's stream
+# (transport "torch") or through the C-ABI ore_allreduce_grads on the exchange stream (transport "rccl"), the waits in front of
+# the raw-pointer SGD kernel, and no AccumulateGrad stream-mismatch warning with the dense part replayed as hipGraphs.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _rccl_one_rank_worker(port, q, transport, graph):
+    import os
+    import sys
+    import warnings
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p_ in (root, os.path.join(root, "faster-orefsdet_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p_)
+    import torch.distributed as dist
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod.train_forward import train_forward
+    from fewx.solver import FlatDataParallel, build_optimizer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        shots = 4
+        img, gt, sup, sbox = T.synth_train_inputs(10, (256, 320), n_gt=6, shots=shots, support_hw=96)
+        inst = Instances((256, 320))
+        inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+        item = {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+
+        def steps(wrap):
+            torch.manual_seed(0)
+            m, sd, cfg = _train_model(shots)
+            m.train_graph = graph
+            opt = build_optimizer(cfg, m)
+            dp = FlatDataParallel(m, cfg, transport=transport, force_exchange=True) if wrap else None
+            logs = []
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                for it in range(3):
+                    g = torch.Generator().manual_seed(77 + it)
+                    losses = train_forward(m, [item], perm=lambda n: torch.randperm(n, generator=g))
+                    opt.zero_grad()
+                    sum(losses.values()).backward()
+                    opt.step()
+                    if dp is not None:
+                        logs.append(list(dp.last_issue_log))
+                torch.cuda.synchronize()
+            msgs = [str(x.message) for x in w if "AccumulateGrad" in str(x.message)]
+            out = opt.bucket.params.detach().cpu().clone()
+            n_slices = len(opt.bucket.slices)
+            if dp is not None:
+                dp.close()
+            return out, logs, msgs, n_slices, m.__dict__.get("_ore_train_graph_error")
+        p_plain, _, msgs0, n_slices, gerr0 = steps(False)
+        p_again, _, _, _, _ = steps(False)                          # the step's own run-to-run noise (ROIAlign backward adds with atomics)
+        p_wrap, logs, msgs1, _, gerr1 = steps(True)
+        torch.manual_seed(0)
+        m0, _, cfg0 = _train_model(shots)
+        p_init = build_optimizer(cfg0, m0).bucket.params.detach().cpu().clone()
+        ar = torch.ones(4, device="cuda")
+        dist.all_reduce(ar)                                        # and a plain RCCL collective of the process group itself
+        q.put({"equal": bool(torch.equal(p_plain, p_wrap)), "noise": float((p_again - p_plain).abs().max()),
+               "diff": float((p_wrap - p_plain).abs().max()), "moved": float((p_plain - p_init).abs().max()),
+               "finite": bool(torch.isfinite(p_wrap).all()), "logs": logs,
+               "warnings": msgs0 + msgs1, "n_slices": n_slices, "backend": dist.get_backend(), "ar": ar.cpu().tolist(),
+               "graph_error": gerr0 or gerr1})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport,graph", [("torch", False), ("rccl", False), ("torch", True), ("rccl", True)])
+def test_rccl_one_rank_rehearsal(oh, transport, graph):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, q, transport, graph))
+    p.start()
+    r = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert r["backend"] == "nccl" and r["ar"] == [1.0] * 4
+    assert r["graph_error"] is None, r["graph_error"]
+    # a one-rank SUM is the identity: the wrapped steps equal the plain ones up to the step's own run-to-run noise (the ROIAlign
+    # backward accumulates with fp32 atomics, so two plain runs differ in the last bits too), which is tiny against the update
+    assert r["finite"] and r["moved"] > 1e-4, r
+    assert r["diff"] <= 4.0 * r["noise"] + 1e-7 and r["diff"] <= 1e-3 * r["moved"], (r["diff"], r["noise"], r["moved"])
+    assert len(r["logs"]) == 3 and r["n_slices"] >= 2
+    for log in r["logs"]:                                          # every slice exactly once per step ...
+        assert sorted(s_ for s_, _ in log) == list(range(r["n_slices"])), log
+        assert sum(1 for _, from_hook in log if from_hook) >= r["n_slices"] - 1, log     # ... and from the backward hooks (overlap)
+    assert not r["warnings"], r["warnings"]                        # the AccumulateGrad stream-mismatch warning is gone
+
+
 def test_small_training_ops_backward(oh):
     """GroupNorm+ReLU, eSE, ceil-mode max-pool and the FPN top-down add (fused in the lateral conv) vs torch CPU autograd."""
     import torch.nn.functional as F

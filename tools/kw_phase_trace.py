@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Phase timeline of k_conv_kw (make -C faster-orefsdet_amd/csrc trace -> lib/libore_hip_trace.so): thread 0 of every block stamps
+s_memtime at the phase boundaries and s_memrealtime (100 MHz) at entry / exit.
+usage: kw_phase_trace.py H W Cin Cout k   -> per-phase shader clocks (median / max over blocks) + the launch's wall-clock picture."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "faster-orefsdet_amd"))
+import ctypes as C  # noqa: E402
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import orehip  # noqa: E402
+
+orehip.LIB_PATH = os.path.join(ROOT, "faster-orefsdet_amd", "lib", "libore_hip_trace.so")
+dev = torch.device("cuda")
+L = orehip.lib()
+
+
+def trace(H, W, Cin, Cout, k, reps=5):
+    x = torch.randn(1, H, W, Cin, device=dev)
+    w = orehip.pack_conv_weight(torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5).to(dev)
+    sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+    out = torch.empty(1, H, W, Cout, device=dev)
+    other = torch.randn(64 << 20, device=dev)                       # 256 MB: evicts L2 / MALL between the timed launches
+
+    def run():
+        orehip.conv2d(x, w, Cout, k, 1, scale=sc, shift=sh, relu_cout=Cout, out=out)
+    for _ in range(3):
+        run()
+    # plain timing, back to back, as the engine's graph replays them
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(50):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(e) / 50 * 1e3
+    nb = 8192
+    res = []
+    for cold in (False, True):
+        rows = []
+        for _ in range(reps):
+            buf = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
+            if cold:
+                other.mul_(1.0001)
+            run()                                                   # the launch in front (warm: the same layer; cold: the sweep)
+            L.ore_debug_set_trace_kw(C.c_void_p(buf.data_ptr()))
+            torch.cuda.synchronize()
+            run()
+            torch.cuda.synchronize()
+            L.ore_debug_set_trace_kw(C.c_void_p(0))
+            t = buf.cpu().numpy().reshape(nb, 16)
+            t = t[t[:, 0] != 0]
+            rows.append(t)
+        res.append(rows[-1])
+    print("== %dx%d Cin %d Cout %d k %d: %.2f us per launch back to back (eager, same stream)" % (H, W, Cin, Cout, k, us))
+    names = ["prologue (row decode, tap masks, pointers)", "issue of the first NS-1 stages", "first stage landed", "K loop (rest)",
+             "drain + barrier (slowest wave)", "partials -> LDS + barrier", "reduce + epilogue (stores issued)", "stores retired"]
+    idx = [(0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9)]
+    for tag, t in zip(("warm", "cold"), res):
+        n = len(t)
+        rt0, rt1 = t[:, 1].min(), t[:, 10].max()
+        print("  [%s] %d blocks; wall (100 MHz clock): first block start -> last block end %.2f us; block start spread %.2f us; "
+              "block lifetime median %.2f max %.2f us" % (tag, n, (rt1 - rt0) / 100.0, (t[:, 1].max() - rt0) / 100.0,
+                                                          np.median(t[:, 10] - t[:, 1]) / 100.0, (t[:, 10] - t[:, 1]).max() / 100.0))
+        clk = np.median((t[:, 9] - t[:, 0]) / np.maximum(t[:, 10] - t[:, 1], 1)) * 100.0 / 1e3
+        print("        shader clock while the blocks ran: %.2f GHz" % clk)
+        for (a_, b_), nm in zip(idx, names):
+            d = t[:, b_] - t[:, a_]
+            print("        %-46s median %6d  max %6d clocks" % (nm, np.median(d), d.max()))
+    return us
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":                 # ring depth / waves per block on the latency-bound shapes
+        for shape in ((20, 20, 112, 112, 3), (40, 40, 96, 96, 3), (20, 20, 512, 128, 1)):
+            for nw, ns in ((4, 2), (4, 3), (4, 4), (8, 2), (16, 2)):
+                L.ore_conv_set_plan_override(-6, nw, 0, 0, 0)
+                L.ore_conv_set_plan_override(-3, 16, 16, ns, 1)
+                print("#### forced tile 16x16, NW %d, NS %d" % (nw, ns))
+                try:
+                    trace(*shape, reps=2)
+                except orehip.OreError as ex:
+                    print("   not built:", ex)
+        L.ore_conv_set_plan_override(-6, 0, 0, 0, 0)
+        L.ore_conv_set_plan_override(-3, 0, 0, 0, 0)
+    elif len(sys.argv) > 5:
+        trace(*(int(v) for v in sys.argv[1:6]))
+    else:
+        for shape in ((20, 20, 112, 112, 3), (20, 20, 384, 112, 3), (20, 20, 720, 512, 1), (20, 20, 512, 128, 1), (40, 40, 96, 96, 3),
+                      (40, 40, 256, 96, 3), (40, 40, 544, 384, 1), (80, 80, 256, 128, 1)):
+            trace(*shape)
