@@ -1298,6 +1298,8 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
     if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
+    if (BM == -10) { conv_rf_mode(BN); return ORE_OK; }                                     // BM = -10: register-fed small-M kernel 0 off / 1 automatic / 2 wherever it applies
+    if (BM == -11) { conv_rf_force(BN, WGM, WGN); return ORE_OK; }                          // BM = -11: force its build (GB, NW, MAXS)
     if (BM == -9) { g_ws_s2_mode = BN; return ORE_OK; }                                     // BM = -9: weight-stationary stride-2 kernel (stem_3) 0 off / 1 on
     if (BM == -8) { g_ws_sb_mode = BN; return ORE_OK; }                                     // BM = -8: bf16-storage weight-stationary 3x3 kernel: 0 off, 1 auto, 4 / 8 tile height
     if (BM == -7) { conv_wino_mode(BN); return ORE_OK; }                                    // BM = -7: Winograd kernel 0 off / 1 automatic / 2 forced
@@ -1326,6 +1328,7 @@ extern "C" int32_t ore_conv_get_precision(void) { return g_conv_mode; }
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    if (!d->storage && conv_rf_forced()) return ceil_div(d->B * Ho * Wo, 16);   // tuning aid: the forced register-fed build has 16-row tiles (a fallback kernel writes fewer rows)
     if (d->storage) {                                         // bf16 storage: always the DMA-fed kernels (conv_kw_launch's sb branch)
         ConvP q{};
         q.sb = 1;

@@ -60,6 +60,12 @@ int conv_xmap_forced();                          // -1 when automatic           
 int conv_wino_launch(const ConvP& p, hipStream_t st);
 void conv_wino_mode(int mode);                             // (-7, mode): 0 off, 1 automatic (by row count), 2 wherever it applies
 bool conv_wino_covers(int Cout, int Cin);                  // a Winograd build exists for this 3x3 stride-1 layer
+// ore_conv_rf.hip: register-fed kernel for the smallest-M layers (stages 4-5, laterals 4-5, the second-stage GEMM).  1 = not covered.
+int conv_rf_launch(ConvP& p, hipStream_t st);
+bool conv_rf_covers(const ConvP& p);
+void conv_rf_mode(int mode);                               // (-10, mode): 0 off, 1 automatic, 2 wherever it applies
+void conv_rf_force(int gb, int nw, int maxs);
+bool conv_rf_forced();              // (-11, gb, nw, maxs): force the build (0 = automatic)
 void conv_gs_force(int bm, int bn, int ns);     // (-4, bm, bn): force the shared-stage kernel k_conv_gs with this tile; 0 -> automatic
 
 }  // namespace oreconv

@@ -877,6 +877,10 @@ void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] =
 
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
+    if (g_kw_force[0] == 0 && g_gs_force[0] == 0) {                         // the smallest-M layers: register-fed kernel (ore_conv_rf.hip)
+        const int rrc = conv_rf_launch(p, st);
+        if (rrc != 1) return rrc;
+    }
     if (p.sb & 1) {                                                         // bf16 storage: every layer runs on one of the two DMA-fed kernels
         // plan from tools/bf16s_sweep.py (profiles/r03_bf16s_sweep.txt): the shared-stage kernel for the two big 1x1 concats and the
         // stride-2 stem_3, the K-split kernel with 32x64 tiles for everything else at M >= 4096 (3x3 at 128 channels: 12-21 vs 21-24 us)

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void k_maxpool(const TS* __restrict__ in, int 
 // ------------------------------------------------------------------------------------------------
 // eSE gate, pass 1: deterministic partial column sums  part[b][p][C]  over ORE_ESE_PARTS row ranges.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int ld, int coff, int HW, int C,
+template <typename TS>
+__global__ __launch_bounds__(256) void k_colsum_partial(const TS* __restrict__ x, int ld, int coff, int HW, int C,
                                                         float* __restrict__ part) {
     __shared__ float red[256 * 4];
     const int b = blockIdx.y, p = blockIdx.x, P = gridDim.x;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (rr < rpar)
             for (int r = r0 + rr; r < r1; r += rpar)
-                acc += *reinterpret_cast<const f32x4*>(x + (size_t)(b * HW + r) * ld + coff + c4 * 4);
+                acc += ld4(x + (size_t)(b * HW + r) * ld + coff + c4 * 4);
         *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = acc;
         __syncthreads();
         if (rr == 0) {
@@ -794,7 +795,24 @@ extern "C" int ore_ese_gate_fwd(const float* x, int32_t ld, int32_t coff, int32_
     hipStream_t st = (hipStream_t)stream;
     int P = ceil_div(HW, 32);                      // >= 32 rows per part; enough blocks to pull HBM bandwidth
     if (P > ORE_ESE_PARTS) P = ORE_ESE_PARTS;
-    hipLaunchKernelGGL(k_colsum_partial, dim3(P, B), dim3(256), 0, st, x, ld, coff, HW, C, workspace);
+    hipLaunchKernelGGL(k_colsum_partial<float>, dim3(P, B), dim3(256), 0, st, x, ld, coff, HW, C, workspace);
+    int rc = ore_launch_status("k_colsum_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ese_gate_fused, dim3(ceil_div(C, 16), B), dim3(ESE_T), 0, st, workspace, P, HW, C, fc_w, fc_b, gate,
+                       (const float*)nullptr, (float*)nullptr, 0, 0);
+    return ore_launch_status("k_ese_gate_fused");
+}
+
+// the same gate from a bf16 tensor (the frozen stages of a bf16 training step keep their maps in bf16; sums and gate stay fp32)
+extern "C" int ore_ese_gate_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C,
+                                     const float* fc_w, const float* fc_b, float* gate, float* workspace, void* stream) {
+    ORE_CHECK_ARG(x && fc_w && fc_b && gate && workspace, "ore_ese_gate_bf16_fwd: null pointer");
+    ORE_CHECK_ARG(B > 0 && HW > 0 && C % 4 == 0 && C <= 4096 && ld % 4 == 0 && coff % 4 == 0, "ore_ese_gate_bf16_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int P = ceil_div(HW, 32);
+    if (P > ORE_ESE_PARTS) P = ORE_ESE_PARTS;
+    hipLaunchKernelGGL(k_colsum_partial<ore_bf16_t>, dim3(P, B), dim3(256), 0, st, reinterpret_cast<const ore_bf16_t*>(x), ld, coff, HW, C,
+                       workspace);
     int rc = ore_launch_status("k_colsum_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(k_ese_gate_fused, dim3(ceil_div(C, 16), B), dim3(ESE_T), 0, st, workspace, P, HW, C, fc_w, fc_b, gate,

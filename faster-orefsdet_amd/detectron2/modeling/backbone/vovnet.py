@@ -40,6 +40,7 @@ class _Unit(nn.Sequential):
         super().__init__(OrderedDict(_conv_bn_relu(name, cin, cout, k, stride, norm)))
         self._n = name
         self._cache = None
+        self._cache_bf16 = None
 
     def parts(self):
         return self._modules[self._n + "/conv"], self._modules[self._n + "/norm"]
@@ -58,6 +59,11 @@ class _Unit(nn.Sequential):
             U = orehip.winograd_weight(w, conv.out_channels, conv.in_channels) if wino_ok and w.is_cuda else None
             self._cache = (key, w, sc.contiguous(), sh.contiguous(), U)
         _, w, sc, sh, U = self._cache
+        if x_nhwc.dtype == torch.bfloat16:              # bf16 STORAGE: bf16 map in, bf16 map out, bf16 weights, fp32 FrozenBN epilogue
+            if self._cache_bf16 is None or self._cache_bf16[0] != key:
+                self._cache_bf16 = (key, orehip.pack_conv_weight_bf16(conv.weight))
+            return orehip.conv2d(x_nhwc, self._cache_bf16[1], conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0],
+                                 scale=sc, shift=sh, relu_cout=conv.out_channels, **kw)
         return orehip.conv2d(x_nhwc, w, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0], scale=sc,
                              shift=sh, relu_cout=conv.out_channels, w_wino=U, **kw)
 
@@ -148,7 +154,14 @@ class VoVNet(Backbone):
                 p.requires_grad = False
 
     # ---- HIP forward -------------------------------------------------------------------------------------
-    def stem_hip(self, x_nchw, raw_norm=None):
+    # "bf16": the FROZEN stages of a training forward keep their maps and weights in bf16 (BASELINE configs[4]: "bf16 MFMA conv path"):
+    # stem_1 writes bf16, every frozen conv runs on the bf16-storage kernels (v_mfma_f32_16x16x32_bf16), max-pool and eSE read bf16;
+    # FrozenBN, the eSE pool / gate and all accumulation stay fp32.  What crosses into the trainable stages is converted to fp32 once.
+    # "auto" (default): bf16 storage exactly when the process-wide conv precision is the bf16 mode (orehip.set_conv_precision("bf16"),
+    # which is how a bf16 training run is selected); "fp32" / "bf16" force it.
+    frozen_storage = "auto"
+
+    def stem_hip(self, x_nchw, raw_norm=None, out_bf16=False):
         """Normalised, padded NCHW input -> stem_1 output (the 3-channel kernel).  raw_norm = (mean, std, Hp, Wp): x_nchw is the RAW
         image batch (uint8 or fp32, all of one size) and the kernel fuses (x - mean) / std and the zero padding to Hp x Wp
         (ref:fewx/modeling/fsod/fsod_cen.py:540-555 + ImageList.from_tensors) -- no normalised copy of the batch is ever written."""
@@ -162,9 +175,9 @@ class VoVNet(Backbone):
             x = x_nchw.contiguous()
             if x.dtype not in (torch.uint8, torch.float32):
                 x = x.float()
-            return orehip.stem1(x, Hp, Wp, mean, std, c1.weight.detach().contiguous(), sc.contiguous(), sh.contiguous())
+            return orehip.stem1(x, Hp, Wp, mean, std, c1.weight.detach().contiguous(), sc.contiguous(), sh.contiguous(), out_bf16=out_bf16)
         y = orehip.stem1(x_nchw.contiguous().float(), H, W, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), c1.weight.detach().contiguous(),
-                         sc.contiguous(), sh.contiguous())
+                         sc.contiguous(), sh.contiguous(), out_bf16=out_bf16)
         return y
 
     def _unit(self, name):
@@ -174,7 +187,7 @@ class VoVNet(Backbone):
             conv, bn = self.stem._modules[name + "/conv"], self.stem._modules[name + "/norm"]
             u = _Unit.__new__(_Unit)
             nn.Module.__init__(u)
-            u._n, u._cache = name, None
+            u._n, u._cache, u._cache_bf16 = name, None, None
             u._modules[name + "/conv"], u._modules[name + "/norm"] = conv, bn
             self._stem_units[name] = u
         return self._stem_units[name]
@@ -187,22 +200,49 @@ class VoVNet(Backbone):
         _require_gpu(x, "VoVNet")
         grad_on = torch.is_grad_enabled()
         outputs = {}
+        # bf16 storage for the frozen stages: only when something trainable follows (a training forward) -- eval goes through the engine
+        want16 = self.frozen_storage == "bf16" or (self.frozen_storage == "auto" and orehip.get_conv_precision() == "bf16")
+        st16 = want16 and grad_on and not any(p.requires_grad for p in self.stem.parameters())
+        fdt = torch.bfloat16 if st16 else torch.float32
+
+        def new_cat(B_, H_, W_, ch):
+            # bf16 rows carry 64 bytes of zeroed slack: a 64-byte K chunk that starts inside the last 16 channels of the last row reads
+            # past it against zero weights (include/ore_hip.h, ORE_ST_BF16)
+            if not st16:
+                return torch.empty(B_, H_, W_, ch, device=x.device, dtype=torch.float32)
+            # zeroed: a chunk that starts inside the last 16 channels of a slice also reads the first channels of the NEXT slice -- which
+            # the block has not written yet -- against zero weights, and 0 x (a NaN bit pattern of fresh memory) would be NaN
+            flat = torch.zeros(B_ * H_ * W_ * ch + 32, device=x.device, dtype=torch.bfloat16)
+            return flat[:-32].view(B_, H_, W_, ch)
         with torch.no_grad():
-            y = self.stem_hip(x, raw_norm)
+            y = self.stem_hip(x, raw_norm, out_bf16=st16)
             y = self._unit("stem_2").hip(y)
             first = getattr(self, "stage2").blocks()[0]
             B, H, W, _ = y.shape
             Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-            cat = torch.empty(B, Ho, Wo, first.cat_ch, device=x.device, dtype=torch.float32)
+            cat = new_cat(B, Ho, Wo, first.cat_ch)
             self._unit("stem_3").hip(y, out=cat, out_coff=0)
         if "stem" in self._out_features:
-            outputs["stem"] = cat[..., : first.in_ch].permute(0, 3, 1, 2)
+            outputs["stem"] = cat[..., : first.in_ch].float().permute(0, 3, 1, 2)
         prev, gate, full = None, None, None      # prev = pre-gate block output (frozen path), full = gated output (train path)
         for name in self.stage_names:
             stage = getattr(self, name)
             blocks = stage.blocks()
             train = grad_on and any(p.requires_grad for p in stage.parameters())
             if train:
+                if prev is not None and prev.dtype == torch.bfloat16:      # the frozen / trainable seam: fp32 from here on
+                    with torch.no_grad():
+                        if stage.pool:
+                            prev, gate = orehip.maxpool3x3s2(prev, gate).float(), None     # round(max(x) * g) once, as a stored bf16 map
+                            stage_pooled = True
+                        else:
+                            prev = prev.float()
+                            stage_pooled = False
+                    full = self._stage_train(stage, blocks, None, prev, gate, None, pooled=stage_pooled)
+                    prev, gate = None, None
+                    if name in self._out_features:
+                        outputs[name] = full.permute(0, 3, 1, 2)
+                    continue
                 full = self._stage_train(stage, blocks, cat if prev is None and full is None else None, prev, gate, full)
                 prev, gate = None, None
                 if name in self._out_features:
@@ -215,11 +255,12 @@ class VoVNet(Backbone):
                         if bi == 0 and stage.pool:
                             B = prev.shape[0]
                             H, W = orehip.maxpool3x3s2_out_hw(prev.shape[1], prev.shape[2])
-                            cat = torch.empty(B, H, W, blk.cat_ch, device=x.device, dtype=torch.float32)
+                            cat = new_cat(B, H, W, blk.cat_ch)
                             # gate folded (max commutes with the positive scale); pooled straight into the concat buffer's first slice
                             orehip.maxpool3x3s2(prev, gate, out=cat, out_coff=0)
                             ident = None
                         else:
+                            assert prev.dtype == torch.float32, "identity blocks (V-39 / V-57) stay on the fp32 path"
                             fullp = orehip.scale_channels(prev, gate) if gate is not None else prev
                             cat = torch.empty(*fullp.shape[:3], blk.cat_ch, device=x.device, dtype=torch.float32)
                             cat[..., : blk.in_ch] = fullp
@@ -230,11 +271,14 @@ class VoVNet(Backbone):
                         g = None
                     prev, gate = y, g
                 if name in self._out_features:
-                    fullp = orehip.scale_channels(prev, gate) if gate is not None else prev
+                    if prev.dtype == torch.bfloat16:               # the gated map leaves the frozen part as fp32: bf16 value x fp32 gate
+                        fullp = prev.float() * gate[:, None, None, :] if gate is not None else prev.float()
+                    else:
+                        fullp = orehip.scale_channels(prev, gate) if gate is not None else prev
                     outputs[name] = fullp.permute(0, 3, 1, 2)
         return outputs
 
-    def _stage_train(self, stage, blocks, cat0, prev, gate, full):
+    def _stage_train(self, stage, blocks, cat0, prev, gate, full, pooled=False):
         """One trainable stage: max-pool, OSA blocks through OSAFn, eSE.  The input comes either from a frozen stage
         (prev, gate: no gradient needed) or from the previous trainable stage (`full`, carries gradient)."""
         import orehip
@@ -244,6 +288,8 @@ class VoVNet(Backbone):
             if bi == 0:
                 if full is not None:
                     x_in = A.maxpool(full) if stage.pool else full
+                elif prev is not None and pooled:
+                    x_in = prev                                    # already pooled (and gated) on the bf16 side of the seam
                 elif prev is not None:
                     with torch.no_grad():
                         x_in = orehip.maxpool3x3s2(prev, gate) if stage.pool else (orehip.scale_channels(prev, gate) if gate is not None else prev)

@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -353,14 +353,19 @@ def _default_ws(device) -> torch.Tensor:
 
 
 def stem1(img: torch.Tensor, Hp: int, Wp: int, mean: Sequence[float], std: Sequence[float], w_oihw: torch.Tensor,
-          scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
-    """img [B,3,H,W] uint8 or fp32 (planar) -> [B,Hp/2,Wp/2,Cout]."""
+          scale: torch.Tensor, shift: torch.Tensor, out_bf16: bool = False) -> torch.Tensor:
+    """img [B,3,H,W] uint8 or fp32 (planar) -> [B,Hp/2,Wp/2,Cout] fp32, or bf16 (rounded once; fp32 arithmetic) when out_bf16."""
     assert img.is_contiguous() and img.dtype in (torch.uint8, torch.float32)
     B, _, H, W = img.shape
     Cout = w_oihw.shape[0]
-    out = torch.empty(B, Hp // 2, Wp // 2, Cout, device=img.device, dtype=torch.float32)
+    out = torch.empty(B, Hp // 2, Wp // 2, Cout, device=img.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
+    if out_bf16:
+        _chk(lib().ore_stem1_bf16_fwd(C.c_void_p(_ptr(img)), int(img.dtype == torch.uint8), B, H, W, Hp, Wp, m, s,
+                                      C.c_void_p(_ptr(_f32(w_oihw))), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)), Cout,
+                                      C.c_void_p(_ptr(out)), Cout, 0, _stream()), "ore_stem1_bf16_fwd")
+        return out
     _chk(lib().ore_stem1_fwd(C.c_void_p(_ptr(img)), int(img.dtype == torch.uint8), B, H, W, Hp, Wp, m, s,
                              C.c_void_p(_ptr(_f32(w_oihw))), C.c_void_p(_ptr(scale)), C.c_void_p(_ptr(shift)), Cout,
                              C.c_void_p(_ptr(out)), Cout, 0, _stream()), "ore_stem1_fwd")
@@ -369,8 +374,10 @@ def stem1(img: torch.Tensor, Hp: int, Wp: int, mean: Sequence[float], std: Seque
 
 def maxpool3x3s2(x: torch.Tensor, in_mul: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
     """MaxPool2d(3, 2, ceil_mode=True) on NHWC (optionally of x * in_mul[b][c], in_mul > 0).  `out` [B,Ho,Wo,ld] + out_coff: write the
-    result into a channel slice of a wider buffer (the next block's concat buffer) instead of a fresh tensor."""
-    _f32(x)
+    result into a channel slice of a wider buffer (the next block's concat buffer) instead of a fresh tensor.  bf16 in -> bf16 out
+    (the product with the fp32 multiplier is rounded once)."""
+    bf = x.dtype == torch.bfloat16
+    assert x.is_contiguous() and (bf or x.dtype == torch.float32)
     B, H, W, Cc = x.shape
 
     def osz(n):
@@ -379,10 +386,14 @@ def maxpool3x3s2(x: torch.Tensor, in_mul: Optional[torch.Tensor] = None, out: Op
             o -= 1
         return max(o, 1)
     if out is None:
-        out = torch.empty(B, osz(H), osz(W), Cc, device=x.device, dtype=torch.float32)
+        out = torch.empty(B, osz(H), osz(W), Cc, device=x.device, dtype=x.dtype)
     else:
-        _f32(out)
+        assert out.dtype == x.dtype and out.is_contiguous()
         assert tuple(out.shape[:3]) == (B, osz(H), osz(W)) and out_coff + Cc <= out.shape[-1] and out_coff % 4 == 0
+    if bf:
+        _chk(lib().ore_maxpool3x3s2_bf16_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(in_mul)),
+                                             C.c_void_p(_ptr(out)), out.shape[-1], out_coff, _stream()), "ore_maxpool3x3s2_bf16_fwd")
+        return out
     _chk(lib().ore_maxpool3x3s2_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H, W, Cc, C.c_void_p(_ptr(in_mul)),
                                     C.c_void_p(_ptr(out)), out.shape[-1], out_coff, _stream()), "ore_maxpool3x3s2_fwd")
     return out
@@ -398,10 +409,17 @@ def maxpool3x3s2_out_hw(H: int, W: int) -> Tuple[int, int]:
 
 
 def ese_gate(x: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
-    _f32(x)
+    """relu6(fc(mean_hw(x)) + 3) / 6 per image: [B,C] fp32, from an fp32 or a bf16 map."""
+    bf = x.dtype == torch.bfloat16
+    assert x.is_contiguous() and (bf or x.dtype == torch.float32)
     B, H, W, Cc = x.shape
     gate = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
     ws = torch.empty(B * (ESE_PARTS + 1) * Cc, device=x.device, dtype=torch.float32)
+    if bf:
+        _chk(lib().ore_ese_gate_bf16_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H * W, Cc, C.c_void_p(_ptr(_f32(fc_w.reshape(Cc, Cc)))),
+                                         C.c_void_p(_ptr(_f32(fc_b))), C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(ws)), _stream()),
+             "ore_ese_gate_bf16_fwd")
+        return gate
     _chk(lib().ore_ese_gate_fwd(C.c_void_p(_ptr(x)), Cc, 0, B, H * W, Cc, C.c_void_p(_ptr(_f32(fc_w.reshape(Cc, Cc)))),
                                 C.c_void_p(_ptr(_f32(fc_b))), C.c_void_p(_ptr(gate)), C.c_void_p(_ptr(ws)), _stream()),
          "ore_ese_gate_fwd")

@@ -476,6 +476,8 @@ int32_t ore_engine_buffer_is_bf16(ore_engine* e, const char* name);
 int ore_stem1_bf16_fwd(const void* img, int32_t img_is_u8, int32_t B, int32_t H, int32_t W, int32_t Hp, int32_t Wp, const float* mean3,
                        const float* std3, const float* w_oihw, const float* scale, const float* shift, int32_t Cout, uint16_t* out,
                        int32_t out_ld, int32_t out_coff, void* stream);
+int ore_ese_gate_bf16_fwd(const uint16_t* x, int32_t ld, int32_t coff, int32_t B, int32_t HW, int32_t C, const float* fc_w,
+                          const float* fc_b, float* gate, float* workspace, void* stream);   /* ore_ese_gate_fwd over a bf16 map */
 int ore_maxpool3x3s2_bf16_fwd(const uint16_t* in, int32_t in_ld, int32_t in_coff, int32_t B, int32_t H, int32_t W, int32_t C,
                               const float* in_mul, uint16_t* out, int32_t out_ld, int32_t out_coff, void* stream);
 int ore_correlation_levels_bf16_fwd(const uint16_t* q, int32_t q_ld, int32_t q_coff, int32_t B, int32_t n_levels, const int32_t* H,

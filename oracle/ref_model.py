@@ -52,6 +52,23 @@ VOVNET_SPECS = {
 # FPN lateral as a weight, round(W * g) (the pair rides on the gated tensor: `_ore_gated`).
 _OPERANDS = "fp32"
 _LINEARS = False
+FROZEN_STAGES = 2      # stage index k <= FROZEN_STAGES + 1 is frozen: stem + stage2 + stage3 (FREEZE_AT = 3, d2z vovnet.py:455-468)
+
+
+class _frozen_storage:
+    """Scope of the frozen stages inside the training form of the bf16 mode: storage rounding on, custom-backward convs off (nothing
+    in there has a gradient)."""
+
+    def __enter__(self):
+        global _OPERANDS, _LINEARS
+        self.saved = (_OPERANDS, _LINEARS)
+        if _OPERANDS == "bf16" and _LINEARS:
+            _OPERANDS, _LINEARS = "bf16s", False
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERANDS, _LINEARS
+        _OPERANDS, _LINEARS = self.saved
 
 
 class operand_precision:
@@ -59,7 +76,11 @@ class operand_precision:
     train=True is the TRAINING form of the mode (tests/test_hip_bf16.py, 5-shot iteration): (i) the Linear / 1x1 layers that the
     product's training forward also runs on the MFMA conv kernel -- SM_Block's Linears, the second stage's DSA convs, fc1 and the
     predictors -- round their operands too; (ii) the backward of every such layer rounds ITS operands: dY and W for the data
-    gradient, X and dY for the weight gradient (bias gradients and everything element-wise stay fp32)."""
+    gradient, X and dY for the weight gradient (bias gradients and everything element-wise stay fp32); (iii) round 4: the FROZEN
+    stages of the backbone (stem, stage 2, stage 3 at FREEZE_AT = 3 -- 70 image-equivalents of a bs-16 step, no gradients) run in the
+    STORAGE form: every map between two of their kernels is a bf16 tensor (`_st`), the eSE gate reaches the max-pool as
+    round(max(x) * g); what leaves them -- the gated stage-3 map (bf16 value x fp32 gate, an fp32 tensor) and stage 4's pooled input
+    (a bf16 map) -- is consumed by the trainable layers in their operand-rounding form."""
 
     def __init__(self, mode: str, train: bool = False):
         assert mode in ("fp32", "bf16", "bf16s")
@@ -199,17 +220,31 @@ def vovnet(x: Tensor, sd: SD, prefix: str = "backbone.bottom_up.",
            body: str = "V-19-slim-eSE") -> Dict[str, Tensor]:
     """VoVNet.forward (vovnet.py:471-481): stem + stage2..stage5."""
     spec = VOVNET_SPECS[body]
-    x = conv_bn_relu(x, sd, prefix + "stem.stem_1", 2, 1)
-    x = conv_bn_relu(x, sd, prefix + "stem.stem_2", 1, 1)
-    x = conv_bn_relu(x, sd, prefix + "stem.stem_3", 2, 1)
+    train_bf16 = _OPERANDS == "bf16" and _LINEARS             # training form of the bf16 mode: frozen stages in the storage form
+    with _frozen_storage():
+        x = conv_bn_relu(x, sd, prefix + "stem.stem_1", 2, 1)
+        x = conv_bn_relu(x, sd, prefix + "stem.stem_2", 1, 1)
+        x = conv_bn_relu(x, sd, prefix + "stem.stem_3", 2, 1)
     out = {"stem": x}
     for si in range(4):
         k = si + 2
+        frozen = train_bf16 and si < FROZEN_STAGES
+        pool_frozen = train_bf16 and si <= FROZEN_STAGES     # the pool in front of stage k reads stage k-1's (frozen) bf16 map
         if k != 2:  # _OSA_stage (vovnet.py:349-350)
-            x = _st(F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True))
+            if pool_frozen:
+                with _frozen_storage():
+                    x = _st(F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True))
+            else:
+                x = _st(F.max_pool2d(x, kernel_size=3, stride=2, ceil_mode=True))
         for b in range(spec["blocks"][si]):
             mod = f"OSA{k}_{b + 1}"
-            x = osa_module(x, sd, f"{prefix}stage{k}.{mod}.", mod, spec["layers"], identity=b > 0)
+            if frozen:
+                with _frozen_storage():
+                    x = osa_module(x, sd, f"{prefix}stage{k}.{mod}.", mod, spec["layers"], identity=b > 0)
+                if hasattr(x, "_ore_gated"):
+                    del x._ore_gated                           # (the weight fold of the lateral belongs to the eval engine only)
+            else:
+                x = osa_module(x, sd, f"{prefix}stage{k}.{mod}.", mod, spec["layers"], identity=b > 0)
         out[f"stage{k}"] = x
     return out
 

@@ -241,7 +241,9 @@ def test_conv_winograd_per_level_weights(ore, HW, B):
 def kw_forced(ore):
     """Force the wave-private K-split LDS-DMA kernel (k_conv_kw, csrc/ore_conv_kw.hip) wherever it applies, then restore the plan."""
     ore.lib().ore_conv_set_plan_override(-2, 2, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)        # (the register-fed kernel would take the smallest shapes first)
     yield
+    ore.lib().ore_conv_set_plan_override(-10, 1, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-2, 1, 0, 0, 0)
 
 
@@ -271,6 +273,92 @@ def test_conv_kw_kernel_vs_oracle(ore, kw_forced, B, H, W, Cin, Cout, k, stride)
     assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
     y2 = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
     assert torch.equal(y, y2)                       # split-K slabs are summed in slice order: bit-reproducible
+
+
+@pytest.fixture
+def rf_forced(ore):
+    """Force the register-fed small-M kernel (k_conv_rf, csrc/ore_conv_rf.hip) wherever it applies, then restore the plan."""
+    ore.lib().ore_conv_set_plan_override(-10, 2, 0, 0, 0)
+    yield
+    ore.lib().ore_conv_set_plan_override(-11, 0, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-10, 1, 0, 0, 0)
+
+
+RF_BUILDS = [(1, 4, 8), (1, 4, 12), (1, 4, 16), (1, 8, 12), (1, 8, 16), (1, 8, 20), (1, 16, 12), (2, 4, 12), (2, 4, 16), (2, 8, 12)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride", [
+    (1, 20, 20, 112, 112, 3, 1),    # stage-5 layers 1 / 2: 63 chunks, 7 per tap
+    (1, 20, 20, 384, 112, 3, 1),    # stage-5 layer 0: 216 chunks -> 16 waves
+    (1, 20, 20, 512, 128, 1, 1),    # FPN lateral 5
+    (1, 40, 40, 96, 96, 3, 1),      # stage-4 layers 1 / 2: 6 chunks per tap
+    (1, 40, 40, 256, 96, 3, 1),     # stage-4 layer 0: 144 chunks -> 8 waves
+    (1, 40, 40, 384, 128, 1, 1),    # FPN lateral 4
+    (1, 1, 320, 8192, 128, 1, 1),   # the second-stage GEMM: 512 chunks, several batches per wave
+    (2, 13, 11, 96, 40, 3, 1),      # two images, odd size, rows not a multiple of 16, Cout = 40 (padded to 48, last quad partly live)
+    (1, 9, 7, 112, 5, 3, 1),        # Cout = 5: one channel quad + one lane of the next
+    (3, 17, 15, 128, 64, 3, 2),     # stride 2, odd size, three images
+    (1, 5, 5, 720, 512, 1, 1),      # many output channels (forced: the plan leaves these to k_conv_kw)
+])
+def test_conv_rf_kernel_vs_oracle(ore, rf_forced, B, H, W, Cin, Cout, k, stride):
+    """k_conv_rf against F.conv2d at 1e-4 on the shapes it serves (and the awkward ones: partial tiles, partial channel quads, border
+    taps through the buffer descriptor's range check, stride 2, empty tail chunks of the last wave), bit-reproducible."""
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc = torch.rand(Cout, generator=g) + 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, None, stride, k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wp = ore.pack_conv_weight(w).cuda()
+    y = ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert chan_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert torch.equal(y, ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout))
+    ore.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)                             # and it really was another kernel than k_conv_kw's sum order
+    y_kw = ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    ore.lib().ore_conv_set_plan_override(-10, 2, 0, 0, 0)
+    assert rel_err(y.cpu().numpy(), y_kw.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("gb,nw,maxs", RF_BUILDS)
+@pytest.mark.parametrize("H,W,Cin,Cout,k", [(20, 20, 112, 112, 3), (7, 9, 96, 48, 3), (1, 96, 2048, 128, 1)])
+def test_conv_rf_every_build(ore, rf_forced, gb, nw, maxs, H, W, Cin, Cout, k):
+    """Every instantiated (tile width, waves, steps per batch) build of k_conv_rf on a 3x3 layer with 7 and with 6 chunks per tap and on
+    a deep 1x1 layer: one batch, several batches, waves whose range lies wholly beyond K."""
+    L = ore.lib()
+    g = torch.Generator().manual_seed(H + Cin + nw + maxs)
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, sh, 1, k // 2)
+    L.ore_conv_set_plan_override(-11, gb, nw, maxs, 0)
+    y = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, 1, shift=dev(sh))
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+
+
+def test_conv_rf_slices_add_colsum(ore, rf_forced):
+    """Channel-slice input / output inside wider buffers, the FPN top-down addend (nearest-2x) and the fused per-tile column sums."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 1, 10, 12, 128, 128
+    buf = torch.randn(B, H, W, 32 + Cin + 16, generator=g)
+    x = buf[..., 32:32 + Cin].permute(0, 3, 1, 2).contiguous()
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    top = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x, w, bias) + F.interpolate(top, scale_factor=2.0, mode="nearest")
+    out = torch.full((B, H, W, 16 + Cout + 16), 7.0).cuda()
+    ore.conv2d(buf.cuda(), ore.pack_conv_weight(w).cuda(), Cout, 1, 1, in_coff=32, Cin=Cin, shift=dev(bias), add=nhwc(top), out=out, out_coff=16)
+    o = out.cpu()
+    assert rel_err(o[..., 16:16 + Cout].permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    assert (o[..., :16] == 7.0).all() and (o[..., 16 + Cout:] == 7.0).all()              # nothing outside the slice is written
+    ore.lib().ore_conv_set_plan_override(-11, 1, 4, 8, 0)                                 # forced build: column sums allowed
+    w3 = torch.randn(48, 96, 3, 3, generator=g) / (96 * 9) ** 0.5
+    x3 = torch.randn(1, 96, 9, 8, generator=g)
+    sc, sh = torch.rand(48, generator=g) + 0.5, torch.randn(48, generator=g) * 0.1
+    ref3 = F.relu(F.conv2d(x3, w3, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    y3, cs = ore.conv2d(nhwc(x3), ore.pack_conv_weight(w3).cuda(), 48, 3, 1, scale=dev(sc), shift=dev(sh), relu_cout=48, want_colsum=True)
+    assert rel_err(nchw(y3).numpy(), ref3.numpy()) < TOL
+    assert rel_err(cs.sum(0)[:48].cpu().numpy(), ref3.sum((0, 2, 3)).numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("nw,tile", [(8, (16, 16)), (8, (16, 32)), (8, (16, 48)), (16, (16, 16)), (16, (16, 32))])

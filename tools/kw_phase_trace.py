@@ -17,6 +17,9 @@ dev = torch.device("cuda")
 L = orehip.lib()
 
 
+RF = False           # True: the layer runs on k_conv_rf (stamps of csrc/ore_conv_rf.hip)
+
+
 def trace(H, W, Cin, Cout, k, reps=5):
     x = torch.randn(1, H, W, Cin, device=dev)
     w = orehip.pack_conv_weight(torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5).to(dev)
@@ -47,10 +50,12 @@ def trace(H, W, Cin, Cout, k, reps=5):
                 other.mul_(1.0001)
             run()                                                   # the launch in front (warm: the same layer; cold: the sweep)
             L.ore_debug_set_trace_kw(C.c_void_p(buf.data_ptr()))
+            L.ore_debug_set_trace_rf(C.c_void_p(buf.data_ptr()))
             torch.cuda.synchronize()
             run()
             torch.cuda.synchronize()
             L.ore_debug_set_trace_kw(C.c_void_p(0))
+            L.ore_debug_set_trace_rf(C.c_void_p(0))
             t = buf.cpu().numpy().reshape(nb, 16)
             t = t[t[:, 0] != 0]
             rows.append(t)
@@ -59,6 +64,10 @@ def trace(H, W, Cin, Cout, k, reps=5):
     names = ["prologue (row decode, tap masks, pointers)", "issue of the first NS-1 stages", "first stage landed", "K loop (rest)",
              "drain + barrier (slowest wave)", "partials -> LDS + barrier", "reduce + epilogue (stores issued)", "stores retired"]
     idx = [(0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9)]
+    if RF:
+        names = ["prologue (decode, descriptors, epilogue operand requests)", "all loads of batch 0 requested", "first fragment landed + 4 MFMAs",
+                 "rest of the K slice (MFMAs behind counted waits)", "partials -> LDS + barrier", "reduce + epilogue (stores issued)", "stores retired"]
+        idx = [(0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 8), (8, 9)]
     for tag, t in zip(("warm", "cold"), res):
         n = len(t)
         rt0, rt1 = t[:, 1].min(), t[:, 10].max()
@@ -74,7 +83,21 @@ def trace(H, W, Cin, Cout, k, reps=5):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sweep":                 # ring depth / waves per block on the latency-bound shapes
+    if len(sys.argv) > 1 and sys.argv[1] == "rf":                     # the register-fed kernel on the layers it serves, forced builds
+        RF = True
+        L.ore_conv_set_plan_override(-10, 2, 0, 0, 0)
+        for shape, builds in (((20, 20, 112, 112, 3), ((1, 4, 16), (1, 8, 12), (2, 4, 16))), ((20, 20, 384, 112, 3), ((1, 16, 12), (1, 8, 16), (1, 8, 20))),
+                              ((20, 20, 512, 128, 1), ((1, 4, 8), (1, 8, 12))), ((40, 40, 96, 96, 3), ((1, 4, 16), (1, 8, 12), (2, 4, 16))),
+                              ((40, 40, 256, 96, 3), ((1, 8, 20), (1, 16, 12), (2, 8, 12))), ((40, 40, 384, 128, 1), ((1, 4, 8), (1, 4, 12))),
+                              ((1, 320, 8192, 128, 1), ((1, 16, 12), (1, 8, 20), (2, 8, 12))), ((20, 20, 720, 512, 1), ((1, 4, 12), (2, 4, 12))),
+                              ((40, 40, 544, 384, 1), ((1, 4, 12), (2, 4, 12)))):
+            for gb, nw, maxs in builds:
+                L.ore_conv_set_plan_override(-11, gb, nw, maxs, 0)
+                print("#### k_conv_rf<GB %d, NW %d, MAXS %d>" % (gb, nw, maxs))
+                trace(*shape, reps=2)
+        L.ore_conv_set_plan_override(-11, 0, 0, 0, 0)
+        L.ore_conv_set_plan_override(-10, 1, 0, 0, 0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "sweep":                 # ring depth / waves per block on the latency-bound shapes
         for shape in ((20, 20, 112, 112, 3), (40, 40, 96, 96, 3), (20, 20, 512, 128, 1)):
             for nw, ns in ((4, 2), (4, 3), (4, 4), (8, 2), (16, 2)):
                 L.ore_conv_set_plan_override(-6, nw, 0, 0, 0)
