@@ -1298,6 +1298,8 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
     if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
+    if (BM == -12) { conv_kd_mode(BN); return ORE_OK; }                                     // BM = -12: lean LDS-DMA kernel 0 off / 1 automatic / 2 wherever it applies
+    if (BM == -13) { conv_kd_force(BN, WGM, WGN, WGK); return ORE_OK; }                     // BM = -13: force its build (BM, BN, NW, SB)
     if (BM == -10) { conv_rf_mode(BN); return ORE_OK; }                                     // BM = -10: register-fed small-M kernel 0 off / 1 automatic / 2 wherever it applies
     if (BM == -11) { conv_rf_force(BN, WGM, WGN); return ORE_OK; }                          // BM = -11: force its build (GB, NW, MAXS)
     if (BM == -9) { g_ws_s2_mode = BN; return ORE_OK; }                                     // BM = -9: weight-stationary stride-2 kernel (stem_3) 0 off / 1 on
@@ -1328,6 +1330,7 @@ extern "C" int32_t ore_conv_get_precision(void) { return g_conv_mode; }
 extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    if (!d->storage && conv_kd_forced()) return ceil_div(d->B * Ho * Wo, conv_kd_forced_bm());   // tuning aids: forced builds
     if (!d->storage && conv_rf_forced()) return ceil_div(d->B * Ho * Wo, 16);   // tuning aid: the forced register-fed build has 16-row tiles (a fallback kernel writes fewer rows)
     if (d->storage) {                                         // bf16 storage: always the DMA-fed kernels (conv_kw_launch's sb branch)
         ConvP q{};
@@ -1340,6 +1343,10 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
         ConvP q{};
         q.bf16 = g_conv_bf16;
         q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (d->Cin / 16); q.kh = d->kh;
+        // what the lean-DMA kernel's "does it apply" test looks at (conv_kd_tile_rows; keep in step with make_conv_params)
+        q.kw = d->kw; q.Cin = d->Cin; q.in_ld = d->in_ld; q.B = d->B; q.nlev = 1; q.K = d->kh * d->kw * d->Cin; q.Cout = d->Cout;
+        q.lv[0] = Lvl{0, 0, d->H, d->W, Ho, Wo}; q.in_add = d->in_add; q.in_relu = d->in_relu;
+        if (d->add) { q.add = d->add; q.add_ld = d->add_ld; q.add_H = (Ho + 1) / 2; q.add_W = (Wo + 1) / 2; }
         const int bm = conv_kw_tile_rows(q);
         if (bm > 0) return ceil_div(q.M, bm);                 // the layer runs on k_conv_kw (same test as conv_launch)
     }

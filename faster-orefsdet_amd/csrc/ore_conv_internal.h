@@ -60,6 +60,13 @@ int conv_xmap_forced();                          // -1 when automatic           
 int conv_wino_launch(const ConvP& p, hipStream_t st);
 void conv_wino_mode(int mode);                             // (-7, mode): 0 off, 1 automatic (by row count), 2 wherever it applies
 bool conv_wino_covers(int Cout, int Cin);                  // a Winograd build exists for this 3x3 stride-1 layer
+// ore_conv_kd.hip: lean LDS-DMA kernel (buffer descriptors, chunk table in the kernel arguments, double-buffered batches).  1 = not covered.
+int conv_kd_launch(ConvP& p, hipStream_t st);
+int conv_kd_tile_rows(const ConvP& p);
+void conv_kd_mode(int mode);                               // (-12, mode): 0 off, 1 automatic, 2 wherever it applies
+void conv_kd_force(int bm, int bn, int nw, int sb);        // (-13, bm, bn, nw, sb): force the build (bm = 0: automatic)
+bool conv_kd_forced();
+int conv_kd_forced_bm();
 // ore_conv_rf.hip: register-fed kernel for the smallest-M layers (stages 4-5, laterals 4-5, the second-stage GEMM).  1 = not covered.
 int conv_rf_launch(ConvP& p, hipStream_t st);
 bool conv_rf_covers(const ConvP& p);

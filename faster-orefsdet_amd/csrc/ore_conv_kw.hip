@@ -797,6 +797,7 @@ namespace oreconv {
 int conv_kw_tile_rows(const ConvP& p) {         // rows per block of the kernel conv_kw_launch will pick (0: not covered) -- keep in step with it
     if (g_kw_force[0] > 0) return g_kw_force[0];
     if (g_gs_force[0] > 0) return g_gs_force[0];
+    if (const int kd = conv_kd_tile_rows(p)) return kd;      // the lean-DMA kernel takes the layer (conv_kw_launch asks it first)
     if (p.sb & 1) {                                            // keep in step with conv_kw_launch's bf16-storage branch
         if (p.M >= 6400 && ((p.kh == 1 && (p.Cout16 == 112 || p.Cout16 >= 256)) || (p.kh == 3 && p.stride == 2 && p.Cout16 % 128 == 0))) return 64;
         if (p.M >= 4096 && (p.Cout16 == 128 || p.Cout16 == 64)) return 32;
@@ -877,7 +878,9 @@ void conv_gs_force(int bm, int bn, int ns) { g_gs_force[0] = bm; g_gs_force[1] =
 
 int conv_kw_launch(ConvP& p, float* workspace, size_t workspace_floats, hipStream_t st) {
     if (p.in_mul || p.Cin % 16 != 0) return 1;                             // input affine not built here
-    if (g_kw_force[0] == 0 && g_gs_force[0] == 0) {                         // the smallest-M layers: register-fed kernel (ore_conv_rf.hip)
+    if (g_kw_force[0] == 0 && g_gs_force[0] == 0) {                         // the lean LDS-DMA kernel (ore_conv_kd.hip), then the register-fed
+        const int drc = conv_kd_launch(p, st);                             // one for the smallest-M layers (ore_conv_rf.hip)
+        if (drc != 1) return drc;
         const int rrc = conv_rf_launch(p, st);
         if (rrc != 1) return rrc;
     }

@@ -298,6 +298,9 @@ bool conv_rf_covers(const ConvP& p) {
     if (g_rf_mode == 2 || g_rf_force[0] > 0) return true;
     // automatic: the latency-bound launches -- few rows, not so many output channels that 16-row tiles re-read the pixels too often,
     // not so deep a K that a wave needs more than two batches (the second-stage GEMM stays on k_conv_kw: measured)
+    // (round 4: k_conv_kd, which moves the same bytes in coalesced 64-byte segments through LDS-DMA, is ahead of this kernel on every
+    // shape measured -- 5.6 vs 6.3 us on stage 5's 112->112 layers, 10.1 vs 17.2 on 384->112 -- and conv_kw_launch asks it first; what
+    // k_conv_kd declines and fits here still comes here)
     return p.M <= 512 && p.Cout16 <= 128 && p.nchunks <= 256;
 }
 

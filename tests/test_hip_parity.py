@@ -241,8 +241,10 @@ def test_conv_winograd_per_level_weights(ore, HW, B):
 def kw_forced(ore):
     """Force the wave-private K-split LDS-DMA kernel (k_conv_kw, csrc/ore_conv_kw.hip) wherever it applies, then restore the plan."""
     ore.lib().ore_conv_set_plan_override(-2, 2, 0, 0, 0)
-    ore.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)        # (the register-fed kernel would take the smallest shapes first)
+    ore.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)        # (the register-fed / lean-DMA kernels would take their shapes first)
+    ore.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
     yield
+    ore.lib().ore_conv_set_plan_override(-12, 1, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-10, 1, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-2, 1, 0, 0, 0)
 
@@ -276,10 +278,104 @@ def test_conv_kw_kernel_vs_oracle(ore, kw_forced, B, H, W, Cin, Cout, k, stride)
 
 
 @pytest.fixture
+def kd_forced(ore):
+    """Force the lean LDS-DMA kernel (k_conv_kd, csrc/ore_conv_kd.hip) wherever it applies, then restore the plan."""
+    ore.lib().ore_conv_set_plan_override(-12, 2, 0, 0, 0)
+    yield
+    ore.lib().ore_conv_set_plan_override(-13, 0, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-12, 1, 0, 0, 0)
+
+
+KD_BUILDS = [(16, 16, 4, 4), (16, 16, 4, 8), (16, 16, 8, 4), (16, 16, 16, 2), (16, 32, 4, 4), (16, 32, 8, 2), (32, 32, 4, 4), (32, 32, 8, 2),
+             (16, 48, 4, 4), (16, 48, 8, 2), (16, 64, 4, 2), (16, 80, 4, 2), (32, 64, 4, 2), (32, 80, 4, 2), (64, 64, 4, 2), (32, 48, 4, 2),
+             (32, 16, 4, 4)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride", [
+    (1, 20, 20, 112, 112, 3, 1),    # stage-5 layers 1 / 2
+    (1, 20, 20, 384, 112, 3, 1),    # stage-5 layer 0
+    (1, 20, 20, 720, 512, 1, 1),    # stage-5 concat
+    (1, 40, 40, 96, 96, 3, 1),      # stage-4 layers 1 / 2
+    (1, 40, 40, 256, 96, 3, 1),     # stage-4 layer 0
+    (1, 40, 40, 544, 384, 1, 1),    # stage-4 concat
+    (1, 80, 80, 256, 128, 1, 1),    # FPN lateral 3
+    (1, 1, 320, 8192, 128, 1, 1),   # the second-stage GEMM
+    (2, 13, 11, 96, 40, 3, 1),      # two images, odd size, rows not a multiple of 16, Cout = 40
+    (1, 9, 7, 112, 5, 3, 1),        # Cout = 5: one channel quad + one lane of the next
+    (3, 17, 15, 128, 64, 3, 2),     # stride 2, odd size, three images
+    (1, 7, 5, 16, 16, 3, 1),        # one chunk per tap
+])
+def test_conv_kd_kernel_vs_oracle(ore, kd_forced, B, H, W, Cin, Cout, k, stride):
+    """k_conv_kd against F.conv2d at 1e-4: border taps, partial tiles and chunks beyond K arrive as the buffer descriptor's zeros
+    through LDS-DMA; bit-reproducible; another summation order than k_conv_kw's (2e-5 of it)."""
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc = torch.rand(Cout, generator=g) + 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, None, stride, k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wp = ore.pack_conv_weight(w).cuda()
+    y = ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert chan_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert torch.equal(y, ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout))
+    ore.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)
+    y_kw = ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    ore.lib().ore_conv_set_plan_override(-10, 1, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-12, 2, 0, 0, 0)
+    assert rel_err(y.cpu().numpy(), y_kw.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("bm,bn,nw,sb", KD_BUILDS)
+@pytest.mark.parametrize("H,W,Cin,Cout,k", [(20, 20, 112, 112, 3), (7, 9, 96, 80, 3), (1, 96, 2048, 128, 1)])
+def test_conv_kd_every_build(ore, kd_forced, bm, bn, nw, sb, H, W, Cin, Cout, k):
+    """Every instantiated (tile, waves, steps per batch) build of k_conv_kd: one batch, many batches (double-buffer reuse), waves whose
+    range lies wholly beyond K, tiles wider than Cout."""
+    L = ore.lib()
+    g = torch.Generator().manual_seed(H + Cin + nw + sb + bm)
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, sh, 1, k // 2)
+    L.ore_conv_set_plan_override(-13, bm, bn, nw, sb)
+    y = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, 1, shift=dev(sh))
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+
+
+def test_conv_kd_slices_add_colsum(ore, kd_forced):
+    """Channel-slice input / output inside wider buffers, the FPN top-down addend (nearest-2x) and the fused per-tile column sums."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 1, 10, 12, 128, 128
+    buf = torch.randn(B, H, W, 32 + Cin + 16, generator=g)
+    x = buf[..., 32:32 + Cin].permute(0, 3, 1, 2).contiguous()
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    top = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x, w, bias) + F.interpolate(top, scale_factor=2.0, mode="nearest")
+    out = torch.full((B, H, W, 16 + Cout + 16), 7.0).cuda()
+    ore.conv2d(buf.cuda(), ore.pack_conv_weight(w).cuda(), Cout, 1, 1, in_coff=32, Cin=Cin, shift=dev(bias), add=nhwc(top), out=out, out_coff=16)
+    o = out.cpu()
+    assert rel_err(o[..., 16:16 + Cout].permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    assert (o[..., :16] == 7.0).all() and (o[..., 16 + Cout:] == 7.0).all()
+    for bm, bn, sb in ((16, 16, 4), (32, 32, 4), (32, 64, 2), (64, 64, 2)):
+        ore.lib().ore_conv_set_plan_override(-13, bm, bn, 4, sb)
+        w3 = torch.randn(80, 96, 3, 3, generator=g) / (96 * 9) ** 0.5
+        x3 = torch.randn(1, 96, 9, 8, generator=g)
+        sc, sh = torch.rand(80, generator=g) + 0.5, torch.randn(80, generator=g) * 0.1
+        ref3 = F.relu(F.conv2d(x3, w3, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        y3, cs = ore.conv2d(nhwc(x3), ore.pack_conv_weight(w3).cuda(), 80, 3, 1, scale=dev(sc), shift=dev(sh), relu_cout=80, want_colsum=True)
+        assert rel_err(nchw(y3).numpy(), ref3.numpy()) < TOL
+        assert rel_err(cs.sum(0)[:80].cpu().numpy(), ref3.sum((0, 2, 3)).numpy()) < 1e-5
+
+
+@pytest.fixture
 def rf_forced(ore):
     """Force the register-fed small-M kernel (k_conv_rf, csrc/ore_conv_rf.hip) wherever it applies, then restore the plan."""
     ore.lib().ore_conv_set_plan_override(-10, 2, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
     yield
+    ore.lib().ore_conv_set_plan_override(-12, 1, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-11, 0, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-10, 1, 0, 0, 0)
 

@@ -775,7 +775,7 @@ def test_rccl_one_rank_rehearsal(oh, transport, graph):
     assert r["finite"] and r["moved"] > 1e-4, r
     # (three optimizer steps amplify last-bit differences through hard decisions -- ReLU masks, the ROI sample -- so the yardstick is
     # the distance between two PLAIN runs, measured in the same process, not a fixed fraction of the update)
-    assert r["diff"] <= 4.0 * r["noise"] + 1e-7 and r["noise"] <= 0.25 * r["moved"], (r["diff"], r["noise"], r["moved"])
+    assert r["diff"] <= 8.0 * r["noise"] + 1e-3 * r["moved"] and r["noise"] <= 0.25 * r["moved"], (r["diff"], r["noise"], r["moved"])
     assert len(r["logs"]) == 3 and r["n_slices"] >= 2
     for log in r["logs"]:                                          # every slice exactly once per step ...
         assert sorted(s_ for s_, _ in log) == list(range(r["n_slices"])), log

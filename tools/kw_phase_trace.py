@@ -18,6 +18,7 @@ L = orehip.lib()
 
 
 RF = False           # True: the layer runs on k_conv_rf (stamps of csrc/ore_conv_rf.hip)
+KD = False           # True: ... on k_conv_kd (csrc/ore_conv_kd.hip)
 
 
 def trace(H, W, Cin, Cout, k, reps=5):
@@ -51,11 +52,13 @@ def trace(H, W, Cin, Cout, k, reps=5):
             run()                                                   # the launch in front (warm: the same layer; cold: the sweep)
             L.ore_debug_set_trace_kw(C.c_void_p(buf.data_ptr()))
             L.ore_debug_set_trace_rf(C.c_void_p(buf.data_ptr()))
+            L.ore_debug_set_trace_kd(C.c_void_p(buf.data_ptr()))
             torch.cuda.synchronize()
             run()
             torch.cuda.synchronize()
             L.ore_debug_set_trace_kw(C.c_void_p(0))
             L.ore_debug_set_trace_rf(C.c_void_p(0))
+            L.ore_debug_set_trace_kd(C.c_void_p(0))
             t = buf.cpu().numpy().reshape(nb, 16)
             t = t[t[:, 0] != 0]
             rows.append(t)
@@ -68,6 +71,10 @@ def trace(H, W, Cin, Cout, k, reps=5):
         names = ["prologue (decode, descriptors, epilogue operand requests)", "all loads of batch 0 requested", "first fragment landed + 4 MFMAs",
                  "rest of the K slice (MFMAs behind counted waits)", "partials -> LDS + barrier", "reduce + epilogue (stores issued)", "stores retired"]
         idx = [(0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 8), (8, 9)]
+    if KD:
+        names = ["prologue (arguments, decode, descriptors)", "DMAs of batch 0 issued", "(next batch issued,) batch 0 landed", "K loop (rest)",
+                 "drain + barrier (slowest wave)", "partials -> LDS + barrier", "reduce + epilogue (stores issued)", "stores retired"]
+        idx = [(0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9)]
     for tag, t in zip(("warm", "cold"), res):
         n = len(t)
         rt0, rt1 = t[:, 1].min(), t[:, 10].max()
@@ -96,6 +103,31 @@ if __name__ == "__main__":
                 print("#### k_conv_rf<GB %d, NW %d, MAXS %d>" % (gb, nw, maxs))
                 trace(*shape, reps=2)
         L.ore_conv_set_plan_override(-11, 0, 0, 0, 0)
+        L.ore_conv_set_plan_override(-10, 1, 0, 0, 0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "kd":                   # the lean LDS-DMA kernel, forced builds, on every small / medium-M layer
+        KD = True
+        L.ore_conv_set_plan_override(-12, 2, 0, 0, 0)
+        L.ore_conv_set_plan_override(-10, 0, 0, 0, 0)
+        for shape, builds in (((20, 20, 112, 112, 3), ((16, 16, 4, 8), (16, 16, 8, 4), (16, 16, 16, 2), (16, 32, 4, 4))),
+                              ((20, 20, 384, 112, 3), ((16, 16, 4, 8), (16, 16, 8, 4), (16, 16, 16, 2), (16, 32, 8, 2))),
+                              ((20, 20, 512, 128, 1), ((16, 16, 4, 8), (16, 16, 8, 4), (16, 32, 4, 4))),
+                              ((20, 20, 720, 512, 1), ((32, 32, 4, 4), (32, 64, 4, 2), (16, 64, 4, 2), (32, 32, 8, 2), (64, 64, 4, 2))),
+                              ((40, 40, 96, 96, 3), ((16, 48, 4, 4), (32, 32, 4, 4), (32, 48, 4, 2), (16, 48, 8, 2))),
+                              ((40, 40, 256, 96, 3), ((16, 48, 4, 4), (16, 48, 8, 2), (32, 48, 4, 2), (32, 32, 8, 2), (16, 32, 8, 2))),
+                              ((40, 40, 384, 128, 1), ((32, 32, 4, 4), (32, 64, 4, 2), (16, 64, 4, 2), (32, 32, 8, 2))),
+                              ((40, 40, 544, 384, 1), ((32, 64, 4, 2), (32, 80, 4, 2), (64, 64, 4, 2), (32, 32, 4, 4), (16, 64, 4, 2))),
+                              ((80, 80, 256, 128, 1), ((32, 64, 4, 2), (64, 64, 4, 2), (32, 32, 4, 4), (16, 64, 4, 2))),
+                              ((80, 105, 256, 128, 1), ((32, 64, 4, 2), (64, 64, 4, 2), (32, 32, 4, 4))),
+                              ((1, 320, 8192, 128, 1), ((16, 16, 8, 4), (16, 16, 16, 2), (16, 32, 8, 2), (32, 32, 8, 2)))):
+            for bm, bn, nw, sb in builds:
+                L.ore_conv_set_plan_override(-13, bm, bn, nw, sb)
+                print("#### k_conv_kd<%dx%d, NW %d, SB %d>" % (bm, bn, nw, sb))
+                try:
+                    trace(*shape, reps=2)
+                except orehip.OreError as ex:
+                    print("   not built:", ex)
+        L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
+        L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
         L.ore_conv_set_plan_override(-10, 1, 0, 0, 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "sweep":                 # ring depth / waves per block on the latency-bound shapes
         for shape in ((20, 20, 112, 112, 3), (40, 40, 96, 96, 3), (20, 20, 512, 128, 1)):
