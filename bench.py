@@ -123,7 +123,7 @@ def cpu_baseline(model, img, budget_s=12.0):
                       f"torch {torch.__version__} CPU, {el:.1f} s)"}
 
 
-def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True, world=1, rank=0, min_time=0.0):
+def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True, world=1, rank=0, min_time=0.0, precision="fp32"):
     """SURVEY 8d metric (ii): forward + backward (+ gradient exchange) + clip/SGD of finetune_vovnet.yaml, `batch` query images with 24
     support crops each per GPU per step.  world > 1 (BASELINE configs[3]): the detector is wrapped in FlatDataParallel, every rank runs
     the same per-GPU batch on its own images and the flat gradient bucket is all-reduced over RCCL from the backward hooks; reported:
@@ -132,6 +132,11 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
     from detectron2.structures import Boxes, Instances
     from detectron2.utils import comm
     from fewx.solver import FlatDataParallel, build_lr_scheduler, build_optimizer
+    import orehip
+    # precision "bf16" = BASELINE configs[4] ("bf16 MFMA conv path + fp32 NMS"): the frozen stem / stage 2 / stage 3 keep bf16 maps and
+    # weights (bf16-storage kernels), every trainable conv / linear multiplies bf16-rounded operands on the bf16 matrix cores in its
+    # forward, data gradient and weight gradient (fp32 accumulation); normalisation, correlation, losses, NMS and the optimizer stay fp32
+    prev_precision = orehip.set_conv_precision(precision)
     model, cfg = build_model(device)
     model.train()
     model.train_graph = graph       # the shape-static dense part (fwd + bwd) replays as two hipGraphs; falls back to eager if capture fails
@@ -188,9 +193,11 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
         e2, losses = timed(steps)
         el, n_steps = el + e2, n_steps + steps
     out = {"images_per_s": round(world * batch * n_steps / el, 2), "n_gpus": world, "batch_per_gpu": batch, "global_batch": world * batch,
-           "ms_per_step": round(el / n_steps * 1e3, 3), "steps": n_steps, "warmup": warmup, "dtype": "f32",
+           "ms_per_step": round(el / n_steps * 1e3, 3), "steps": n_steps, "warmup": warmup, "dtype": "bf16" if precision == "bf16" else "f32",
            "workload": "finetune_vovnet.yaml train step: %d x (1 query %dx%d + %d support 240x240) per GPU, fwd + bwd (HIP backward kernels) + "
-                       "%sflat-bucket clip/SGD, FREEZE_AT=3" % (batch, size, size, shots, "RCCL all-reduce of the gradient bucket + " if world > 1 else ""),
+                       "%sflat-bucket clip/SGD, FREEZE_AT=3%s" % (batch, size, size, shots, "RCCL all-reduce of the gradient bucket + " if world > 1 else "",
+                                                                   "; bf16: frozen stages in bf16 storage, bf16 MFMA operands in the trainable convs' forward / "
+                                                                   "data / weight gradients, fp32 accumulation, fp32 NMS / losses / optimizer" if precision == "bf16" else ""),
            "dense_part_hipgraph": bool(graph) and model.__dict__.get("_ore_train_graph_error") is None,
            "exchanged_bytes_per_step": 4 * opt.bucket.size if world > 1 else 0, "bucket_bytes": 4 * opt.bucket.size,
            "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
@@ -223,6 +230,7 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
                     "ms_per_step_without_exchange": round(base_ms, 3), "exposed_exchange_ms": round(exposed, 3),
                     "overlap_frac": round(min(max(1.0 - exposed / ar_ms, 0.0), 1.0), 3) if ar_ms > 0 else None,
                     "rccl_ranks_seen": int(comm.sum_over_ranks(1, device)), "backend": dist.get_backend()})
+    orehip.set_conv_precision(prev_precision)
     return out
 
 
@@ -549,12 +557,68 @@ def main():
             roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                          "algorithmic_bytes_per_image": alg_bytes, "mfma_tflops": round(ach, 2), "mfma_frac_of_bf16_peak": round(ach / PEAK_BF16_MFMA_TFLOPS, 4)})
 
+    # BASELINE configs[4]'s precision as an EVAL leg of the default (fp32) run: a second detector whose engine keeps bf16 activations and
+    # weights (ORE_CONV_BF16S), timed on the same protocol, with its own dtype and its own HBM-priced roofline -- reported beside the
+    # fp32 line, never as `value` (the bf16 numbers must be driver-visible)
+    bf16_leg = {}
+    if not bf16 and not args.no_extras and rank == 0:
+        try:
+            m16, _ = build_model(device)
+            m16.conv_operands = "bf16s"
+
+            def p16(i):
+                m16(requests[i % len(requests)])
+                torch.cuda.synchronize()
+            for i in range(8):
+                p16(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n16 = 0
+            while time.perf_counter() - t0 < 0.6:
+                p16(n16)
+                n16 += 1
+            el16 = time.perf_counter() - t0
+            e16 = m16.engine()
+            e16.set_profiling(True)
+            for i in range(3):
+                e16.eval_forward(imgs[0], use_graph=False)
+            e16.read_profile()
+            for i in range(10):
+                e16.eval_forward(imgs[i % len(imgs)], use_graph=False)
+            ms16, fl16, nl16 = e16.read_profile()
+            e16.set_profiling(False)
+            alg_bytes = 336e6 / 2 + 2.0 * 5.06e6              # every conv layer round-trips once in bf16 + the bf16 weights (see --conv-operands bf16s)
+            gbs = alg_bytes / (ms16 / 10 * 1e-3) / 1e9
+            t16, t16_src = None, None
+            import glob as _g
+            for tf in sorted(_g.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bf16s.json")), reverse=True):
+                try:
+                    with open(tf) as f:
+                        tj = json.load(f)
+                    if int(tj.get("ore_version", -1)) == int(__import__("orehip").lib().ore_version()):
+                        t16, t16_src = float(tj["conv_hbm_bytes_per_image"]), os.path.basename(tf)
+                    break
+                except Exception:
+                    pass
+            bf16_leg["eval_bf16s"] = {
+                "images_per_s": round(n16 / el16, 2), "ms_per_image": round(el16 / n16 * 1e3, 4), "dtype": "bf16",
+                "workload": "the headline protocol on an engine in the bf16 STORAGE mode (bf16 activations / weights in HBM and LDS, "
+                            "v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 top-k / NMS / second stage): BASELINE configs[4]'s precision",
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                             "traffic": t16, "traffic_src": t16_src, "algorithmic_bytes_per_image": alg_bytes,
+                             "kernel_ms_per_image": round(ms16 / 10, 4), "launches_per_image": nl16 // 10,
+                             "mfma_tflops": round(fl16 / (ms16 * 1e-3) / 1e12, 2)}}
+        except Exception as ex:                             # a side measurement must not take the headline line down
+            bf16_leg["eval_bf16s_error"] = repr(ex)[:300]
+
     train = {}
     if not args.no_train_leg:
         try:
             if world == 1:
                 train["train_step"] = train_leg(device, min_time=0.3)
                 train["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, min_time=0.8)   # BASELINE configs[2]
+                # BASELINE configs[4] ("bf16 MFMA conv path + fp32 NMS") on one GPU: its own dtype, never mixed into `value`
+                train["train_step_bs16_bf16"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, min_time=0.8, precision="bf16")
             else:                                           # BASELINE configs[3]: 16 per GPU, gradients over RCCL
                 train["train_step"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, world=world, rank=rank, min_time=0.8)
         except Exception as ex:                             # the headline line must survive a failure of the side measurement
@@ -580,7 +644,7 @@ def main():
                        "input": "uint8 BGR CHW image resident in HBM when the timed region starts (the tier rule for `value`); the same protocol fed the "
                                 "dataloader's host tensor, PCIe copy inside the step, is \"protocol_host_image\"", "proposals_last_image": n_prop, "detections_last_image": n_det,
                        "detections_returned": n_det_proto},
-            **extras, "roofline": roof, **train,
+            **extras, "roofline": roof, **bf16_leg, **train,
         }
         if not args.no_cpu_baseline:                           # rank 0 only; the other ranks wait in the final barrier meanwhile
             out["cpu_baseline"] = cpu_baseline(model, host_imgs[0], budget_s=12.0 if world == 1 else 6.0)

@@ -282,6 +282,174 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     }
 }
 
+// ---- bf16 MFMA weight gradient (ORE_CONV_BF16, BASELINE configs[4]; round 4) ---------------------------------------------------------
+// The same tile, row split and slab reduction as k_wgrad / k_wgrad3, but the two operands travel through LDS as bf16 (rounded once,
+// nearest even, as the fp32 rows are staged: half the LDS bytes) and meet on v_mfma_f32_16x16x32_bf16: ONE matrix instruction per 16 x 16
+// tile and 32 rows where the fp32 kernels issue eight.  The contraction runs over ROWS, i.e. down the columns of the row-major staged
+// tiles: `ds_read_b64_tr_b16` hands every lane 4 consecutive rows of its column (two reads = the 8 k of the instruction) -- the tiles are
+// written as they arrive (16 contiguous bytes per thread), no transposed stores, no bank conflicts on the way in.
+//   K3 = true: 3x3 / pad 1, one block owns the three dx taps of kernel row dy: X rows m0 + dy W - 1 .. m0 + dy W + 32 are staged once
+//     (34 rows), tap dx reads them shifted by dx; taps that leave the image are masked on the dZ side, which is staged in three copies
+//     (dZ * valid(row, dx)) so that the MFMA operand needs no per-element select;
+//   K3 = false: one tap per block (1x1 layers, Linear-over-rows, other kernel sizes).
+// fp32 accumulation, fp32 bias column sums of the UNROUNDED dZ; results differ from the fp32-MFMA build of the same mode only by the
+// summation order (bf16 x bf16 products are exact in fp32) -- tests/test_hip_bf16.py::test_conv_backward_bf16_vs_oracle holds both
+// to 1e-4 of the oracle's bf16 restatement.
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+constexpr int WB_K = 32;      // rows per step
+constexpr int WB_LD = 72;     // bf16 per staged row: 64 + 8 (144 bytes: 16-byte aligned rows)
+
+__device__ __forceinline__ s16x8v pack_bf16x8(f32x4 a, f32x4 b) {
+    const s16x4 lo = to_bf16x4(a), hi = to_bf16x4(b);
+    return s16x8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// the 16 x 16 x 32 operand of one MFMA tile: 8 consecutive rows (k) of column (lane & 15), rows 8 (lane >> 4) .. + 7 of a staged tile
+__device__ __forceinline__ bf16x8_t wb_frag(const short* tile_row0_col0) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const short* a = tile_row0_col0 + (8 * g + q) * WB_LD + 4 * pp;
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)a);
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(a + 4 * WB_LD));
+    const s16x8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <bool K3>
+__global__ __launch_bounds__(256) void k_wgrad_bf(WgradP p) {
+    constexpr int ND = K3 ? 3 : 1;                        // dZ copies (one per dx tap)
+    constexpr int XR = K3 ? WB_K + 2 : WB_K;              // staged X rows
+    __shared__ __attribute__((aligned(16))) short sA[2][ND][WB_K][WB_LD];
+    __shared__ __attribute__((aligned(16))) short sB[2][XR][WB_LD];          // (tap dx reads rows dx .. dx + 31 of the 34)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_ci_tiles = (p.Cin + WG_T - 1) / WG_T;
+    const int co0 = blockIdx.x * WG_T;
+    const int ci0 = (blockIdx.y % n_ci_tiles) * WG_T;
+    const int tsel = blockIdx.y / n_ci_tiles;             // K3: kernel row 0..2; else the tap index
+    const int dy = K3 ? tsel - 1 : tsel / p.kw - p.pad;
+    const int dx1 = K3 ? 0 : tsel % p.kw - p.pad;
+    const int m_begin = blockIdx.z * p.chunk, m_end = min(p.M, m_begin + p.chunk);
+    const int lr = tid >> 3, lc = (tid & 7) * 8;          // this thread stages row lr, columns lc .. lc + 7 of both tiles
+    f32x4 acc[ND][2][2];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[d][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto ld8 = [&](const float* base, bool ok, int cbase, int cmax, f32x4& a, f32x4& b) {
+        a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a;
+        if (ok && cbase < cmax) a = *reinterpret_cast<const f32x4*>(base);
+        if (ok && cbase + 4 < cmax) b = *reinterpret_cast<const f32x4*>(base + 4);
+    };
+    f32x4 za, zb, xa, xb, ya, yb;                          // dZ row, X row, (K3) the extra X row of threads lr < 2
+    int msk = 0;
+    auto load = [&](int m0) {
+        const int m = m0 + lr;
+        const bool rv = m < m_end;
+        ld8(p.dz + (size_t)(rv ? m : 0) * p.dz_ld + p.dz_coff + co0 + lc, rv, co0 + lc, p.Cout, za, zb);
+        if constexpr (K3) {
+            msk = 0;
+            if (rv) {
+                const int xq = m % p.W, ys = (m / p.W) % p.H + dy;
+                if (ys >= 0 && ys < p.H) msk = (xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.W ? 4 : 0);
+            }
+            const int r = m0 + lr + dy * p.W - 1;
+            ld8(p.x + (size_t)(r >= 0 && r < p.M ? r : 0) * p.x_ld + p.x_coff + ci0 + lc, r >= 0 && r < p.M, ci0 + lc, p.Cin, xa, xb);
+            const int r2 = m0 + WB_K + lr + dy * p.W - 1;
+            ld8(p.x + (size_t)(r2 >= 0 && r2 < p.M ? r2 : 0) * p.x_ld + p.x_coff + ci0 + lc, lr < 2 && r2 >= 0 && r2 < p.M, ci0 + lc, p.Cin, ya, yb);
+        } else {
+            bool xv = false;
+            if (rv) {
+                const int xq = m % p.W, yq = (m / p.W) % p.H;
+                const int ys = yq + dy, xs = xq + dx1;
+                xv = ys >= 0 && ys < p.H && xs >= 0 && xs < p.W;
+            }
+            ld8(p.x + (size_t)(xv ? m + dy * p.W + dx1 : 0) * p.x_ld + p.x_coff + ci0 + lc, xv, ci0 + lc, p.Cin, xa, xb);
+        }
+    };
+    load(m_begin);
+    const bool do_b = p.db != nullptr && blockIdx.y == 0;
+    f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += WB_K) {
+        if (do_b) { bs0 += za; bs1 += zb; }
+        if constexpr (K3) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const bool on = (msk >> d) & 1;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<s16x8v*>(&sA[buf][d][lr][lc]) = pack_bf16x8(on ? za : z, on ? zb : z);
+            }
+            *reinterpret_cast<s16x8v*>(&sB[buf][lr][lc]) = pack_bf16x8(xa, xb);
+            if (lr < 2) *reinterpret_cast<s16x8v*>(&sB[buf][WB_K + lr][lc]) = pack_bf16x8(ya, yb);
+        } else {
+            *reinterpret_cast<s16x8v*>(&sA[buf][0][lr][lc]) = pack_bf16x8(za, zb);
+            *reinterpret_cast<s16x8v*>(&sB[buf][lr][lc]) = pack_bf16x8(xa, xb);
+        }
+        __syncthreads();
+        if (m0 + WB_K < m_end) load(m0 + WB_K);                  // next step's global loads fly under this step's MFMAs
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = wb_frag(&sA[buf][d][0][wm * 32 + t * 16]);
+                b[t] = wb_frag(&sB[buf][K3 ? d : 0][wn * 32 + t * 16]);     // tap dx: the X rows shifted by d
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[d][tm][tn], 0, 0, 0);
+        }
+        buf ^= 1;                                                // the other buffer was last read two barriers ago
+    }
+    const int taps = p.kh * p.kw;
+    float* slab = p.slab + (size_t)blockIdx.z * p.slab_stride;
+    if (do_b) {                                                  // column sums of the fp32 dZ rows this block staged: 32 rows meet in LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&sA[0][0][0][0]);  // [32][64] floats = 8 KB of the 13.8+ KB staging area
+        *reinterpret_cast<f32x4*>(red + lr * 64 + lc) = bs0;
+        *reinterpret_cast<f32x4*>(red + lr * 64 + lc + 4) = bs1;
+        __syncthreads();
+        if (tid < 64 && co0 + tid < p.Cout) {
+            float sacc = red[tid];
+#pragma unroll
+            for (int r = 1; r < 32; ++r) sacc += red[r * 64 + tid];
+            if (p.dw) {
+                float* o = p.db + co0 + tid;
+                *o = p.beta_b != 0.0f ? p.beta_b * *o + sacc : sacc;
+            } else {
+                slab[(size_t)p.Cout * taps * p.Cin + co0 + tid] = sacc;
+            }
+        }
+    }
+    // D: column = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int tap = K3 ? tsel * 3 + d : tsel;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int ci = ci0 + wn * 32 + tn * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wm * 32 + tm * 16 + (lane >> 4) * 4 + r;
+                    if (co < p.Cout && ci < p.Cin) {
+                        if (p.dw) {
+                            float* o = p.dw + ((size_t)co * p.Cin + ci) * taps + tap;
+                            *o = p.beta != 0.0f ? p.beta * *o + acc[d][tm][tn][r] : acc[d][tm][tn][r];
+                        } else {
+                            slab[((size_t)co * taps + tap) * p.Cin + ci] = acc[d][tm][tn][r];
+                        }
+                    }
+                }
+            }
+    }
+}
+
 // dw_oihw[co][ci][tap] = beta * dw + sum_z slab[z][co][tap][ci].  Fixed summation order: slab z belongs to group z % G, every group is
 // summed ascending by one thread, the G partial sums are added ascending (deterministic for a given S).  One thread = (4 consecutive
 // ci, one group): 16-byte slab loads, G x as many loads in flight as one thread per output has -- the 1x1 layers split their rows 192-745
@@ -707,14 +875,17 @@ extern "C" int ore_conv2d_wgrad_bias_fwd(const float* x, int32_t x_ld, int32_t x
     WgradP p{};
     p.x = x; p.x_ld = x_ld; p.x_coff = x_coff; p.dz = dz; p.dz_ld = dz_ld; p.dz_coff = dz_coff;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.kh = kh; p.kw = kw; p.pad = pad;
-    p.M = (int)M; p.chunk = round_up(ceil_div((int)M, S), WG_K);
+    const bool bfm = ore_conv_get_precision() == ORE_CONV_BF16;        // bf16 MFMA build: 32-row steps
+    p.M = (int)M; p.chunk = round_up(ceil_div((int)M, S), bfm ? WB_K : WG_K);
     S = ceil_div((int)M, p.chunk);
     p.slab = workspace; p.slab_stride = per;
     p.db = db; p.beta_b = beta_b;
     if (S == 1) { p.dw = dw_oihw; p.beta = beta; }
     p.bf16 = ore_conv_get_precision() == ORE_CONV_BF16;   // the STORAGE mode (2) is an engine property, plain calls stay fp32 (ore_hip.h)
     hipStream_t st = (hipStream_t)stream;
-    if (kh == 3 && kw == 3) hipLaunchKernelGGL(k_wgrad3, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * 3, S), dim3(256), 0, st, p);
+    if (bfm && kh == 3 && kw == 3) hipLaunchKernelGGL(k_wgrad_bf<true>, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * 3, S), dim3(256), 0, st, p);
+    else if (bfm) hipLaunchKernelGGL(k_wgrad_bf<false>, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
+    else if (kh == 3 && kw == 3) hipLaunchKernelGGL(k_wgrad3, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * 3, S), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_wgrad, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);
     int rc = ore_launch_status("k_wgrad");
     if (rc || S == 1) return rc;

@@ -186,11 +186,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
         w_c += SB;
     };
 
-    f32x4 acc[2][GA][GB];
+    // small tiles: even / odd steps accumulate into two independent chains (a dependent fp32 MFMA waits 40 clocks for its predecessor);
+    // tiles of 4+ MFMA tiles have enough independent accumulators as they are
+    constexpr int NACC = GA * GB >= 4 ? 1 : 2;
+    f32x4 acc[NACC][GA][GB];
 #pragma unroll
-    for (int i = 0; i < GA; ++i)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int j = 0; j < GB; ++j) acc[0][i][j] = acc[1][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < GA; ++i)
+#pragma unroll
+            for (int j = 0; j < GB; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // fragment read offsets (floats) inside a 16-row group: row = lane & 15, logical quad = lane >> 4
     const int frow = lane & 15;
     const int foff = frow * 16 + (((lane >> 4) ^ swz(frow)) << 2);
@@ -209,8 +214,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
             wait_vmcnt<0>();
         }
         if (bt == 0) KD_TR(4);
-        // fragments of step t+1 are requested before the MFMAs of step t issue (two register sets); even / odd steps accumulate into
-        // two independent chains (a dependent fp32 MFMA waits 40 clocks for its predecessor)
+        // fragments of step t+1 are requested before the MFMAs of step t issue (two register sets)
         f32x4 af[2][GA], bf[2][GB];
 #pragma unroll
         for (int i = 0; i < GA; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(cur + i * 256 + foff);
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
                 for (int i = 0; i < GA; ++i)
 #pragma unroll
                     for (int j = 0; j < GB; ++j)
-                        acc[t & 1][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][j][tt], af[t & 1][i][tt], acc[t & 1][i][j], 0, 0, 0);   // D^T: lane = pixel
+                        acc[t & (NACC - 1)][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][j][tt], af[t & 1][i][tt], acc[t & (NACC - 1)][i][j], 0, 0, 0);   // D^T: lane = pixel
         }
     }
     KD_TR(5);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
     for (int i = 0; i < GA; ++i)
 #pragma unroll
         for (int j = 0; j < GB; ++j)
-            *reinterpret_cast<f32x4*>(lds + ((wave * NT) + i * GB + j) * 256 + lane * 4) = acc[0][i][j] + acc[1][i][j];
+            *reinterpret_cast<f32x4*>(lds + ((wave * NT) + i * GB + j) * 256 + lane * 4) = NACC == 2 ? acc[0][i][j] + acc[NACC - 1][i][j] : acc[0][i][j];
     __syncthreads();
     KD_TR(7);
     constexpr int RED_F = NW * NT * 256;
@@ -350,11 +354,14 @@ void conv_kd_force(int bm, int bn, int nw, int sb) { g_kd_force[0] = bm; g_kd_fo
 
 struct KdPlan { int bm, bn, nw, sb; };
 
+// several pyramid levels in one launch: a 1x1 stride-1 layer over the level-major row matrix is one flat GEMM (row m reads row m)
+static bool kd_flat(const ConvP& p) { return p.nlev > 1 && p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.add; }
+
 static bool kd_applies(const ConvP& p) {
-    if (p.sb || p.bf16 || p.in_mul || p.in_add || p.in_relu || p.nlev != 1 || p.ep_stride) return false;
+    if (p.sb || p.bf16 || p.in_mul || p.in_add || p.in_relu || (p.nlev != 1 && !kd_flat(p)) || p.ep_stride) return false;
     if (p.Cin % 16 != 0 || p.in_ld % 16 != 0 || p.kh != p.kw || (p.kh != 1 && p.kh != 3)) return false;
     if ((long long)p.M * p.Cout16 >= (1ll << 31) || p.M >= (1 << 22) || p.nchunks > kTab) return false;
-    const long long in_rows = (long long)p.lv[0].irow0 + (long long)p.B * p.lv[0].H * p.lv[0].W;
+    const long long in_rows = kd_flat(p) ? (long long)p.lv[0].irow0 + p.M : (long long)p.lv[0].irow0 + (long long)p.B * p.lv[0].H * p.lv[0].W;
     if (in_rows * p.in_ld * 4 >= (long long)kOOB - (1 << 24) || (long long)p.Cout16 * p.K * 4 >= (long long)kOOB) return false;
     if (p.add && (long long)p.B * p.add_H * p.add_W * p.add_ld * 4 >= (long long)kOOB) return false;
     return true;
@@ -379,7 +386,7 @@ static KdPlan kd_plan(const ConvP& p) {
         if (p.Cout16 >= 320 && p.Cout16 % 80 == 64) return {32, 80, 4, 2};       // 384 = 4 x 80 + 64: five column tiles
         return {0, 0, 0, 0};
     }
-    if (p.M <= 8192 && p.Cout16 == 128 && p.kh == 1) return {64, 64, 4, 2};
+    if (p.M <= 9216 && p.Cout16 == 128 && p.kh == 1) return {64, 64, 4, 2};       // FPN lateral 3, conv3 over the three levels
     return {0, 0, 0, 0};
 }
 
@@ -396,11 +403,13 @@ int conv_kd_launch(ConvP& p, hipStream_t st) {
     const int bn = pl.bn < p.Cout16 ? pl.bn : p.Cout16;
     const int steps = ceil_div(p.nchunks, pl.nw);
     const int gx = ceil_div(p.M, pl.bm), gy = ceil_div(p.Cout16, bn);
-    const Lvl& L = p.lv[0];
+    Lvl L = p.lv[0];
+    int Bimg = p.B;
+    if (kd_flat(p)) { L.H = 1; L.W = p.M; L.Ho = 1; L.Wo = p.M; Bimg = 1; }      // one "image" of M pixels in a row
     KdP q;
     KdK& k = q.k;
     k.in = p.in; k.w = p.w; k.scale = p.scale; k.shift = p.shift; k.add = p.add; k.out = p.out; k.colsum = p.colsum;
-    k.in_bytes = (unsigned)(((long long)L.irow0 + (long long)p.B * L.H * L.W) * p.in_ld * 4);
+    k.in_bytes = (unsigned)(((long long)L.irow0 + (long long)Bimg * L.H * L.W) * p.in_ld * 4);
     k.w_bytes = (unsigned)((long long)p.Cout16 * p.K * 4);
     k.sc_bytes = (unsigned)p.Cout * 4u;
     k.add_bytes = p.add ? (unsigned)((long long)p.B * p.add_H * p.add_W * p.add_ld * 4) : 0u;

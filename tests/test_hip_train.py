@@ -716,12 +716,14 @@ def _rccl_one_rank_worker(port, q, transport, graph):
         item = {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
 
         def steps(wrap):
+            """Three optimizer steps; returns the bucket after step 1 (parameters + the gradients the optimizer consumed) and at the end."""
             torch.manual_seed(0)
             m, sd, cfg = _train_model(shots)
             m.train_graph = graph
             opt = build_optimizer(cfg, m)
+            p0 = opt.bucket.params.detach().cpu().clone()
             dp = FlatDataParallel(m, cfg, transport=transport, force_exchange=True) if wrap else None
-            logs = []
+            logs, g1, p1 = [], None, None
             with warnings.catch_warnings(record=True) as w:
                 warnings.simplefilter("always")
                 for it in range(3):
@@ -729,7 +731,10 @@ def _rccl_one_rank_worker(port, q, transport, graph):
                     losses = train_forward(m, [item], perm=lambda n: torch.randperm(n, generator=g))
                     opt.zero_grad()
                     sum(losses.values()).backward()
-                    opt.step()
+                    opt.step()                                     # (the fused kernel reads the gradients, it does not rewrite them)
+                    if it == 0:
+                        torch.cuda.synchronize()
+                        g1, p1 = opt.bucket.grads.detach().cpu().clone(), opt.bucket.params.detach().cpu().clone()
                     if dp is not None:
                         logs.append(list(dp.last_issue_log))
                 torch.cuda.synchronize()
@@ -738,20 +743,19 @@ def _rccl_one_rank_worker(port, q, transport, graph):
             n_slices = len(opt.bucket.slices)
             if dp is not None:
                 dp.close()
-            return out, logs, msgs, n_slices, m.__dict__.get("_ore_train_graph_error")
-        p_plain, _, msgs0, n_slices, gerr0 = steps(False)
-        p_again, _, _, _, _ = steps(False)                          # the step's own run-to-run noise (ROIAlign backward adds with atomics)
-        p_wrap, logs, msgs1, _, gerr1 = steps(True)
-        torch.manual_seed(0)
-        m0, _, cfg0 = _train_model(shots)
-        p_init = build_optimizer(cfg0, m0).bucket.params.detach().cpu().clone()
+            return {"p0": p0, "g1": g1, "p1": p1, "p3": out, "logs": logs, "msgs": msgs, "n_slices": n_slices,
+                    "gerr": m.__dict__.get("_ore_train_graph_error")}
+        a, a2, b = steps(False), steps(False), steps(True)
         ar = torch.ones(4, device="cuda")
         dist.all_reduce(ar)                                        # and a plain RCCL collective of the process group itself
-        q.put({"equal": bool(torch.equal(p_plain, p_wrap)), "noise": float((p_again - p_plain).abs().max()),
-               "diff": float((p_wrap - p_plain).abs().max()), "moved": float((p_plain - p_init).abs().max()),
-               "finite": bool(torch.isfinite(p_wrap).all()), "logs": logs,
-               "warnings": msgs0 + msgs1, "n_slices": n_slices, "backend": dist.get_backend(), "ar": ar.cpu().tolist(),
-               "graph_error": gerr0 or gerr1})
+
+        def dist_(x, y):
+            return float((x - y).abs().max())
+        q.put({"g_scale": float(a["g1"].abs().max()), "g_noise": dist_(a["g1"], a2["g1"]), "g_diff": dist_(a["g1"], b["g1"]),
+               "moved1": dist_(a["p1"], a["p0"]), "p1_noise": dist_(a["p1"], a2["p1"]), "p1_diff": dist_(a["p1"], b["p1"]),
+               "finite": bool(torch.isfinite(b["p3"]).all()), "moved3": dist_(b["p3"], b["p0"]), "logs": b["logs"],
+               "warnings": a["msgs"] + b["msgs"], "n_slices": b["n_slices"], "backend": dist.get_backend(), "ar": ar.cpu().tolist(),
+               "graph_error": a["gerr"] or b["gerr"]})
     finally:
         dist.destroy_process_group()
 
@@ -770,12 +774,12 @@ def test_rccl_one_rank_rehearsal(oh, transport, graph):
     assert p.exitcode == 0
     assert r["backend"] == "nccl" and r["ar"] == [1.0] * 4
     assert r["graph_error"] is None, r["graph_error"]
-    # a one-rank SUM is the identity: the wrapped steps equal the plain ones up to the step's own run-to-run noise (the ROIAlign
-    # backward accumulates with fp32 atomics, so two plain runs differ in the last bits too), which is tiny against the update
-    assert r["finite"] and r["moved"] > 1e-4, r
-    # (three optimizer steps amplify last-bit differences through hard decisions -- ReLU masks, the ROI sample -- so the yardstick is
-    # the distance between two PLAIN runs, measured in the same process, not a fixed fraction of the update)
-    assert r["diff"] <= 8.0 * r["noise"] + 1e-3 * r["moved"] and r["noise"] <= 0.25 * r["moved"], (r["diff"], r["noise"], r["moved"])
+    # A one-rank SUM is the identity: after ONE step the gradients the optimizer consumed and the parameters it wrote equal the plain
+    # step's up to the step's own run-to-run noise (the ROIAlign backward accumulates with fp32 atomics, so two plain runs differ in
+    # the last bits too; one step, because later steps amplify such bits through hard decisions -- ReLU masks, the ROI sample).
+    assert r["finite"] and r["moved1"] > 1e-5 and r["moved3"] > r["moved1"] * 0.5, r
+    assert r["g_diff"] <= 8.0 * r["g_noise"] + 1e-5 * r["g_scale"], (r["g_diff"], r["g_noise"], r["g_scale"])
+    assert r["p1_diff"] <= 8.0 * r["p1_noise"] + 1e-3 * r["moved1"], (r["p1_diff"], r["p1_noise"], r["moved1"])
     assert len(r["logs"]) == 3 and r["n_slices"] >= 2
     for log in r["logs"]:                                          # every slice exactly once per step ...
         assert sorted(s_ for s_, _ in log) == list(range(r["n_slices"])), log

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="query images per GPU per step (BASELINE configs[2]: 16)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the shape-static dense part (fwd + bwd) into hipGraphs")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"), help="bf16 = BASELINE configs[4]: frozen stages in bf16 storage, "
+                    "bf16 MFMA operands in the trainable convs' forward / data / weight gradients, everything else fp32")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -53,6 +55,8 @@ def main():
     m.load_state_dict(sd, strict=False)
     m.train()
     m.train_graph = bool(a.graph)
+    import orehip
+    orehip.set_conv_precision(a.precision)
     model = FlatDataParallel(m, cfg, overlap=not a.no_overlap) if world > 1 else m
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
@@ -90,7 +94,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "train_images_per_second", "value": world * a.batch * a.steps / el, "unit": "img/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
-                          "scaling": "weak", "dtype": "f32", "data": "synthetic",
+                          "scaling": "weak", "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
                           "config": {"workload": "finetune_vovnet.yaml train step, %d x (1 query %dx%d + %d support 240x240) per GPU" % (a.batch, a.size, a.size, a.shots),
                                      "batch_per_gpu": a.batch,
                                      "bucket_bytes": 4 * opt.bucket.size},

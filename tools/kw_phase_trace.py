@@ -21,15 +21,16 @@ RF = False           # True: the layer runs on k_conv_rf (stamps of csrc/ore_con
 KD = False           # True: ... on k_conv_kd (csrc/ore_conv_kd.hip)
 
 
-def trace(H, W, Cin, Cout, k, reps=5):
+def trace(H, W, Cin, Cout, k, reps=5, stride=1):
     x = torch.randn(1, H, W, Cin, device=dev)
     w = orehip.pack_conv_weight(torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5).to(dev)
     sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
-    out = torch.empty(1, H, W, Cout, device=dev)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    out = torch.empty(1, Ho, Wo, Cout, device=dev)
     other = torch.randn(64 << 20, device=dev)                       # 256 MB: evicts L2 / MALL between the timed launches
 
     def run():
-        orehip.conv2d(x, w, Cout, k, 1, scale=sc, shift=sh, relu_cout=Cout, out=out)
+        orehip.conv2d(x, w, Cout, k, stride, scale=sc, shift=sh, relu_cout=Cout, out=out)
     for _ in range(3):
         run()
     # plain timing, back to back, as the engine's graph replays them
@@ -77,6 +78,9 @@ def trace(H, W, Cin, Cout, k, reps=5):
         idx = [(0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9)]
     for tag, t in zip(("warm", "cold"), res):
         n = len(t)
+        if n == 0:
+            print("  [%s] (this kernel carries no stamps)" % tag)
+            continue
         rt0, rt1 = t[:, 1].min(), t[:, 10].max()
         print("  [%s] %d blocks; wall (100 MHz clock): first block start -> last block end %.2f us; block start spread %.2f us; "
               "block lifetime median %.2f max %.2f us" % (tag, n, (rt1 - rt0) / 100.0, (t[:, 1].max() - rt0) / 100.0,
@@ -129,6 +133,26 @@ if __name__ == "__main__":
         L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
         L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
         L.ore_conv_set_plan_override(-10, 1, 0, 0, 0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "kdbig":                # the lean-DMA kernel on the LARGE-M layers (stem_3, the stage-2 / 3 concats)
+        KD = True
+        L.ore_conv_set_plan_override(-12, 2, 0, 0, 0)
+        for shape, stride in (((80, 80, 352, 256, 1), 1), ((160, 160, 320, 112, 1), 1), ((320, 320, 64, 128, 3), 2), ((80, 80, 256, 128, 1), 1)):
+            L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
+            L.ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+            print("#### the plan's kernel (k_conv_gs / k_conv_igemm / k_conv_kw)")
+            KD = False
+            us = trace(*shape, reps=1, stride=stride)
+            KD = True
+            L.ore_conv_set_plan_override(-12, 2, 0, 0, 0)
+            for bm, bn, nw, sb in ((64, 64, 4, 2), (32, 64, 4, 2), (32, 80, 4, 2), (64, 128, 4, 1), (64, 112, 4, 1), (128, 64, 4, 1)):
+                L.ore_conv_set_plan_override(-13, bm, bn, nw, sb)
+                print("#### k_conv_kd<%dx%d, NW %d, SB %d>" % (bm, bn, nw, sb))
+                try:
+                    trace(*shape, reps=2, stride=stride)
+                except orehip.OreError as ex:
+                    print("   not built:", str(ex)[:100])
+        L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
+        L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "sweep":                 # ring depth / waves per block on the latency-bound shapes
         for shape in ((20, 20, 112, 112, 3), (40, 40, 96, 96, 3), (20, 20, 512, 128, 1)):
             for nw, ns in ((4, 2), (4, 3), (4, 4), (8, 2), (16, 2)):
