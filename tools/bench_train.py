@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="query images per GPU per step (BASELINE configs[2]: 16)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the shape-static dense part (fwd + bwd) into hipGraphs")
+    ap.add_argument("--no-kd", action="store_true", help="A/B aid: keep the small-M layers on k_conv_kw (plan override -12 0)")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"), help="bf16 = BASELINE configs[4]: frozen stages in bf16 storage, "
                     "bf16 MFMA operands in the trainable convs' forward / data / weight gradients, everything else fp32")
     a = ap.parse_args()
@@ -57,6 +58,9 @@ def main():
     m.train_graph = bool(a.graph)
     import orehip
     orehip.set_conv_precision(a.precision)
+    if a.no_kd:
+        orehip.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+        orehip.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)
     model = FlatDataParallel(m, cfg, overlap=not a.no_overlap) if world > 1 else m
     opt = build_optimizer(cfg, model)
     sched = build_lr_scheduler(cfg, opt)
