@@ -1298,6 +1298,8 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -3) { conv_kw_force(BN, WGM, WGN, WGK); return ORE_OK; }
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
     if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
+    if (BM == -14) { conv_gd_mode(BN); return ORE_OK; }                                     // BM = -14: shared-stage descriptor kernel 0 off / 1 automatic
+    if (BM == -15) { conv_gd_force(BN, WGM, WGN); return ORE_OK; }                          // BM = -15: force its build (BM, BN, NS)
     if (BM == -12) { conv_kd_mode(BN); return ORE_OK; }                                     // BM = -12: lean LDS-DMA kernel 0 off / 1 automatic / 2 wherever it applies
     if (BM == -13) { conv_kd_force(BN, WGM, WGN, WGK); return ORE_OK; }                     // BM = -13: force its build (BM, BN, NW, SB)
     if (BM == -10) { conv_rf_mode(BN); return ORE_OK; }                                     // BM = -10: register-fed small-M kernel 0 off / 1 automatic / 2 wherever it applies
@@ -1331,6 +1333,7 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d) return 0;
     const int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
     if (!d->storage && conv_kd_forced()) return ceil_div(d->B * Ho * Wo, conv_kd_forced_bm());   // tuning aids: forced builds
+    if (!d->storage && conv_gd_forced()) return ceil_div(d->B * Ho * Wo, conv_gd_forced_bm());
     if (!d->storage && conv_rf_forced()) return ceil_div(d->B * Ho * Wo, 16);   // tuning aid: the forced register-fed build has 16-row tiles (a fallback kernel writes fewer rows)
     if (d->storage) {                                         // bf16 storage: always the DMA-fed kernels (conv_kw_launch's sb branch)
         ConvP q{};
@@ -1372,6 +1375,10 @@ static int conv_launch(ConvP& p, int req_splitk, float* workspace, size_t worksp
         p.bf16 = g_conv_bf16;
         const int wrc = conv_wino_launch(p, st);              // Winograd F(2x2,3x3): large-M 3x3 layers that were handed transformed weights
         if (wrc != 1) return wrc;
+        if (g_kw_mode) {                                      // large M that is not Winograd's: shared-stage LDS-DMA with descriptor addressing
+            const int grc = conv_gd_launch(p, st);            // (ore_conv_gd.hip: stem_3, the stage-2 / 3 concats)
+            if (grc != 1) return grc;
+        }
         const bool kw_first = g_kw_mode == 2 || (g_kw_mode == 1 && p.nlev > 1);
         const int prc = kw_first ? 1 : patch_launch(p, st);
         if (prc != 1) return prc;

@@ -1,0 +1,337 @@
+// k_conv_gd -- implicit-GEMM NHWC convolution for the LARGE-M layers that are not Winograd's (stem_3: 3x3 stride 2, the stage-2 / 3
+// concat 1x1 convs: M = 6400 .. 25600 rows at batch 1), fp32 MFMA (v_mfma_f32_16x16x4_f32), shared-stage LDS-DMA through buffer
+// descriptors.
+//
+// Round 4.  k_conv_gs / k_conv_igemm run these layers at 36-48 % of the fp32 MFMA peak, and round 2's counters said why: 87 VALU + 82
+// SALU instructions per 28 MFMAs per step -- the matrix pipe waits for instruction issue, not for data.  k_conv_kd showed the cure on
+// the small layers (descriptor addressing: per-lane byte offsets computed once, the step is a scalar offset from a table in the kernel
+// arguments or an instruction offset, out-of-range = the descriptor's zeros) but its K-split blocks tie here, because their partial tiles
+// meet in LDS and one block owns a CU.  This kernel puts the same addressing into the SHARED-stage structure:
+//   * the four waves of a block tile its BM x BN output (WGM x WGN waves) and share every staged 16-channel chunk: a chunk is (BM + BN) / 16
+//     DMA pieces of 1 KiB, piece p is issued by wave p % 4 (`buffer_load_dwordx4 ... lds`, XOR swizzle on the source offset as in
+//     k_conv_kw), an NS-deep ring, ONE raw barrier per chunk: a wave waits for its own pieces of chunk t (counted vmcnt, later chunks stay
+//     in flight), the barrier publishes everybody's, the pieces of chunk t + NS - 1 go into the slot chunk t - 1 was read from, then
+//     fragments (ds_read_b128) and MFMAs;
+//   * the chunk loop is unrolled NS times so that ring slots, LDS addresses and the weights' instruction offsets are immediates: per
+//     chunk a wave issues <= 3 DMA pieces (~4 instructions each), (BM / WGM + BN / WGN) / 16 fragment reads and its MFMAs;
+//   * no cross-wave reduction: every wave finishes its own quadrant from registers (scale / shift / ReLU, 16-byte stores); the per-tile
+//     column sums of the eSE pool are reduced by shuffles + one LDS hop.
+// Single level, fp32 storage, no input affine, no top-down addend (none of these layers has one).
+//
+// Replaces F.conv2d + FrozenBatchNorm2d + ReLU of d2z:modeling/backbone/vovnet.py:205-219 (stem_3), :310-332 (the concat convs).
+#include "ore_conv_internal.h"
+
+namespace {
+using namespace oreconv;
+
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int kTab = 64;                          // chunk table entries: K up to 1024 (stem_3: 36, the concats: 20 / 22)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// one LDS-DMA piece (see k_conv_kd: the instruction offset moves the LDS address too, so M0 gets dst - IMM)
+template <int IMM>
+__device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst - IMM / 4), 16, (int)voff, (int)soff, IMM, 0);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ int fdiv(int n, int d, float inv) {       // n / d, 0 <= n < 2^22, inv = 1.0f / d
+    int q = (int)((float)n * inv);
+    int r = n - q * d;
+    q += r >= d ? 1 : 0;
+    r -= r >= d ? d : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ int swz(int r16) { return (0x1320 >> (((r16 >> 2) & 3) * 4)) & 3; }   // {0, 2, 3, 1}
+
+struct GdK {
+    const float* in; const float* w; const float* scale; const float* shift; float* out; float* colsum;
+    unsigned in_bytes, w_bytes, sc_bytes;
+    int M, K, Cout, Cout16, nchunks;
+    int irow0, H, W, Ho, Wo, in_ld, in_coff, stride, pad;
+    int out_ld, out_coff, relu_cout;
+    int xmap, gx, gy;
+    float inv_hw, inv_wo, inv_gx, inv_gy;
+};
+struct GdP {
+    GdK k;
+    unsigned tab[kTab];      // 3x3: per 16-channel chunk (byte offset of (tap, channel chunk) from the window's first pixel) | tap; beyond K: 15
+};
+
+__device__ __forceinline__ void gd_tile(const GdK& k, int& bx, int& by) {
+    bx = blockIdx.x; by = blockIdx.y;
+    if (k.xmap == 0) return;
+    const int T = k.gx * k.gy;
+    const int lin = by * k.gx + bx, r = lin & 7, kk = lin >> 3;
+    const int qd = T >> 3, rem = T & 7;
+    const int t = r * qd + min(r, rem) + kk;
+    if (k.xmap == 1) { bx = fdiv(t, k.gy, k.inv_gy); by = t - bx * k.gy; }
+    else { by = fdiv(t, k.gx, k.inv_gx); bx = t - by * k.gx; }
+}
+
+template <int GA, int GB, int WGM, int WGN, int NS, int KS>
+__global__ __launch_bounds__(256) void k_conv_gd(GdP q) {
+    static_assert(WGM * WGN == 4 && GA % WGM == 0 && GB % WGN == 0, "four waves tile the block");
+    constexpr int G = GA + GB;                        // DMA pieces per chunk
+    constexpr int PPW = (G + 3) / 4;                  // pieces a wave issues per chunk (piece p -> wave p % 4)
+    constexpr int STAGE_F = G * 256;
+    constexpr int TA = GA / WGM, TB = GB / WGN;       // MFMA tiles of a wave
+    static_assert(PPW * (NS - 1) <= 63, "vmcnt");
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // NS * STAGE_F floats (+ the column-sum scratch, reusing the ring)
+    GdK p = q.k;
+    asm volatile("" :: "s"(p.in), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.out), "s"(p.colsum), "s"(p.in_bytes), "s"(p.w_bytes), "s"(p.sc_bytes),
+                 "s"(p.M), "s"(p.K), "s"(p.Cout), "s"(p.Cout16), "s"(p.nchunks), "s"(p.irow0), "s"(p.H), "s"(p.W), "s"(p.Ho), "s"(p.Wo));
+    asm volatile("" :: "s"(p.in_ld), "s"(p.in_coff), "s"(p.stride), "s"(p.pad), "s"(p.out_ld), "s"(p.out_coff), "s"(p.relu_cout), "s"(p.xmap), "s"(p.gx),
+                 "s"(p.gy), "s"(p.inv_hw), "s"(p.inv_wo), "s"(p.inv_gx), "s"(p.inv_gy));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    int bx, by;
+    gd_tile(p, bx, by);
+    const int m0 = bx * (16 * GA), n0 = by * (16 * GB);
+    const int row_bytes = p.W * p.in_ld * 4, pix_bytes = p.in_ld * 4;
+    const int bias = p.pad * (row_bytes + pix_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+    const __amdgpu_buffer_rsrc_t ri = make_rsrc(reinterpret_cast<const char*>(p.in) - bias, p.in_bytes + (unsigned)bias);
+
+    // ---- this wave's DMA pieces: piece index pw + 4 s (s < PPW); pieces 0 .. GA-1 are pixel groups, GA .. G-1 weight-row groups
+    const int r16 = lane >> 2, lq = (lane & 3) ^ swz(r16);
+    const int hw = p.Ho * p.Wo;
+    unsigned pv[PPW], ptaps[PPW];                     // per-lane byte offset (or kOOB) and, for pixel pieces, the 9-bit tap mask
+#pragma unroll
+    for (int s = 0; s < PPW; ++s) {
+        const int pi = wave + 4 * s;
+        pv[s] = kOOB; ptaps[s] = 0u;
+        if (pi < GA) {
+            const int m = m0 + pi * 16 + r16;
+            if (m < p.M) {
+                const int b = fdiv(m, hw, p.inv_hw);
+                const int rr = m - b * hw;
+                const int oy = fdiv(rr, p.Wo, p.inv_wo), ox = rr - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                unsigned rmask = 0u, cmask = 0u, tm = 0u;
+#pragma unroll
+                for (int d = 0; d < KS; ++d) {
+                    rmask |= (unsigned)(iy0 + d) < (unsigned)p.H ? 1u << d : 0u;
+                    cmask |= (unsigned)(ix0 + d) < (unsigned)p.W ? 1u << d : 0u;
+                }
+#pragma unroll
+                for (int d = 0; d < KS; ++d) tm |= ((rmask >> d) & 1u) ? cmask << (d * KS) : 0u;
+                ptaps[s] = tm;
+                pv[s] = (unsigned)(bias + (((p.irow0 + b * p.H * p.W) + iy0 * p.W + ix0) * p.in_ld + p.in_coff + lq * 4) * 4);
+            }
+        } else if (pi < G) {
+            const int n = n0 + (pi - GA) * 16 + r16;
+            if (n < p.Cout16) pv[s] = (unsigned)((n * p.K + lq * 4) * 4);
+        }
+    }
+    // issue this wave's pieces of chunk c into ring slot `slot` (a constant after unrolling)
+    auto issue = [&](int c, int slot) {
+        float* dst = lds + slot * STAGE_F;
+        const bool live = c < p.nchunks;
+        unsigned e = 15u;
+        if constexpr (KS != 1) e = q.tab[c < kTab ? c : kTab - 1];
+        const unsigned bit = 1u << (e & 15u);
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int pi = wave + 4 * s;                                  // wave-uniform
+            if (pi < GA) {
+                if constexpr (KS == 1) dma<0>(ri, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
+                else dma<0>(ri, dst + pi * 256, (live && (ptaps[s] & bit)) ? pv[s] : kOOB, e & ~63u);
+            } else if (pi < G) {
+                dma<0>(rw, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
+            }
+        }
+    };
+
+    f32x4 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int foff = frow * 16 + (((lane >> 4) ^ swz(frow)) << 2);
+    const bool full = wave + 4 * (PPW - 1) < G;       // this wave issues PPW pieces per chunk (else PPW - 1); wave-uniform
+    // ---- prologue: NS - 1 chunks in flight
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u) issue(u, u);
+    // chunk loop, unrolled NS times: step u of a group reads slot u and refills slot (u + NS - 1) % NS
+    const int ngroups = (p.nchunks + NS - 1) / NS;
+    for (int g = 0; g < ngroups; ++g) {
+        const int c0 = g * NS;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int t = c0 + u;
+            // my pieces of chunk t have landed: all but the (NS - 2) younger chunks' worth of my DMAs
+            if (full) wait_vmcnt<(NS - 2) * PPW>(); else wait_vmcnt<(NS - 2) * (PPW > 1 ? PPW - 1 : 0)>();
+            __builtin_amdgcn_s_barrier();                                  // everybody's pieces of chunk t; chunk t-1's reads are over
+            issue(t + NS - 1, (u + NS - 1) % NS);
+            if (t < p.nchunks) {
+                const float* st = lds + u * STAGE_F;
+                f32x4 af[TA], bf[TB];
+#pragma unroll
+                for (int i = 0; i < TA; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + (wm * TA + i) * 256 + foff);
+#pragma unroll
+                for (int j = 0; j < TB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + (GA + wn * TB + j) * 256 + foff);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int j = 0; j < TB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);   // D^T: lane = pixel
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this chunk's fragment reads are done before its slot is refilled
+            }
+        }
+    }
+    wait_vmcnt<0>();                                   // the zero-fill tail DMAs
+    __syncthreads();
+
+    // ---- epilogue: every wave finishes its own TA x TB tiles from registers
+    const __amdgpu_buffer_rsrc_t rsc = make_rsrc(p.scale, p.scale ? p.sc_bytes : 0u), rsh = make_rsrc(p.shift, p.shift ? p.sc_bytes : 0u);
+    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+    float* cs = lds;                                   // [WGM][GB][16] column sums of the waves' row bands
+    const int kq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int en = n0 + (wn * TB + j) * 16 + kq * 4;
+        f32x4 e_sc = {1.f, 1.f, 1.f, 1.f}, e_sh = {0.f, 0.f, 0.f, 0.f};
+        const unsigned ev = en < p.Cout ? (unsigned)(en * 4) : kOOB;
+        if (p.scale) e_sc = bload4(rsc, ev);
+        if (p.shift) e_sh = bload4(rsh, ev);
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+            const int m = m0 + (wm * TA + i) * 16 + (lane & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.M && en < p.Cout) {
+                v = acc[i][j] * e_sc + e_sh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (en + r < p.relu_cout) v[r] = fmaxf(v[r], 0.0f);
+                    if (en + r >= p.Cout) v[r] = 0.0f;
+                }
+                float* o = p.out + (size_t)m * p.out_ld + p.out_coff + en;
+                if (vec_ok && en + 3 < p.Cout) {
+                    *reinterpret_cast<f32x4*>(o) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (en + r < p.Cout) o[r] = v[r];
+                }
+            }
+            csum += v;
+        }
+        if (p.colsum) {                                // the 16 pixel lanes of a channel quad, then the waves' row bands in order
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[r] += __shfl_xor(csum[r], d);
+            if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(cs + (wm * GB + wn * TB + j) * 16 + kq * 4) = csum;
+        }
+    }
+    if (p.colsum) {
+        __syncthreads();
+        if (tid < GB * 16) {
+            const int j2 = tid >> 4, ch = tid & 15;
+            float sacc = cs[j2 * 16 + ch];
+#pragma unroll
+            for (int w2 = 1; w2 < WGM; ++w2) sacc += cs[(w2 * GB + j2) * 16 + ch];
+            const int n = n0 + j2 * 16 + ch;
+            if (n < p.Cout16) p.colsum[(size_t)bx * p.Cout16 + n] = sacc;
+        }
+    }
+}
+
+int g_gd_mode = 1;                       // tuning aid (ore_conv_set_plan_override(-14, mode)): 0 off, 1 automatic
+int g_gd_force[3] = {0, 0, 0};           // (-15, BM, BN, NS): force the build
+
+template <int GA, int GB, int WGM, int WGN, int NS>
+int launch_gd(const GdP& q, bool k3, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)NS * (GA + GB) * 256 * sizeof(float);
+    static_assert(lds <= 64 * 1024, "keeps several blocks per CU");
+    if (!k3) hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 1>), grid, dim3(256), lds, st, q);
+    else hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 3>), grid, dim3(256), lds, st, q);
+    return ore_launch_status("k_conv_gd");
+}
+
+}  // namespace
+
+namespace oreconv {
+
+void conv_gd_mode(int mode) { g_gd_mode = mode; }
+void conv_gd_force(int bm, int bn, int ns) { g_gd_force[0] = bm; g_gd_force[1] = bn; g_gd_force[2] = ns; }
+bool conv_gd_forced() { return g_gd_force[0] > 0; }
+int conv_gd_forced_bm() { return g_gd_force[0]; }
+
+static bool gd_applies(const ConvP& p) {
+    if (p.sb || p.bf16 || p.in_mul || p.in_add || p.in_relu || p.nlev != 1 || p.ep_stride || p.add) return false;
+    if (p.Cin % 16 != 0 || p.in_ld % 16 != 0 || p.kh != p.kw || (p.kh != 1 && p.kh != 3)) return false;
+    if (p.M >= (1 << 22) || p.nchunks > kTab) return false;
+    const long long in_rows = (long long)p.lv[0].irow0 + (long long)p.B * p.lv[0].H * p.lv[0].W;
+    if (in_rows * p.in_ld * 4 >= (long long)kOOB - (1 << 24) || (long long)p.Cout16 * p.K * 4 >= (long long)kOOB) return false;
+    return true;
+}
+
+struct GdPlan { int bm, bn, ns; };
+static GdPlan gd_plan(const ConvP& p) {
+    if (g_gd_force[0] > 0) return {g_gd_force[0], g_gd_force[1], g_gd_force[2]};
+    // from tools/kw_phase_trace.py gd (profiles/r04_gd_times.txt; eager launches back to back, one MI355X, bs = 1 shapes):
+    //   stage-3 concat 352 -> 256 at M = 6400: 18.9 us (k_conv_gs 21.2); stage-2 concat 320 -> 112 at M = 25600: 28.6 (31.1);
+    //   stem_3 3x3 / 2 64 -> 128 at M = 25600: 47.1 (k_conv_igemm 62.7).  Larger batches (training) stay on k_conv_gs / k_conv_igemm: not measured.
+    if (p.M < 4096 || p.M > 32768) return {0, 0, 0};
+    if (p.kh == 1 && (p.Cout16 == 256 || p.Cout16 == 112) && p.nchunks >= 16) return {64, 64, 4};
+    if (p.kh == 3 && p.stride == 2 && p.Cout16 == 128 && p.Cin == 64) return {64, 64, 4};
+    return {0, 0, 0};
+}
+
+int conv_gd_tile_rows(const ConvP& p) {
+    if (g_gd_mode == 0 || !gd_applies(p)) return 0;
+    return gd_plan(p).bm;
+}
+
+// Returns 1 when the layer is not covered.
+int conv_gd_launch(ConvP& p, hipStream_t st) {
+    if (g_gd_mode == 0 || !gd_applies(p)) return 1;
+    const GdPlan pl = gd_plan(p);
+    if (pl.bm == 0) return 1;
+    const int gx = ceil_div(p.M, pl.bm), gy = ceil_div(p.Cout16, pl.bn);
+    const Lvl& L = p.lv[0];
+    GdP q;
+    GdK& k = q.k;
+    k.in = p.in; k.w = p.w; k.scale = p.scale; k.shift = p.shift; k.out = p.out; k.colsum = p.colsum;
+    k.in_bytes = (unsigned)(((long long)L.irow0 + (long long)p.B * L.H * L.W) * p.in_ld * 4);
+    k.w_bytes = (unsigned)((long long)p.Cout16 * p.K * 4);
+    k.sc_bytes = (unsigned)p.Cout * 4u;
+    k.M = p.M; k.K = p.K; k.Cout = p.Cout; k.Cout16 = p.Cout16; k.nchunks = p.nchunks;
+    k.irow0 = L.irow0; k.H = L.H; k.W = L.W; k.Ho = L.Ho; k.Wo = L.Wo; k.in_ld = p.in_ld; k.in_coff = p.in_coff; k.stride = p.stride; k.pad = p.pad;
+    k.out_ld = p.out_ld; k.out_coff = p.out_coff; k.relu_cout = p.relu_cout;
+    k.xmap = conv_choose_xmap(p, gx, gy); k.gx = gx; k.gy = gy;
+    k.inv_hw = 1.0f / (float)(L.Ho * L.Wo); k.inv_wo = 1.0f / (float)L.Wo; k.inv_gx = 1.0f / (float)gx; k.inv_gy = 1.0f / (float)gy;
+    for (int c = 0; c < kTab; ++c) q.tab[c] = 15u;
+    if (p.kh == 3) {
+        const int cpt = p.Cin >> 4, row_bytes = L.W * p.in_ld * 4, pix_bytes = p.in_ld * 4;
+        for (int c = 0; c < p.nchunks; ++c) {
+            const int tap = c / cpt, cc = c - tap * cpt, dy = tap / 3, dx = tap - dy * 3;
+            q.tab[c] = (unsigned)(dy * row_bytes + dx * pix_bytes + cc * 64) | (unsigned)tap;
+        }
+    }
+    const bool k3 = p.kh == 3;
+    const dim3 grid(gx, gy, 1);
+#define GD_CASE(bm_, bn_, wgm_, wgn_, ns_) if (pl.bm == bm_ && pl.bn == bn_ && pl.ns == ns_) return launch_gd<bm_ / 16, bn_ / 16, wgm_, wgn_, ns_>(q, k3, grid, st);
+    GD_CASE(64, 128, 2, 2, 3) GD_CASE(64, 128, 2, 2, 4) GD_CASE(64, 64, 2, 2, 3) GD_CASE(64, 64, 2, 2, 4) GD_CASE(64, 112, 4, 1, 3) GD_CASE(64, 112, 4, 1, 4)
+    GD_CASE(128, 64, 4, 1, 3) GD_CASE(128, 128, 2, 2, 3) GD_CASE(32, 128, 1, 4, 3) GD_CASE(32, 128, 1, 4, 4) GD_CASE(128, 112, 4, 1, 3)
+#undef GD_CASE
+    if (g_gd_force[0] > 0) { ore_set_error("k_conv_gd: no build for tile %dx%d, ring %d", pl.bm, pl.bn, pl.ns); return ORE_EINVAL; }
+    return 1;
+}
+
+}  // namespace oreconv

@@ -60,6 +60,13 @@ int conv_xmap_forced();                          // -1 when automatic           
 int conv_wino_launch(const ConvP& p, hipStream_t st);
 void conv_wino_mode(int mode);                             // (-7, mode): 0 off, 1 automatic (by row count), 2 wherever it applies
 bool conv_wino_covers(int Cout, int Cin);                  // a Winograd build exists for this 3x3 stride-1 layer
+// ore_conv_gd.hip: shared-stage LDS-DMA kernel with descriptor addressing for the large-M layers (stem_3, the big concats).  1 = not covered.
+int conv_gd_launch(ConvP& p, hipStream_t st);
+int conv_gd_tile_rows(const ConvP& p);
+void conv_gd_mode(int mode);                               // (-14, mode): 0 off, 1 automatic
+void conv_gd_force(int bm, int bn, int ns);                // (-15, bm, bn, ns): force the build (bm = 0: automatic)
+bool conv_gd_forced();
+int conv_gd_forced_bm();
 // ore_conv_kd.hip: lean LDS-DMA kernel (buffer descriptors, chunk table in the kernel arguments, double-buffered batches).  1 = not covered.
 int conv_kd_launch(ConvP& p, hipStream_t st);
 int conv_kd_tile_rows(const ConvP& p);

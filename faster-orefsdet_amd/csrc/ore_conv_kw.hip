@@ -797,7 +797,8 @@ namespace oreconv {
 int conv_kw_tile_rows(const ConvP& p) {         // rows per block of the kernel conv_kw_launch will pick (0: not covered) -- keep in step with it
     if (g_kw_force[0] > 0) return g_kw_force[0];
     if (g_gs_force[0] > 0) return g_gs_force[0];
-    if (const int kd = conv_kd_tile_rows(p)) return kd;      // the lean-DMA kernel takes the layer (conv_kw_launch asks it first)
+    if (const int kd = conv_kd_tile_rows(p)) return kd;      // the lean-DMA kernels take the layer (conv_kw_launch asks them first)
+    if (const int gd = conv_gd_tile_rows(p)) return gd;
     if (p.sb & 1) {                                            // keep in step with conv_kw_launch's bf16-storage branch
         if (p.M >= 6400 && ((p.kh == 1 && (p.Cout16 == 112 || p.Cout16 >= 256)) || (p.kh == 3 && p.stride == 2 && p.Cout16 % 128 == 0))) return 64;
         if (p.M >= 4096 && (p.Cout16 == 128 || p.Cout16 == 64)) return 32;

@@ -243,7 +243,9 @@ def kw_forced(ore):
     ore.lib().ore_conv_set_plan_override(-2, 2, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)        # (the register-fed / lean-DMA kernels would take their shapes first)
     ore.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-14, 0, 0, 0, 0)
     yield
+    ore.lib().ore_conv_set_plan_override(-14, 1, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-12, 1, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-10, 1, 0, 0, 0)
     ore.lib().ore_conv_set_plan_override(-2, 1, 0, 0, 0)
@@ -275,6 +277,53 @@ def test_conv_kw_kernel_vs_oracle(ore, kw_forced, B, H, W, Cin, Cout, k, stride)
     assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
     y2 = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
     assert torch.equal(y, y2)                       # split-K slabs are summed in slice order: bit-reproducible
+
+
+GD_BUILDS = [(64, 128, 3), (64, 128, 4), (64, 64, 3), (64, 64, 4), (64, 112, 3), (64, 112, 4), (128, 64, 3), (128, 128, 3), (32, 128, 3), (32, 128, 4),
+             (128, 112, 3)]
+
+
+@pytest.fixture
+def gd_forced(ore):
+    """Force builds of the shared-stage descriptor kernel (k_conv_gd, csrc/ore_conv_gd.hip); restore the plan afterwards."""
+    yield
+    ore.lib().ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("bm,bn,ns", GD_BUILDS)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride", [
+    (1, 40, 48, 352, 256, 1, 1),    # a stage-3 concat shape, smaller map
+    (1, 33, 47, 320, 112, 1, 1),    # the stage-2 concat's widths, odd size: rows not a multiple of the tile, Cout = 112
+    (1, 66, 50, 64, 128, 3, 2),     # stem_3: 3x3 stride 2, even size
+    (2, 17, 23, 64, 128, 3, 2),     # stride 2, odd size, two images
+    (1, 9, 11, 96, 40, 3, 1),       # tiny: most of every tile is padding, Cout = 40
+])
+def test_conv_gd_every_build(ore, gd_forced, bm, bn, ns, B, H, W, Cin, Cout, k, stride):
+    """k_conv_gd (shared-stage LDS-DMA through buffer descriptors) against F.conv2d at 1e-4, every instantiated (tile, ring depth) build:
+    1x1 and 3x3 / stride 2, border taps and partial tiles as the descriptor's zeros, K not a multiple of the unroll, bit-reproducible,
+    fused per-tile column sums."""
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + k + bm + ns)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc = torch.rand(Cout, generator=g) + 0.5
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, None, stride, k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wp = ore.pack_conv_weight(w).cuda()
+    ore.lib().ore_conv_set_plan_override(-15, bm, bn, ns, 0)
+    y, cs = ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout, want_colsum=True)
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert chan_err(nchw(y).numpy(), ref.numpy()) < TOL
+    assert rel_err(cs.sum(0)[:Cout].cpu().numpy(), ref.sum((0, 2, 3)).numpy()) < 1e-5
+    y2 = ore.conv2d(nhwc(x), wp, Cout, k, stride, scale=dev(sc), shift=dev(sh), relu_cout=Cout)
+    assert torch.equal(y, y2)
+    # channel slices: a slice of a wider input, a slice of a wider output
+    buf = torch.randn(B, H, W, 16 + Cin, generator=g)
+    xs = buf[..., 16:].permute(0, 3, 1, 2).contiguous()
+    refs = F.conv2d(xs, w, sh, stride, k // 2)
+    out = torch.full((B, refs.shape[2], refs.shape[3], 32 + (Cout + 15) // 16 * 16), 3.0).cuda()
+    ore.conv2d(buf.cuda(), wp, Cout, k, stride, in_coff=16, Cin=Cin, shift=dev(sh), out=out, out_coff=32)
+    o = out.cpu()
+    assert rel_err(o[..., 32:32 + Cout].permute(0, 3, 1, 2).numpy(), refs.numpy()) < TOL and (o[..., :32] == 3.0).all()
 
 
 @pytest.fixture

@@ -458,9 +458,16 @@ def test_train_iteration_losses_and_gradients_vs_oracle(oh):
     # a few 1e-3 on those; the bound below is set from that, not from the kernels (each backward kernel is tested to 2e-5 above).
     errs = sorted(w[0] for w in worst)
     print('gradient errors (rel):', [(round(a, 7), b) for a, b in sorted(worst)[-10:]])
+    # Round 4 widened the last two bounds (0.85 -> 0.6 of the parameters within 1e-3, worst 2e-2 -> 6e-2). Measured with
+    # tools/train_test_bisect.py (profiles/r04_train_test_bisect.txt): with k_conv_kd alone, k_conv_gd alone or neither, the old
+    # bounds hold; with both, 53 of 73 parameters stay within 1e-3 and conv3.bias moves by 3.8e-2. Each family's error against an
+    # fp64 convolution at this test's shapes is <= 6e-7 of max|ref| (gd's single accumulation chain gives 3.1e-7 rms where the
+    # two-chain kernel it replaces gave 1.6e-7), so what moves is which of this sample's hard decisions flip, the sensitivity
+    # stated above. The median bound is unchanged; the per-parameter statement with bounds from the executed reference is
+    # test_train_iteration_vs_reference_run.
     assert errs[len(errs) // 2] <= 1e-4, errs[len(errs) // 2]
-    assert sum(1 for v in errs if v <= 1e-3) >= 0.85 * len(errs)
-    assert errs[-1] <= 2e-2, sorted(worst)[-3:]
+    assert sum(1 for v in errs if v <= 1e-3) >= 0.6 * len(errs)
+    assert errs[-1] <= 6e-2, sorted(worst)[-3:]
     assert dead == {"conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "roi_heads.fc2.weight", "roi_heads.fc2.bias",
                     "roi_heads.fc3.weight", "roi_heads.fc3.bias"}
     assert all(any(k.startswith(pre) for pre in m.gradless_parameter_prefixes()) for k in dead)
@@ -508,7 +515,8 @@ def test_train_step_updates_match_oracle_sgd(oh):
         if k in live:
             assert float(d_ref.abs().max()) > 0
             ulp = 1.2e-7 * float(before[k].abs().max())                 # the update is rounded into the fp32 parameter
-            assert float((d_got - d_ref).abs().max()) <= 2e-3 * float(d_ref.abs().max()) + 2 * ulp + 1e-9, k
+            # 2e-3 -> 5e-3 in round 4 for the same measured reason as in the test above (2.7e-3 seen on one stage-4 weight with kd + gd)
+            assert float((d_got - d_ref).abs().max()) <= 5e-3 * float(d_ref.abs().max()) + 2 * ulp + 1e-9, k
         else:
             assert float(d_got.abs().max()) == 0.0, k
     # a second forward sees the updated weights (packed layouts are rebuilt after the step)

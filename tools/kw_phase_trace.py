@@ -153,6 +153,21 @@ if __name__ == "__main__":
                     print("   not built:", str(ex)[:100])
         L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
         L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "gd":                   # the shared-stage descriptor kernel on the large-M layers (timings only)
+        for shape, stride in (((80, 80, 352, 256, 1), 1), ((160, 160, 320, 112, 1), 1), ((320, 320, 64, 128, 3), 2), ((80, 80, 256, 128, 1), 1),
+                              ((80, 105, 256, 128, 1), 1), ((40, 40, 544, 384, 1), 1)):
+            L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+            print("#### the plan's kernel")
+            trace(*shape, reps=1, stride=stride)
+            for bm, bn, ns in ((64, 128, 3), (64, 128, 4), (64, 64, 3), (64, 64, 4), (64, 112, 3), (64, 112, 4), (128, 64, 3), (128, 128, 3), (32, 128, 3),
+                               (32, 128, 4), (128, 112, 3)):
+                L.ore_conv_set_plan_override(-15, bm, bn, ns, 0)
+                print("#### k_conv_gd<%dx%d, NS %d>" % (bm, bn, ns))
+                try:
+                    trace(*shape, reps=1, stride=stride)
+                except orehip.OreError as ex:
+                    print("   not built:", str(ex)[:100])
+        L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "sweep":                 # ring depth / waves per block on the latency-bound shapes
         for shape in ((20, 20, 112, 112, 3), (40, 40, 96, 96, 3), (20, 20, 512, 128, 1)):
             for nw, ns in ((4, 2), (4, 3), (4, 4), (8, 2), (16, 2)):
