@@ -414,7 +414,7 @@ def test_train_iteration_losses_and_gradients_vs_oracle(oh):
     from fewx.modeling.fsod.train_forward import train_forward
     shots = 4
     m, sd, cfg = _train_model(shots)
-    img, gt, sup, sbox = T.synth_train_inputs(0, (320, 384), n_gt=9, shots=shots, support_hw=112)
+    img, gt, sup, sbox = T.synth_train_inputs(5, (320, 384), n_gt=9, shots=shots, support_hw=112)   # seed: see the comment at the bounds
     # ---- oracle
     leaf = T.leaf_state(sd)
     g = torch.Generator().manual_seed(11)
@@ -458,16 +458,15 @@ def test_train_iteration_losses_and_gradients_vs_oracle(oh):
     # a few 1e-3 on those; the bound below is set from that, not from the kernels (each backward kernel is tested to 2e-5 above).
     errs = sorted(w[0] for w in worst)
     print('gradient errors (rel):', [(round(a, 7), b) for a, b in sorted(worst)[-10:]])
-    # Round 4 widened the last two bounds (0.85 -> 0.6 of the parameters within 1e-3, worst 2e-2 -> 6e-2). Measured with
-    # tools/train_test_bisect.py (profiles/r04_train_test_bisect.txt): with k_conv_kd alone, k_conv_gd alone or neither, the old
-    # bounds hold; with both, 53 of 73 parameters stay within 1e-3 and conv3.bias moves by 3.8e-2. Each family's error against an
-    # fp64 convolution at this test's shapes is <= 6e-7 of max|ref| (gd's single accumulation chain gives 3.1e-7 rms where the
-    # two-chain kernel it replaces gave 1.6e-7), so what moves is which of this sample's hard decisions flip, the sensitivity
-    # stated above. The median bound is unchanged; the per-parameter statement with bounds from the executed reference is
-    # test_train_iteration_vs_reference_run.
+    # Which sample: tests/sensitivity_train_sample.py (profiles/r04_train_sample_sensitivity.txt) measures how far these gradients
+    # move when the frozen weights are multiplied by (1 + 3e-7 n) or the image by (1 + 1e-6 n) on unchanged kernels.  On input seed 0,
+    # used until round 4, up to 37 of 72 parameters move by more than 1e-3 and the worst by 4.2e-2 -- the bounds below held on it by
+    # luck and stopped holding when k_conv_kd + k_conv_gd changed a summation order (either alone passes: r04_train_test_bisect.txt).
+    # On input seed 5 at most 2 parameters move beyond 1e-3 and the worst by 2.6e-3, so the bounds sit above the sample's own
+    # sensitivity.  Every candidate sample flips somewhere at the 1e-3 level; none is free of it.
     assert errs[len(errs) // 2] <= 1e-4, errs[len(errs) // 2]
-    assert sum(1 for v in errs if v <= 1e-3) >= 0.6 * len(errs)
-    assert errs[-1] <= 6e-2, sorted(worst)[-3:]
+    assert sum(1 for v in errs if v <= 1e-3) >= 0.85 * len(errs)
+    assert errs[-1] <= 2e-2, sorted(worst)[-3:]
     assert dead == {"conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "roi_heads.fc2.weight", "roi_heads.fc2.bias",
                     "roi_heads.fc3.weight", "roi_heads.fc3.bias"}
     assert all(any(k.startswith(pre) for pre in m.gradless_parameter_prefixes()) for k in dead)
@@ -483,7 +482,7 @@ def test_train_step_updates_match_oracle_sgd(oh):
     from fewx.solver import build_optimizer, param_groups_like_reference
     shots = 4
     m, sd, cfg = _train_model(shots)
-    img, gt, sup, sbox = T.synth_train_inputs(1, (256, 320), n_gt=7, shots=shots, support_hw=96)
+    img, gt, sup, sbox = T.synth_train_inputs(0, (256, 320), n_gt=7, shots=shots, support_hw=96)      # seed: see bound (2)
     leaf = T.leaf_state(sd)
     g = torch.Generator().manual_seed(3)
     ref = T.train_iteration(leaf, img, gt, sup, sbox, lambda n: torch.randperm(n, generator=g))
@@ -493,6 +492,7 @@ def test_train_step_updates_match_oracle_sgd(oh):
     ropt = torch.optim.SGD([{"params": [leaf[k]], "lr": groups[k][0], "weight_decay": groups[k][1]} for k in live], cfg.SOLVER.BASE_LR,
                            momentum=cfg.SOLVER.MOMENTUM)
     before = {k: leaf[k].detach().clone() for k in leaf}
+    gmax = {k: float(leaf[k].grad.abs().max()) for k in live}           # before clipping
     torch.nn.utils.clip_grad_value_([leaf[k] for k in live], cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE)
     ropt.step()
     opt = build_optimizer(cfg, m)
@@ -505,8 +505,10 @@ def test_train_step_updates_match_oracle_sgd(oh):
     losses = train_forward(m, [item], roi_override=over)
     opt.zero_grad()
     sum(losses.values()).backward()
-    opt.step()
     named = dict(m.named_parameters())
+    own = {k: named[k].grad.detach().cpu().clone() for k in live}        # this path's gradients, before the step clips them in place
+    opt.step()
+    clip = cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE
     for k in leaf:
         if k not in named:
             continue
@@ -515,8 +517,14 @@ def test_train_step_updates_match_oracle_sgd(oh):
         if k in live:
             assert float(d_ref.abs().max()) > 0
             ulp = 1.2e-7 * float(before[k].abs().max())                 # the update is rounded into the fp32 parameter
-            # 2e-3 -> 5e-3 in round 4 for the same measured reason as in the test above (2.7e-3 seen on one stage-4 weight with kd + gd)
-            assert float((d_got - d_ref).abs().max()) <= 5e-3 * float(d_ref.abs().max()) + 2 * ulp + 1e-9, k
+            # (1) the step's arithmetic, on this path's own gradients: clip_grad_value_ + first SGD step with the reference's groups
+            lr, wd = groups[k]
+            d_own = -lr * (own[k].clamp(-clip, clip) + wd * before[k])
+            assert float((d_got - d_own).abs().max()) <= 1e-6 * float(d_own.abs().max()) + 2 * ulp + 1e-12, k
+            # (2) against the oracle's step, in gradient terms (a clipped update hides the gradient's scale): on this sample (input
+            # seed 0) perturbations at rounding level move a gradient by up to 4.0e-3 of its maximum (2 parameters; on seed 1, used
+            # until round 4, 6.9e-3 on up to 9 -- profiles/r04_train_sample_sensitivity.txt); the bound is three times that.
+            assert float((d_got - d_ref).abs().max()) <= lr * min(clip, 1.2e-2 * gmax[k]) + 2 * ulp + 1e-9, k
         else:
             assert float(d_got.abs().max()) == 0.0, k
     # a second forward sees the updated weights (packed layouts are rebuilt after the step)
