@@ -1299,6 +1299,7 @@ extern "C" int ore_conv_set_plan_override(int32_t BM, int32_t BN, int32_t WGM, i
     if (BM == -4) { conv_gs_force(BN, WGM, WGN); return ORE_OK; }
     if (BM == -5) { conv_xmap_force(BN); return ORE_OK; }
     if (BM == -14) { conv_gd_mode(BN); return ORE_OK; }                                     // BM = -14: shared-stage descriptor kernel 0 off / 1 automatic
+    if (BM == -16) { conv_gd_dbg(BN); return ORE_OK; }                                      // BM = -16: its ablation flags (trace build only; no effect in the product library)
     if (BM == -15) { conv_gd_force(BN, WGM, WGN); return ORE_OK; }                          // BM = -15: force its build (BM, BN, NS)
     if (BM == -12) { conv_kd_mode(BN); return ORE_OK; }                                     // BM = -12: lean LDS-DMA kernel 0 off / 1 automatic / 2 wherever it applies
     if (BM == -13) { conv_kd_force(BN, WGM, WGN, WGK); return ORE_OK; }                     // BM = -13: force its build (BM, BN, NW, SB)

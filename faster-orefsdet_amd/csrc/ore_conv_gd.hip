@@ -60,6 +60,9 @@ struct GdK {
     int out_ld, out_coff, relu_cout;
     int xmap, gx, gy;
     float inv_hw, inv_wo, inv_gx, inv_gy;
+#ifdef ORE_TRACE
+    int dbg;                 // ablation (trace build only): 1 no MFMAs, 2 no DMA in the loop, 4 no fragment reads, 8 no barrier, 16 no stores, 32 no prologue DMA
+#endif
 };
 struct GdP {
     GdK k;
@@ -78,10 +81,11 @@ __device__ __forceinline__ void gd_tile(const GdK& k, int& bx, int& by) {
 }
 
 template <int GA, int GB, int WGM, int WGN, int NS, int KS>
-__global__ __launch_bounds__(256) void k_conv_gd(GdP q) {
-    static_assert(WGM * WGN == 4 && GA % WGM == 0 && GB % WGN == 0, "four waves tile the block");
+__global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
+    constexpr int NW = WGM * WGN;                     // 4 waves, or 8 (two per SIMD: the builds whose blocks own a CU alone)
+    static_assert((NW == 4 || NW == 8) && GA % WGM == 0 && GB % WGN == 0, "the waves tile the block");
     constexpr int G = GA + GB;                        // DMA pieces per chunk
-    constexpr int PPW = (G + 3) / 4;                  // pieces a wave issues per chunk (piece p -> wave p % 4)
+    constexpr int PPW = (G + NW - 1) / NW;            // pieces a wave issues per chunk (piece p -> wave p % NW)
     constexpr int STAGE_F = G * 256;
     constexpr int TA = GA / WGM, TB = GB / WGN;       // MFMA tiles of a wave
     static_assert(PPW * (NS - 1) <= 63, "vmcnt");
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void k_conv_gd(GdP q) {
     unsigned pv[PPW], ptaps[PPW];                     // per-lane byte offset (or kOOB) and, for pixel pieces, the 9-bit tap mask
 #pragma unroll
     for (int s = 0; s < PPW; ++s) {
-        const int pi = wave + 4 * s;
+        const int pi = wave + NW * s;
         pv[s] = kOOB; ptaps[s] = 0u;
         if (pi < GA) {
             const int m = m0 + pi * 16 + r16;
@@ -133,23 +137,24 @@ __global__ __launch_bounds__(256) void k_conv_gd(GdP q) {
             if (n < p.Cout16) pv[s] = (unsigned)((n * p.K + lq * 4) * 4);
         }
     }
-    // issue this wave's pieces of chunk c into ring slot `slot` (a constant after unrolling)
-    auto issue = [&](int c, int slot) {
+    // issue piece s of this wave's pieces of chunk c into ring slot `slot` (s, slot: constants after unrolling)
+    auto issue_piece = [&](int c, int slot, int s) {
         float* dst = lds + slot * STAGE_F;
         const bool live = c < p.nchunks;
         unsigned e = 15u;
         if constexpr (KS != 1) e = q.tab[c < kTab ? c : kTab - 1];
         const unsigned bit = 1u << (e & 15u);
-#pragma unroll
-        for (int s = 0; s < PPW; ++s) {
-            const int pi = wave + 4 * s;                                  // wave-uniform
-            if (pi < GA) {
-                if constexpr (KS == 1) dma<0>(ri, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
-                else dma<0>(ri, dst + pi * 256, (live && (ptaps[s] & bit)) ? pv[s] : kOOB, e & ~63u);
-            } else if (pi < G) {
-                dma<0>(rw, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
-            }
+        const int pi = wave + NW * s;                                      // wave-uniform
+        if (pi < GA) {
+            if constexpr (KS == 1) dma<0>(ri, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
+            else dma<0>(ri, dst + pi * 256, (live && (ptaps[s] & bit)) ? pv[s] : kOOB, e & ~63u);
+        } else if (pi < G) {
+            dma<0>(rw, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
         }
+    };
+    auto issue = [&](int c, int slot) {
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) issue_piece(c, slot, s);
     };
 
     f32x4 acc[TA][TB];
@@ -159,37 +164,70 @@ __global__ __launch_bounds__(256) void k_conv_gd(GdP q) {
         for (int j = 0; j < TB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15;
     const int foff = frow * 16 + (((lane >> 4) ^ swz(frow)) << 2);
-    const bool full = wave + 4 * (PPW - 1) < G;       // this wave issues PPW pieces per chunk (else PPW - 1); wave-uniform
+    const bool full = wave + NW * (PPW - 1) < G;       // this wave issues PPW pieces per chunk (else PPW - 1); wave-uniform
     // ---- prologue: NS - 1 chunks in flight
+#ifdef ORE_TRACE
+    if (!(q.k.dbg & 32))
+#endif
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u) issue(u, u);
-    // chunk loop, unrolled NS times: step u of a group reads slot u and refills slot (u + NS - 1) % NS
-    const int ngroups = (p.nchunks + NS - 1) / NS;
+    // Chunk loop, unrolled NS times (NS even): step t waits for chunk t's pieces, passes the barrier, refills the slot chunk t-1 was
+    // read from, reads chunk t's fragments into one register set and runs chunk t-1's MFMAs from the other -- a block may own its CU
+    // alone (one wave per SIMD), so the fragment reads, the DMA issue and the barrier skew have to hide behind this wave's own MFMAs.
+    // nchunks + 1 steps: the last one only multiplies.
+    static_assert(NS % 2 == 0, "two fragment register sets alternate inside the unrolled group");
+    f32x4 af[2][TA], bf[2][TB];
+    const int ngroups = (p.nchunks + 1 + NS - 1) / NS;
     for (int g = 0; g < ngroups; ++g) {
         const int c0 = g * NS;
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int t = c0 + u;
+            if (t > p.nchunks) break;                                      // uniform
             // my pieces of chunk t have landed: all but the (NS - 2) younger chunks' worth of my DMAs
             if (full) wait_vmcnt<(NS - 2) * PPW>(); else wait_vmcnt<(NS - 2) * (PPW > 1 ? PPW - 1 : 0)>();
-            __builtin_amdgcn_s_barrier();                                  // everybody's pieces of chunk t; chunk t-1's reads are over
-            issue(t + NS - 1, (u + NS - 1) % NS);
-            if (t < p.nchunks) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my fragment reads of chunk t-1 are done: its slot may be refilled
+#ifdef ORE_TRACE
+            const int dbg = q.k.dbg;
+#else
+            constexpr int dbg = 0;
+#endif
+            if (!(dbg & 8)) __builtin_amdgcn_s_barrier();                  // everybody's pieces of chunk t; everybody's reads of chunk t-1
+            if (t < p.nchunks && !(dbg & 4)) {
                 const float* st = lds + u * STAGE_F;
-                f32x4 af[TA], bf[TB];
 #pragma unroll
-                for (int i = 0; i < TA; ++i) af[i] = *reinterpret_cast<const f32x4*>(st + (wm * TA + i) * 256 + foff);
+                for (int i = 0; i < TA; ++i) af[u & 1][i] = *reinterpret_cast<const f32x4*>(st + (wm * TA + i) * 256 + foff);
 #pragma unroll
-                for (int j = 0; j < TB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(st + (GA + wn * TB + j) * 256 + foff);
+                for (int j = 0; j < TB; ++j) bf[u & 1][j] = *reinterpret_cast<const f32x4*>(st + (GA + wn * TB + j) * 256 + foff);
+            }
+            __builtin_amdgcn_sched_barrier(0);                             // the reads above are issued before the MFMAs below
+            // The refill of the slot chunk t-1 was read from -- this wave's pieces of chunk t + NS - 1 -- goes out BETWEEN the MFMAs
+            // of chunk t-1, one piece per segment: a DMA instruction holds the wave at issue while the texture addresser works off
+            // the pieces queued in front of it (every wave of the CU queues its own right after the same barrier), and issued in
+            // one go ahead of the MFMAs that wait left the matrix pipe idle for as long as the staging takes.
+            constexpr int MF = 4 * TA * TB, SEG = (MF + PPW) / (PPW + 1);  // MFMAs per segment; piece s follows segment s
+            if (t > 0 && !(dbg & 1)) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                     for (int i = 0; i < TA; ++i)
 #pragma unroll
-                        for (int j = 0; j < TB; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][tt], af[i][tt], acc[i][j], 0, 0, 0);   // D^T: lane = pixel
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this chunk's fragment reads are done before its slot is refilled
+                        for (int j = 0; j < TB; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[(u & 1) ^ 1][j][tt], af[(u & 1) ^ 1][i][tt], acc[i][j], 0, 0, 0);   // D^T: lane = pixel
+                            const int idx = (tt * TA + i) * TB + j;
+                            if (idx % SEG == SEG - 1 && idx / SEG < PPW && !(dbg & 2)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(t + NS - 1, (u + NS - 1) % NS, idx / SEG);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+#pragma unroll
+                for (int s2 = (MF / SEG < PPW ? MF / SEG : PPW); s2 < PPW; ++s2)       // pieces no segment end was left for
+                    if (!(dbg & 2)) issue_piece(t + NS - 1, (u + NS - 1) % NS, s2);
+            } else if (!(dbg & 2)) {
+                issue(t + NS - 1, (u + NS - 1) % NS);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     wait_vmcnt<0>();                                   // the zero-fill tail DMAs
@@ -212,7 +250,11 @@ __global__ __launch_bounds__(256) void k_conv_gd(GdP q) {
         for (int i = 0; i < TA; ++i) {
             const int m = m0 + (wm * TA + i) * 16 + (lane & 15);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#ifdef ORE_TRACE
+            if (m < p.M && en < p.Cout && !(q.k.dbg & 16)) {
+#else
             if (m < p.M && en < p.Cout) {
+#endif
                 v = acc[i][j] * e_sc + e_sh;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -253,13 +295,23 @@ __global__ __launch_bounds__(256) void k_conv_gd(GdP q) {
 
 int g_gd_mode = 1;                       // tuning aid (ore_conv_set_plan_override(-14, mode)): 0 off, 1 automatic
 int g_gd_force[3] = {0, 0, 0};           // (-15, BM, BN, NS): force the build
+int g_gd_dbg = 0;                        // trace build: ablation flags, ore_conv_set_plan_override(-16, flags)
 
 template <int GA, int GB, int WGM, int WGN, int NS>
 int launch_gd(const GdP& q, bool k3, dim3 grid, hipStream_t st) {
+    const dim3 block(64 * WGM * WGN);
     constexpr size_t lds = (size_t)NS * (GA + GB) * 256 * sizeof(float);
-    static_assert(lds <= 64 * 1024, "keeps several blocks per CU");
-    if (!k3) hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 1>), grid, dim3(256), lds, st, q);
-    else hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 3>), grid, dim3(256), lds, st, q);
+    static_assert(lds <= 128 * 1024, "LDS ring");
+    if constexpr (lds > 64 * 1024) {                   // the one-block-per-CU builds
+        static bool attr[2] = {false, false};
+        if (!attr[k3]) {
+            const void* f = k3 ? (const void*)k_conv_gd<GA, GB, WGM, WGN, NS, 3> : (const void*)k_conv_gd<GA, GB, WGM, WGN, NS, 1>;
+            ORE_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[k3] = true;
+        }
+    }
+    if (!k3) hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 1>), grid, block, lds, st, q);
+    else hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 3>), grid, block, lds, st, q);
     return ore_launch_status("k_conv_gd");
 }
 
@@ -268,6 +320,7 @@ int launch_gd(const GdP& q, bool k3, dim3 grid, hipStream_t st) {
 namespace oreconv {
 
 void conv_gd_mode(int mode) { g_gd_mode = mode; }
+void conv_gd_dbg(int flags) { g_gd_dbg = flags; }
 void conv_gd_force(int bm, int bn, int ns) { g_gd_force[0] = bm; g_gd_force[1] = bn; g_gd_force[2] = ns; }
 bool conv_gd_forced() { return g_gd_force[0] > 0; }
 int conv_gd_forced_bm() { return g_gd_force[0]; }
@@ -284,12 +337,15 @@ static bool gd_applies(const ConvP& p) {
 struct GdPlan { int bm, bn, ns; };
 static GdPlan gd_plan(const ConvP& p) {
     if (g_gd_force[0] > 0) return {g_gd_force[0], g_gd_force[1], g_gd_force[2]};
-    // from tools/kw_phase_trace.py gd (profiles/r04_gd_times.txt; eager launches back to back, one MI355X, bs = 1 shapes):
-    //   stage-3 concat 352 -> 256 at M = 6400: 18.9 us (k_conv_gs 21.2); stage-2 concat 320 -> 112 at M = 25600: 28.6 (31.1);
-    //   stem_3 3x3 / 2 64 -> 128 at M = 25600: 47.1 (k_conv_igemm 62.7).  Larger batches (training) stay on k_conv_gs / k_conv_igemm: not measured.
+    // from tools/kw_phase_trace.py gd (profiles/r04_gd_times.txt; eager launches back to back, one MI355X, bs = 1 shapes; ns >= 10: eight waves):
+    //   stage-3 concat 352 -> 256 at M = 6400: 17.9 us (k_conv_gs 21.2); stage-2 concat 320 -> 112 at M = 25600: 27.7 (31.1);
+    //   stem_3 3x3 / 2 64 -> 128 at M = 25600: 44.0 (k_conv_igemm 62.7).  Larger batches (training) stay on k_conv_gs / k_conv_igemm: not measured.
+    // Every tiling of a layer lands within ~10 % of the others (r04_gd_ablation.txt: the MFMA phase alone runs at ~75 % of the peak,
+    // staging adds to it instead of hiding behind it); the choices below are the fastest measured, not a structural preference.
     if (p.M < 4096 || p.M > 32768) return {0, 0, 0};
-    if (p.kh == 1 && (p.Cout16 == 256 || p.Cout16 == 112) && p.nchunks >= 16) return {64, 64, 4};
-    if (p.kh == 3 && p.stride == 2 && p.Cout16 == 128 && p.Cin == 64) return {64, 64, 4};
+    if (p.kh == 1 && p.Cout16 == 256 && p.nchunks >= 16) return {64, 64, 4};
+    if (p.kh == 1 && p.Cout16 == 112 && p.nchunks >= 16) return {128, 64, 14};
+    if (p.kh == 3 && p.stride == 2 && p.Cout16 == 128 && p.Cin == 64) return {112, 128, 14};
     return {0, 0, 0};
 }
 
@@ -315,6 +371,9 @@ int conv_gd_launch(ConvP& p, hipStream_t st) {
     k.irow0 = L.irow0; k.H = L.H; k.W = L.W; k.Ho = L.Ho; k.Wo = L.Wo; k.in_ld = p.in_ld; k.in_coff = p.in_coff; k.stride = p.stride; k.pad = p.pad;
     k.out_ld = p.out_ld; k.out_coff = p.out_coff; k.relu_cout = p.relu_cout;
     k.xmap = conv_choose_xmap(p, gx, gy); k.gx = gx; k.gy = gy;
+#ifdef ORE_TRACE
+    k.dbg = g_gd_dbg;
+#endif
     k.inv_hw = 1.0f / (float)(L.Ho * L.Wo); k.inv_wo = 1.0f / (float)L.Wo; k.inv_gx = 1.0f / (float)gx; k.inv_gy = 1.0f / (float)gy;
     for (int c = 0; c < kTab; ++c) q.tab[c] = 15u;
     if (p.kh == 3) {
@@ -326,9 +385,13 @@ int conv_gd_launch(ConvP& p, hipStream_t st) {
     }
     const bool k3 = p.kh == 3;
     const dim3 grid(gx, gy, 1);
-#define GD_CASE(bm_, bn_, wgm_, wgn_, ns_) if (pl.bm == bm_ && pl.bn == bn_ && pl.ns == ns_) return launch_gd<bm_ / 16, bn_ / 16, wgm_, wgn_, ns_>(q, k3, grid, st);
-    GD_CASE(64, 128, 2, 2, 3) GD_CASE(64, 128, 2, 2, 4) GD_CASE(64, 64, 2, 2, 3) GD_CASE(64, 64, 2, 2, 4) GD_CASE(64, 112, 4, 1, 3) GD_CASE(64, 112, 4, 1, 4)
-    GD_CASE(128, 64, 4, 1, 3) GD_CASE(128, 128, 2, 2, 3) GD_CASE(32, 128, 1, 4, 3) GD_CASE(32, 128, 1, 4, 4) GD_CASE(128, 112, 4, 1, 3)
+    // ring depth as forced / planned: ns, or 10 + ns for the eight-wave build of the tile
+#define GD_CASE(bm_, bn_, wgm_, wgn_, ns_) if (pl.bm == bm_ && pl.bn == bn_ && pl.ns == ((wgm_) * (wgn_) == 8 ? 10 + ns_ : ns_)) return launch_gd<bm_ / 16, bn_ / 16, wgm_, wgn_, ns_>(q, k3, grid, st);
+    GD_CASE(64, 128, 2, 2, 4) GD_CASE(64, 64, 2, 2, 4) GD_CASE(64, 112, 4, 1, 4) GD_CASE(128, 64, 4, 1, 4) GD_CASE(128, 128, 2, 2, 4) GD_CASE(32, 128, 1, 4, 4)
+    GD_CASE(128, 112, 4, 1, 4) GD_CASE(208, 64, 1, 4, 4) GD_CASE(224, 64, 1, 4, 4) GD_CASE(112, 64, 1, 4, 4) GD_CASE(96, 128, 2, 2, 4) GD_CASE(64, 128, 2, 2, 2)
+    GD_CASE(128, 128, 2, 2, 2) GD_CASE(208, 64, 1, 4, 2) GD_CASE(128, 112, 4, 1, 2)
+    GD_CASE(128, 128, 2, 4, 4) GD_CASE(112, 128, 1, 8, 4) GD_CASE(128, 112, 8, 1, 4) GD_CASE(64, 128, 2, 4, 4) GD_CASE(128, 64, 4, 2, 4) GD_CASE(64, 64, 2, 4, 4)
+    GD_CASE(128, 128, 2, 4, 2) GD_CASE(112, 128, 1, 8, 2)
 #undef GD_CASE
     if (g_gd_force[0] > 0) { ore_set_error("k_conv_gd: no build for tile %dx%d, ring %d", pl.bm, pl.bn, pl.ns); return ORE_EINVAL; }
     return 1;

@@ -63,7 +63,8 @@ bool conv_wino_covers(int Cout, int Cin);                  // a Winograd build e
 // ore_conv_gd.hip: shared-stage LDS-DMA kernel with descriptor addressing for the large-M layers (stem_3, the big concats).  1 = not covered.
 int conv_gd_launch(ConvP& p, hipStream_t st);
 int conv_gd_tile_rows(const ConvP& p);
-void conv_gd_mode(int mode);                               // (-14, mode): 0 off, 1 automatic
+void conv_gd_mode(int mode);
+void conv_gd_dbg(int flags);                               // (-14, mode): 0 off, 1 automatic
 void conv_gd_force(int bm, int bn, int ns);                // (-15, bm, bn, ns): force the build (bm = 0: automatic)
 bool conv_gd_forced();
 int conv_gd_forced_bm();

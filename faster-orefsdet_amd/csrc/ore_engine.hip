@@ -789,9 +789,9 @@ extern "C" int ore_engine_eval_fwd(ore_engine* e, const void* img, int32_t is_u8
     return ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, use_graph, stream);
 }
 
-extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
-                                     void* out_record, void* stream, int32_t* n_det) {
-    ORE_CHECK_ARG(e && e->roi_set && n_det && out_h >= 1 && out_w >= 1, "ore_engine_detect_fwd: needs the second stage (ore_engine_set_roi_head)");
+extern "C" int ore_engine_detect_begin(ore_engine* e, const void* img, int32_t is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                                       void* out_record, void* stream) {
+    ORE_CHECK_ARG(e && e->roi_set && out_record && out_h >= 1 && out_w >= 1, "ore_engine_detect_begin: needs the second stage (ore_engine_set_roi_head)");
     hipStream_t st = (hipStream_t)stream;
     // detector_postprocess parameters: sx = out_w / W, sy = out_h / H evaluated like the reference's Python floats, rounded once to
     // fp32 (what `boxes *= scale` does to a float32 tensor); uploaded only when the requested size changes
@@ -810,8 +810,17 @@ extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_
     volatile int32_t* cnt_word = e->pin_count;
     *cnt_word = -1;                                          // sentinel: the last kernel of the graph overwrites it with the count (>= 0)
     __atomic_thread_fence(__ATOMIC_RELEASE);
-    int rc = ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, 1, stream);
-    if (rc) { *rec_word = 0ull; return rc; }
+    const int rc = ore_engine_eval_batch_fwd(e, img, is_u8, 1, H, W, 1, stream);
+    if (rc) *rec_word = 0ull;
+    return rc;
+}
+
+extern "C" int ore_engine_detect_end(ore_engine* e, void* stream, int32_t* n_det) {
+    ORE_CHECK_ARG(e && e->roi_set && n_det, "ore_engine_detect_end: null");
+    hipStream_t st = (hipStream_t)stream;
+    volatile unsigned long long* rec_word = reinterpret_cast<volatile unsigned long long*>(e->pin_count) + 1;
+    volatile int32_t* cnt_word = e->pin_count;
+    ORE_CHECK_ARG(*rec_word != 0ull, "ore_engine_detect_end: no ore_engine_detect_begin is pending on this engine");
     // Wait for the count word instead of the stream: the kernel writes it as its very last action (after its result stores), and a
     // poll of pinned memory sees it a wake-up latency earlier than hipStreamSynchronize returns.  Everything the caller does with the
     // record afterwards is stream-ordered behind the kernel anyway.  Bounded spin, then the ordinary synchronise (also the error path).
@@ -823,14 +832,21 @@ extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_
     }
     if (n < 0) {
         const hipError_t se = hipStreamSynchronize(st);
-        if (se != hipSuccess) { *rec_word = 0ull; ore_set_error("ore_engine_detect_fwd: %s", hipGetErrorString(se)); return ORE_EHIP; }
+        if (se != hipSuccess) { *rec_word = 0ull; ore_set_error("ore_engine_detect_end: %s", hipGetErrorString(se)); return ORE_EHIP; }
         n = *cnt_word;
-        if (n < 0) { *rec_word = 0ull; ore_set_error("ore_engine_detect_fwd: the pass finished without writing the detection count"); return ORE_EHIP; }
+        if (n < 0) { *rec_word = 0ull; ore_set_error("ore_engine_detect_end: the pass finished without writing the detection count"); return ORE_EHIP; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     *rec_word = 0ull;                                        // no later replay of this engine may write into the caller's tensor
     *n_det = n;
     return ORE_OK;
+}
+
+extern "C" int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                                     void* out_record, void* stream, int32_t* n_det) {
+    ORE_CHECK_ARG(n_det, "ore_engine_detect_fwd: null count");
+    const int rc = ore_engine_detect_begin(e, img, is_u8, H, W, out_h, out_w, out_record, stream);
+    return rc ? rc : ore_engine_detect_end(e, stream, n_det);
 }
 
 extern "C" int ore_engine_eval_batch_fwd(ore_engine* e, const void* img, int32_t is_u8, int32_t B, int32_t H, int32_t W,

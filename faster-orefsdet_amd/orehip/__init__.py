@@ -72,7 +72,7 @@ SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd
            "ore_roi_predict_fwd", "ore_roi_align_batched_fwd", "ore_roi_align_bwd", "ore_centernet_targets_fwd", "ore_centernet_losses_fwd", "ore_centernet_losses_bwd", "ore_sgd_step_fwd", "ore_pack_conv_weight_fwd", "ore_conv_wgrad_workspace_floats",
            "ore_conv_set_precision", "ore_conv_get_precision", "ore_conv2d_wgrad_fwd", "ore_conv2d_wgrad_bias_fwd", "ore_granule_transpose_fwd", "ore_combine2_fwd", "ore_combine2_bwd", "ore_adaptive_avgpool_nhwc_fwd", "ore_adaptive_avgpool_nhwc_bwd", "ore_group_mean_fwd", "ore_group_mean_bwd", "ore_relu_affine_bwd", "ore_colsum_fwd", "ore_colsum_segments_fwd", "ore_correlation_train_fwd", "ore_correlation_train_bwd",
            "ore_groupnorm_apply_fwd", "ore_groupnorm_bwd", "ore_prod_colsum_fwd", "ore_scale_add_channels_fwd", "ore_maxpool3x3s2_bwd", "ore_sumpool2x2_fwd", "ore_engine_create", "ore_engine_destroy", "ore_engine_set_tensor",
-           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_roi_predict_post_fwd",
+           "ore_engine_set_support", "ore_engine_finalize", "ore_engine_set_roi_head", "ore_engine_backbone_fwd", "ore_engine_eval_fwd", "ore_engine_eval_batch_fwd", "ore_engine_detect_fwd", "ore_engine_detect_begin", "ore_engine_detect_end", "ore_roi_predict_post_fwd",
            "ore_engine_buffer", "ore_engine_last_flops", "ore_engine_set_profiling", "ore_engine_read_profile", "ore_event_pair_overhead_us",
            "ore_rccl_load", "ore_rccl_unique_id", "ore_rccl_comm_create", "ore_rccl_comm_destroy", "ore_allreduce_grads"]
 
@@ -1146,20 +1146,30 @@ class Engine:
         _chk(lib().ore_engine_eval_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W,
                                        int(use_graph), _stream()), "ore_engine_eval_fwd")
 
-    def detect(self, img: torch.Tensor, out_h: int, out_w: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """The reference's eval call for one image, end to end, in ONE C-ABI call (ore_engine_detect_fwd): image [3,H,W] u8/f32 on
-        the device or on the host -> both stages + detector_postprocess as one hipGraph replay whose last kernel writes the results into
-        a freshly allocated tensor, the count through a device-mapped pinned word the call polls.
-        Returns (boxes [n,4], scores [n], classes [n] int64) -- the caller's own tensors, nothing of the engine aliases them."""
+    def detect_begin(self, img: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+        """First half of `detect`: enqueue the pass (ore_engine_detect_begin) and return the result record it will fill.  Host work
+        done before `detect_end` runs in the shadow of the device pass."""
         assert img.is_contiguous() and img.dim() == 3
         _, H, W = img.shape
         R = self.__dict__.get("_rec_rows") or self.__dict__.setdefault("_rec_rows", int(lib().ore_det_record_rows()))   # ORE_DET_RECORD_ROWS of the loaded library (= the engine's roi_cap)
         rec = torch.empty(R * 7, dtype=torch.float32, device=self.device)  # [R][4] f32 | [R] f32 | [R] i64, written by the last kernel
+        _chk(lib().ore_engine_detect_begin(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W, int(out_h), int(out_w),
+                                           C.c_void_p(rec.data_ptr()), _stream()), "ore_engine_detect_begin")
+        return rec
+
+    def detect_end(self, rec: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Second half: wait for the count (ore_engine_detect_end) and cut the record into (boxes [n,4], scores [n], classes [n] int64)."""
         n = C.c_int32(0)
-        _chk(lib().ore_engine_detect_fwd(self._h, C.c_void_p(img.data_ptr()), int(img.dtype == torch.uint8), H, W, int(out_h), int(out_w),
-                                         C.c_void_p(rec.data_ptr()), _stream(), C.byref(n)), "ore_engine_detect_fwd")
-        k = n.value
-        return rec[: k * 4].view(k, 4), rec[R * 4: R * 4 + k], rec[R * 5:].view(torch.int64)[:k]
+        _chk(lib().ore_engine_detect_end(self._h, _stream(), C.byref(n)), "ore_engine_detect_end")
+        k, R = n.value, self._rec_rows                                     # one strided view each: the protocol pays per torch call
+        return rec.as_strided((k, 4), (4, 1)), rec.as_strided((k,), (1,), R * 4), rec.view(torch.int64).as_strided((k,), (1,), R * 5 // 2)
+
+    def detect(self, img: torch.Tensor, out_h: int, out_w: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The reference's eval call for one image, end to end (ore_engine_detect_begin + _end): image [3,H,W] u8/f32 on
+        the device or on the host -> both stages + detector_postprocess as one hipGraph replay whose last kernel writes the results into
+        a freshly allocated tensor, the count through a device-mapped pinned word the call polls.
+        Returns (boxes [n,4], scores [n], classes [n] int64) -- the caller's own tensors, nothing of the engine aliases them."""
+        return self.detect_end(self.detect_begin(img, out_h, out_w))
 
     def eval_forward_batch(self, imgs: torch.Tensor, use_graph: bool = True) -> None:
         """imgs [B,3,H,W] u8/f32 on device, B <= max_batch: dense stages batched, detection tail + second stage per image

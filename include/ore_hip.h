@@ -527,6 +527,14 @@ int ore_roi_align_bf16_fwd(const uint16_t* const* feat, const int32_t* ld, const
                            const int32_t* n_dev, int32_t n_host, int32_t cap, float* out, void* stream);
 int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
                           void* out_record, void* stream, int32_t* n_det);
+/* ore_engine_detect_fwd in two halves: _begin enqueues the pass (and returns at once), _end waits for its detection count.  What the
+ * host does in between runs in the shadow of the device pass: the module-level forward uses it to validate its cached engine against
+ * the parameters' version counters AFTER launching on it (a stale engine is the rare case: its result is dropped and the pass
+ * repeated), which takes that check out of the per-image critical path of the reference's protocol
+ * (d2z:evaluation/evaluator.py:138-161).  One pass may be pending per engine; _end without _begin is ORE_EINVAL. */
+int ore_engine_detect_begin(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                            void* out_record, void* stream);
+int ore_engine_detect_end(ore_engine* e, void* stream, int32_t* n_det);
 /* The same for B images of one size in ONE pass (B <= cfg.max_batch; img [B][3][H][W] contiguous): the dense stages -- backbone, FPN,
  * correlation, conv3, head -- run batched (a CU fetches every layer's weights once for B images instead of once per image, which is
  * what bounds the bs = 1 kernels), the detection tail and the second stage run per image.  This is how a server folds concurrent

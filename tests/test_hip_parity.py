@@ -279,8 +279,9 @@ def test_conv_kw_kernel_vs_oracle(ore, kw_forced, B, H, W, Cin, Cout, k, stride)
     assert torch.equal(y, y2)                       # split-K slabs are summed in slice order: bit-reproducible
 
 
-GD_BUILDS = [(64, 128, 3), (64, 128, 4), (64, 64, 3), (64, 64, 4), (64, 112, 3), (64, 112, 4), (128, 64, 3), (128, 128, 3), (32, 128, 3), (32, 128, 4),
-             (128, 112, 3)]
+GD_BUILDS = [(64, 128, 4), (64, 64, 4), (64, 112, 4), (128, 64, 4), (128, 128, 4), (32, 128, 4), (128, 112, 4), (208, 64, 4), (224, 64, 4), (112, 64, 4), (96, 128, 4),
+             (64, 128, 2), (128, 128, 2), (208, 64, 2), (128, 112, 2),
+             (128, 128, 14), (112, 128, 14), (128, 112, 14), (64, 128, 14), (128, 64, 14), (64, 64, 14), (128, 128, 12), (112, 128, 12)]   # 10 + ns: the eight-wave builds
 
 
 @pytest.fixture

@@ -582,6 +582,23 @@ def test_eval_after_optimizer_step_uses_the_new_weights(oh):
     m2.set_support_dict(support)
     s2, b2, p2 = run(m2)
     assert torch.equal(p1, p2) and torch.equal(s1, s2) and torch.equal(b1, b2)
+    # an in-place edit in eval mode, no optimizer involved: the next call launches on the cached engine, finds it stale in the shadow
+    # of that pass (ore_engine_detect_begin / _end), drops its result and repeats the pass on a rebuilt engine
+    e1 = m._engine
+    with torch.no_grad():
+        dict(m.named_parameters())["backbone.fpn_output3.weight"].mul_(1.5)
+    s3, b3, p3 = run(m)
+    assert m._engine is not e1 and not torch.equal(p3, p1)
+    m3 = build_model(cfg)
+    m3.load_state_dict(m.state_dict())
+    m3.set_support_dict(support)
+    s4, b4, p4 = run(m3)
+    assert torch.equal(p3, p4) and torch.equal(s3, s4) and torch.equal(b3, b4)
+    # _end with no pass pending is an argument error, not a wait
+    import ctypes
+    import orehip
+    n = ctypes.c_int32(0)
+    assert orehip.lib().ore_engine_detect_end(m._engine._h, None, ctypes.byref(n)) == -22      # ORE_EINVAL
 
 
 def test_correlation_fn_backward(oh):

@@ -154,19 +154,30 @@ if __name__ == "__main__":
         L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
         L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "gd":                   # the shared-stage descriptor kernel on the large-M layers (timings only)
-        for shape, stride in (((80, 80, 352, 256, 1), 1), ((160, 160, 320, 112, 1), 1), ((320, 320, 64, 128, 3), 2), ((80, 80, 256, 128, 1), 1),
-                              ((80, 105, 256, 128, 1), 1), ((40, 40, 544, 384, 1), 1)):
+        for shape, stride in (((80, 80, 352, 256, 1), 1), ((160, 160, 320, 112, 1), 1), ((320, 320, 64, 128, 3), 2)):
             L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
             print("#### the plan's kernel")
             trace(*shape, reps=1, stride=stride)
-            for bm, bn, ns in ((64, 128, 3), (64, 128, 4), (64, 64, 3), (64, 64, 4), (64, 112, 3), (64, 112, 4), (128, 64, 3), (128, 128, 3), (32, 128, 3),
-                               (32, 128, 4), (128, 112, 3)):
+            for bm, bn, ns in ((64, 128, 4), (64, 64, 4), (64, 112, 4), (128, 64, 4), (128, 128, 4), (32, 128, 4), (128, 112, 4), (208, 64, 4), (224, 64, 4),
+                               (112, 64, 4), (96, 128, 4), (64, 128, 2), (128, 128, 2), (208, 64, 2), (128, 112, 2),
+                               (128, 128, 14), (112, 128, 14), (128, 112, 14), (64, 128, 14), (128, 64, 14), (64, 64, 14), (128, 128, 12), (112, 128, 12)):
                 L.ore_conv_set_plan_override(-15, bm, bn, ns, 0)
                 print("#### k_conv_gd<%dx%d, NS %d>" % (bm, bn, ns))
                 try:
                     trace(*shape, reps=1, stride=stride)
                 except orehip.OreError as ex:
                     print("   not built:", str(ex)[:100])
+        L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "gdabl":                # k_conv_gd with parts of its chunk loop switched off (trace build; results are wrong by design)
+        for shape, stride in (((80, 80, 352, 256, 1), 1), ((160, 160, 320, 112, 1), 1), ((320, 320, 64, 128, 3), 2)):
+            for bm, bn, ns in ((64, 64, 4), (64, 64, 14), (112, 128, 14)):
+                L.ore_conv_set_plan_override(-15, bm, bn, ns, 0)
+                for flags, what in ((0, "all"), (1, "no MFMA"), (2, "no DMA in loop"), (6, "no DMA, no reads"), (7, "barriers only"), (7 + 16, "barriers only, no stores"),
+                                    (7 + 16 + 32, "barriers only, no stores, no prologue DMA"), (15 + 16 + 32, "nothing"), (16, "all but the stores")):
+                    L.ore_conv_set_plan_override(-16, flags, 0, 0, 0)
+                    print("#### k_conv_gd<%dx%d, NS %d> %s" % (bm, bn, ns, what))
+                    trace(*shape, reps=1, stride=stride)
+        L.ore_conv_set_plan_override(-16, 0, 0, 0, 0)
         L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "sweep":                 # ring depth / waves per block on the latency-bound shapes
         for shape in ((20, 20, 112, 112, 3), (40, 40, 96, 96, 3), (20, 20, 512, 128, 1)):
