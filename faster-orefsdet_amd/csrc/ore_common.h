@@ -65,3 +65,13 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 __device__ __forceinline__ void st4(ore_bf16_t* p, f32x4 v) { *reinterpret_cast<s16x4*>(p) = to_bf16x4(v); }
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const ore_bf16_t* p) { return bf16_bits_to_f32(p->v); }
+
+namespace oreroi {
+// ore_roi_predict_post_fwd with the fc1 rows still in K-split partial sums (csrc/ore_roi.hip; h_parts = 0: as the C-ABI entry)
+int roi_predict_post(const float* h, int32_t C, int32_t h_parts, const float* h_bias, const float* cls_w, const float* cls_b,
+                     const float* box_w, const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
+                     const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
+                     int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
+                     const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
+                     int32_t* host_count, void* workspace, size_t workspace_bytes, void* stream);
+}

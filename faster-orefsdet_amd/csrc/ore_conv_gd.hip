@@ -58,6 +58,7 @@ struct GdK {
     int M, K, Cout, Cout16, nchunks;
     int irow0, H, W, Ho, Wo, in_ld, in_coff, stride, pad;
     int out_ld, out_coff, relu_cout;
+    int zc_stride, out_zstride;   // K split over blockIdx.z: slice z stages chunks z * zc_stride + [0, nchunks) and writes raw sums at out + z * out_zstride (0, 0: no split)
     int xmap, gx, gy;
     float inv_hw, inv_wo, inv_gx, inv_gy;
 #ifdef ORE_TRACE
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
     GdK p = q.k;
     asm volatile("" :: "s"(p.in), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.out), "s"(p.colsum), "s"(p.in_bytes), "s"(p.w_bytes), "s"(p.sc_bytes),
                  "s"(p.M), "s"(p.K), "s"(p.Cout), "s"(p.Cout16), "s"(p.nchunks), "s"(p.irow0), "s"(p.H), "s"(p.W), "s"(p.Ho), "s"(p.Wo));
-    asm volatile("" :: "s"(p.in_ld), "s"(p.in_coff), "s"(p.stride), "s"(p.pad), "s"(p.out_ld), "s"(p.out_coff), "s"(p.relu_cout), "s"(p.xmap), "s"(p.gx),
+    asm volatile("" :: "s"(p.in_ld), "s"(p.in_coff), "s"(p.stride), "s"(p.pad), "s"(p.out_ld), "s"(p.out_coff), "s"(p.relu_cout), "s"(p.zc_stride), "s"(p.out_zstride), "s"(p.xmap), "s"(p.gx),
                  "s"(p.gy), "s"(p.inv_hw), "s"(p.inv_wo), "s"(p.inv_gx), "s"(p.inv_gy));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,19 +138,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
             if (n < p.Cout16) pv[s] = (unsigned)((n * p.K + lq * 4) * 4);
         }
     }
+    const int zc0 = (int)blockIdx.z * p.zc_stride;
     // issue piece s of this wave's pieces of chunk c into ring slot `slot` (s, slot: constants after unrolling)
     auto issue_piece = [&](int c, int slot, int s) {
         float* dst = lds + slot * STAGE_F;
         const bool live = c < p.nchunks;
+        const int cz = c + zc0;                                            // the chunk's place in K (zc0 = 0 without a K split)
         unsigned e = 15u;
-        if constexpr (KS != 1) e = q.tab[c < kTab ? c : kTab - 1];
+        if constexpr (KS != 1) e = q.tab[cz < kTab ? cz : kTab - 1];
         const unsigned bit = 1u << (e & 15u);
         const int pi = wave + NW * s;                                      // wave-uniform
         if (pi < GA) {
-            if constexpr (KS == 1) dma<0>(ri, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
+            if constexpr (KS == 1) dma<0>(ri, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)cz * 64u);
             else dma<0>(ri, dst + pi * 256, (live && (ptaps[s] & bit)) ? pv[s] : kOOB, e & ~63u);
         } else if (pi < G) {
-            dma<0>(rw, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)c * 64u);
+            dma<0>(rw, dst + pi * 256, live ? pv[s] : kOOB, (unsigned)cz * 64u);
         }
     };
     auto issue = [&](int c, int slot) {
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
                     if (en + r < p.relu_cout) v[r] = fmaxf(v[r], 0.0f);
                     if (en + r >= p.Cout) v[r] = 0.0f;
                 }
-                float* o = p.out + (size_t)m * p.out_ld + p.out_coff + en;
+                float* o = p.out + (size_t)blockIdx.z * p.out_zstride + (size_t)m * p.out_ld + p.out_coff + en;
                 if (vec_ok && en + 3 < p.Cout) {
                     *reinterpret_cast<f32x4*>(o) = v;
                 } else {
@@ -369,7 +372,7 @@ int conv_gd_launch(ConvP& p, hipStream_t st) {
     k.sc_bytes = (unsigned)p.Cout * 4u;
     k.M = p.M; k.K = p.K; k.Cout = p.Cout; k.Cout16 = p.Cout16; k.nchunks = p.nchunks;
     k.irow0 = L.irow0; k.H = L.H; k.W = L.W; k.Ho = L.Ho; k.Wo = L.Wo; k.in_ld = p.in_ld; k.in_coff = p.in_coff; k.stride = p.stride; k.pad = p.pad;
-    k.out_ld = p.out_ld; k.out_coff = p.out_coff; k.relu_cout = p.relu_cout;
+    k.out_ld = p.out_ld; k.out_coff = p.out_coff; k.relu_cout = p.relu_cout; k.zc_stride = 0; k.out_zstride = 0;
     k.xmap = conv_choose_xmap(p, gx, gy); k.gx = gx; k.gy = gy;
 #ifdef ORE_TRACE
     k.dbg = g_gd_dbg;
@@ -395,6 +398,33 @@ int conv_gd_launch(ConvP& p, hipStream_t st) {
 #undef GD_CASE
     if (g_gd_force[0] > 0) { ore_set_error("k_conv_gd: no build for tile %dx%d, ring %d", pl.bm, pl.bn, pl.ns); return ORE_EINVAL; }
     return 1;
+}
+
+// The second-stage GEMM (d2z:modeling/roi_heads/box_head.py FastRCNNConvFCHead.fc1 with the DSA mix pre-composed into it: M <= 512
+// ROIs, K = 8192, 128 outputs) as a K split over blocks: tiles of 80 x 64 outputs, S slices of K -> ceil(M / 80) * (Cout16 / 64) * S
+// blocks (4 * 2 * 32 = 256 at 320 ROIs), slice z writes its raw partial sums to parts + z * M * Cout16.  Whoever consumes them adds
+// the slices in z order, then bias and ReLU (k_roi_predict_mb) -- a fixed order, so the result is reproducible.  With K this long and
+// M x N this small a block that walks all of K stages 1 MB through one CU (k_conv_kw / k_conv_kd on 160 blocks: 19 us, 46 MB of L2
+// fills); here a block stages 144 KB.
+int conv_gd_splitk(const float* in, int in_ld, const float* w, int M, int K, int Cout16, float* parts, int S, hipStream_t st) {
+    ORE_CHECK_ARG(in && w && parts && M >= 1 && M < (1 << 20) && K % 16 == 0 && Cout16 % 64 == 0 && in_ld % 16 == 0 && in_ld >= K && S >= 1 &&
+                      (K / 16) % S == 0, "conv_gd_splitk: bad shape M %d K %d Cout16 %d S %d", M, K, Cout16, S);
+    ORE_CHECK_ARG((long long)M * in_ld * 4 < (long long)kOOB - (1 << 24) && (long long)Cout16 * K * 4 < (long long)kOOB, "conv_gd_splitk: operand beyond a buffer descriptor");
+    GdP q;
+    GdK& k = q.k;
+    k.in = in; k.w = w; k.scale = nullptr; k.shift = nullptr; k.out = parts; k.colsum = nullptr;
+    k.in_bytes = (unsigned)((long long)M * in_ld * 4); k.w_bytes = (unsigned)((long long)Cout16 * K * 4); k.sc_bytes = 0u;
+    k.M = M; k.K = K; k.Cout = Cout16; k.Cout16 = Cout16; k.nchunks = K / 16 / S;
+    k.irow0 = 0; k.H = 1; k.W = M; k.Ho = 1; k.Wo = M; k.in_ld = in_ld; k.in_coff = 0; k.stride = 1; k.pad = 0;
+    k.out_ld = Cout16; k.out_coff = 0; k.relu_cout = 0; k.zc_stride = K / 16 / S; k.out_zstride = M * Cout16;
+    const int gx = ceil_div(M, 80), gy = Cout16 / 64;
+    k.xmap = 0; k.gx = gx; k.gy = gy;
+    k.inv_hw = 1.0f / (float)M; k.inv_wo = 1.0f / (float)M; k.inv_gx = 1.0f / (float)gx; k.inv_gy = 1.0f / (float)gy;
+#ifdef ORE_TRACE
+    k.dbg = 0;
+#endif
+    for (int c = 0; c < kTab; ++c) q.tab[c] = 15u;
+    return launch_gd<5, 4, 1, 4, 4>(q, false, dim3(gx, gy, S), st);
 }
 
 }  // namespace oreconv

@@ -64,7 +64,8 @@ bool conv_wino_covers(int Cout, int Cin);                  // a Winograd build e
 int conv_gd_launch(ConvP& p, hipStream_t st);
 int conv_gd_tile_rows(const ConvP& p);
 void conv_gd_mode(int mode);
-void conv_gd_dbg(int flags);                               // (-14, mode): 0 off, 1 automatic
+void conv_gd_dbg(int flags);
+int conv_gd_splitk(const float* in, int in_ld, const float* w, int M, int K, int Cout16, float* parts, int S, hipStream_t st);                               // (-14, mode): 0 off, 1 automatic
 void conv_gd_force(int bm, int bn, int ns);                // (-15, bm, bn, ns): force the build (bm = 0: automatic)
 bool conv_gd_forced();
 int conv_gd_forced_bm();

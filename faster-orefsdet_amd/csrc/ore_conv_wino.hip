@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
 
     // ---- which batches this block walks: all levels with one set of weights, or (per-level weights: the three FPN output convs
     // in one launch) the batches of ITS level only, since the weights never leave the registers
-    int bat_first = blockIdx.x, bat_step = gridDim.x, bat_end = p.nbat;
+    int set_s0 = 0, set_s1 = gridDim.x, set_b0 = 0, set_b1 = p.nbat;      // the blocks [s0, s1) of this row share the batches [b0, b1)
     const float* Ub = p.U;
     if (p.u_lstride) {
         int lb = 0;
@@ -129,8 +129,29 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino(WinoP p) {
         for (int l = 1; l < 4; ++l)
             if (l < p.nlev && (int)blockIdx.x >= p.blk0[l]) lb = l;
         Ub += lb * p.u_lstride;
-        bat_first = p.bat0[lb] + ((int)blockIdx.x - p.blk0[lb]); bat_step = p.blk0[lb + 1] - p.blk0[lb]; bat_end = p.bat0[lb + 1];
+        set_s0 = p.blk0[lb]; set_s1 = p.blk0[lb + 1]; set_b0 = p.bat0[lb]; set_b1 = p.bat0[lb + 1];
     }
+    // Batches are numbered in raster order and a batch shares two of its six input rows with the batch above and two with the one
+    // below.  Workgroups are dealt to the eight XCDs round-robin, so block ids congruent mod 8 share an L2: the set's blocks are
+    // ranked XCD by XCD and every block walks ONE contiguous run of batches -- an XCD then owns a band of image rows and the halo
+    // rows are fetched into one L2 instead of two (round 3 dealt batch b to block b mod gridDim.x: neighbours on different XCDs).
+    int bat_first, bat_end;
+    {
+        auto below = [](int n, int c) { return (n - c + 7) >> 3; };      // how many ids in [0, n) are congruent to c mod 8
+        const int lin0 = blockIdx.y * gridDim.x;                          // the XCD follows the LINEAR workgroup id
+        const int x = (lin0 + (int)blockIdx.x) & 7;
+        int v = 0;
+        for (int c = 0; c < 8; ++c) {
+            const int cc = (c - lin0) & 7;                                // block ids of this row that land on XCD c
+            const int n_c = below(set_s1, cc) - below(set_s0, cc);
+            if (c < x) v += n_c;
+        }
+        v += below((int)blockIdx.x, (x - lin0) & 7) - below(set_s0, (x - lin0) & 7);
+        const int n = set_s1 - set_s0, cnt = set_b1 - set_b0;
+        bat_first = set_b0 + (int)(((long long)v * cnt) / n);
+        bat_end = set_b0 + (int)(((long long)(v + 1) * cnt) / n);
+    }
+    constexpr int bat_step = 1;
     // ---- transformed weights -> registers (MFMA A operand: row = output channel, 4 consecutive k per lane)
     f32x4 wf[4][2][4];
 #pragma unroll

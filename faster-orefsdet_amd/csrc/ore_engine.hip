@@ -15,6 +15,7 @@
 #include <math.h>
 #include <string.h>
 #include "ore_common.h"
+#include "ore_conv_internal.h"
 #include <algorithm>
 
 
@@ -87,6 +88,7 @@ struct ore_engine {
     float* roi_W = nullptr; float* roi_b = nullptr; float* roi_cls_w = nullptr; float* roi_cls_b = nullptr;
     float* roi_box_w = nullptr; float* roi_box_b = nullptr;
     float* roi_feat = nullptr; float* roi_h = nullptr;
+    float* roi_hp = nullptr; int roi_ksplit = 1;       // K-split partial sums of the second-stage GEMM [roi_ksplit][roi_cap][roi_fc]
     float* det_boxes = nullptr; float* det_scores = nullptr; int64_t* det_src = nullptr; int32_t* det_count = nullptr;
     void* roi_ws = nullptr; size_t roi_ws_bytes = 0;
     // detector_postprocess inside the graph (ore_engine_detect_fwd): device {sx, sy, out_w, out_h} per image slot, the postprocessed
@@ -483,13 +485,26 @@ int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops, int b = 
     Conv fc{};
     fc.w = e->roi_W; fc.scale = nullptr; fc.shift = e->roi_b; fc.Cin = K; fc.Cout = e->roi_fc; fc.k = 1; fc.stride = 1; fc.pad = 0;
     fc.relu_cout = e->roi_fc;
-    {
-        PrecisionScope fp32(ORE_CONV_FP32);              // the second-stage GEMM stays fp32 in every mode (include/ore_hip.h)
-        r.conv(fc, e->roi_feat, K, 0, 1, 1, e->roi_cap, e->roi_h, e->roi_fc, 0);    // pre-composed DSA mix + flatten + fc1, ReLU
+    // pre-composed DSA mix + flatten + fc1 (+ bias, ReLU).  The second-stage GEMM stays fp32 in every mode (include/ore_hip.h).
+    const int S = e->roi_ksplit;
+    if (S > 1) {
+        // K split over blocks (oreconv::conv_gd_splitk): raw partial sums, added in slice order with bias and ReLU by the predictor kernel
+        const double fl = 2.0 * (double)e->roi_cap * K * e->roi_fc;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        size_t ia = 0;
+        if (r.prof) { ia = e->ev_used; ea = e->next_event(); eb = e->next_event(); if (ea) (void)hipEventRecord(ea, st); }
+        rc = oreconv::conv_gd_splitk(e->roi_feat, K, e->roi_W, e->roi_cap, K, e->roi_fc, e->roi_hp, S, st);
+        if (r.prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl}); }
+        if (rc) return rc;
+        *flops = fl;
+    } else {
+        PrecisionScope fp32(ORE_CONV_FP32);
+        r.conv(fc, e->roi_feat, K, 0, 1, 1, e->roi_cap, e->roi_h, e->roi_fc, 0);
+        if (r.rc) return r.rc;
+        *flops = r.flops;
     }
-    if (r.rc) return r.rc;
-    *flops = r.flops;
-    return ore_roi_predict_post_fwd(e->roi_h, e->roi_fc, e->roi_cls_w, e->roi_cls_b, e->roi_box_w, e->roi_box_b, out_boxes, counts + 1, 0,
+    return oreroi::roi_predict_post(S > 1 ? e->roi_hp : e->roi_h, e->roi_fc, S > 1 ? S : 0, S > 1 ? e->roi_b : nullptr, e->roi_cls_w, e->roi_cls_b,
+                                    e->roi_box_w, e->roi_box_b, out_boxes, counts + 1, 0,
                                     e->roi_cap, e->roi_reg_w, (float)g.H, (float)g.W, e->roi_score_thresh, e->roi_nms_thresh, e->roi_topk,
                                     e->det_boxes + b * rcap * 4, e->det_scores + b * rcap, e->det_src + b * rcap, e->det_count + b * 4,
                                     e->post, e->fin_boxes_of(b), e->fin_scores_of(b), e->fin_count + b * 4,
@@ -525,6 +540,9 @@ extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const
     if (!e->roi_set) {
         const size_t cap = (size_t)e->roi_cap;
         const size_t MB = (size_t)e->cfg.max_batch;
+        // K split of the second-stage GEMM: 32 slices when the shape allows it (k_conv_gd's 80 x 64 tiles, whole 16-channel chunks per slice)
+        e->roi_ksplit = (fc_dim % 64 == 0 && K % (16 * 32) == 0 && K >= 2048 && cap <= 512) ? 32 : 1;
+        if (e->roi_ksplit > 1 && (rc = e->dalloc(&e->roi_hp, (size_t)e->roi_ksplit * cap * fc_dim))) return rc;
         if ((rc = e->dalloc(&e->roi_feat, cap * K)) || (rc = e->dalloc(&e->roi_h, cap * fc_dim)) || (rc = e->dalloc(&e->det_boxes, MB * cap * 4)) ||
             (rc = e->dalloc(&e->det_scores, MB * cap)) || (rc = e->dalloc(&e->det_src, MB * cap)) || (rc = e->dalloc(&e->det_count, MB * 4))) return rc;
         e->roi_ws_bytes = ore_roi_predict_workspace_bytes(e->roi_cap);

@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_col(RoiBwdP p, int split)
 }
 
 struct PredP {
-    const float* h; int C;                       // [cap][C] after fc1+ReLU
+    const float* h; int C;                       // [cap][C] after fc1+ReLU, or (h_parts > 0) the raw K-split partial sums [h_parts][cap][C]
+    int h_parts; const float* h_bias;            // h_parts > 0: row = ReLU(bias + sum_z h[z]) added in z order (oreconv::conv_gd_splitk)
     const float* cls_w; const float* cls_b;      // [K+1][C], [K+1]  (K = 1 foreground class)
     const float* box_w; const float* box_b;      // [4][C], [4]
     const float* boxes; const int* n_ptr; int n_host; int cap;
@@ -423,19 +424,54 @@ __global__ __launch_bounds__(256) void k_roi_finalize(const long long* __restric
 //                      scale to the requested output size, clip, drop empty boxes) -> final_*.
 constexpr int ROI_FUSED_CAP = 512;
 
+// RPB ROIs per block (64, or 8 when the rows first have to be summed from K-split partials: more blocks share that read)
+template <int RPB>
 __global__ __launch_bounds__(256) void k_roi_predict_mb(PredP p, int* __restrict__ ok_out) {
-    extern __shared__ float hs[];                 // [64][C+1] rows, then dots [6][64]
+    extern __shared__ float hs[];                 // [RPB][C+1] rows, then dots [6][64]
     const int C = p.C, LDH = C + 1;
-    float* dots = hs + 64 * LDH;
+    float* dots = hs + RPB * LDH;
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = blockIdx.x * 64;
+    const int r0 = blockIdx.x * RPB;
     if (r0 >= n) {                                // rows beyond the count: flag them out (the tail reads ok[0..cap))
-        if (tid < 64 && r0 + tid < p.cap) ok_out[r0 + tid] = 0;
+        if (tid < RPB && r0 + tid < p.cap) ok_out[r0 + tid] = 0;
         return;
     }
-    const int rows = min(64, n - r0);
-    for (int i = tid; i < rows * C; i += 256) hs[(i / C) * LDH + (i % C)] = p.h[(size_t)r0 * C + i];
+    const int rows = min(RPB, n - r0);
+    if (p.h_parts > 0) {
+        // four elements per thread and sixteen slices per step: 64 independent loads in flight (a plain z loop is one dependent L2 round
+        // trip per slice and element: 69 us for 32 slices); every element still adds its slices in the order z = 0, 1, 2, ...
+        const size_t zs = (size_t)p.cap * C;
+        const int ne = rows * C;
+        for (int i0 = tid; i0 < ne; i0 += 256 * 4) {
+            float v[4];
+            const float* src[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(i0 + 256 * j, ne - 1);
+                v[j] = p.h_bias ? p.h_bias[i % C] : 0.0f;
+                src[j] = p.h + (size_t)r0 * C + i;
+            }
+            for (int z0 = 0; z0 < p.h_parts; z0 += 16) {
+                float t[16][4];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[k][j] = z0 + k < p.h_parts ? src[j][(size_t)(z0 + k) * zs] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += t[k][j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + 256 * j;
+                if (i < ne) hs[(i / C) * LDH + (i % C)] = fmaxf(v[j], 0.0f);
+            }
+        }
+    } else {
+        for (int i = tid; i < rows * C; i += 256) hs[(i / C) * LDH + (i % C)] = p.h[(size_t)r0 * C + i];
+    }
     __syncthreads();
     if (wave < 3 && lane < rows) {
         // the weight index is wave-uniform: the compiler fetches the rows through the scalar cache (s_load), the LDS port only
@@ -455,7 +491,7 @@ __global__ __launch_bounds__(256) void k_roi_predict_mb(PredP p, int* __restrict
         dots[(2 * wave + 1) * 64 + lane] = a1;
     }
     __syncthreads();
-    if (wave == 0 && r0 + lane < p.cap) {
+    if (wave == 0 && lane < RPB && r0 + lane < p.cap) {
         const int r = r0 + lane;
         int ok = 0;
         if (lane < rows) {
@@ -769,6 +805,18 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
                                         int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
                                         const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
                                         int32_t* host_count, void* workspace, size_t workspace_bytes, void* stream) {
+    return oreroi::roi_predict_post(h, C, 0, nullptr, cls_w, cls_b, box_w, box_b, boxes, n_dev, n_host, cap, reg_weights4_host, img_h, img_w,
+                                    score_thresh, nms_thresh, topk, det_boxes, det_scores, det_src, det_count, post_dev, fin_boxes, fin_scores,
+                                    fin_count, host_count, workspace, workspace_bytes, stream);
+}
+
+// The same with the fc1 rows still in K-split partial sums (h = [h_parts][cap][C] raw sums, h_bias [C]): the engine's second stage.
+int oreroi::roi_predict_post(const float* h, int32_t C, int32_t h_parts, const float* h_bias, const float* cls_w, const float* cls_b,
+                             const float* box_w, const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,
+                             const float* reg_weights4_host, float img_h, float img_w, float score_thresh, float nms_thresh,
+                             int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
+                             const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
+                             int32_t* host_count, void* workspace, size_t workspace_bytes, void* stream) {
     ORE_CHECK_ARG(h && cls_w && cls_b && box_w && box_b && boxes && reg_weights4_host && det_boxes && det_scores && det_src && det_count &&
                       workspace, "ore_roi_predict_fwd: null pointer");
     ORE_CHECK_ARG(cap >= 1 && C >= 1, "ore_roi_predict_fwd: bad args");
@@ -792,7 +840,7 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
     o = (o + 255) & ~(size_t)255;
     void* nms_ws = ws + o;
     PredP p{};
-    p.h = h; p.C = C; p.cls_w = cls_w; p.cls_b = cls_b; p.box_w = box_w; p.box_b = box_b;
+    p.h = h; p.C = C; p.h_parts = h_parts; p.h_bias = h_bias; p.cls_w = cls_w; p.cls_b = cls_b; p.box_w = box_w; p.box_b = box_b;
     p.boxes = boxes; p.n_ptr = n_dev; p.n_host = n_host; p.cap = cap;
     p.wx = reg_weights4_host[0]; p.wy = reg_weights4_host[1]; p.ww = reg_weights4_host[2]; p.wh = reg_weights4_host[3];
     p.scale_clamp = logf(1000.0f / 16.0f);
@@ -801,7 +849,8 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
     hipStream_t st = (hipStream_t)stream;
     if (cap <= ROI_FUSED_CAP && (size_t)C * 4 * 71 + 6 * 64 * 4 <= 60 * 1024) {
         const size_t lds = ((size_t)64 * (C + 1) + 6 * 64) * sizeof(float);
-        hipLaunchKernelGGL(k_roi_predict_mb, dim3(ceil_div(cap, 64)), dim3(256), lds, st, p, ok);
+        if (h_parts > 0) hipLaunchKernelGGL(k_roi_predict_mb<8>, dim3(ceil_div(cap, 8)), dim3(256), lds, st, p, ok);
+        else hipLaunchKernelGGL(k_roi_predict_mb<64>, dim3(ceil_div(cap, 64)), dim3(256), lds, st, p, ok);
         int rc = ore_launch_status("k_roi_predict_mb");
         if (rc) return rc;
         TailP t{};
@@ -813,6 +862,7 @@ extern "C" int ore_roi_predict_post_fwd(const float* h, int32_t C, const float* 
         hipLaunchKernelGGL(k_roi_tail<1024>, dim3(1), dim3(1024), 0, st, t);
         return ore_launch_status("k_roi_tail");
     }
+    ORE_CHECK_ARG(h_parts == 0, "roi_predict_post: K-split partial sums are summed by the fused path only (cap <= %d)", ROI_FUSED_CAP);
     // general path (wide fc / large caps): it produces det_* only.  A caller that asked for the fused postprocess (the engine's detect
     // call polls host_count) must not get ORE_OK from a path that never writes fin_* / host_count.
     ORE_CHECK_ARG(!post_dev, "ore_roi_predict_post_fwd: the fused postprocess covers fc width <= %d (got %d) and cap <= %d (got %d)",
