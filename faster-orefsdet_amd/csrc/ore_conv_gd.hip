@@ -16,7 +16,7 @@
 //     chunk a wave issues <= 3 DMA pieces (~4 instructions each), (BM / WGM + BN / WGN) / 16 fragment reads and its MFMAs;
 //   * no cross-wave reduction: every wave finishes its own quadrant from registers (scale / shift / ReLU, 16-byte stores); the per-tile
 //     column sums of the eSE pool are reduced by shuffles + one LDS hop.
-// Single level, fp32 storage, no input affine, no top-down addend (none of these layers has one).
+// fp32 storage, no input affine; a single level (with the FPN top-down addend if the layer has one) or several levels of a 1x1 layer as one flat GEMM.
 //
 // Replaces F.conv2d + FrozenBatchNorm2d + ReLU of d2z:modeling/backbone/vovnet.py:205-219 (stem_3), :310-332 (the concat convs).
 #include "ore_conv_internal.h"
@@ -53,11 +53,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ int swz(int r16) { return (0x1320 >> (((r16 >> 2) & 3) * 4)) & 3; }   // {0, 2, 3, 1}
 
 struct GdK {
-    const float* in; const float* w; const float* scale; const float* shift; float* out; float* colsum;
-    unsigned in_bytes, w_bytes, sc_bytes;
+    const float* in; const float* w; const float* scale; const float* shift; const float* add; float* out; float* colsum;
+    unsigned in_bytes, w_bytes, sc_bytes, add_bytes;
     int M, K, Cout, Cout16, nchunks;
     int irow0, H, W, Ho, Wo, in_ld, in_coff, stride, pad;
-    int out_ld, out_coff, relu_cout;
+    int out_ld, out_coff, relu_cout, add_H, add_W, add_ld, add_coff;   // add: the FPN top-down addend [B][add_H][add_W][add_ld], read at (oy / 2, ox / 2)
     int zc_stride, out_zstride;   // K split over blockIdx.z: slice z stages chunks z * zc_stride + [0, nchunks) and writes raw sums at out + z * out_zstride (0, 0: no split)
     int xmap, gx, gy;
     float inv_hw, inv_wo, inv_gx, inv_gy;
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
     static_assert(PPW * (NS - 1) <= 63, "vmcnt");
     extern __shared__ __attribute__((aligned(16))) float lds[];      // NS * STAGE_F floats (+ the column-sum scratch, reusing the ring)
     GdK p = q.k;
-    asm volatile("" :: "s"(p.in), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.out), "s"(p.colsum), "s"(p.in_bytes), "s"(p.w_bytes), "s"(p.sc_bytes),
+    asm volatile("" :: "s"(p.in), "s"(p.w), "s"(p.scale), "s"(p.shift), "s"(p.add), "s"(p.out), "s"(p.colsum), "s"(p.in_bytes), "s"(p.w_bytes), "s"(p.sc_bytes), "s"(p.add_bytes),
                  "s"(p.M), "s"(p.K), "s"(p.Cout), "s"(p.Cout16), "s"(p.nchunks), "s"(p.irow0), "s"(p.H), "s"(p.W), "s"(p.Ho), "s"(p.Wo));
-    asm volatile("" :: "s"(p.in_ld), "s"(p.in_coff), "s"(p.stride), "s"(p.pad), "s"(p.out_ld), "s"(p.out_coff), "s"(p.relu_cout), "s"(p.zc_stride), "s"(p.out_zstride), "s"(p.xmap), "s"(p.gx),
+    asm volatile("" :: "s"(p.in_ld), "s"(p.in_coff), "s"(p.stride), "s"(p.pad), "s"(p.out_ld), "s"(p.out_coff), "s"(p.relu_cout), "s"(p.add_H), "s"(p.add_W), "s"(p.add_ld), "s"(p.add_coff), "s"(p.zc_stride), "s"(p.out_zstride), "s"(p.xmap), "s"(p.gx),
                  "s"(p.gy), "s"(p.inv_hw), "s"(p.inv_wo), "s"(p.inv_gx), "s"(p.inv_gy));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
 
     // ---- epilogue: every wave finishes its own TA x TB tiles from registers
     const __amdgpu_buffer_rsrc_t rsc = make_rsrc(p.scale, p.scale ? p.sc_bytes : 0u), rsh = make_rsrc(p.shift, p.shift ? p.sc_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(p.add, p.add ? p.add_bytes : 0u);
     const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
     float* cs = lds;                                   // [WGM][GB][16] column sums of the waves' row bands
     const int kq = lane >> 4;
@@ -259,6 +260,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
             if (m < p.M && en < p.Cout) {
 #endif
                 v = acc[i][j] * e_sc + e_sh;
+                if (p.add) {                                       // nearest-neighbour upsampled coarser level (d2z:modeling/backbone/fpn.py:140-144)
+                    const int b = fdiv(m, hw, p.inv_hw);
+                    const int rr = m - b * hw;
+                    const int oy = fdiv(rr, p.Wo, p.inv_wo), ox = rr - oy * p.Wo;
+                    v += bload4(rad, (unsigned)((((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + en) * 4));
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (en + r < p.relu_cout) v[r] = fmaxf(v[r], 0.0f);
@@ -328,12 +335,16 @@ void conv_gd_force(int bm, int bn, int ns) { g_gd_force[0] = bm; g_gd_force[1] =
 bool conv_gd_forced() { return g_gd_force[0] > 0; }
 int conv_gd_forced_bm() { return g_gd_force[0]; }
 
+// several pyramid levels in one launch: a 1x1 stride-1 layer over the level-major row matrix is one flat GEMM (as in k_conv_kd)
+static bool gd_flat(const ConvP& p) { return p.nlev > 1 && p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0; }
+
 static bool gd_applies(const ConvP& p) {
-    if (p.sb || p.bf16 || p.in_mul || p.in_add || p.in_relu || p.nlev != 1 || p.ep_stride || p.add) return false;
+    if (p.sb || p.bf16 || p.in_mul || p.in_add || p.in_relu || (p.nlev != 1 && !gd_flat(p)) || p.ep_stride || (p.add && p.nlev != 1)) return false;
     if (p.Cin % 16 != 0 || p.in_ld % 16 != 0 || p.kh != p.kw || (p.kh != 1 && p.kh != 3)) return false;
     if (p.M >= (1 << 22) || p.nchunks > kTab) return false;
-    const long long in_rows = (long long)p.lv[0].irow0 + (long long)p.B * p.lv[0].H * p.lv[0].W;
+    const long long in_rows = gd_flat(p) ? (long long)p.lv[0].irow0 + p.M : (long long)p.lv[0].irow0 + (long long)p.B * p.lv[0].H * p.lv[0].W;
     if (in_rows * p.in_ld * 4 >= (long long)kOOB - (1 << 24) || (long long)p.Cout16 * p.K * 4 >= (long long)kOOB) return false;
+    if (p.add && (long long)p.B * p.add_H * p.add_W * p.add_ld * 4 >= (long long)kOOB) return false;
     return true;
 }
 
@@ -349,6 +360,10 @@ static GdPlan gd_plan(const ConvP& p) {
     if (p.kh == 1 && p.Cout16 == 256 && p.nchunks >= 16) return {64, 64, 4};
     if (p.kh == 1 && p.Cout16 == 112 && p.nchunks >= 16) return {128, 64, 14};
     if (p.kh == 3 && p.stride == 2 && p.Cout16 == 128 && p.Cin == 64) return {112, 128, 14};
+    // the FPN lateral of stage 3 (M = 6400) and conv3 over the three levels (M = 8400), 256 -> 128 (profiles/r04_gd_mid.txt):
+    // 9.4 us against k_conv_kd's 11.7 when 64 x 64 tiles fill the CUs once, 12.6 against 20.1 when they would spill into a second round
+    if (p.kh == 1 && p.Cout16 == 128 && p.nchunks == 16 && !p.colsum)
+        return ceil_div(p.M, 64) * 2 <= 256 ? GdPlan{64, 64, 14} : GdPlan{32, 64, 4};
     return {0, 0, 0};
 }
 
@@ -363,11 +378,15 @@ int conv_gd_launch(ConvP& p, hipStream_t st) {
     const GdPlan pl = gd_plan(p);
     if (pl.bm == 0) return 1;
     const int gx = ceil_div(p.M, pl.bm), gy = ceil_div(p.Cout16, pl.bn);
-    const Lvl& L = p.lv[0];
+    Lvl L = p.lv[0];
+    int Bimg = p.B;
+    if (gd_flat(p)) { L.H = 1; L.W = p.M; L.Ho = 1; L.Wo = p.M; Bimg = 1; }      // one "image" of M pixels in a row
     GdP q;
     GdK& k = q.k;
-    k.in = p.in; k.w = p.w; k.scale = p.scale; k.shift = p.shift; k.out = p.out; k.colsum = p.colsum;
-    k.in_bytes = (unsigned)(((long long)L.irow0 + (long long)p.B * L.H * L.W) * p.in_ld * 4);
+    k.in = p.in; k.w = p.w; k.scale = p.scale; k.shift = p.shift; k.add = p.add; k.out = p.out; k.colsum = p.colsum;
+    k.add_bytes = p.add ? (unsigned)((long long)p.B * p.add_H * p.add_W * p.add_ld * 4) : 0u;
+    k.add_H = p.add_H; k.add_W = p.add_W; k.add_ld = p.add_ld; k.add_coff = p.add_coff;
+    k.in_bytes = (unsigned)(((long long)L.irow0 + (long long)Bimg * L.H * L.W) * p.in_ld * 4);
     k.w_bytes = (unsigned)((long long)p.Cout16 * p.K * 4);
     k.sc_bytes = (unsigned)p.Cout * 4u;
     k.M = p.M; k.K = p.K; k.Cout = p.Cout; k.Cout16 = p.Cout16; k.nchunks = p.nchunks;
@@ -394,7 +413,7 @@ int conv_gd_launch(ConvP& p, hipStream_t st) {
     GD_CASE(128, 112, 4, 1, 4) GD_CASE(208, 64, 1, 4, 4) GD_CASE(224, 64, 1, 4, 4) GD_CASE(112, 64, 1, 4, 4) GD_CASE(96, 128, 2, 2, 4) GD_CASE(64, 128, 2, 2, 2)
     GD_CASE(128, 128, 2, 2, 2) GD_CASE(208, 64, 1, 4, 2) GD_CASE(128, 112, 4, 1, 2)
     GD_CASE(128, 128, 2, 4, 4) GD_CASE(112, 128, 1, 8, 4) GD_CASE(128, 112, 8, 1, 4) GD_CASE(64, 128, 2, 4, 4) GD_CASE(128, 64, 4, 2, 4) GD_CASE(64, 64, 2, 4, 4)
-    GD_CASE(128, 128, 2, 4, 2) GD_CASE(112, 128, 1, 8, 2)
+    GD_CASE(128, 128, 2, 4, 2) GD_CASE(112, 128, 1, 8, 2) GD_CASE(80, 64, 1, 4, 4) GD_CASE(80, 128, 1, 4, 4) GD_CASE(48, 64, 1, 4, 4) GD_CASE(32, 64, 1, 4, 4)
 #undef GD_CASE
     if (g_gd_force[0] > 0) { ore_set_error("k_conv_gd: no build for tile %dx%d, ring %d", pl.bm, pl.bn, pl.ns); return ORE_EINVAL; }
     return 1;
@@ -412,7 +431,8 @@ int conv_gd_splitk(const float* in, int in_ld, const float* w, int M, int K, int
     ORE_CHECK_ARG((long long)M * in_ld * 4 < (long long)kOOB - (1 << 24) && (long long)Cout16 * K * 4 < (long long)kOOB, "conv_gd_splitk: operand beyond a buffer descriptor");
     GdP q;
     GdK& k = q.k;
-    k.in = in; k.w = w; k.scale = nullptr; k.shift = nullptr; k.out = parts; k.colsum = nullptr;
+    k.in = in; k.w = w; k.scale = nullptr; k.shift = nullptr; k.add = nullptr; k.out = parts; k.colsum = nullptr;
+    k.add_bytes = 0u; k.add_H = k.add_W = k.add_ld = k.add_coff = 0;
     k.in_bytes = (unsigned)((long long)M * in_ld * 4); k.w_bytes = (unsigned)((long long)Cout16 * K * 4); k.sc_bytes = 0u;
     k.M = M; k.K = K; k.Cout = Cout16; k.Cout16 = Cout16; k.nchunks = K / 16 / S;
     k.irow0 = 0; k.H = 1; k.W = M; k.Ho = 1; k.Wo = M; k.in_ld = in_ld; k.in_coff = 0; k.stride = 1; k.pad = 0;

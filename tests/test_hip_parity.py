@@ -281,7 +281,7 @@ def test_conv_kw_kernel_vs_oracle(ore, kw_forced, B, H, W, Cin, Cout, k, stride)
 
 GD_BUILDS = [(64, 128, 4), (64, 64, 4), (64, 112, 4), (128, 64, 4), (128, 128, 4), (32, 128, 4), (128, 112, 4), (208, 64, 4), (224, 64, 4), (112, 64, 4), (96, 128, 4),
              (64, 128, 2), (128, 128, 2), (208, 64, 2), (128, 112, 2),
-             (128, 128, 14), (112, 128, 14), (128, 112, 14), (64, 128, 14), (128, 64, 14), (64, 64, 14), (128, 128, 12), (112, 128, 12)]   # 10 + ns: the eight-wave builds
+             (128, 128, 14), (112, 128, 14), (128, 112, 14), (64, 128, 14), (128, 64, 14), (64, 64, 14), (128, 128, 12), (112, 128, 12), (80, 64, 4), (80, 128, 4), (48, 64, 4), (32, 64, 4)]   # 10 + ns: the eight-wave builds
 
 
 @pytest.fixture
@@ -325,6 +325,74 @@ def test_conv_gd_every_build(ore, gd_forced, bm, bn, ns, B, H, W, Cin, Cout, k, 
     ore.conv2d(buf.cuda(), wp, Cout, k, stride, in_coff=16, Cin=Cin, shift=dev(sh), out=out, out_coff=32)
     o = out.cpu()
     assert rel_err(o[..., 32:32 + Cout].permute(0, 3, 1, 2).numpy(), refs.numpy()) < TOL and (o[..., :32] == 3.0).all()
+
+
+@pytest.mark.parametrize("bm,bn,ns", [(64, 64, 14), (32, 64, 4), (80, 64, 4), (64, 128, 4)])
+def test_conv_gd_levels_flat(ore, gd_forced, bm, bn, ns):
+    """A 1x1 stride-1 layer over several pyramid levels is one flat GEMM over the level-major rows for k_conv_gd too (conv3 after the
+    correlation: 256 -> 128 over p3..p5): forced builds against F.conv2d per level, and the automatic plan at the 640^2 row counts
+    (6400 + 1600 + 400) bit-identical to the forced build it names."""
+    g = torch.Generator().manual_seed(bm + ns)
+    HW = [(21, 19), (11, 10), (6, 5)]
+    B, Cin, Cout = 2, 256, 128
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    xs = [torch.randn(B, Cin, h, ww, generator=g) for h, ww in HW]
+    rows = torch.cat([nhwc(x).reshape(-1, Cin) for x in xs], 0).contiguous()
+    wp = ore.pack_conv_weight(w).cuda()
+    ore.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)          # k_conv_kd would take these rows first
+    ore.lib().ore_conv_set_plan_override(-15, bm, bn, ns, 0)
+    y = ore.conv2d_levels(rows.cuda(), HW, B, wp, Cout, 1, shift=dev(b), relu_cout=Cout).cpu()
+    ore.lib().ore_conv_set_plan_override(-12, 1, 0, 0, 0)
+    o = 0
+    for x, (h, ww) in zip(xs, HW):
+        ref = F.relu(F.conv2d(x, w, b))
+        got = y[o:o + B * h * ww].reshape(B, h, ww, Cout).permute(0, 3, 1, 2)
+        assert rel_err(got.numpy(), ref.numpy()) < TOL
+        o += B * h * ww
+
+
+@pytest.mark.parametrize("bm,bn,ns", [(64, 64, 14), (64, 64, 4), (32, 128, 4)])
+def test_conv_gd_topdown_add(ore, gd_forced, bm, bn, ns):
+    """k_conv_gd's epilogue adds the nearest-upsampled coarser level (the FPN lateral): odd sizes, two images."""
+    g = torch.Generator().manual_seed(ns + bm)
+    B, H, W, Cin, Cout = 2, 13, 18, 64, 48
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / 8
+    b = torch.randn(Cout, generator=g) * 0.1
+    top = torch.randn(B, Cout, (H + 1) // 2, (W + 1) // 2, generator=g)
+    ref = F.conv2d(x, w, b) + F.interpolate(top, scale_factor=2, mode="nearest")[:, :, :H, :W]
+    ore.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+    ore.lib().ore_conv_set_plan_override(-15, bm, bn, ns, 0)
+    y = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, 1, 1, shift=dev(b), add=nhwc(top))
+    ore.lib().ore_conv_set_plan_override(-12, 1, 0, 0, 0)
+    assert rel_err(nchw(y).numpy(), ref.numpy()) < TOL
+
+
+def test_conv_gd_plan_takes_conv3_and_lat3(ore):
+    """The automatic plan at the 640^2 shapes: conv3 over three levels (8400 rows) and the stage-3 lateral (6400 rows), 256 -> 128, run on
+    k_conv_gd -- the results equal the forced builds the plan names bit for bit, and differ in rounding from k_conv_kd's."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(128, 256, 1, 1, generator=g) / 16
+    wp = ore.pack_conv_weight(w).cuda()
+    for HW, build in (([(80, 80), (40, 40), (20, 20)], (32, 64, 4)), ([(80, 80)], (64, 64, 14))):
+        rows = torch.randn(sum(h * ww for h, ww in HW), 256, generator=g).cuda()
+        top = torch.randn(1, 40, 40, 128, generator=g).cuda()          # the lateral adds the upsampled coarser level (FPN top-down)
+        run = (lambda: ore.conv2d_levels(rows, HW, 1, wp, 128, 1)) if len(HW) > 1 else (lambda: ore.conv2d(rows.view(1, 80, 80, 256), wp, 128, 1, add=top).view(-1, 128))
+        y_plan = run().clone()
+        ore.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+        ore.lib().ore_conv_set_plan_override(-15, *build, 0)
+        y_forced = run().clone()
+        ore.lib().ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+        ore.lib().ore_conv_set_plan_override(-14, 0, 0, 0, 0)
+        y_other = run().clone()                                        # gd and kd off: the round-3 kernel
+        ore.lib().ore_conv_set_plan_override(-14, 1, 0, 0, 0)
+        ore.lib().ore_conv_set_plan_override(-12, 1, 0, 0, 0)
+        assert torch.equal(y_plan, y_forced)
+        ref = rows.cpu() @ w.view(128, 256).t()
+        if len(HW) == 1:
+            ref = ref + top.cpu()[0].repeat_interleave(2, 0).repeat_interleave(2, 1).reshape(-1, 128)
+        assert rel_err(y_plan.cpu().numpy(), ref.numpy()) < TOL and rel_err(y_other.cpu().numpy(), ref.numpy()) < TOL
 
 
 @pytest.fixture

@@ -168,6 +168,22 @@ if __name__ == "__main__":
                 except orehip.OreError as ex:
                     print("   not built:", str(ex)[:100])
         L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+    elif len(sys.argv) > 1 and sys.argv[1] == "gdmid":                # k_conv_gd forced on the mid-size 1x1 layers k_conv_kd serves (kd off while forced)
+        for shape in ((80, 80, 256, 128, 1), (80, 105, 256, 128, 1), (40, 40, 544, 384, 1), (40, 40, 512, 128, 1), (20, 20, 768, 512, 1), (40, 40, 96, 96, 3), (40, 40, 256, 96, 3)):
+            L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+            L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
+            print("#### the plan's kernel")
+            trace(*shape, reps=1)
+            L.ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+            for bm, bn, ns in ((64, 64, 4), (64, 128, 4), (80, 64, 4), (80, 128, 4), (48, 64, 4), (32, 64, 4), (32, 128, 4), (64, 64, 14), (128, 64, 14), (112, 64, 4)):
+                L.ore_conv_set_plan_override(-15, bm, bn, ns, 0)
+                print("#### k_conv_gd<%dx%d, NS %d>" % (bm, bn, ns))
+                try:
+                    trace(*shape, reps=1)
+                except orehip.OreError as ex:
+                    print("   not built:", str(ex)[:100])
+        L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+        L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
     elif len(sys.argv) > 1 and sys.argv[1] == "gdabl":                # k_conv_gd with parts of its chunk loop switched off (trace build; results are wrong by design)
         for shape, stride in (((80, 80, 352, 256, 1), 1), ((160, 160, 320, 112, 1), 1), ((320, 320, 64, 128, 3), 2)):
             for bm, bn, ns in ((64, 64, 4), (64, 64, 14), (112, 128, 14)):
