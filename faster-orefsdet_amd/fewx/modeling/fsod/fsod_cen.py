@@ -357,15 +357,18 @@ class CenterNet2Detector(nn.Module):
             oh, ow = int(inp.get("height", H)), int(inp.get("width", W))
             rec = e.detect_begin(img, oh, ow)                     # a fresh tensor, filled behind the graph
             fresh = self._engine_key == self._engine_key_now()
-            res = Instances((oh, ow))
+            res = Instances((oh, ow))                             # the result objects are made while the device works, too
+            bx = Boxes.__new__(Boxes)
+            out = [{"instances": res}]
             boxes, scores, classes = e.detect_end(rec)
             if not fresh:
                 e = self.engine()                                 # rebuilds
                 boxes, scores, classes = e.detect(img, oh, ow)
-            res.pred_boxes = Boxes(boxes)
-            res.scores = scores
-            res.pred_classes = classes
-            return [{"instances": res}]
+            # three views of one record cut at the same count by detect_end: [k, 4] fp32, [k] fp32, [k] int64 -- what Boxes() and
+            # Instances.set() would check again, per image, on the protocol's critical path
+            bx.tensor = boxes
+            res._fields = {"pred_boxes": bx, "scores": scores, "pred_classes": classes}
+            return out
         e = self.engine()
         if do_postprocess and getattr(e, "has_roi", False):
             from detectron2.structures import Boxes, Instances
