@@ -250,8 +250,8 @@ def roi_stage_losses(rh, qf: List[torch.Tensor], sup8: torch.Tensor, roi_boxes, 
 
 def first_stage_batch(pg, heads: List[torch.Tensor], gts: List[torch.Tensor], norm_avg: Optional[torch.Tensor] = None):
     """CenterNet.forward, training branch, after the head, for the B images of a call (ref:fewx/modeling/fsod/fsod_rpn.py:658-700) with
-    NO host sync: ground truth of all images in one launch, the three losses over all rows in one (normalisers as the reference's
-    reduce_sum / num_gpus with every image counted as a GPU -- orehip.autograd.CenterNetLossFn), the *_TRAIN proposals per image.
+    NO host sync: ground truth of all images in one launch, the three losses over all rows in one (normalisers the reference's
+    max(reduce_sum / num_gpus, 1) over the rank's whole batch -- orehip.autograd.CenterNetLossFn), the *_TRAIN proposals per image.
     heads[l] [B,H,W,16].  Returns (per-image detect outputs, losses dict, targets dict, this call's [reg rows, positives])."""
     import orehip
     from orehip import autograd as A

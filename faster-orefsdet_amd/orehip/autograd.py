@@ -529,10 +529,13 @@ def roi_align_batched(feats, boxes, box_image, strides=(8, 16, 32), pooled: int 
 class CenterNetLossFn(Function):
     """head [rows, ld>=5] (cols 0..3 ltrb after Scale+ReLU, col 4 heatmap logit) -> [loss_loc, loss_agn_pos, loss_agn_neg, reg rows,
     positives] (ref:fewx/modeling/fsod/fsod_rpn.py:702-779; the last two are this rank's un-normalised counts, no gradient).
-    Normalisers as the reference's `reduce_sum(n) / num_gpus` (fsod_rpn.py:712-716,748-751) with every image counted as one of its
-    GPUs: a rank holding `images` images divides its sums by images * max(total / (world * images), 1), so that B images on one
-    rank, B ranks with one image each, or any mix give the same averaged gradient.  The totals are summed over ranks on device.
-    hp["norm_avg"] (2 floats, optional) replaces the averaged normalisers (tests: one image of a larger virtual batch)."""
+    Normalisers exactly the reference's (fsod_rpn.py:712-716,748-751): `max(reduce_sum(n) / num_gpus, 1)` -- this rank's sums over ALL
+    its images divided by the per-rank average of the totals, clamped at 1.  (Rounds 2-3 clamped at the number of images on the rank,
+    `max(total / world, images)`, so that B images on one rank and B single-image ranks agreed even in the clamped regime; that was this
+    implementation's own rule, not the reference's, and differed from it whenever a rank's batch averaged less than one positive per
+    image.  Outside the clamp the two are the same number.)  The totals are summed over ranks on device.
+    hp["norm_avg"] (2 floats, optional): PER-IMAGE averaged normalisers of a larger virtual batch this call is one part of (tests);
+    the call then divides by norm_avg * images."""
 
     @staticmethod
     def forward(ctx, head, reg_targets, hm_targets, pos_inds, pos_count, hp):
@@ -549,7 +552,7 @@ class CenterNetLossFn(Function):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 world = dist.get_world_size()
                 dist.all_reduce(norm)                                 # the only other exchange of the step: 2 scalars
-            avg = torch.clamp(norm / (world * images), min=1.0)
+            avg = torch.clamp(norm / world, min=1.0) / images         # den = max(total / world, 1)
         den = avg * images
         coef = torch.stack([hp["reg_weight"] / den[0], hp["pos_weight"] * hp["alpha"] / den[1],
                             hp["neg_weight"] * (1.0 - hp["alpha"]) / den[1]])

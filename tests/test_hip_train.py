@@ -935,6 +935,40 @@ def test_graph_captured_dense_part_matches_eager(oh):
     assert float((res["eager"][1] - res["graph"][1]).abs().max()) <= 1e-5        # ROIAlign backward uses fp32 atomics: order differs run to run
 
 
+def test_centernet_normaliser_is_the_references(oh):
+    """ref:fewx/modeling/fsod/fsod_rpn.py:712-716,748-751: the CenterNet sums of a rank's WHOLE batch are divided by
+    max(reduce_sum(n) / num_gpus, 1).  In the clamped regime -- here two images without any ground truth, n = 0 -- the batch loss is
+    therefore the SUM of the two single-image losses (each divided by 1), not their mean (what max(total / world, images), the rule of
+    rounds 2-3, gave); with positives the batch loss is the positives-weighted combination and both rules coincide."""
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.modeling.fsod import train_forward as TF
+    shots = 4
+    m, sd, cfg = _train_model(shots)
+
+    def item(seed, n_gt):
+        img, gt, sup, sbox = T.synth_train_inputs(seed, (256, 320), n_gt=max(n_gt, 1), shots=shots, support_hw=96)
+        gt = gt[:n_gt]
+        inst = Instances((256, 320))
+        inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+        return {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+    e1, e2 = item(2, 0), item(3, 0)
+    l1, l2, l12 = TF.train_forward(m, [e1]), TF.train_forward(m, [e2]), TF.train_forward(m, [e1, e2])
+    k = "loss_centernet_agn_neg"
+    want = float(l1[k]) + float(l2[k])
+    assert float(l1[k]) > 0 and abs(float(l12[k]) - want) <= 1e-5 * want, (float(l12[k]), want)
+    # with positives: sums over the batch / total positives
+    a, b = item(1, 5), item(4, 3)
+    la, aux_a = TF.train_forward(m, [a], return_aux=True)
+    lb, aux_b = TF.train_forward(m, [b], return_aux=True)
+    lab, aux = TF.train_forward(m, [a, b], return_aux=True)
+    ca, cb, cab = aux_a["cn_counts"].cpu(), aux_b["cn_counts"].cpu(), aux["cn_counts"].cpu()
+    assert torch.allclose(ca + cb, cab) and float(cab.min()) >= 2
+    for key, idx in (("loss_centernet_loc", 0), ("loss_centernet_agn_pos", 1), ("loss_centernet_agn_neg", 1)):
+        want = (float(la[key]) * float(ca[idx]) + float(lb[key]) * float(cb[idx])) / float(cab[idx])
+        assert abs(float(lab[key]) - want) <= 2e-5 * max(abs(want), 1e-3), (key, float(lab[key]), want)
+
+
 def test_train_forward_batch_and_empty_gt(oh):
     """A list of B images gives what B data-parallel single-image ranks of the reference give after gradient averaging (the
     reference itself returns the last image's losses for a longer list: SURVEY App. C.1); an image without ground truth trains on
