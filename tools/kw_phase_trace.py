@@ -188,7 +188,8 @@ if __name__ == "__main__":
         for shape, stride in (((80, 80, 352, 256, 1), 1), ((160, 160, 320, 112, 1), 1), ((320, 320, 64, 128, 3), 2)):
             for bm, bn, ns in ((64, 64, 4), (64, 64, 14), (112, 128, 14)):
                 L.ore_conv_set_plan_override(-15, bm, bn, ns, 0)
-                for flags, what in ((0, "all"), (1, "no MFMA"), (2, "no DMA in loop"), (6, "no DMA, no reads"), (7, "barriers only"), (7 + 16, "barriers only, no stores"),
+                for flags, what in ((0, "all"), (8, "all but the barriers"), (1, "no MFMA"), (2, "no DMA in loop"), (6, "no DMA, no reads"), (6 + 8, "MFMAs only (no DMA, reads, barriers)"),
+                                    (7, "barriers only"), (7 + 16, "barriers only, no stores"),
                                     (7 + 16 + 32, "barriers only, no stores, no prologue DMA"), (15 + 16 + 32, "nothing"), (16, "all but the stores")):
                     L.ore_conv_set_plan_override(-16, flags, 0, 0, 0)
                     print("#### k_conv_gd<%dx%d, NS %d> %s" % (bm, bn, ns, what))
