@@ -538,6 +538,11 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
 
 template <int T>
 __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
+    // The address of the caller's result record travels in a pinned host word (see the end of this kernel): that system-scope load is a
+    // PCIe round trip, so it is issued FIRST and consumed last (the host wrote the word before it launched the graph).
+    unsigned long long rec_early = 0ull;
+    if (p.post != nullptr && p.host_count)
+        rec_early = __hip_atomic_load(reinterpret_cast<unsigned long long*>(p.host_count) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // LDS: compacted + sorted boxes / scores / source rows, then the suppression words
     __shared__ __attribute__((aligned(16))) float cb[ROI_FUSED_CAP * 4];    // compacted (filter order)
     __shared__ float cs[ROI_FUSED_CAP];
@@ -684,10 +689,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
         // The caller's result record (boxes [cap][4] f32 | scores [cap] f32 | classes [cap] i64): its device address is handed over in
         // the 64-bit word behind the pinned count word (written by the host before the launch, read here with a system-scope load):
         // the last kernel of the graph fills the caller's own tensor, no copy behind the graph.  0 = none.
-        char* rec = nullptr;
-        if (p.host_count)
-            rec = reinterpret_cast<char*>(__hip_atomic_load(reinterpret_cast<unsigned long long*>(p.host_count) + 1, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_SYSTEM));
+        char* rec = reinterpret_cast<char*>(rec_early);
         float* rec_boxes = reinterpret_cast<float*>(rec);
         float* rec_scores = rec ? reinterpret_cast<float*>(rec + (size_t)p.cap * 16) : nullptr;
         long long* rec_cls = rec ? reinterpret_cast<long long*>(rec + (size_t)p.cap * 20) : nullptr;
