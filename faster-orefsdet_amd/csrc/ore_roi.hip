@@ -630,8 +630,15 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
                 const float xx2 = fminf(a.z, q.z), yy2 = fminf(a.w, q.w);
                 const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
                 const float inter = ww * hh;
-                const float ovr = inter / (ai + aq - inter);
-                if (cvalid && ovr > p.nms_thresh && (!dg || rq + rr < lane)) acc |= 1ull << (rq + rr);   // own block: earlier rows only
+                const float uni = ai + aq - inter;
+                // ovr > thr with ovr = fl(inter / uni), decided without the division wherever the answer is not within 2^-20 of the
+                // threshold (the products below are off by <= 3 * 2^-24 relative): this phase is one CU's VALU throughput -- 41 000 pairs
+                // at ~40 instructions -- and the IEEE division is a quarter of them.  Inside the band (and for uni = 0: NaN, not
+                // suppressed) the exact expression decides, so the bit matrix is the one k_nms_mask / the CPU twin compute.
+                const float tu = p.nms_thresh * uni;
+                bool sup = inter > tu * 1.00000095367431640625f;
+                if (!sup && inter >= tu * 0.99999904632568359375f) sup = inter / uni > p.nms_thresh;
+                if (cvalid && sup && (!dg || rq + rr < lane)) acc |= 1ull << (rq + rr);   // own block: earlier rows only
             }
             if (acc) atomicOr(&supT[col * WPR + bi], acc);
         }
