@@ -1,24 +1,29 @@
-// k_conv_gd -- implicit-GEMM NHWC convolution for the LARGE-M layers that are not Winograd's (stem_3: 3x3 stride 2, the stage-2 / 3
-// concat 1x1 convs: M = 6400 .. 25600 rows at batch 1), fp32 MFMA (v_mfma_f32_16x16x4_f32), shared-stage LDS-DMA through buffer
-// descriptors.
+// k_conv_gd -- implicit-GEMM NHWC convolution, fp32 MFMA (v_mfma_f32_16x16x4_f32), shared-stage LDS-DMA through buffer descriptors.
+// Serves (bs = 1 plan): stem_3 (3x3 stride 2), the stage-2 / 3 concat 1x1 convs (M = 6400 .. 25600 rows), the stage-3 FPN lateral (with
+// its top-down add), conv3 over the three pyramid levels as one flat GEMM, and -- with K split over blockIdx.z -- the second-stage GEMM.
 //
-// Round 4.  k_conv_gs / k_conv_igemm run these layers at 36-48 % of the fp32 MFMA peak, and round 2's counters said why: 87 VALU + 82
+// Round 4.  k_conv_gs / k_conv_igemm ran the large layers at 36-48 % of the fp32 MFMA peak, and round 2's counters said why: 87 VALU + 82
 // SALU instructions per 28 MFMAs per step -- the matrix pipe waits for instruction issue, not for data.  k_conv_kd showed the cure on
 // the small layers (descriptor addressing: per-lane byte offsets computed once, the step is a scalar offset from a table in the kernel
 // arguments or an instruction offset, out-of-range = the descriptor's zeros) but its K-split blocks tie here, because their partial tiles
 // meet in LDS and one block owns a CU.  This kernel puts the same addressing into the SHARED-stage structure:
-//   * the four waves of a block tile its BM x BN output (WGM x WGN waves) and share every staged 16-channel chunk: a chunk is (BM + BN) / 16
-//     DMA pieces of 1 KiB, piece p is issued by wave p % 4 (`buffer_load_dwordx4 ... lds`, XOR swizzle on the source offset as in
-//     k_conv_kw), an NS-deep ring, ONE raw barrier per chunk: a wave waits for its own pieces of chunk t (counted vmcnt, later chunks stay
-//     in flight), the barrier publishes everybody's, the pieces of chunk t + NS - 1 go into the slot chunk t - 1 was read from, then
-//     fragments (ds_read_b128) and MFMAs;
-//   * the chunk loop is unrolled NS times so that ring slots, LDS addresses and the weights' instruction offsets are immediates: per
-//     chunk a wave issues <= 3 DMA pieces (~4 instructions each), (BM / WGM + BN / WGN) / 16 fragment reads and its MFMAs;
-//   * no cross-wave reduction: every wave finishes its own quadrant from registers (scale / shift / ReLU, 16-byte stores); the per-tile
-//     column sums of the eSE pool are reduced by shuffles + one LDS hop.
-// fp32 storage, no input affine; a single level (with the FPN top-down addend if the layer has one) or several levels of a 1x1 layer as one flat GEMM.
+//   * the NW = 4 or 8 waves of a block tile its BM x BN output (WGM x WGN waves) and share every staged 16-channel chunk: a chunk is
+//     (BM + BN) / 16 DMA pieces of 1 KiB, piece p is issued by wave p % NW (`buffer_load_dwordx4 ... lds`, XOR swizzle on the source
+//     offset as in k_conv_kw), an NS-deep ring, ONE raw barrier per chunk: a wave waits for its own pieces of chunk t (counted vmcnt,
+//     later chunks stay in flight), the barrier publishes everybody's;
+//   * the chunk loop is unrolled NS times (NS even) so that ring slots and LDS addresses are immediates; in step t a wave reads chunk t's
+//     fragments (ds_read_b128) into one register set and multiplies chunk t-1 from the other, and its refill pieces for chunk
+//     t + NS - 1 go out BETWEEN those MFMAs (a DMA instruction holds the wave at issue while the texture addresser works off its queue);
+//   * no cross-wave reduction: every wave finishes its own tiles from registers (scale / shift / ReLU / top-down add, 16-byte stores); the
+//     per-tile column sums of the eSE pool are reduced by shuffles + one LDS hop.
+// What bounds it (profiles/r04_gd_ablation.txt): the MFMA loop with prologue and epilogue is 38 of stem_3's 45 us,
+// staging adds ~6 instead of hiding, the barriers <= 2; every tiling lands within ~10 % of the others.
+// fp32 storage, no input affine; a single level (with the FPN top-down addend if the layer has one) or several levels of a 1x1 layer as
+// one flat GEMM.
 //
-// Replaces F.conv2d + FrozenBatchNorm2d + ReLU of d2z:modeling/backbone/vovnet.py:205-219 (stem_3), :310-332 (the concat convs).
+// Replaces F.conv2d + FrozenBatchNorm2d + ReLU of d2z:modeling/backbone/vovnet.py:205-219 (stem_3), :310-332 (the concat convs);
+// d2z:modeling/backbone/fpn.py:130-150 (lateral 3); ref:fewx/modeling/fsod/fsod_cen.py conv3 after the correlation;
+// d2z:modeling/roi_heads/box_head.py fc1 (conv_gd_splitk).
 #include "ore_conv_internal.h"
 
 namespace {
