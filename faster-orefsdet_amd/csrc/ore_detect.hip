@@ -436,7 +436,11 @@ __global__ __launch_bounds__(256) void k_nms_scan_multi(ScanBatch sb) {
 // columns into an LDS ring by LDS-DMA three steps ahead of the scan (16 waves x 16 bytes per lane), and the greedy walk itself
 // never waits for global memory: removed[w] = OR over the kept rows r < 64 w of col_w[r] (all 1024 threads, from LDS), then the
 // same in-block fixpoint as k_nms_scan on wave 0.  48 -> ~20 us at n = 2400 (it was one dependent global round trip per block).
-constexpr int NMS_COL_CAP = 3072, NMS_COL_SLOT = 4096, NMS_COL_RING = 4, NMS_COL_T = 1024;   // slot = 32 DMA instructions x 128 rows
+#ifndef ORE_NMS_COL_T
+#define ORE_NMS_COL_T 1024
+#endif
+constexpr int NMS_COL_CAP = 3072, NMS_COL_SLOT = 4096, NMS_COL_RING = 4, NMS_COL_T = ORE_NMS_COL_T;   // slot = 32 DMA instructions x 128 rows
+constexpr int NMS_COL_NWV = NMS_COL_T / 64, NMS_COL_PPW = 32 / NMS_COL_NWV;          // DMA instructions per wave and column
 
 __global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_col(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
                                                             const int* __restrict__ s_order, const int* __restrict__ n_ptr,
@@ -460,11 +464,11 @@ __global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_col(const float* __restr
         const unsigned long long* base = maskT + (size_t)c * col_ld;
         unsigned long long* dst = cl + (c % NMS_COL_RING) * NMS_COL_SLOT;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int piece = (wave + 16 * k) * 64 + lane;    // 16-byte piece = rows 2 piece, 2 piece + 1
+        for (int k = 0; k < NMS_COL_PPW; ++k) {
+            const int piece = (wave + NMS_COL_NWV * k) * 64 + lane;    // 16-byte piece = rows 2 piece, 2 piece + 1
             const unsigned long long* src = piece * 2 < rows ? base + piece * 2 : zero_page;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + (wave + 16 * k) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + (wave + NMS_COL_NWV * k) * 128), 16, 0, 0);
         }
     };
     // scores first (ordinary loads: issued and retired before any DMA is in flight)
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_col(const float* __restr
     // the barrier does not help: the barrier needs lgkmcnt(0) first -- measured 33.8 vs 31.4 us).  The all-thread reduction and its
     // second barrier are off wave 0's dependent chain (0.86 -> ~0.45 us per block).
     for (int w = 0; w < nb; ++w) {
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // this wave's pieces of columns w and w+1 have landed (column w+2 in flight)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NMS_COL_PPW) : "memory");   // this wave's pieces of columns w and w+1 have landed (column w+2 in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // everybody's have; step w-1 is over: kept_w[w-1], part[w] and the verdict are published
         if (misc[(w + 1) & 1]) break;                          // verdict of step w-1 (parity slots: wave 0 may already be writing step w's)
