@@ -356,10 +356,14 @@ class CenterNet2Detector(nn.Module):
             H, W = img.shape[-2:]
             oh, ow = int(inp.get("height", H)), int(inp.get("width", W))
             rec = e.detect_begin(img, oh, ow)                     # a fresh tensor, filled behind the graph
-            fresh = self._engine_key == self._engine_key_now()
-            res = Instances((oh, ow))                             # the result objects are made while the device works, too
-            bx = Boxes.__new__(Boxes)
-            out = [{"instances": res}]
+            try:
+                fresh = self._engine_key == self._engine_key_now()
+                res = Instances((oh, ow))                         # the result objects are made while the device works, too
+                bx = Boxes.__new__(Boxes)
+                out = [{"instances": res}]
+            except BaseException:
+                e.detect_end(rec)                                 # never leave a pass pending that writes into a tensor about to be freed
+                raise
             boxes, scores, classes = e.detect_end(rec)
             if not fresh:
                 e = self.engine()                                 # rebuilds
