@@ -20,11 +20,17 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
                                                int out_ld, int out_coff, int groups_per_wave) {
     // GEMM view: M = output pixels (16 per MFMA tile), N = Cout (NT tiles of 16), K = 27 padded to 28 = 7 k-steps of 4.
     // lane (i = lane&15, g = lane>>4) feeds A[pixel i][k = 4j+g] and B[k = 4j+g][n = i] in step j.
+    // Round 4 (s_memtime stamps: a wave lived 30 000 clocks -- 5 400 staging the weights, 8 500 decoding and gathering the first pixel
+    // group, 2 100 in its MFMAs, 4 200 storing, 10 000 for the second group; removing the loads, the stores, the MFMAs or the divisions
+    // one at a time changed nothing): the kernel issues instructions, it does not wait for memory.  So: the tap address is ONE 32-bit add
+    // per tap (per-lane tap offsets computed once), the pixel decode uses a float reciprocal instead of two integer divisions, the
+    // first group's gathers are issued BEFORE the weights are staged and every next group's before the current one is multiplied,
+    // scale / shift are loaded once per wave.  Same arithmetic per output, bit-identical results.
     constexpr int MAXNT = NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
     // per-lane tap decode for the 7 k-steps (independent of the pixel)
-    int kc[7], kdy[7], kdx[7];
+    int kdy[7], kdx[7], koff[7];
     bool kv[7];
     float kmean[7], kstd[7];
 #pragma unroll
@@ -32,10 +38,49 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
         const int k = 4 * j + g;
         kv[j] = k < 27;
         const int kk = kv[j] ? k : 0;
-        kc[j] = kk / 9; kdy[j] = (kk % 9) / 3 - 1; kdx[j] = kk % 3 - 1;
-        kmean[j] = kc[j] == 0 ? m0 : (kc[j] == 1 ? m1 : m2);
-        kstd[j] = kc[j] == 0 ? s0 : (kc[j] == 1 ? s1 : s2);
+        const int kc = kk / 9;
+        kdy[j] = (kk % 9) / 3 - 1; kdx[j] = kk % 3 - 1;
+        koff[j] = (kc * H + kdy[j]) * W + kdx[j];           // from the pixel's (channel 0, iy = 2 oy, ix = 2 ox) element; B * 3 * H * W < 2^31 (host-checked)
+        kmean[j] = kc == 0 ? m0 : (kc == 1 ? m1 : m2);
+        kstd[j] = kc == 0 ? s0 : (kc == 1 ? s1 : s2);
     }
+    const int M = B * Ho * Wo, HoWo = Ho * Wo;
+    const float inv_hw = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)Wo;
+    const int ngroups = (M + 15) >> 4;
+    const int gw0 = (blockIdx.x * 4 + wave) * groups_per_wave;
+    // n / d for 0 <= n < 2^22 with inv = 1.0f / d (one correction step each way); larger batches (the support crops of a training
+    // step: 384 x 120 x 120 output pixels) take the integer division for the image index
+    const bool big = M >= (1 << 22);
+    auto fdiv = [](int n, int d, float inv) {
+        int q = (int)((float)n * inv);
+        int r = n - q * d;
+        q += r >= d ? 1 : 0;
+        r -= r >= d ? d : 0;
+        q -= r < 0 ? 1 : 0;
+        return q;
+    };
+    T raw[7];                                               // the gathered taps of the NEXT group to multiply
+    unsigned okm = 0u;                                      // bit j: tap j of that group is inside the image
+    auto gather = [&](int grp) {
+        okm = 0u;
+        const int pix = grp * 16 + li;
+        if (grp >= ngroups || pix >= M) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) raw[j] = (T)0;
+            return;
+        }
+        const int b = big ? pix / HoWo : fdiv(pix, HoWo, inv_hw), r = pix - b * HoWo;
+        const int oy = fdiv(r, Wo, inv_wo), ox = r - oy * Wo;
+        const int base = (b * 3 * H + oy * 2) * W + ox * 2;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int iy = oy * 2 + kdy[j], ix = ox * 2 + kdx[j];
+            const bool ok = kv[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            raw[j] = ok ? img[base + koff[j]] : (T)0;
+            okm |= ok ? 1u << j : 0u;
+        }
+    };
+    gather(gw0);
     // weights: one coalesced pass into LDS (rows padded to 28), then each lane picks its 7 x NT values -- the direct per-lane gather
     // (28 loads with a 108-byte lane stride) was ~18 us of latency in front of every wave's first pixel group
     __shared__ float sw[NT * 16 * 28];
@@ -43,32 +88,25 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
         const int n = i / 28, k = i - n * 28;
         sw[i] = k < 27 ? w[n * 27 + k] : 0.f;
     }
+    f32x4 esc[MAXNT], esh[MAXNT];                           // this lane's 4 channels of every tile: FrozenBN scale / shift
+#pragma unroll
+    for (int t = 0; t < MAXNT; ++t) {
+        esc[t] = *reinterpret_cast<const f32x4*>(scale + t * 16 + g * 4);
+        esh[t] = *reinterpret_cast<const f32x4*>(shift + t * 16 + g * 4);
+    }
     __syncthreads();
     float bw[MAXNT][7];
 #pragma unroll
     for (int t = 0; t < MAXNT; ++t)
 #pragma unroll
         for (int j = 0; j < 7; ++j) bw[t][j] = sw[(t * 16 + li) * 28 + 4 * j + g];
-    const int M = B * Ho * Wo;
-    const int ngroups = (M + 15) >> 4;
-    const int gw0 = (blockIdx.x * 4 + wave) * groups_per_wave;
     for (int gi = 0; gi < groups_per_wave; ++gi) {
         const int grp = gw0 + gi;
         if (grp >= ngroups) break;
-        const int pix = grp * 16 + li;
-        const bool pv = pix < M;
-        const int pp = pv ? pix : 0;
-        const int b = pp / (Ho * Wo), r = pp - b * Ho * Wo;
-        const int oy = r / Wo, ox = r - oy * Wo;
         float a[7];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int iy = oy * 2 + kdy[j], ix = ox * 2 + kdx[j];
-            float v = 0.f;
-            if (pv && kv[j] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = ((float)img[((size_t)(b * 3 + kc[j]) * H + iy) * W + ix] - kmean[j]) / kstd[j];
-            a[j] = v;
-        }
+        for (int j = 0; j < 7; ++j) a[j] = ((okm >> j) & 1u) ? ((float)raw[j] - kmean[j]) / kstd[j] : 0.f;
+        if (gi + 1 < groups_per_wave) gather(grp + 1);      // in flight under this group's MFMAs and stores
         f32x4 acc[MAXNT];
 #pragma unroll
         for (int t = 0; t < MAXNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -80,14 +118,13 @@ __global__ __launch_bounds__(256) void k_stem1(const T* __restrict__ img, int B,
         // weights are the MFMA "A" operand, so acc[t] = 4 consecutive channels (t*16 + g*4 ..) of pixel grp*16 + li: 16-byte stores
         const int m = grp * 16 + li;
         if (m < M) {
+            TO* orow = out + (size_t)m * out_ld + out_coff + g * 4;
 #pragma unroll
             for (int t = 0; t < MAXNT; ++t) {
                 if (t < NT) {
-                    const int n = t * 16 + g * 4;
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n), sh = *reinterpret_cast<const f32x4*>(shift + n);
-                    f32x4 v = acc[t] * sc + sh;
+                    f32x4 v = acc[t] * esc[t] + esh[t];
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    st4(out + (size_t)m * out_ld + out_coff + n, v);
+                    st4(orow + t * 16, v);
                 }
             }
         }
@@ -728,6 +765,8 @@ static int stem1_launch(const void* img, int32_t img_is_u8, int32_t B, int32_t H
                   "ore_stem1_fwd: Cout=%d ld=%d coff=%d", Cout, out_ld, out_coff);
     const int Ho = Hp / 2, Wo = Wp / 2;
     const int M = B * Ho * Wo;
+    ORE_CHECK_ARG((long long)Ho * Wo < (1ll << 22) && (long long)B * Ho * Wo < (1ll << 31) && (long long)B * 3 * H * W < (1ll << 31),
+                  "ore_stem1_fwd: %d images of %dx%d exceed the kernel's 32-bit indexing", B, H, W);
     hipStream_t st = (hipStream_t)stream;
     // mean/std are host-readable by contract (3 floats each)
     const int ngroups = ceil_div(M, 16);
