@@ -295,14 +295,38 @@ __global__ __launch_bounds__(ESE_T) void k_ese_gate_pool(const float* __restrict
                                                          TS* __restrict__ out, int out_ld, int out_coff) {
     __shared__ EseSm sm;
     const int pb = blockIdx.y;
-    ese_gate16(sm, part, P, HW, C, fw, fb, gate, 0, pb == 0);
-    if (lws && pb == 0) ese_scale_columns(sm, C, lw, lws, lrows, lws_bf16);
     const int npx = Ho * Wo, per = (npx + gridDim.y - 1) / gridDim.y;
     const int p1 = min((pb + 1) * per, npx);
     const int j = threadIdx.x & 3, c = blockIdx.x * 16 + j * 4;
+    // The pooling does not need the gate until its last multiply (max(x) * g == max(x * g): g >= 0): the nine loads of this thread's
+    // FIRST pixel are issued before the block reduces the column sums and runs its fc rows, so that they share a memory round trip
+    // with the partial-sum loads instead of following 4-5 us of dependent latency; they are consumed after the gate.  (At bs = 1 a
+    // thread has one pixel; further pixels follow the gate as before.)
+    const int px0 = pb * per + (threadIdx.x >> 2);
+    const bool first = c < C && px0 < p1;
+    f32x4 v9[9];
+    {
+        const int oy = first ? px0 / Wo : 0, ox = first ? px0 - oy * Wo : 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * 2 + ky, ix = ox * 2 + kx;
+                v9[ky * 3 + kx] = (first && iy < H && ix < W) ? ld4(in + (size_t)(iy * W + ix) * in_ld + in_coff + c)
+                                                              : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+    }
+    ese_gate16(sm, part, P, HW, C, fw, fb, gate, 0, pb == 0);
+    if (lws && pb == 0) ese_scale_columns(sm, C, lw, lws, lrows, lws_bf16);
     if (c >= C) return;
     const f32x4 g4 = {sm.g16[j * 4], sm.g16[j * 4 + 1], sm.g16[j * 4 + 2], sm.g16[j * 4 + 3]};
-    for (int px = pb * per + (threadIdx.x >> 2); px < p1; px += ESE_T / 4) {
+    if (first) {
+        f32x4 m = v9[0];
+#pragma unroll
+        for (int t = 1; t < 9; ++t) { m.x = fmaxf(m.x, v9[t].x); m.y = fmaxf(m.y, v9[t].y); m.z = fmaxf(m.z, v9[t].z); m.w = fmaxf(m.w, v9[t].w); }
+        st4(out + (size_t)px0 * out_ld + out_coff + c, m * g4);
+    }
+    for (int px = px0 + ESE_T / 4; px < p1; px += ESE_T / 4) {
         const int oy = px / Wo, ox = px - oy * Wo;
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
