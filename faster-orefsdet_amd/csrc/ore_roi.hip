@@ -430,19 +430,16 @@ __global__ __launch_bounds__(256) void k_roi_predict_mb(PredP p, int* __restrict
     extern __shared__ float hs[];                 // [RPB][C+1] rows, then dots [6][64]
     const int C = p.C, LDH = C + 1;
     float* dots = hs + RPB * LDH;
-    const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = blockIdx.x * RPB;
-    if (r0 >= n) {                                // rows beyond the count: flag them out (the tail reads ok[0..cap))
-        if (tid < RPB && r0 + tid < p.cap) ok_out[r0 + tid] = 0;
-        return;
-    }
-    const int rows = min(RPB, n - r0);
     if (p.h_parts > 0) {
         // four elements per thread and sixteen slices per step: 64 independent loads in flight (a plain z loop is one dependent L2 round
         // trip per slice and element: 69 us for 32 slices); every element still adds its slices in the order z = 0, 1, 2, ...
+        // The rows are summed for every row of the block up to the CAPACITY, before the device-side count is looked at: the count is one
+        // more dependent round trip in front of these loads otherwise, and the slices hold cap rows each (rows beyond the count are
+        // summed and never used).
         const size_t zs = (size_t)p.cap * C;
-        const int ne = rows * C;
+        const int ne = max(min(RPB, p.cap - r0), 0) * C;
         for (int i0 = tid; i0 < ne; i0 += 256 * 4) {
             float v[4];
             const float* src[4];
@@ -469,7 +466,14 @@ __global__ __launch_bounds__(256) void k_roi_predict_mb(PredP p, int* __restrict
                 if (i < ne) hs[(i / C) * LDH + (i % C)] = fmaxf(v[j], 0.0f);
             }
         }
-    } else {
+    }
+    const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
+    if (r0 >= n) {                                // rows beyond the count: flag them out (the tail reads ok[0..cap))
+        if (tid < RPB && r0 + tid < p.cap) ok_out[r0 + tid] = 0;
+        return;
+    }
+    const int rows = min(RPB, n - r0);
+    if (p.h_parts <= 0) {
         for (int i = tid; i < rows * C; i += 256) hs[(i / C) * LDH + (i % C)] = p.h[(size_t)r0 * C + i];
     }
     __syncthreads();
@@ -558,12 +562,22 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
     __shared__ int sh_keep;
     constexpr int NW = T / 64, WPR = ROI_FUSED_CAP / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the first T rows' filter flag, box and score are requested before the device-side count is read (one dependent round trip
+    // less in front of them; the arrays hold cap rows, flags beyond the count are 0)
+    int ok_first = 0;
+    f32x4 box_first = {0.f, 0.f, 0.f, 0.f};
+    float score_first = 0.f;
+    if (tid < p.cap) {
+        ok_first = p.ok[tid];
+        box_first = *reinterpret_cast<const f32x4*>(p.raw_boxes + (size_t)tid * 4);
+        score_first = p.raw_scores[tid];
+    }
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
     // ---- ordered compaction of the rows that pass the filter
     int base = 0;
     for (int r0 = 0; r0 < n; r0 += T) {
         const int r = r0 + tid;
-        const int ok = (r < n) ? p.ok[r] : 0;
+        const int ok = (r < n) ? (r0 == 0 ? ok_first : p.ok[r]) : 0;
         int inc = ok;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
@@ -573,8 +587,8 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
         for (int w2 = 0; w2 < NW; ++w2) { const int s2 = wsum[w2]; if (w2 < wave) pre += s2; tot += s2; }
         if (ok) {
             const int pos = pre + inc - 1;
-            *reinterpret_cast<f32x4*>(cb + pos * 4) = *reinterpret_cast<const f32x4*>(p.raw_boxes + (size_t)r * 4);
-            cs[pos] = p.raw_scores[r];
+            *reinterpret_cast<f32x4*>(cb + pos * 4) = r0 == 0 ? box_first : *reinterpret_cast<const f32x4*>(p.raw_boxes + (size_t)r * 4);
+            cs[pos] = r0 == 0 ? score_first : p.raw_scores[r];
             csrc[pos] = r;
         }
         base += tot;
