@@ -823,6 +823,7 @@ extern "C" int ore_engine_detect_begin(ore_engine* e, const void* img, int32_t i
     // the caller's freshly allocated result record is filled by the LAST KERNEL of the graph: its address travels in the pinned,
     // device-mapped word behind the count (k_roi_tail reads it with a system-scope load), so nothing is queued behind the replay
     volatile unsigned long long* rec_word = reinterpret_cast<volatile unsigned long long*>(e->pin_count) + 1;
+    ORE_CHECK_ARG(*rec_word == 0ull, "ore_engine_detect_begin: a pass is already pending on this engine (ore_engine_detect_end first)");
     *rec_word = (unsigned long long)(uintptr_t)out_record;
     __atomic_thread_fence(__ATOMIC_RELEASE);
     volatile int32_t* cnt_word = e->pin_count;

@@ -531,7 +531,7 @@ int ore_engine_detect_fwd(ore_engine* e, const void* img, int32_t img_is_u8, int
  * host does in between runs in the shadow of the device pass: the module-level forward uses it to validate its cached engine against
  * the parameters' version counters AFTER launching on it (a stale engine is the rare case: its result is dropped and the pass
  * repeated), which takes that check out of the per-image critical path of the reference's protocol
- * (d2z:evaluation/evaluator.py:138-161).  One pass may be pending per engine; _end without _begin is ORE_EINVAL. */
+ * (d2z:evaluation/evaluator.py:138-161).  One pass may be pending per engine: a second _begin before _end, and _end without _begin, are ORE_EINVAL. */
 int ore_engine_detect_begin(ore_engine* e, const void* img, int32_t img_is_u8, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
                             void* out_record, void* stream);
 int ore_engine_detect_end(ore_engine* e, void* stream, int32_t* n_det);

@@ -599,6 +599,15 @@ def test_eval_after_optimizer_step_uses_the_new_weights(oh):
     import orehip
     n = ctypes.c_int32(0)
     assert orehip.lib().ore_engine_detect_end(m._engine._h, None, ctypes.byref(n)) == -22      # ORE_EINVAL
+    # ... and a second _begin while a pass is pending is refused (its record would be overwritten under the running pass)
+    e = m._engine
+    rec = e.detect_begin(q, 256, 320)
+    rec2 = torch.empty_like(rec)
+    rc = orehip.lib().ore_engine_detect_begin(e._h, ctypes.c_void_p(q.data_ptr()), int(q.dtype == torch.uint8), 256, 320, 256, 320,
+                                              ctypes.c_void_p(rec2.data_ptr()), None)
+    assert rc == -22
+    b5, s5, c5 = e.detect_end(rec)
+    assert torch.equal(s5.cpu(), s3) and torch.equal(b5.cpu(), b3)
 
 
 def test_correlation_fn_backward(oh):
