@@ -130,6 +130,42 @@ def test_winograd_kernels_linearity_full_size(oh):
         oh.lib().ore_conv_set_plan_override(-7, 1, 0, 0, 0)
 
 
+def test_descriptor_kernels_properties_full_size(oh):
+    """k_conv_gd / k_conv_kd at the 640x640 shapes the plan gives them, without an oracle: the automatic plan does not run the round-3
+    kernel (switching both families off changes bits somewhere), the result is linear in the input, bit-reproducible, within fp32
+    rounding of the round-3 kernel, and the eSE column sums a launch emits add up to the column sums of its output."""
+    g = torch.Generator().manual_seed(28)
+    a, b = 0.75, -1.5
+    L = oh.lib()
+    shapes = [(320, 320, 64, 128, 3, 2),      # stem_3                      -> k_conv_gd 112 x 128, eight waves
+              (160, 160, 320, 112, 1, 1),     # stage-2 concat              -> k_conv_gd 128 x 64, eight waves
+              (80, 80, 352, 256, 1, 1),       # stage-3 concat              -> k_conv_gd 64 x 64
+              (80, 80, 256, 128, 1, 1),       # lateral 3 (without its add) -> k_conv_gd 64 x 64, eight waves
+              (40, 40, 256, 96, 3, 1),        # stage 4, layer 0            -> k_conv_kd
+              (20, 20, 112, 112, 3, 1),       # stage 5, layers 1 / 2       -> k_conv_kd
+              (20, 20, 720, 512, 1, 1)]       # stage-5 concat              -> k_conv_kd
+    differs = 0
+    for (H, W, Cin, Cout, k, st) in shapes:
+        x1, x2 = torch.randn(1, H, W, Cin, generator=g).cuda(), torch.randn(1, H, W, Cin, generator=g).cuda()
+        w = oh.pack_conv_weight(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda()
+        y1, y2 = oh.conv2d(x1, w, Cout, k, st), oh.conv2d(x2, w, Cout, k, st)
+        y12 = oh.conv2d(a * x1 + b * x2, w, Cout, k, st)
+        assert float((y12 - (a * y1 + b * y2)).abs().max()) <= 3e-5 * float(y12.abs().max())
+        assert torch.equal(oh.conv2d(x1, w, Cout, k, st), y1)
+        yc, cs = oh.conv2d(x1, w, Cout, k, st, want_colsum=True)              # (the plan may pick another kernel when column sums are asked for)
+        ref_cs = yc.double().sum((0, 1, 2))
+        assert float((cs.double().sum(0)[:Cout] - ref_cs).abs().max()) <= 2e-5 * float(ref_cs.abs().max() + yc.abs().sum() / Cout * 1e-2)
+        assert float((yc - y1).abs().max()) <= 2e-5 * float(y1.abs().max())
+        L.ore_conv_set_plan_override(-14, 0, 0, 0, 0); L.ore_conv_set_plan_override(-12, 0, 0, 0, 0)
+        try:
+            y_old = oh.conv2d(x1, w, Cout, k, st)
+        finally:
+            L.ore_conv_set_plan_override(-14, 1, 0, 0, 0); L.ore_conv_set_plan_override(-12, 1, 0, 0, 0)
+        assert float((y1 - y_old).abs().max()) <= 2e-5 * float(y_old.abs().max())
+        differs += int(not torch.equal(y1, y_old))
+    assert differs >= 3, "the descriptor kernels did not run (the plan fell back to the round-3 kernels everywhere)"
+
+
 def test_centernet_targets_properties_full_size(oh):
     """640x640, 128 boxes: every positive index addresses the cell containing its box centre on a level that cares for the box size;
     a location with a regression target lies inside that box; heat-map in [0, 1] and exactly 1 at positive cells."""
