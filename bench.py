@@ -539,8 +539,8 @@ def main():
                                 "--pmc passes (tools/pmc_pass.py -> profiles/%s)" % traffic_src,
                 "kernel": ("the DMA-fed conv kernels on bf16 tensors (k_conv_gs / k_conv_kw, v_mfma_f32_16x16x32_bf16, fp32 accumulate) + the fp32 ROI fc GEMM" if bf16s else
                            "the MFMA conv kernels with bf16 operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) + the fp32 ROI fc GEMM" if bf16 else
-                           "the fp32 MFMA conv kernels (v_mfma_f32_16x16x4_f32: Winograd F(2x2,3x3) k_conv3x3_wino on the large-M 3x3 layers, implicit GEMM "
-                           "k_conv_kw / k_conv_gs / k_conv_igemm on the rest) + the second-stage GEMM; FLOPs are the ALGORITHMIC (direct-convolution) "
+                           "the fp32 MFMA conv kernels (v_mfma_f32_16x16x4_f32: Winograd F(2x2,3x3) k_conv3x3_wino on the large-M 3x3 layers, the descriptor-addressed "
+                           "LDS-DMA implicit GEMMs k_conv_gd / k_conv_kd on the rest) + the second-stage GEMM (k_conv_gd, K split); FLOPs are the ALGORITHMIC (direct-convolution) "
                            "count, so the Winograd layers, which execute 2.25x fewer multiplies, can exceed the MFMA peak"),
                 "launches_per_image": nl // npp, "gflop_per_image": round(fl / npp / 1e9, 3),
                 "kernel_ms_per_image": round(ms / npp, 4), "kernel_ms_per_image_calibrated": round(ms_cal / npp, 4),
