@@ -1338,9 +1338,13 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
     if (!d->storage && conv_rf_forced()) return ceil_div(d->B * Ho * Wo, 16);   // tuning aid: the forced register-fed build has 16-row tiles (a fallback kernel writes fewer rows)
     if (d->storage) {                                         // bf16 storage: always the DMA-fed kernels (conv_kw_launch's sb branch)
         ConvP q{};
-        q.sb = 1;
+        q.sb = 1 | (d->storage == ORE_ST_BF16 ? 2 : 0) | (d->add ? 4 : 0);
         q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (round_up(d->Cin, 32) / 32); q.kh = d->kh;
         q.stride = d->stride;
+        // what the lean-DMA kernel's "does it apply" test looks at, in the 4-byte units of this mode (keep in step with fill_common)
+        q.kw = d->kw; q.Cin = round_up(d->Cin, 32) / 2; q.in_ld = d->in_ld / 2; q.in_coff = d->in_coff / 2; q.B = d->B; q.nlev = 1; q.K = d->kh * d->kw * q.Cin; q.Cout = d->Cout;
+        q.lv[0] = Lvl{0, 0, d->H, d->W, Ho, Wo}; q.in_add = d->in_add; q.in_relu = d->in_relu; q.in_mul = d->in_mul; q.colsum = d->colsum;
+        if (d->add) { q.add = d->add; q.add_ld = d->add_ld; q.add_H = (Ho + 1) / 2; q.add_W = (Wo + 1) / 2; }
         return ceil_div(q.M, conv_kw_tile_rows(q));
     }
     if (g_override.BM == 0 && d->splitk <= 1 && g_kw_mode && !d->in_mul && d->Cin % 16 == 0) {
@@ -1348,7 +1352,7 @@ extern "C" int32_t ore_conv_colsum_rows(const ore_conv_desc* d) {
         q.bf16 = g_conv_bf16;
         q.M = d->B * Ho * Wo; q.Cout16 = round_up(d->Cout, 16); q.nchunks = d->kh * d->kw * (d->Cin / 16); q.kh = d->kh;
         // what the lean-DMA kernel's "does it apply" test looks at (conv_kd_tile_rows; keep in step with make_conv_params)
-        q.kw = d->kw; q.Cin = d->Cin; q.in_ld = d->in_ld; q.B = d->B; q.nlev = 1; q.K = d->kh * d->kw * d->Cin; q.Cout = d->Cout;
+        q.kw = d->kw; q.Cin = d->Cin; q.in_ld = d->in_ld; q.in_coff = d->in_coff; q.B = d->B; q.nlev = 1; q.K = d->kh * d->kw * d->Cin; q.Cout = d->Cout;
         q.lv[0] = Lvl{0, 0, d->H, d->W, Ho, Wo}; q.in_add = d->in_add; q.in_relu = d->in_relu;
         if (d->add) { q.add = d->add; q.add_ld = d->add_ld; q.add_H = (Ho + 1) / 2; q.add_W = (Wo + 1) / 2; }
         const int bm = conv_kw_tile_rows(q);

@@ -72,10 +72,11 @@ struct KdK {
     int out_ld, out_coff, relu_cout, add_H, add_W, add_ld, add_coff;
     int xmap, gx, gy;
     float inv_hw, inv_wo, inv_gx, inv_gy;
+    int sb;                  // bf16 STORAGE (ConvP::sb): bit 0 in / w are bf16 (sizes above in 4-byte units), bit 1 out is bf16, bit 2 add is bf16
 };
 struct KdP {
     KdK k;
-    unsigned tab[kTab];      // 3x3: per 16-channel chunk (byte offset of (tap, channel chunk) from the window's first pixel) | tap; beyond K: 15
+    unsigned tab[kTab];      // 3x3: per 16-channel chunk (byte offset of (tap, channel chunk) from the window's first pixel) | tap << 28; beyond K: tap 15
 };
 
 __device__ __forceinline__ void kd_tile(const KdK& k, int& bx, int& by) {
@@ -89,7 +90,7 @@ __device__ __forceinline__ void kd_tile(const KdK& k, int& bx, int& by) {
     else { by = fdiv(t, k.gx, k.inv_gx); bx = t - by * k.gx; }
 }
 
-template <int GA, int GB, int NW, int SB, int KS>
+template <int GA, int GB, int NW, int SB, int KS, bool SBF = false>
 __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
     constexpr int T = NW * 64;
     constexpr int G = GA + GB;                                    // DMA pieces (16-row groups) per step
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
                  "s"(p.sc_bytes), "s"(p.add_bytes), "s"(p.M), "s"(p.K), "s"(p.Cout), "s"(p.Cout16), "s"(p.nchunks), "s"(p.nb));
     asm volatile("" :: "s"(p.irow0), "s"(p.H), "s"(p.W), "s"(p.Ho), "s"(p.Wo), "s"(p.in_ld), "s"(p.in_coff), "s"(p.stride), "s"(p.pad), "s"(p.out_ld),
                  "s"(p.out_coff), "s"(p.relu_cout), "s"(p.add_H), "s"(p.add_W), "s"(p.add_ld), "s"(p.add_coff), "s"(p.xmap), "s"(p.gx), "s"(p.gy),
-                 "s"(p.inv_hw), "s"(p.inv_wo), "s"(p.inv_gx), "s"(p.inv_gy));
+                 "s"(p.inv_hw), "s"(p.inv_wo), "s"(p.inv_gx), "s"(p.inv_gy), "s"(p.sb));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
@@ -157,8 +158,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
 #pragma unroll
         for (int t = 0; t < SB; ++t) {
             float* dst = half + t * STAGE_F;
+            const bool live = w_c + t < p.nchunks;                // a step beyond K stages zeros on both sides (descriptor range check via kOOB:
+                                                                  // the scalar offset of a step is NOT range-checked, a weight row read past K would run
+                                                                  // off the end of the tensor for the last output channel)
             if constexpr (KS == 1) {
-                const bool live = w_c + t < p.nchunks;            // a step beyond K multiplies (finite or zero) weights by zeros
 #pragma unroll
                 for (int i = 0; i < GA; ++i) {
                     const unsigned v = live ? a_voff[i] : kOOB;
@@ -170,14 +173,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
                 }
             } else {
                 const unsigned e = q.tab[w_c + t];
-                const unsigned bit = 1u << (e & 15u);
+                const unsigned bit = 1u << (e >> 28);             // tap in the top four bits, byte offset below (a bf16 pixel pitch need not be a multiple of 64)
 #pragma unroll
-                for (int i = 0; i < GA; ++i) dma<0>(ri, dst + i * 256, (a_taps[i] & bit) ? a_voff[i] : kOOB, e & ~63u);
+                for (int i = 0; i < GA; ++i) dma<0>(ri, dst + i * 256, (a_taps[i] & bit) ? a_voff[i] : kOOB, e & 0x0fffffffu);
             }
 #pragma unroll
             for (int j = 0; j < GB; ++j) {
                 switch (t) {
-#define KD_B(tt) case tt: dma<tt * 64>(rw, dst + (GA + j) * 256, b_voff[j], s_b); break;
+#define KD_B(tt) case tt: dma<tt * 64>(rw, dst + (GA + j) * 256, live ? b_voff[j] : kOOB, s_b); break;
                     KD_B(0) KD_B(1) KD_B(2) KD_B(3) KD_B(4) KD_B(5) KD_B(6) KD_B(7) KD_B(8) KD_B(9) KD_B(10) KD_B(11) KD_B(12) KD_B(13) KD_B(14) KD_B(15)
 #undef KD_B
                 }
@@ -230,13 +233,22 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
                 for (int j = 0; j < GB; ++j) bf[(t + 1) & 1][j] = *reinterpret_cast<const f32x4*>(st + (GA + j) * 256 + foff);
             }
             __builtin_amdgcn_sched_barrier(0);                    // (keep the next step's reads in front of this step's MFMAs)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
+            if constexpr (SBF) {                                  // bf16 storage: the 64-byte row of a fragment is 32 channels, one MFMA per step
 #pragma unroll
                 for (int i = 0; i < GA; ++i)
 #pragma unroll
                     for (int j = 0; j < GB; ++j)
-                        acc[t & (NACC - 1)][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][j][tt], af[t & 1][i][tt], acc[t & (NACC - 1)][i][j], 0, 0, 0);   // D^T: lane = pixel
+                        acc[t & (NACC - 1)][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[t & 1][j]), __builtin_bit_cast(bf16x8_t, af[t & 1][i]),
+                                                                                            acc[t & (NACC - 1)][i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < GA; ++i)
+#pragma unroll
+                        for (int j = 0; j < GB; ++j)
+                            acc[t & (NACC - 1)][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][j][tt], af[t & 1][i][tt], acc[t & (NACC - 1)][i][j], 0, 0, 0);   // D^T: lane = pixel
+            }
         }
     }
     KD_TR(5);
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
     float* cs = lds + RED_F;
     const __amdgpu_buffer_rsrc_t rsc = make_rsrc(p.scale, p.scale ? p.sc_bytes : 0u), rsh = make_rsrc(p.shift, p.shift ? p.sc_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rad = make_rsrc(p.add, p.add ? p.add_bytes : 0u);
-    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+    const bool vec_ok = (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)p.out & ((p.sb & 2) ? 7 : 15)) == 0;
 #pragma unroll
     for (int q0 = 0; q0 < NT * 64; q0 += T) {
         const int it = q0 + tid;                                  // a wave's 64 items are one 16x16 tile: lane = accumulator lane
@@ -271,7 +283,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
                 const int b = fdiv(m, hw, p.inv_hw);
                 const int rr = m - b * hw;
                 const int oy = fdiv(rr, p.Wo, p.inv_wo), ox = rr - oy * p.Wo;
-                e_add = bload4(rad, on ? (unsigned)((((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + en) * 4) : kOOB);
+                const unsigned ai = (unsigned)(((b * p.add_H + (oy >> 1)) * p.add_W + (ox >> 1)) * p.add_ld + p.add_coff + en);
+                if (p.sb & 4) {                                   // bf16 addend: four channels = 8 bytes
+                    const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rad, on ? (int)(ai * 2u) : (int)kOOB, 0, 0));
+                    e_add = from_bf16x4(__builtin_bit_cast(s16x4, h));
+                } else {
+                    e_add = bload4(rad, on ? ai * 4u : kOOB);
+                }
             }
             f32x4 a = *reinterpret_cast<const f32x4*>(lds + (0 * NT + tl) * 256 + ln * 4);
 #pragma unroll
@@ -284,13 +302,29 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
                     if (en + r < p.relu_cout) v[r] = fmaxf(v[r], 0.0f);
                     if (en + r >= p.Cout) v[r] = 0.0f;
                 }
-                float* o = p.out + (size_t)m * p.out_ld + p.out_coff + en;
-                if (vec_ok && en + 3 < p.Cout) {
-                    *reinterpret_cast<f32x4*>(o) = v;
-                } else {
+                if (p.sb & 2) {                                   // bf16 output tensor: rounded once, here; the eSE pool sums the ROUNDED values
+                    const s16x4 h = to_bf16x4(v);
+                    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * p.out_ld + p.out_coff + en;
+                    if (vec_ok && en + 3 < p.Cout) {
+                        *reinterpret_cast<s16x4*>(o) = h;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (en + r < p.Cout) o[r] = (unsigned short)h[r];
+                    }
+                    v = from_bf16x4(h);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (en + r < p.Cout) o[r] = v[r];
+                        if (en + r >= p.Cout) v[r] = 0.0f;
+                } else {
+                    float* o = p.out + (size_t)m * p.out_ld + p.out_coff + en;
+                    if (vec_ok && en + 3 < p.Cout) {
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (en + r < p.Cout) o[r] = v[r];
+                    }
                 }
             }
             if (p.colsum) {                                       // column sums of the tile: the 16 pixel lanes of a channel quad
@@ -323,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_kd(KdP q) {
 int g_kd_mode = 1;                       // tuning aid (ore_conv_set_plan_override(-12, mode)): 0 off, 1 automatic, 2 wherever it applies
 int g_kd_force[4] = {0, 0, 0, 0};        // (-13, BM, BN, NW, SB): force the build
 
-template <int GA, int GB, int NW, int SB>
+template <int GA, int GB, int NW, int SB, bool SBF>
 int launch_kd(const KdP& q, bool k3, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)NW * 2 * SB * (GA + GB) * 256, red = (size_t)NW * GA * GB * 256;
     constexpr size_t lds = ((ring > red ? ring : red) + GA * GB * 16) * sizeof(float);
@@ -333,11 +367,11 @@ int launch_kd(const KdP& q, bool k3, dim3 grid, hipStream_t st) {
     } else {
         static bool attr1 = false, attr3 = false;
         if (!k3) {
-            if (!attr1) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kd<GA, GB, NW, SB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr1 = true; }
-            hipLaunchKernelGGL((k_conv_kd<GA, GB, NW, SB, 1>), grid, dim3(NW * 64), lds, st, q);
+            if (!attr1) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kd<GA, GB, NW, SB, 1, SBF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr1 = true; }
+            hipLaunchKernelGGL((k_conv_kd<GA, GB, NW, SB, 1, SBF>), grid, dim3(NW * 64), lds, st, q);
         } else {
-            if (!attr3) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kd<GA, GB, NW, SB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr3 = true; }
-            hipLaunchKernelGGL((k_conv_kd<GA, GB, NW, SB, 3>), grid, dim3(NW * 64), lds, st, q);
+            if (!attr3) { ORE_HIP(hipFuncSetAttribute((const void*)k_conv_kd<GA, GB, NW, SB, 3, SBF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr3 = true; }
+            hipLaunchKernelGGL((k_conv_kd<GA, GB, NW, SB, 3, SBF>), grid, dim3(NW * 64), lds, st, q);
         }
         return ore_launch_status("k_conv_kd");
     }
@@ -358,12 +392,16 @@ struct KdPlan { int bm, bn, nw, sb; };
 static bool kd_flat(const ConvP& p) { return p.nlev > 1 && p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && !p.add; }
 
 static bool kd_applies(const ConvP& p) {
-    if (p.sb || p.bf16 || p.in_mul || p.in_add || p.in_relu || (p.nlev != 1 && !kd_flat(p)) || p.ep_stride) return false;
-    if (p.Cin % 16 != 0 || p.in_ld % 16 != 0 || p.kh != p.kw || (p.kh != 1 && p.kh != 3)) return false;
+    // (bf16 STORAGE, p.sb & 1, is served: its sizes arrive in 4-byte units, so the staging is byte for byte the fp32 one)
+    if (p.bf16 || p.in_mul || p.in_add || p.in_relu || (p.nlev != 1 && !kd_flat(p)) || p.ep_stride) return false;
+    // a pixel's channel vector starts on a 16-byte boundary (the DMA piece of a lane); fp32 layers of this model all have 64-byte rows
+    if (p.Cin % 16 != 0 || p.in_ld % ((p.sb & 1) ? 4 : 16) != 0 || p.in_coff % 4 != 0 || p.kh != p.kw || (p.kh != 1 && p.kh != 3)) return false;
     if ((long long)p.M * p.Cout16 >= (1ll << 31) || p.M >= (1 << 22) || p.nchunks > kTab) return false;
     const long long in_rows = kd_flat(p) ? (long long)p.lv[0].irow0 + p.M : (long long)p.lv[0].irow0 + (long long)p.B * p.lv[0].H * p.lv[0].W;
     if (in_rows * p.in_ld * 4 >= (long long)kOOB - (1 << 24) || (long long)p.Cout16 * p.K * 4 >= (long long)kOOB) return false;
     if (p.add && (long long)p.B * p.add_H * p.add_W * p.add_ld * 4 >= (long long)kOOB) return false;
+    if ((p.sb & 1) && p.colsum && !(p.sb & 2)) return false;
+    if (p.kh == 3 && (2ll * p.lv[0].W + 2) * p.in_ld * 4 + (long long)p.Cin * 4 >= (1ll << 28)) return false;   // the chunk table keeps 28 bits of offset   // (fp32 output of a bf16 layer with column sums: no caller, not built)
     return true;
 }
 
@@ -412,7 +450,8 @@ int conv_kd_launch(ConvP& p, hipStream_t st) {
     k.in_bytes = (unsigned)(((long long)L.irow0 + (long long)Bimg * L.H * L.W) * p.in_ld * 4);
     k.w_bytes = (unsigned)((long long)p.Cout16 * p.K * 4);
     k.sc_bytes = (unsigned)p.Cout * 4u;
-    k.add_bytes = p.add ? (unsigned)((long long)p.B * p.add_H * p.add_W * p.add_ld * 4) : 0u;
+    k.add_bytes = p.add ? (unsigned)((long long)p.B * p.add_H * p.add_W * p.add_ld * ((p.sb & 4) ? 2 : 4)) : 0u;
+    k.sb = p.sb;
     k.M = p.M; k.K = p.K; k.Cout = p.Cout; k.Cout16 = p.Cout16; k.nchunks = p.nchunks; k.nb = ceil_div(steps, pl.sb);
     k.irow0 = L.irow0; k.H = L.H; k.W = L.W; k.Ho = L.Ho; k.Wo = L.Wo; k.in_ld = p.in_ld; k.in_coff = p.in_coff; k.stride = p.stride; k.pad = p.pad;
     k.out_ld = p.out_ld; k.out_coff = p.out_coff; k.relu_cout = p.relu_cout;
@@ -423,14 +462,15 @@ int conv_kd_launch(ConvP& p, hipStream_t st) {
     if (p.kh == 3) {
         const int cpt = p.Cin >> 4, row_bytes = L.W * p.in_ld * 4, pix_bytes = p.in_ld * 4;
         for (int c = 0; c < kTab; ++c) {
-            if (c >= p.nchunks) { q.tab[c] = 15u; continue; }
+            if (c >= p.nchunks) { q.tab[c] = 15u << 28; continue; }
             const int tap = c / cpt, cc = c - tap * cpt, dy = tap / 3, dx = tap - dy * 3;
-            q.tab[c] = (unsigned)(dy * row_bytes + dx * pix_bytes + cc * 64) | (unsigned)tap;
+            q.tab[c] = (unsigned)(dy * row_bytes + dx * pix_bytes + cc * 64) | ((unsigned)tap << 28);
         }
     }
     const bool k3 = p.kh == 3;
     const dim3 grid(gx, gy, 1);
-#define KD_CASE(bm_, bn_, nw_, sb_) if (pl.bm == bm_ && bn == bn_ && pl.nw == nw_ && pl.sb == sb_) return launch_kd<bm_ / 16, bn_ / 16, nw_, sb_>(q, k3, grid, st);
+#define KD_CASE(bm_, bn_, nw_, sb_) if (pl.bm == bm_ && bn == bn_ && pl.nw == nw_ && pl.sb == sb_) \
+        return (p.sb & 1) ? launch_kd<bm_ / 16, bn_ / 16, nw_, sb_, true>(q, k3, grid, st) : launch_kd<bm_ / 16, bn_ / 16, nw_, sb_, false>(q, k3, grid, st);
     // every build keeps NW x 2 x SB x (BM + BN) / 16 KiB of LDS <= 160 KiB (16x16 at 4 waves x 8 steps = 128 KiB: one block per CU)
     KD_CASE(16, 16, 4, 4) KD_CASE(16, 16, 4, 8) KD_CASE(16, 16, 8, 4) KD_CASE(16, 16, 16, 2)
     KD_CASE(16, 32, 4, 4) KD_CASE(16, 32, 8, 2) KD_CASE(32, 32, 4, 4) KD_CASE(32, 32, 8, 2)

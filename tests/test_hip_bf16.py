@@ -293,6 +293,44 @@ def test_conv_bf16_storage_vs_oracle(B, H, W, Cin, Cout, k, stride):
     assert torch.equal(y, y2)
 
 
+KD_BUILDS = [(16, 16, 4, 4), (16, 16, 4, 8), (16, 16, 8, 4), (16, 16, 16, 2), (16, 32, 4, 4), (16, 32, 8, 2), (32, 32, 4, 4), (32, 32, 8, 2),
+             (16, 48, 4, 4), (16, 48, 8, 2), (16, 64, 4, 2), (16, 80, 4, 2), (32, 64, 4, 2), (32, 80, 4, 2), (64, 64, 4, 2), (32, 48, 4, 2),
+             (32, 16, 4, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bm,bn,nw,sb", KD_BUILDS)
+@pytest.mark.parametrize("H,W,Cin,Cout,k", [(20, 20, 112, 112, 3),     # Cin % 32 == 16: half-empty last chunk of every tap
+                                            (13, 19, 544, 384, 1),     # 1x1, odd size, Cout wider than every tile
+                                            (9, 11, 96, 40, 3)])       # tiny, Cout = 40
+def test_conv_kd_bf16_storage_every_build(bm, bn, nw, sb, H, W, Cin, Cout, k):
+    """k_conv_kd's bf16-STORAGE builds (round 4: the staging is byte for byte the fp32 one, a 64-byte row is 32 channels, one
+    v_mfma_f32_16x16x32_bf16 per step): every (tile, waves, batch) build against F.conv2d on the same bf16 values -- fp32 output at the
+    fp32 tolerance, bf16 output within one ulp of it, column sums of the STORED values, bit-reproducible."""
+    import orehip as ore
+    if bn > (Cout + 15) // 16 * 16:
+        pytest.skip("tile wider than the layer: the launcher narrows it to another build")
+    g = torch.Generator().manual_seed(H + Cin + Cout + k + bm + bn + nw)
+    x = _bf(torch.randn(1, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    sh = torch.randn(Cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.float(), w.float(), sh, 1, k // 2))
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = ore.pack_conv_weight_bf16(w.float()).cuda()
+    L = ore.lib()
+    L.ore_conv_set_plan_override(-13, bm, bn, nw, sb)
+    try:
+        y32 = ore.conv2d(xd, wp, Cout, k, 1, shift=sh.cuda(), relu_cout=Cout, out_f32=True)
+        y, cs = ore.conv2d(xd, wp, Cout, k, 1, shift=sh.cuda(), relu_cout=Cout, want_colsum=True)
+        y2 = ore.conv2d(xd, wp, Cout, k, 1, shift=sh.cuda(), relu_cout=Cout)
+    finally:
+        L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
+    assert float((y32.cpu().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()) < 1e-4
+    assert y.dtype == torch.bfloat16 and _ulp_close(y.cpu(), y32.cpu()) and torch.equal(y, y2)
+    want_cs = y.float().sum((0, 1, 2)).cpu()
+    assert float((cs.sum(0)[:Cout].cpu() - want_cs).abs().max()) <= 1e-5 * float(want_cs.abs().max() + y.float().abs().sum().cpu() / Cout * 1e-2)
+
+
 @pytest.mark.gpu
 def test_conv_bf16_storage_slices_add_colsum_levels():
     """Channel-slice input / output inside wider bf16 buffers, the FPN top-down add from a bf16 tensor, fused column sums of the ROUNDED
