@@ -424,7 +424,15 @@ static KdPlan kd_plan(const ConvP& p) {
         if (p.Cout16 >= 320 && p.Cout16 % 80 == 64) return {32, 80, 4, 2};       // 384 = 4 x 80 + 64: five column tiles
         return {0, 0, 0, 0};
     }
-    if (p.M <= 9216 && p.Cout16 == 128 && p.kh == 1) return {64, 64, 4, 2};       // FPN lateral 3, conv3 over the three levels
+    if (p.M <= 9216 && p.Cout16 == 128 && p.kh == 1) {                            // FPN lateral 3, conv3 over the three levels
+        // (fp32: k_conv_gd takes both first.)  bf16 storage: 64 x 64 tiles of conv3's 8400 rows are 264 blocks -- a second round on 256
+        // CUs: 10.0 us against 8.5 on k_conv_kw's 32 x 64 tiles (tools/bf16s_sweep.py) -- so only what fits one round comes here
+        if ((p.sb & 1) && ceil_div(p.M, 64) * 2 > 256) return {0, 0, 0, 0};
+        return {64, 64, 4, 2};
+    }
+    // bf16 storage, stage 3's 3x3 layers (M = 6400, 80 output channels; fp32 runs them on the Winograd kernel): 7.0-7.6 us against
+    // k_conv_kw's 9.7-10.9 (tools/bf16s_sweep.py)
+    if ((p.sb & 1) && p.M <= 9216 && p.kh == 3 && p.Cout16 == 80) return {32, 80, 4, 2};
     return {0, 0, 0, 0};
 }
 

@@ -14,4 +14,4 @@ void ore_set_error(const char* fmt, ...) {
 
 extern "C" const char* ore_last_error(void) { return g_err; }
 extern "C" int32_t ore_det_record_rows(void) { return ORE_DET_RECORD_ROWS; }
-extern "C" int ore_version(void) { return 405; }   // round*100 + revision: bumped whenever a kernel on the eval path changes (bench.py keys the PMC traffic file on it)
+extern "C" int ore_version(void) { return 406; }   // round*100 + revision: bumped whenever a kernel on the eval path changes (bench.py keys the PMC traffic file on it)

@@ -14,6 +14,8 @@ shapes += [("conv3", 1, 8400, 1, 256, 128, 1, 1), ("tower", 1, 8400, 1, 128, 128
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 GS = [(64, 64), (128, 64), (128, 128), (64, 128), (32, 64), (32, 128), (64, 112), (128, 112), (64, 80)]
 KW = [(16, 16), (16, 32), (16, 48), (16, 64), (16, 80), (32, 16), (32, 32), (32, 48), (32, 64), (32, 80)]
+KD = [(16, 16, 4, 4), (16, 16, 4, 8), (16, 16, 8, 4), (16, 16, 16, 2), (16, 32, 4, 4), (16, 32, 8, 2), (32, 32, 4, 4), (32, 32, 8, 2), (16, 48, 4, 4), (16, 48, 8, 2),
+      (16, 64, 4, 2), (16, 80, 4, 2), (32, 64, 4, 2), (32, 80, 4, 2), (64, 64, 4, 2), (32, 48, 4, 2), (32, 16, 4, 4)]
 
 
 def timed(fn, n=30):
@@ -60,6 +62,15 @@ for name, B, H, W, Cin, Cout, k, stride in shapes:
             except Exception:
                 pass
     L.ore_conv_set_plan_override(-3, 0, 0, 0, 0)
+    for bm, bn, nw, sb in KD:                                    # k_conv_kd's bf16-storage builds (round 4)
+        if bn > (Cout + 15) // 16 * 16:
+            continue
+        L.ore_conv_set_plan_override(-13, bm, bn, nw, sb)
+        try:
+            res.append((f"kd {bm}x{bn} w{nw} b{sb}", timed(fn)))
+        except Exception:
+            pass
+    L.ore_conv_set_plan_override(-13, 0, 0, 0, 0)
     res.sort(key=lambda t: t[1])
     print("%-7s M=%6d Cin=%4d Cout=%4d k=%d s=%d | auto %.1f | best: %s" % (name, B * Ho * Wo, Cin, Cout, k, stride, dict(res)["auto"],
           "  ".join("%s %.1f" % r for r in res[:5])), flush=True)
