@@ -432,7 +432,7 @@ static KdPlan kd_plan(const ConvP& p) {
     }
     // bf16 storage, stage 3's 3x3 layers (M = 6400, 80 output channels; fp32 runs them on the Winograd kernel): 7.0-7.6 us against
     // k_conv_kw's 9.7-10.9 (tools/bf16s_sweep.py)
-    if ((p.sb & 1) && p.M <= 9216 && p.kh == 3 && p.Cout16 == 80) return {32, 80, 4, 2};
+    if ((p.sb & 1) && p.kh == 3 && p.Cout16 == 80) return {32, 80, 4, 2};   // (any M: the frozen stage 3 of a bf16 training step runs 16 queries and 384 support crops through it)
     return {0, 0, 0, 0};
 }
 
