@@ -355,7 +355,13 @@ class CenterNet2Detector(nn.Module):
             img = img.contiguous()
             H, W = img.shape[-2:]
             oh, ow = int(inp.get("height", H)), int(inp.get("width", W))
-            rec = e.detect_begin(img, oh, ow)                     # a fresh tensor, filled behind the graph
+            import orehip
+            try:
+                rec = e.detect_begin(img, oh, ow)                 # a fresh tensor, filled behind the graph
+            except orehip.OreError:
+                rec = None                                        # e.g. the cached engine belongs to another device / size: the checked path below decides
+            if rec is None:
+                return self._inference_checked(inp, img, do_postprocess)
             try:
                 fresh = self._engine_key == self._engine_key_now()
                 res = Instances((oh, ow))                         # the result objects are made while the device works, too
@@ -373,6 +379,11 @@ class CenterNet2Detector(nn.Module):
             bx.tensor = boxes
             res._fields = {"pred_boxes": bx, "scores": scores, "pred_classes": classes}
             return out
+        return self._inference_checked(inp, img, do_postprocess)
+
+    def _inference_checked(self, inp, img, do_postprocess):
+        """The eval call with the engine validated BEFORE it is used (first call, stale engine, other entry conditions)."""
+        batched_inputs = [inp]
         e = self.engine()
         if do_postprocess and getattr(e, "has_roi", False):
             from detectron2.structures import Boxes, Instances
