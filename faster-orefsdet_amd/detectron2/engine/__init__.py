@@ -147,6 +147,38 @@ class DefaultTrainer(SimpleTrainer):
     def build_evaluator(cls, cfg, dataset_name, output_folder=None):
         raise NotImplementedError("COCO evaluation is outside the hot path (SURVEY 8f)")
 
+    @classmethod
+    def test(cls, cfg, model, evaluators=None):
+        """d2z:engine/defaults.py:570-621 (`Trainer.test(cfg, model)` of ref:fsod_train_net.py:100): every dataset of cfg.DATASETS.TEST
+        through `build_test_loader` + `inference_on_dataset`; a `build_evaluator` that raises NotImplementedError is logged and leaves
+        an empty result for that dataset (no inference pass), exactly as there; a single dataset's result is returned unwrapped."""
+        from collections import OrderedDict
+        from detectron2.evaluation import DatasetEvaluator, inference_on_dataset
+        logger = logging.getLogger(__name__)
+        if isinstance(evaluators, DatasetEvaluator):
+            evaluators = [evaluators]
+        if evaluators is not None:
+            assert len(cfg.DATASETS.TEST) == len(evaluators), "{} != {}".format(len(cfg.DATASETS.TEST), len(evaluators))
+        results = OrderedDict()
+        for idx, dataset_name in enumerate(cfg.DATASETS.TEST):
+            data_loader = cls.build_test_loader(cfg, dataset_name)
+            if evaluators is not None:
+                evaluator = evaluators[idx]
+            else:
+                try:
+                    evaluator = cls.build_evaluator(cfg, dataset_name)
+                except NotImplementedError:
+                    logger.warning("No evaluator found. Use `DefaultTrainer.test(evaluators=)`, or implement its `build_evaluator` method.")
+                    results[dataset_name] = {}
+                    continue
+            results_i = inference_on_dataset(model, data_loader, evaluator)
+            results[dataset_name] = results_i
+            if comm.is_main_process():
+                assert isinstance(results_i, dict), "Evaluator must return a dict on the main process. Got {} instead.".format(results_i)
+        if len(results) == 1:
+            results = list(results.values())[0]
+        return results
+
     def resume_or_load(self, resume=True):
         self.checkpointer.resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
         if resume and self.checkpointer.has_checkpoint():
