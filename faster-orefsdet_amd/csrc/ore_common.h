@@ -74,4 +74,20 @@ int roi_predict_post(const float* h, int32_t C, int32_t h_parts, const float* h_
                      int32_t topk, float* det_boxes, float* det_scores, int64_t* det_src, int32_t* det_count,
                      const float* post_dev, float* fin_boxes, float* fin_scores, int32_t* fin_count,
                      int32_t* host_count, void* workspace, size_t workspace_bytes, void* stream);
+// where the per-ROI rows of the predictor live inside that workspace (read-back for tests: ore_engine_buffer "roi_raw_*")
+struct PredictWs { size_t raw_boxes, c_boxes, raw_scores, c_scores, c_src, ok, keep, nms; };
+inline PredictWs predict_ws_layout(int32_t cap) {
+    const size_t c = (size_t)(cap > 0 ? cap : 1);
+    PredictWs w{};
+    size_t o = 256;                                   // [0, 256): c_count, n_keep
+    w.raw_boxes = o; o += c * 16;
+    w.c_boxes = o; o += c * 16;
+    w.raw_scores = o; o += c * 4;
+    w.c_scores = o; o += c * 4;
+    w.c_src = o; o += c * 4;
+    w.ok = o; o += c * 4;
+    w.keep = o; o += c * 8;
+    w.nms = (o + 255) & ~(size_t)255;
+    return w;
+}
 }

@@ -1025,6 +1025,11 @@ extern "C" int ore_engine_buffer(ore_engine* e, const char* name, void** ptr, in
         if (base == "final_scores") return set(e->fin_scores_of(ib), e->roi_cap, 1, 1, 0);
         if (base == "final_count") return set(e->fin_count + ib * 4, 4, 1, 1, 0);
         if (n == "roi_h") return set(e->roi_h, e->roi_cap, e->roi_fc, e->roi_fc, 0);
+        // the predictor's per-ROI rows BEFORE the score filter / NMS (row r = proposal r of the image the second stage ran last on)
+        const oreroi::PredictWs L = oreroi::predict_ws_layout(e->roi_cap);
+        if (n == "roi_raw_boxes") return set((float*)((char*)e->roi_ws + L.raw_boxes), e->roi_cap, 4, 4, 0);
+        if (n == "roi_raw_scores") return set((float*)((char*)e->roi_ws + L.raw_scores), e->roi_cap, 1, 1, 0);
+        if (n == "roi_ok") return set((float*)((char*)e->roi_ws + L.ok), e->roi_cap, 1, 1, 0);
     }
     ore_set_error("ore_engine_buffer: unknown buffer '%s'", name);
     return ORE_ENOENT;

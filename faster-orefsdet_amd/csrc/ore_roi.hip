@@ -850,17 +850,16 @@ int oreroi::roi_predict_post(const float* h, int32_t C, int32_t h_parts, const f
         return ORE_ENOMEM;
     }
     char* ws = (char*)workspace;
-    const size_t c = (size_t)cap;
-    size_t o = 0;
-    int* c_count = (int*)(ws + o); int* n_keep = c_count + 1; o += 256;
-    float* raw_boxes = (float*)(ws + o); o += c * 16;
-    float* c_boxes = (float*)(ws + o); o += c * 16;
-    float* raw_scores = (float*)(ws + o); o += c * 4;
-    float* c_scores = (float*)(ws + o); o += c * 4;
-    int* c_src = (int*)(ws + o); o += c * 4;
-    int* ok = (int*)(ws + o); o += c * 4;
-    long long* keep = (long long*)(ws + o); o += c * 8;
-    o = (o + 255) & ~(size_t)255;
+    const oreroi::PredictWs L = oreroi::predict_ws_layout(cap);
+    int* c_count = (int*)ws; int* n_keep = c_count + 1;
+    float* raw_boxes = (float*)(ws + L.raw_boxes);
+    float* c_boxes = (float*)(ws + L.c_boxes);
+    float* raw_scores = (float*)(ws + L.raw_scores);
+    float* c_scores = (float*)(ws + L.c_scores);
+    int* c_src = (int*)(ws + L.c_src);
+    int* ok = (int*)(ws + L.ok);
+    long long* keep = (long long*)(ws + L.keep);
+    const size_t o = L.nms;
     void* nms_ws = ws + o;
     PredP p{};
     p.h = h; p.C = C; p.h_parts = h_parts; p.h_bias = h_bias; p.cls_w = cls_w; p.cls_b = cls_b; p.box_w = box_w; p.box_b = box_b;

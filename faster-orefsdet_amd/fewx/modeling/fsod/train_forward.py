@@ -476,6 +476,7 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
                    roi_gt=[roi_gt[b, :nv[b]] for b in range(B)], rois_per_image=nv, cn_counts=cn_counts, heads=heads,
                    pos_inds=tg["pos_inds"], pos_count=tg["pos_count"], valid=valid, **a2)
         if B == 1:
-            aux.update(proposals=dets[0]["out_boxes"][:counts_host[0]], roi_boxes=aux["roi_boxes"][0], roi_labels=aux["roi_labels"][0],
+            aux.update(proposals=dets[0]["out_boxes"][:counts_host[0]], proposal_scores=dets[0]["out_scores"][:counts_host[0]],
+                       detect=dets[0], roi_boxes=aux["roi_boxes"][0], roi_labels=aux["roi_labels"][0],
                        roi_gt=aux["roi_gt"][0], features={k: f[0].permute(2, 0, 1)[None] for k, f in zip(LEVELS, qf)})
     return (losses, aux) if return_aux else losses

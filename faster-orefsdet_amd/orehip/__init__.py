@@ -1198,7 +1198,7 @@ class Engine:
         _chk(lib().ore_engine_buffer(self._h, name.encode(), C.byref(p), dims), f"ore_engine_buffer({name})")
         rows, ch, ld, coff = (int(x) for x in dims)
         dt = {"pre_loc": torch.int64, "keep_idx": torch.int64, "pre_level": torch.int32, "counts": torch.int32, "det_src": torch.int64,
-              "det_count": torch.int32}.get(name.split("#")[0], torch.float32)
+              "det_count": torch.int32, "roi_ok": torch.int32}.get(name.split("#")[0], torch.float32)
         if lib().ore_engine_buffer_is_bf16(self._h, name.encode()):
             dt = torch.bfloat16                               # activation buffers of a bf16-storage engine
         flat = _from_ptr(p.value, rows * ld, dt, self.device)

@@ -753,13 +753,31 @@ def gen_eval_end_to_end(sd0, shots=5):
     det.support_dict = support
     out = {f"support_{k}": np_(v[1]) for k, v in support.items()}
     imgs = np.load(os.path.join(OUT, "demo_images_320.npz"))["images"]
+    # what never leaves `inference`: the first stage's proposals (a forward hook on the reference's CenterNet module) and the second
+    # stage's per-proposal rows as the reference hands them to fast_rcnn_inference (boxes after apply_deltas, class probabilities) --
+    # the inputs of the two NMS decisions, so a test can tell a near-tie flip from a wrong value
+    seen = {}
+    hook = det.proposal_generator.register_forward_hook(lambda mod, inp, o: seen.__setitem__("prop", o[0][0]))
+    rh_glob = type(det.roi_heads)._forward_box.__globals__         # the namespace the reference's method resolves the name in
+    fri = rh_glob["fast_rcnn_inference"]
+
+    def spy(boxes, scores, *a, **k):
+        seen["s2_boxes"], seen["s2_scores"] = boxes[0].detach().clone(), scores[0].detach().clone()
+        return fri(boxes, scores, *a, **k)
+    rh_glob["fast_rcnn_inference"] = spy
     for i in range(2):
         with torch.no_grad():
             res = det.inference([{"image": torch.from_numpy(imgs[i]), "height": 300, "width": 300}])[0]["instances"]
+        out[f"img{i}_prop_boxes"] = np_(seen["prop"].proposal_boxes.tensor)
+        out[f"img{i}_prop_scores"] = np_(seen["prop"].objectness_logits)
+        out[f"img{i}_stage2_boxes"] = np_(seen["s2_boxes"])
+        out[f"img{i}_stage2_scores"] = np_(seen["s2_scores"])
         out[f"img{i}_boxes"] = np_(res.pred_boxes.tensor)
         out[f"img{i}_scores"] = np_(res.scores)
         out[f"img{i}_classes"] = np_(res.pred_classes)
         print(f"  image {i}: {len(res)} detections, scores {res.scores[:4].tolist()}")
+    hook.remove()
+    rh_glob["fast_rcnn_inference"] = fri
     save("eval_end_to_end", shots=np.int64(shots), df_seed=np.int64(23), **out)
 
 

@@ -1509,15 +1509,48 @@ def test_eval_end_to_end_vs_reference_run(ore, golden, tmp_path):
     for k in ("p3", "p4", "p5", "rcnn_8", "rcnn_4"):
         assert set(m.support_dict[k]) == {1}
         assert rel_err(m.support_dict[k][1].cpu().numpy(), g["support_" + k]) < TOL, k
+    from near_tie import guided_nms_explain, match_rows
     imgs = golden("demo_images_320")["images"]
+    H = W = imgs.shape[-1]
     for i in range(2):
         for rep in range(2):                                                # second call = hipGraph replay
             out = m([{"image": torch.from_numpy(imgs[i]), "height": 300, "width": 300}])[0]["instances"]
         rb, rs = g[f"img{i}_boxes"], g[f"img{i}_scores"]
-        assert out.image_size == (300, 300) and abs(len(out) - len(rs)) <= 1, (len(out), len(rs))
-        ok = _match_detections(out.pred_boxes.tensor.cpu().numpy(), out.scores.cpu().numpy(), rb, rs, 0.05, 1e-3)
-        assert ok.mean() >= 0.97, (i, ok.mean())
-        assert (out.pred_classes == 0).all()
+        ob, osc = out.pred_boxes.tensor.cpu().numpy(), out.scores.cpu().numpy()
+        assert out.image_size == (300, 300) and (out.pred_classes == 0).all()
+        ok = _match_detections(ob, osc, rb, rs, 0.05, 1e-3)
+        # ---- every row on which the two outputs differ is a near-tie of one of the two greedy NMS passes, or its cascade (tests/near_tie.py).
+        # The walk runs on THIS path's candidate rows (read back from the engine that just served the call) and lets the reference's
+        # output decide only decisions within 2e-5 of the IoU threshold / 2e-6 relative of a score cut; with identical outputs it
+        # needs no such decision (measured on MI355X, round 5: both images match row for row, boxes to 1e-3 px, 0 ambiguous decisions).
+        e = m._engine
+        n_pre, n_prop = (int(v) for v in e.buffer("counts")[:2, 0].tolist())
+        pb, ps = e.buffer("pre_boxes")[:n_pre].cpu().numpy(), e.buffer("pre_scores")[:n_pre, 0].cpu().numpy()
+        # first stage: candidates -> NMS 0.6 -> score >= 256th (ref:fewx/modeling/fsod/fsod_rpn.py:1185-1210)
+        s1 = guided_nms_explain(pb, ps, g[f"img{i}_prop_boxes"], g[f"img{i}_prop_scores"], 0.6, post_topk=256, box_tol=2e-2, score_rtol=2e-4)
+        assert s1["unexplained"] == [], (i, "proposals", s1["unexplained"][:6])
+        props = e.proposals()[0].cpu().numpy()
+        which = match_rows(props, e.proposals()[1].cpu().numpy(), g[f"img{i}_prop_boxes"], g[f"img{i}_prop_scores"], 2e-2, 2e-4)
+        # second stage VALUES, proposal by proposal: box after apply_deltas + clip and foreground probability of every proposal both sides
+        # have (ref:fewx/modeling/fsod/fsod_roi_heads.py:404-455 -> d2z:modeling/roi_heads/fast_rcnn.py:118-171 clips inside)
+        raw_b, raw_s = e.buffer("roi_raw_boxes")[:n_prop].cpu().numpy(), e.buffer("roi_raw_scores")[:n_prop, 0].cpu().numpy()
+        ref_b = g[f"img{i}_stage2_boxes"].copy()
+        ref_b[:, 0::2] = ref_b[:, 0::2].clip(0, W)
+        ref_b[:, 1::2] = ref_b[:, 1::2].clip(0, H)
+        ref_s = g[f"img{i}_stage2_scores"][:, 0]
+        both = np.where(which >= 0)[0]
+        assert len(both) >= 0.97 * len(which), (len(both), len(which))
+        assert np.abs(raw_b[which[both]] - ref_b[both]).max() <= 5e-2, float(np.abs(raw_b[which[both]] - ref_b[both]).max())
+        assert (np.abs(raw_s[which[both]] - ref_s[both]) <= 1e-3 * ref_s[both] + 1e-6).all()
+        # second stage decisions: score > 0.05 -> NMS 0.9 -> the best 100, in output coordinates (detector_postprocess scales by 300/320)
+        okf = e.buffer("roi_ok")[:n_prop, 0].cpu().numpy() != 0
+        s2 = guided_nms_explain(raw_b[okf] * (300.0 / W), raw_s[okf], rb, rs, 0.9, max_out=100, box_tol=5e-2, score_rtol=1e-3, drop_empty=True)
+        assert s2["unexplained"] == [], (i, "detections", s2["unexplained"][:6])
+        print(f"image {i}: {int(ok.sum())}/{len(ok)} detections match row for row; near-tie decisions used: proposals {s1['ambiguous']}, "
+              f"detections {s2['ambiguous']}")
+        # ... and the number of rows that needed an explanation at all stays small (a broken kernel would not hide behind "ties")
+        assert ok.mean() >= 0.97 and abs(len(out) - len(rs)) <= 2, (i, ok.mean(), len(out), len(rs))
+        assert s1["ambiguous"] + s2["ambiguous"] <= 4, (s1["ambiguous"], s2["ambiguous"])
 
 
 def test_engine_batched_eval_matches_single_image_engines(ore, sd):

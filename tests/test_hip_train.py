@@ -1269,6 +1269,15 @@ def test_train_iteration_vs_reference_run(oh, golden, tag):
     assert abs(len(pb) - len(rb)) <= 2, (len(pb), len(rb))
     d = (pb[:, None, :] - rb[None, :, :]).abs().amax(2).min(1)[0]       # order may swap on 1-ulp score ties: compare as sets
     assert float((d < 1e-2).float().mean()) >= 0.99, float((d < 1e-2).float().mean())
+    # every row on which the two proposal sets differ is a near-tie of the train-mode NMS (IoU within 2e-5 of 0.9) or of the 2000th-score
+    # cut, or the cascade of one (tests/near_tie.py: the greedy walk re-run on THIS path's candidates, the reference deciding near-ties
+    # only).  Measured on MI355X, round 5: all 2000 rows match within 1e-2 px on both samples.
+    from near_tie import guided_nms_explain
+    det = aux["detect"]
+    n_pre = int(det["counts"][0].item())
+    ex = guided_nms_explain(det["pre_boxes"][:n_pre].cpu().numpy(), det["pre_scores"][:n_pre].cpu().numpy(), g["proposals"],
+                            g["proposal_scores"], 0.9, post_topk=2000, box_tol=1e-2, score_rtol=2e-4)
+    assert ex["unexplained"] == [] and ex["ambiguous"] <= 8, (ex["unexplained"][:6], ex["ambiguous"])
     for k in ("loss_cls_stage0", "loss_box_reg_stage0", "loss_centernet_loc", "loss_centernet_agn_pos", "loss_centernet_agn_neg"):
         want = float(g["loss/" + k])
         assert abs(float(losses[k].detach()) - want) <= 1e-4 * max(abs(want), 1e-3), (k, float(losses[k]), want)

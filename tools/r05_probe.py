@@ -143,9 +143,12 @@ def probe_traj(steps=200):
         cfg.freeze()
         torch.manual_seed(0)
         m = build_model(cfg)
-        sd = R.synth_roi_state(R.synth_state_dict(0), 0)
-        sd["roi_heads.box_head.0.fc1.weight"] = sd["roi_heads.box_head.0.fc1.weight"] * 0.02
-        sd["proposal_generator.centernet_head.agn_hm.bias"] = torch.full((1,), -2.0)
+        if os.environ.get("TRAJ_INIT", "synth") == "ref":      # backbone: seeded He-init + non-trivial FrozenBN; heads: the reference's own initialisers
+            sd = {k: v for k, v in R.synth_state_dict(0).items() if k.startswith("backbone.bottom_up.")}
+        else:
+            sd = R.synth_roi_state(R.synth_state_dict(0), 0)
+            sd["roi_heads.box_head.0.fc1.weight"] = sd["roi_heads.box_head.0.fc1.weight"] * 0.02
+            sd["proposal_generator.centernet_head.agn_hm.bias"] = torch.full((1,), -2.0)
         m.load_state_dict(sd, strict=False)
         m.train()
         for lvl in (3, 4, 5):
@@ -177,6 +180,8 @@ def probe_traj(steps=200):
         finals[mode] = (torch.cat([p.detach().reshape(-1) for p in m.parameters() if p.requires_grad]) - p0).cpu()
         tot = curve.sum(1)
         print(f"[traj {mode}] {steps} steps in {el:.1f}s; total loss every 20th: {np.round(tot[::20], 4).tolist()} last {tot[-1]:.4f}; keys {list(losses)}")
+        for j, k in enumerate(losses):
+            print(f"    {k}: {np.round(curve[::20, j], 4).tolist()}")
         orehip.set_conv_precision(prev)
         del m, opt
     a, b, c = curves["fp32"].sum(1), curves["bf16"].sum(1), curves["fp32b"].sum(1)
