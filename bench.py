@@ -83,6 +83,69 @@ def build_model(device):
     return model, cfg
 
 
+def _pool_out(h):
+    return -((h - 3) // -2) + 1                                   # max-pool 3x3 s2, ceil_mode (d2z:modeling/backbone/vovnet.py:310-332)
+
+
+def layer_table_macs(H, W, fpn_ch=128):
+    """MACs of ONE image of HxW through VoVNet-19-slim-eSE + FPN, layer by layer (SURVEY Appendix A restated as a function of the input
+    size): returns (frozen part = stem + stage 2 + stage 3, trainable part = stage 4 + stage 5 + FPN, rows of p3 / p4 / p5, and the
+    MACs of the trainable convs whose INPUT is a frozen map -- their data gradient is never needed)."""
+    Hp, Wp = -(-H // 32) * 32, -(-W // 32) * 32
+    h1, w1 = Hp // 2, Wp // 2
+    h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+    frozen = h1 * w1 * 27 * 64 + h1 * w1 * 9 * 64 * 64 + h2 * w2 * 9 * 64 * 128
+    spec = ((64, 112), (80, 256), (96, 384), (112, 512))           # (3x3 width, concat output) of stages 2..5
+    cin, h, w = 128, h2, w2
+    stage, first_in = [], []
+    rows = {}
+    for k, (c, oc) in enumerate(spec):
+        if k > 0:
+            h, w = _pool_out(h), _pool_out(w)
+        m = h * w * 9 * (cin * c + 2 * c * c) + h * w * (cin + 3 * c) * oc + oc * oc
+        stage.append(m)
+        first_in.append(h * w * 9 * cin * c + h * w * cin * oc)     # layers.0 and the concat's slice that reads the stage input
+        rows[k + 2] = h * w
+        cin = oc
+    frozen += stage[0] + stage[1]
+    fpn = sum(rows[k] * (cc * fpn_ch + 9 * fpn_ch * fpn_ch) for k, cc in ((3, 256), (4, 384), (5, 512)))
+    trainable = stage[2] + stage[3] + fpn
+    no_dgrad = first_in[2] + rows[3] * 256 * fpn_ch                # stage 4's reads of stage 3's (frozen) output + lateral 3
+    return frozen, trainable, (rows[3], rows[4], rows[5]), no_dgrad
+
+
+def train_step_gflop_expected(batch, size, shots, support_hw=240, rois=128, fpn_ch=128):
+    """Algorithmic GFLOP of one training step from the layer table (BASELINE.md section 2 / SURVEY 8d): forward of the conv stack on
+    `batch` query images and batch*shots support crops (padded to /32), data + weight gradients of stage 4 / 5 / FPN on both, the
+    correlation's conv3 + CenterNet head (forward, data, weight gradient) on the query pyramid, SM_Block's three Linear(128,128) per
+    level on the support maps, and the second stage on `rois` sampled ROIs per image.  MAC = 2 FLOP."""
+    fq, tq, rq, ndq = layer_table_macs(size, size, fpn_ch)
+    fs, ts, _, nds = layer_table_macs(support_hw, support_hw, fpn_ch)
+    n_sup = batch * shots
+    conv = batch * (fq + 3 * tq - ndq) + n_sup * (fs + 3 * ts - nds)
+    rows_q = sum(rq)
+    heads = batch * rows_q * (2 * fpn_ch * fpn_ch + 9 * fpn_ch * fpn_ch + 9 * fpn_ch * 5) * 3
+    sm = n_sup * (32 * 32 + 16 * 16 + 8 * 8) * 3 * fpn_ch * fpn_ch * 3
+    roi = batch * rois * (64 * 2 * fpn_ch * fpn_ch + 2 * 64 * fpn_ch * (fpn_ch // 2) + 64 * fpn_ch * 128 + 128 * 6) * 3
+    return 2.0 * (conv + heads + sm + roi) / 1e9
+
+
+def _profile_summary(name):
+    """profiles/r*_<name>.json written by tools/bench_train.py --rocprof-summary (launches and kernel time of one step by rocprofv3), only if
+    it was taken with this library version."""
+    import glob
+    import orehip
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % name)), reverse=True):
+        try:
+            with open(tf) as f:
+                tj = json.load(f)
+            if int(tj.get("ore_version", -1)) == int(orehip.lib().ore_version()):
+                return dict(tj, source=os.path.basename(tf))
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(model, img, budget_s=12.0):
     """Oracle (CPU restatement of the reference) on the host cores; bounded sample of the same workload."""
     from oracle import decode as odec
@@ -187,6 +250,14 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
 
     for _ in range(warmup):
         step()
+    # algorithmic FLOPs of one step, counted by the library as the per-op conv calls are made (ore_flop_counter_read): one EAGER step (a
+    # replayed hipGraph makes no calls), outside the timed region
+    model.train_graph = False
+    orehip.flop_counter(reset=True)
+    step()
+    step_flops, conv_calls = orehip.flop_counter(reset=True)
+    model.train_graph = graph
+    step()
     el, losses = timed(steps)
     n_steps = steps
     while el < min_time and n_steps < 64 * steps:             # every rank sees the same max-over-ranks time: same decision
@@ -201,6 +272,23 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
            "dense_part_hipgraph": bool(graph) and model.__dict__.get("_ore_train_graph_error") is None,
            "exchanged_bytes_per_step": 4 * opt.bucket.size if world > 1 else 0, "bucket_bytes": 4 * opt.bucket.size,
            "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    ach = step_flops / (el / n_steps) / 1e12
+    expected = train_step_gflop_expected(batch, size, shots)
+    out["roofline"] = {
+        "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+        "gflop_per_step": round(step_flops / 1e9, 2), "gflop_per_query_image": round(step_flops / 1e9 / batch, 2),
+        "gflop_per_step_layer_table": round(expected, 2), "counted_over_layer_table": round(step_flops / 1e9 / expected, 4),
+        "conv_calls_per_step": conv_calls,
+        "note": "END-TO-END: algorithmic (direct-convolution) FLOPs of every conv / linear / weight-gradient call of one step (counted by the "
+                "library at its C-ABI entry points during one eager step; gflop_per_step_layer_table is the same sum from the layer table) "
+                "/ wall time of the step (all kernels, host included), against the dense MFMA peak of the leg's dtype"
+                + ("; only the trainable convs multiply in bf16 -- frozen stages run bf16 STORAGE kernels, normalisation / correlation / "
+                   "losses / optimizer stay fp32 -- so this fraction prices a mixed step against the pure-bf16 peak" if precision == "bf16" else "")}
+    prof = _profile_summary("train_step_bs%d_%s_summary" % (batch, "bf16" if precision == "bf16" else "fp32"))
+    if prof is not None:
+        out["roofline"].update({"launches_per_step": prof.get("launches_per_step"), "kernel_ms_per_step": prof.get("kernel_ms_per_step"),
+                                "rocprof_source": prof.get("source")})
     if world > 1:
         # the exchange alone: the same slices, same order, nothing else running
         bk = opt.bucket
@@ -506,15 +594,13 @@ def main():
         for i in range(args.profile_passes):
             eng.eval_forward(imgs[i % len(imgs)], use_graph=False)
         ms_raw, fl, nl = eng.read_profile()
+        fl_exec = eng.profile_executed_flops()
         eng.set_profiling(False)
         import glob
         import orehip
         # `achieved` uses the RAW event time (conservative: each bracket also contains the dispatch latency of its launch, ~10 % over
-        # the durations rocprofv3 reports for the same kernels).  The calibrated figure subtracts what an event pair adds around an
-        # empty launch beyond back-to-back issue (2*T(1) - T(2)) and is printed beside it.
-        ev_us = orehip.event_pair_overhead_us(300)
+        # the durations rocprofv3 reports for the same kernels; the rocprofv3-based figure of the committed profile is `frac_rocprof`)
         ms = ms_raw
-        ms_cal = max(ms_raw - nl * ev_us * 1e-3, 1e-6)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM bytes of the conv launches of one image, from the committed PMC passes -- only if they were taken with THIS library version
         traffic, traffic_src, lib_ver = None, None, int(orehip.lib().ore_version())
@@ -543,11 +629,17 @@ def main():
                            "LDS-DMA implicit GEMMs k_conv_gd / k_conv_kd on the rest) + the second-stage GEMM (k_conv_gd, K split); FLOPs are the ALGORITHMIC (direct-convolution) "
                            "count, so the Winograd layers, which execute 2.25x fewer multiplies, can exceed the MFMA peak"),
                 "launches_per_image": nl // npp, "gflop_per_image": round(fl / npp / 1e9, 3),
-                "kernel_ms_per_image": round(ms / npp, 4), "kernel_ms_per_image_calibrated": round(ms_cal / npp, 4),
-                "event_pair_overhead_us": round(ev_us, 3), "achieved_calibrated": round(fl / (ms_cal * 1e-3) / 1e12, 2),
+                "kernel_ms_per_image": round(ms / npp, 4),
+                # what the matrix cores actually executed: a layer on the Winograd F(2x2,3x3) kernel runs its algorithmic count / 2.25
+                "gflop_executed_per_image": round(fl_exec / npp / 1e9, 3),
+                "mfma_executed_frac": round(fl_exec / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else None,
                 "note": "FLOP-weighted over all conv launches of one image (different shapes), isolated one-image-at-a-time launches; "
                         "profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command"}
         roof["end_to_end_tflops"] = round(total_images / elapsed * roof["gflop_per_image"] / 1e3, 2)
+        cl = _profile_summary("conv_layers_bf16s" if bf16s else "conv_layers") if not (bf16 and not bf16s) else None
+        if cl is not None:        # the same launches by rocprofv3 durations (tools/conv_layers_table.py --json on the committed kernel trace)
+            roof.update({"frac_rocprof": cl.get("frac"), "kernel_us_per_image_rocprof": cl.get("conv_us_per_image"),
+                         "mfma_executed_frac_rocprof": cl.get("mfma_executed_frac"), "rocprof_source": cl.get("source")})
         if bf16s:
             # bf16 storage: at 16x the fp32 MFMA rate the conv stack is bound by the bytes it moves, so the roofline is priced against
             # HBM: algorithmic bytes = every conv layer reads its input and writes its output once in bf16 (half of the 336 MB fp32

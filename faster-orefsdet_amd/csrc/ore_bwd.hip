@@ -882,6 +882,7 @@ extern "C" int ore_conv2d_wgrad_bias_fwd(const float* x, int32_t x_ld, int32_t x
     p.db = db; p.beta_b = beta_b;
     if (S == 1) { p.dw = dw_oihw; p.beta = beta; }
     p.bf16 = ore_conv_get_precision() == ORE_CONV_BF16;   // the STORAGE mode (2) is an engine property, plain calls stay fp32 (ore_hip.h)
+    ore_flop_count_add(2.0 * (double)M * Cout * Cin * kh * kw);
     hipStream_t st = (hipStream_t)stream;
     if (bfm && kh == 3 && kw == 3) hipLaunchKernelGGL(k_wgrad_bf<true>, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * 3, S), dim3(256), 0, st, p);
     else if (bfm) hipLaunchKernelGGL(k_wgrad_bf<false>, dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T) * kh * kw, S), dim3(256), 0, st, p);

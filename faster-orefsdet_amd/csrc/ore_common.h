@@ -6,6 +6,9 @@
 #include "ore_hip.h"
 
 void ore_set_error(const char* fmt, ...);
+void ore_note_wino(int v);
+int ore_last_wino(void);                // 1: this thread's last ore_conv2d_fwd / _levels_fwd call ran on the Winograd kernel
+void ore_flop_count_add(double flops);   // csrc/ore_util.cpp: algorithmic FLOPs of the per-op conv entry points (ore_flop_counter_read)
 
 #define ORE_CHECK_ARG(cond, ...)              \
     do {                                      \

@@ -1467,6 +1467,7 @@ static void fill_common(ConvP& p, const ore_conv_desc* d) {
 }
 
 extern "C" int ore_conv2d_fwd(const ore_conv_desc* d, void* stream) {
+    ore_note_wino(0);
     int rc = conv_common_checks(d);
     if (rc) return rc;
     ORE_CHECK_ARG(d->H > 0 && d->W > 0, "ore_conv2d_fwd: bad geometry");
@@ -1482,6 +1483,7 @@ extern "C" int ore_conv2d_fwd(const ore_conv_desc* d, void* stream) {
     p.ep_stride = 0;
     p.add = d->add; p.add_ld = d->add_ld; p.add_coff = d->add_coff;
     p.add_H = (L.Ho + 1) / 2; p.add_W = (L.Wo + 1) / 2;
+    ore_flop_count_add(2.0 * (double)p.M * d->Cout * d->Cin * d->kh * d->kw);
     return conv_launch(p, d->splitk, d->workspace, d->workspace_floats, (hipStream_t)stream);
 }
 
@@ -1489,6 +1491,7 @@ extern "C" int ore_conv2d_fwd(const ore_conv_desc* d, void* stream) {
 // and the output matrix; scale/shift may differ per level (ep_stride floats apart); in_mul/in_add are [level*B+b][Cin].
 extern "C" int ore_conv2d_levels_fwd(const ore_conv_desc* d, int32_t n_levels, const int32_t* H, const int32_t* W,
                                      int32_t ep_stride, void* stream) {
+    ore_note_wino(0);
     int rc = conv_common_checks(d);
     if (rc) return rc;
     ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && H && W, "ore_conv2d_levels_fwd: 1..4 levels");
@@ -1504,6 +1507,7 @@ extern "C" int ore_conv2d_levels_fwd(const ore_conv_desc* d, int32_t n_levels, c
     }
     p.M = rows;
     p.ep_stride = ep_stride;
+    ore_flop_count_add(2.0 * (double)rows * d->Cout * d->Cin * d->kh * d->kw);
     if (d->w_level_stride) {                                  // per-level layers, bf16 storage: the weight-stationary 3x3 kernel or nothing
         ORE_CHECK_ARG(d->w_level_stride > 0 && d->w_level_stride % 2 == 0 && d->kh == 3 && d->storage == ORE_ST_BF16 && !d->in_mul && !d->colsum &&
                           !d->w_wino_level_stride,

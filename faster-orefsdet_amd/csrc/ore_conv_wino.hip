@@ -451,7 +451,7 @@ static int wino_nu_go(const WinoP& p, int nb, hipStream_t st) {
 }
 
 // ORE_OK if launched, 1 if the layer is not covered (the caller goes on to the direct kernels)
-int conv_wino_launch(const ConvP& c, hipStream_t st) {
+static int conv_wino_launch_impl(const ConvP& c, hipStream_t st) {
     if ((!g_wino_mode && !c.wino_lstride) || !c.wino || c.bf16) return 1;   // (per-level launches have no direct twin: mode 0 does not apply)
     if (c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.in_mul || c.add || c.colsum) return 1;
     if (c.Cout != c.Cout16 || !conv_wino_covers(c.Cout, c.Cin)) return 1;
@@ -509,6 +509,12 @@ int conv_wino_launch(const ConvP& c, hipStream_t st) {
     if (c.Cin == 64) hipLaunchKernelGGL(k_conv3x3_wino<64>, dim3(gx, gy), dim3(512), lds, st, p);
     else hipLaunchKernelGGL(k_conv3x3_wino<128>, dim3(gx, gy), dim3(512), lds, st, p);
     return ore_launch_status("k_conv3x3_wino");
+}
+
+int conv_wino_launch(const ConvP& c, hipStream_t st) {
+    const int rc = conv_wino_launch_impl(c, st);
+    if (rc == 0) ore_note_wino(1);                      // the engine's profile separates algorithmic from executed multiplies
+    return rc;
 }
 
 }  // namespace oreconv

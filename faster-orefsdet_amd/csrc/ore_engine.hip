@@ -108,7 +108,8 @@ struct ore_engine {
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    struct EvSpan { size_t a, b; double flops; };
+    struct EvSpan { size_t a, b; double flops; double flops_exec; };   // algorithmic / executed (Winograd: 2.25x fewer multiplies)
+    double last_profile_exec_flops = 0.0;
     std::vector<EvSpan> spans;
     hipEvent_t next_event() {
         if (ev_used == ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev_pool.push_back(e); }
@@ -255,7 +256,7 @@ struct Run {
         size_t ia = 0;
         if (prof) { ia = e->ev_used; ea = e->next_event(); eb = e->next_event(); if (ea) (void)hipEventRecord(ea, st); }
         rc = ore_conv2d_levels_fwd(&d, 3, H, W, ep_stride, st);
-        if (prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl}); }
+        if (prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl, ore_last_wino() ? fl / 2.25 : fl}); }
         flops += fl;
     }
     void conv(const Conv& c, const float* in, int in_ld, int in_coff, int B, int H, int W, float* out, int out_ld,
@@ -282,7 +283,7 @@ struct Run {
         size_t ia = 0;
         if (prof) { ia = e->ev_used; ea = e->next_event(); eb = e->next_event(); if (ea) (void)hipEventRecord(ea, st); }
         rc = ore_conv2d_fwd(&d, st);
-        if (prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl}); }
+        if (prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl, ore_last_wino() ? fl / 2.25 : fl}); }
         flops += fl;
     }
 };
@@ -494,7 +495,7 @@ int run_roi(ore_engine* e, const Geo& g, hipStream_t st, double* flops, int b = 
         size_t ia = 0;
         if (r.prof) { ia = e->ev_used; ea = e->next_event(); eb = e->next_event(); if (ea) (void)hipEventRecord(ea, st); }
         rc = oreconv::conv_gd_splitk(e->roi_feat, K, e->roi_W, e->roi_cap, K, e->roi_fc, e->roi_hp, S, st);
-        if (r.prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl}); }
+        if (r.prof && ea && eb) { (void)hipEventRecord(eb, st); e->spans.push_back({ia, ia + 1, fl, fl}); }
         if (rc) return rc;
         *flops = fl;
     } else {
@@ -919,6 +920,7 @@ extern "C" int ore_engine_eval_batch_fwd(ore_engine* e, const void* img, int32_t
 }
 
 extern "C" double ore_engine_last_flops(ore_engine* e) { return e ? e->last_flops : 0.0; }
+extern "C" double ore_engine_profile_executed_flops(ore_engine* e) { return e ? e->last_profile_exec_flops : 0.0; }
 
 extern "C" int ore_engine_set_profiling(ore_engine* e, int32_t enable) {
     ORE_CHECK_ARG(e, "ore_engine_set_profiling: null");
@@ -931,13 +933,14 @@ extern "C" int ore_engine_set_profiling(ore_engine* e, int32_t enable) {
 extern "C" int ore_engine_read_profile(ore_engine* e, double* conv_ms, double* conv_flops, int32_t* n_launches) {
     ORE_CHECK_ARG(e && conv_ms && conv_flops && n_launches, "ore_engine_read_profile: null");
     ORE_HIP(hipDeviceSynchronize());
-    double ms = 0.0, fl = 0.0;
+    double ms = 0.0, fl = 0.0, fe = 0.0;
     for (auto& s : e->spans) {
         float t = 0.f;
         ORE_HIP(hipEventElapsedTime(&t, e->ev_pool[s.a], e->ev_pool[s.b]));
-        ms += t; fl += s.flops;
+        ms += t; fl += s.flops; fe += s.flops_exec;
     }
     *conv_ms = ms; *conv_flops = fl; *n_launches = (int32_t)e->spans.size();
+    e->last_profile_exec_flops = fe;
     e->ev_used = 0;
     e->spans.clear();
     return ORE_OK;

@@ -789,6 +789,7 @@ static int stem1_launch(const void* img, int32_t img_is_u8, int32_t B, int32_t H
                   "ore_stem1_fwd: Cout=%d ld=%d coff=%d", Cout, out_ld, out_coff);
     const int Ho = Hp / 2, Wo = Wp / 2;
     const int M = B * Ho * Wo;
+    ore_flop_count_add(2.0 * (double)M * Cout * 27.0);
     ORE_CHECK_ARG((long long)Ho * Wo < (1ll << 22) && (long long)B * Ho * Wo < (1ll << 31) && (long long)B * 3 * H * W < (1ll << 31),
                   "ore_stem1_fwd: %d images of %dx%d exceed the kernel's 32-bit indexing", B, H, W);
     hipStream_t st = (hipStream_t)stream;

@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         L.ore_conv_wgrad_workspace_floats.restype = C.c_size_t
         L.ore_engine_last_flops.restype = C.c_double
         L.ore_engine_last_flops.argtypes = [C.c_void_p]
+        L.ore_engine_profile_executed_flops.restype = C.c_double
+        L.ore_engine_profile_executed_flops.argtypes = [C.c_void_p]
         L.ore_engine_destroy.argtypes = [C.c_void_p]
         L.ore_engine_destroy.restype = None
         _lib = L
@@ -1019,6 +1021,13 @@ def sumpool2x2(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def flop_counter(reset: bool = False) -> Tuple[float, int]:
+    """(algorithmic FLOPs, calls) of the per-op conv entry points since the last reset (ore_flop_counter_read)."""
+    v, n = C.c_double(0.0), C.c_int64(0)
+    _chk(lib().ore_flop_counter_read(C.byref(v), C.byref(n), int(reset)), "ore_flop_counter_read")
+    return float(v.value), int(n.value)
+
+
 def event_pair_overhead_us(reps: int = 200) -> float:
     """Median (event, empty launch, event) time on the current stream (see ore_event_pair_overhead_us)."""
     v = C.c_double(0.0)
@@ -1190,6 +1199,10 @@ class Engine:
         ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
         _chk(lib().ore_engine_read_profile(self._h, C.byref(ms), C.byref(fl), C.byref(n)), "ore_engine_read_profile")
         return ms.value, fl.value, n.value
+
+    def profile_executed_flops(self) -> float:
+        """Of the FLOPs the last read_profile() reported, the multiplies actually executed (Winograd layers: algorithmic / 2.25)."""
+        return float(lib().ore_engine_profile_executed_flops(self._h))
 
     def buffer(self, name: str, bhw: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
         """Zero-copy torch view of a named engine buffer.  With bhw=(B,H,W): logical NCHW view of the channel slice."""

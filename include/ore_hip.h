@@ -32,6 +32,11 @@ extern "C" {
 
 const char* ore_last_error(void);
 int ore_version(void);
+/* Algorithmic (direct-convolution) FLOPs of the per-op conv calls made by this process since the last reset -- ore_conv2d_fwd,
+ * ore_conv2d_levels_fwd, the two weight-gradient calls, the two stem_1 calls: 2 * rows * Cout * Cin * kh * kw each -- and the number of such
+ * calls.  Host-side bookkeeping only (calls captured into a hipGraph count when captured, not when replayed).  bench.py prices the
+ * training step with it ("report exact sum from the layer table in code"). */
+int ore_flop_counter_read(double* flops, int64_t* calls, int32_t reset);
 
 /* ------------------------------------------------------------------ low-level ops ------------ */
 
@@ -553,6 +558,9 @@ double ore_engine_last_flops(ore_engine* e);
  * the algorithmic FLOPs of those launches and the launch count since the last read, and resets the counters. */
 int ore_engine_set_profiling(ore_engine* e, int32_t enable);
 int ore_engine_read_profile(ore_engine* e, double* conv_ms, double* conv_flops, int32_t* n_launches);
+/* Of the conv FLOPs the last ore_engine_read_profile reported: the multiplies the matrix cores actually executed (a layer on the
+ * Winograd F(2x2,3x3) kernel executes its algorithmic count / 2.25). */
+double ore_engine_profile_executed_flops(ore_engine* e);
 /* What bracketing ONE launch with hipEvents adds beyond the launch itself: 2*T(1) - T(2), T(n) = median time of (event, n empty
  * launches, event) on `stream`; subtracting launches x this value makes the event-based kernel time agree with rocprofv3's. */
 int ore_event_pair_overhead_us(void* stream, int32_t reps, double* median_us);

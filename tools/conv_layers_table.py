@@ -30,7 +30,7 @@ def main():
     out = ["# per-conv-launch efficiency of ONE image, strictly sequential mode (rocprofv3 --kernel-trace of the headline protocol, tools/protocol_loop.py,",
            "# %s); algorithmic FLOPs = 2*M*Cout*Cin*k*k; peak = %.1f TFLOP/s (fp32 MFMA, gfx950)" % (src, PEAK),
            "%-28s %-44s %9s %8s %8s %7s" % ("layer", "kernel / grid", "us", "GFLOP", "TFLOP/s", "% peak")]
-    tu = tg = 0.0
+    tu = tg = te = 0.0
     for i, l in enumerate(tl):
         m = re.match(r"(\S+.*?)\s+grid=(\([^)]*\))\s+dur=\s*([\d.]+)", l)
         kn, grid, us = m.group(1).strip(), m.group(2), float(m.group(3))
@@ -42,10 +42,19 @@ def main():
             gf = 2.0 * M * co * ci * k * k / 1e9
         tu += us
         tg += gf
+        te += gf / 2.25 if "wino" in kn else gf                    # a Winograd F(2x2,3x3) launch executes 16 of 36 multiplies per tile
         out.append("%-28s %-44s %9.2f %8.3f %8.1f %7.1f" % (n, (kn + " " + grid)[:44], us, gf, gf / us * 1e3, gf / us * 1e3 / PEAK * 100))
     out.append("%-28s %-44s %9.2f %8.3f %8.1f %7.1f" % ("all %d conv launches" % len(tl), "", tu, tg, tg / tu * 1e3, tg / tu * 1e3 / PEAK * 100))
+    out.append("# multiplies actually executed by the matrix cores (Winograd launches count 1/2.25): %.3f GFLOP = %.1f TFLOP/s = %.1f %% of peak"
+               % (te, te / tu * 1e3, te / tu * 1e3 / PEAK * 100))
     open(dst, "w").write("\n".join(out) + "\n")
-    print(out[-1])
+    print(out[-2])
+    if len(sys.argv) > 3:                                          # ore_version: also the JSON bench.py reads (roofline.frac_rocprof)
+        import json
+        with open(dst.rsplit(".", 1)[0] + ".json", "w") as f:
+            json.dump({"ore_version": int(sys.argv[3]), "conv_us_per_image": round(tu, 2), "gflop_per_image": round(tg, 3),
+                       "frac": round(tg / tu * 1e3 / PEAK, 4), "gflop_executed_per_image": round(te, 3),
+                       "mfma_executed_frac": round(te / tu * 1e3 / PEAK, 4), "launches": len(tl), "from": src.split("/")[-1]}, f)
 
 
 if __name__ == "__main__":

@@ -17,21 +17,30 @@ ORE_OPERANDS=bf16s timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -
 ORE_OPERANDS=bf16s timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_s -- python3 tools/pmc_pass.py > $OUT/pmc_write_s.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_fetch_s $OUT/pmc_write_s $OUT/${TAG}_pmc_traffic_bf16s.json $VER > $OUT/${TAG}_pmc_traffic_bf16s.txt
 cp $OUT/${TAG}_pmc_traffic_bf16s.json profiles/${TAG}_pmc_traffic_bf16s.json
-# 2. the default bench command under the kernel trace (the judged line + its rocprof summary)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-cp $(ls $OUT/bench/bench_kernel_stats.csv $OUT/bench/*/bench_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_bench_kernel_stats.csv
-# 3. one image of the headline protocol, kernel by kernel, and the per-layer conv table
+# 2. one image of the headline protocol, kernel by kernel, and the per-layer conv table
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proto -o proto -- python3 tools/protocol_loop.py 300 > $OUT/proto.log 2>&1
 cp $(ls $OUT/proto/proto_kernel_stats.csv $OUT/proto/*/proto_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_protocol_kernel_stats.csv
 python3 tools/trace_summary.py $OUT/proto 30 > $OUT/${TAG}_bench_image_timeline.txt
-python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline.txt $OUT/${TAG}_conv_layers.txt
+python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline.txt $OUT/${TAG}_conv_layers.txt $VER
+cp $OUT/${TAG}_conv_layers.json profiles/${TAG}_conv_layers.json
+# 3b. the bs-16 training step kernel by kernel, fp32 and bf16 (bench.py reads the summaries into the train legs' roofline)
+for PR in fp32 bf16; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_$PR -o train -- python3 tools/bench_train.py --batch 16 --steps 5 --warmup 2 --precision $PR > $OUT/train_$PR.log 2>&1
+  python3 tools/stats_top.py $(ls $OUT/train_$PR/train_kernel_stats.csv $OUT/train_$PR/*/train_kernel_stats.csv 2>/dev/null | head -1) 7 45 $OUT/${TAG}_train_step_bs16_${PR}_summary.json $VER > $OUT/${TAG}_train_step_bs16_${PR}_kernel_stats.txt
+  cp $OUT/${TAG}_train_step_bs16_${PR}_summary.json profiles/${TAG}_train_step_bs16_${PR}_summary.json
+  rm -rf $OUT/train_$PR
+done
+# 3c. the default bench command under the kernel trace (the judged line + its rocprof summary)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+cp $(ls $OUT/bench/bench_kernel_stats.csv $OUT/bench/*/bench_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 # 4. the same without the profiler (the numbers quoted in DESIGN.md), fp32 and bf16-operand mode
 timeout -k 10 300 python3 bench.py > $OUT/${TAG}_bench_noprof.json 2> $OUT/bench_noprof.err
 timeout -k 10 300 python3 bench.py --conv-operands bf16s --no-cpu-baseline --no-train-leg > $OUT/${TAG}_bench_bf16s.json 2> $OUT/bench_bf16s.err
 # 5. the bf16-storage mode kernel by kernel
 ORE_OPERANDS=bf16s timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proto_s -o proto -- python3 tools/protocol_loop.py 300 > $OUT/proto_s.log 2>&1
 python3 tools/trace_summary.py $OUT/proto_s 30 > $OUT/${TAG}_bench_image_timeline_bf16s.txt
-python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline_bf16s.txt $OUT/${TAG}_conv_layers_bf16s.txt
+python3 tools/conv_layers_table.py $OUT/${TAG}_bench_image_timeline_bf16s.txt $OUT/${TAG}_conv_layers_bf16s.txt $VER
+cp $OUT/${TAG}_conv_layers_bf16s.json profiles/${TAG}_conv_layers_bf16s.json
 rm -rf $OUT/proto $OUT/proto_s $OUT/bench $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch_s $OUT/pmc_write_s
 tail -3 $OUT/${TAG}_conv_layers.txt
 echo "done: $OUT"
