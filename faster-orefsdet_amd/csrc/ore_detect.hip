@@ -19,6 +19,18 @@
 //                   set; stops early once post_topk survivors (plus score ties) are known.
 #include "ore_common.h"
 
+#ifdef ORE_TRACE
+// make -C csrc trace: s_memtime stamps of block 0 / thread 0 of k_level_select (slots 0..15) and of the consumer wave of k_nms_scan_t
+// (slots 16..): tools/det_phase_trace.py.  Never part of the product library.
+__device__ unsigned long long* g_trace_det = nullptr;
+#define DET_TR(i) do { if (g_trace_det && (i) < 512) g_trace_det[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ int g_det_ablate = 0;      // tools/det_ablate.py: parts of k_nms_scan_t switched off (results are garbage by design)
+#define DET_ABL(bit) (g_det_ablate & (bit))
+#else
+#define DET_ABL(bit) 0
+#define DET_TR(i) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float ore_expf(float x) {
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(256) void k_rank_scatter(DetP p) {
 // One block = one 64 x 64 tile of the IoU matrix, 4 waves: wave q tests the tile's rows against columns 16q .. 16q+15 (a quarter of
 // the serial IoU chain of the one-wave form: 12 -> ~6 us at n = 3000), the four partial words of a row are OR-ed through LDS.
 __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ n_ptr,
-                                                   float thr, unsigned long long* __restrict__ mask, int words, int col_ld) {
+                                                   float thr, unsigned long long* __restrict__ mask, int words) {
     const int n = *n_ptr;
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
@@ -292,8 +304,54 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
     __syncthreads();
     if (q != 0 || i >= n) return;
     bits = (part[0][t] | part[1][t]) | (part[2][t] | part[3][t]);
-    if (col_ld > 0) mask[(size_t)bj * col_ld + i] = bits;        // column-major [word][row]: what k_nms_scan_col streams into LDS
-    else mask[(size_t)i * words + bj] = bits;
+    mask[(size_t)i * words + bj] = bits;
+}
+
+// The same tile for the column scan (k_nms_scan_t), TRANSPOSED: word T[bj][bi][c] = the rows of block bi that suppress column bj*64+c
+// (in the diagonal tile only EARLIER rows: bit r with r < c) -- a lane of the scan that owns row bj*64+c then ANDs its own words with the
+// kept masks of the earlier blocks and needs no cross-lane reduction.  Column block bj is ONE contiguous run of (bj+1)*64 words at
+// maskT + bj * col_ld.  Lane t is still the ROW (same operands, same float expression as above: IoU is symmetric in its operands up to
+// the commutative sum of the areas); the word of a column is the ballot of the 64 rows' verdicts.
+__global__ __launch_bounds__(256) void k_nms_mask_t(const float* __restrict__ boxes, const int* __restrict__ n_ptr, float thr,
+                                                     unsigned long long* __restrict__ maskT, int col_ld) {
+    const int n = *n_ptr;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
+    __shared__ float cb[64 * 4];
+    __shared__ float ca[64];
+    const int t = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (q == 0) {
+        const int j = bj * 64 + t;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (j < n) b = *reinterpret_cast<const f32x4*>(boxes + (size_t)j * 4);
+        cb[t * 4 + 0] = b.x; cb[t * 4 + 1] = b.y; cb[t * 4 + 2] = b.z; cb[t * 4 + 3] = b.w;
+        ca[t] = (b.z - b.x) * (b.w - b.y);
+    }
+    __syncthreads();
+    const int i = bi * 64 + t;
+    const bool rvalid = i < n;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (rvalid) a = *reinterpret_cast<const f32x4*>(boxes + (size_t)i * 4);
+    const float ai = (a.z - a.x) * (a.w - a.y);
+    const int jmax = min(64, n - bj * 64);
+    const bool dg = bi == bj;
+    unsigned long long mine = 0ull;                          // lane 16q + k keeps the word of column 16q + k
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int c = q * 16 + k;
+        bool sup = false;
+        if (rvalid && c < jmax && (!dg || t < c)) {
+            const float xx1 = fmaxf(a.x, cb[c * 4 + 0]), yy1 = fmaxf(a.y, cb[c * 4 + 1]);
+            const float xx2 = fminf(a.z, cb[c * 4 + 2]), yy2 = fminf(a.w, cb[c * 4 + 3]);
+            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+            const float inter = w * h;
+            const float ovr = inter / (ai + ca[c] - inter);
+            sup = ovr > thr;
+        }
+        const unsigned long long word = __ballot(sup);
+        if (t == c) mine = word;
+    }
+    if ((t >> 4) == q) maskT[(size_t)bj * col_ld + (size_t)bi * 64 + t] = mine;   // 16 consecutive words per wave
 }
 
 // One block (256 threads).  removed[] lives in LDS as 64-bit words.  All global latency is taken one 64-row block
@@ -430,153 +488,220 @@ __global__ __launch_bounds__(256) void k_nms_scan_multi(ScanBatch sb) {
                       a.out_scores, a.n_keep_out);
 }
 
-// Column-streaming scan for n <= NMS_COL_CAP candidates (the eval path: <= 3000).  The mask is column-major ([word][row], written
-// that way by k_nms_mask): column block w -- "who suppresses the rows of block w", plus the transposed diagonal words of block w
-// itself -- is ONE contiguous run of (w+1)*64 8-byte words.  Its loads do not depend on which rows survive, so the block streams the
-// columns into an LDS ring by LDS-DMA three steps ahead of the scan (16 waves x 16 bytes per lane), and the greedy walk itself
-// never waits for global memory: removed[w] = OR over the kept rows r < 64 w of col_w[r] (all 1024 threads, from LDS), then the
-// same in-block fixpoint as k_nms_scan on wave 0.  48 -> ~20 us at n = 2400 (it was one dependent global round trip per block).
-#ifndef ORE_NMS_COL_T
-#define ORE_NMS_COL_T 1024
-#endif
-constexpr int NMS_COL_CAP = 3072, NMS_COL_SLOT = 4096, NMS_COL_RING = 4, NMS_COL_T = ORE_NMS_COL_T;   // slot = 32 DMA instructions x 128 rows
-constexpr int NMS_COL_NWV = NMS_COL_T / 64, NMS_COL_PPW = 32 / NMS_COL_NWV;          // DMA instructions per wave and column
+// Column scan for n <= NMS_COL_CAP candidates (the eval path: <= 3000), round 5.  The mask arrives TRANSPOSED per tile (k_nms_mask_t):
+// column block w = the words T[w][b][j], b <= w -- "which rows of block b suppress row 64 w + j" -- one contiguous run of (w+1)*64
+// words.  ONE wave walks the 64-row blocks; lane j owns row 64 w + j and ORs (T[w][b][j] & kept[b]) over the earlier blocks b: no
+// cross-lane reduction and no workgroup barrier on the dependent chain.  The other 15 waves only feed it: wave p streams the columns
+// c = p, p + 15, ... into an LDS ring by LDS-DMA, publishes a column with an LDS flag once its pieces have landed, and waits for the
+// consumer's progress counter before it writes over columns that may still be read.
+// What bounded round 4's form (31 us for 38 blocks) was neither its barrier nor its reduction but the DEPTH of its ring: the mask has
+// just been written by blocks on all eight XCDs, so a column comes from the fabric with ~2 us of latency, and four 32 KiB slots keep
+// three columns in flight: 38 columns / 3 x 2 us.  The ring here is PACKED -- a column takes its own size (512 B ... 24 KiB, 1 KiB
+// granules), 128 KiB hold 6 (the last, widest columns) to 15+ (the first) of them, and every producer wave has a column in flight.
+// Positions and the progress a column has to wait for depend on the column index only: compile-time tables.
+// kept[b] lives in lane b of one VGPR pair and is broadcast by v_readlane (b is wave-uniform).  Survivors are emitted by all waves at the end.
+constexpr int NMS_COL_CAP = 3072, NMS_COL_T = 1024, NMS_COL_NPROD = NMS_COL_T / 64 - 1;
+constexpr int NMS_COL_NB = NMS_COL_CAP / 64;                              // 48 column blocks at most
+constexpr int NMS_COL_RING_WORDS = 14336, NMS_COL_SLACK = 512;            // 112 KiB ring + 4 KiB the batched reads may run over
+constexpr int NMS_COL_SPIN_MAX = 1 << 21;                                  // ~0.1 s of polling: a stuck ring gives up instead of hanging the card
+struct NmsColPlan { int start[NMS_COL_NB]; int need[NMS_COL_NB]; };
+constexpr int nms_col_words(int c) { return ((c + 2) / 2) * 128; }        // (c + 1) * 64 words rounded up to whole 1 KiB pieces
+constexpr NmsColPlan nms_col_plan() {
+    NmsColPlan pl{};
+    int pos = 0;
+    for (int c = 0; c < NMS_COL_NB; ++c) {
+        const int sz = nms_col_words(c);
+        if (pos + sz > NMS_COL_RING_WORDS) pos = 0;                        // a column never wraps: skip to the start
+        pl.start[c] = pos;
+        pos += sz;
+    }
+    for (int c = 0; c < NMS_COL_NB; ++c) {                                 // need[c]: blocks the consumer must be done with before column c may be written
+        int d = 0;
+        for (int k = c - 1; k >= 0; --k) {
+            const bool overlap = pl.start[k] < pl.start[c] + nms_col_words(c) && pl.start[c] < pl.start[k] + nms_col_words(k);
+            if (overlap) { d = k + 1; break; }
+        }
+        pl.need[c] = d;
+    }
+    return pl;
+}
+__device__ const NmsColPlan g_nms_col_plan = nms_col_plan();             // lane c of every wave loads entry c once (a vector load: off the LDS / scalar counter)
+static_assert(nms_col_words(NMS_COL_NB - 1) <= NMS_COL_RING_WORDS, "ring geometry");
 
-__global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_col(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
-                                                            const int* __restrict__ s_order, const int* __restrict__ n_ptr,
-                                                            const unsigned long long* __restrict__ maskT, int col_ld, int post_topk,
-                                                            long long* __restrict__ keep_idx, float* __restrict__ out_boxes,
-                                                            float* __restrict__ out_scores, int* __restrict__ n_keep_out,
-                                                            const unsigned long long* __restrict__ zero_page) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long cl[];    // ring [RING][SLOT] + kept[64] + part[64] + misc[8] + scores[CAP] (float)
-    unsigned long long* kept_w = cl + NMS_COL_RING * NMS_COL_SLOT;
-    unsigned long long* part = kept_w + 64;                  // [64] part[w]: column w reduced over the survivors of blocks 0 .. w-2
-    unsigned long long* misc = part + 64;                    // [0], [1] stop flag of even / odd steps, [3] survivors, [4..6] final broadcast
-    float* sc = reinterpret_cast<float*>(misc + 8);          // the sorted scores: the threshold logic never touches global memory
-    int* pre = reinterpret_cast<int*>(sc + NMS_COL_CAP);     // [64] exclusive prefix of the kept counts per block
+__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ __launch_bounds__(NMS_COL_T) void k_nms_scan_t(const float* __restrict__ s_boxes, const float* __restrict__ s_scores,
+                                                          const int* __restrict__ s_order, const int* __restrict__ n_ptr,
+                                                          const unsigned long long* __restrict__ maskT, int col_ld, int post_topk,
+                                                          long long* __restrict__ keep_idx, float* __restrict__ out_boxes,
+                                                          float* __restrict__ out_scores, int* __restrict__ n_keep_out,
+                                                          const unsigned long long* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long cl[];    // ring [RING_WORDS] | slack | kept_w[64] | ready[64] | pre[64] | ctl[16] | scores[CAP]
+    unsigned long long* kept_w = cl + NMS_COL_RING_WORDS + NMS_COL_SLACK;     // [64] kept mask of block b, once decided
+    int* ready = reinterpret_cast<int*>(kept_w + 64);        // [64] 1: column c has landed
+    int* pre = ready + 64;                                   // [64] survivors in front of block b
+    int* ctl = pre + 64;                                     // [0] blocks decided, [1] stop, [6] protocol error, [7] producer waves whose scores are in
+    float* sc = reinterpret_cast<float*>(ctl + 16);          // the sorted scores
     const int n = min(*n_ptr, NMS_COL_CAP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = (n + 63) >> 6;
-    // DMA of column c: rows [0, min(n, 64 (c+1))) = that many 8-byte words; every wave issues exactly 2 instructions of 1 KiB (128 rows)
-    auto issue = [&](int c) {
-        const int rows = c < nb ? min(n, (c + 1) * 64) : 0;
-        const unsigned long long* base = maskT + (size_t)c * col_ld;
-        unsigned long long* dst = cl + (c % NMS_COL_RING) * NMS_COL_SLOT;
-#pragma unroll
-        for (int k = 0; k < NMS_COL_PPW; ++k) {
-            const int piece = (wave + NMS_COL_NWV * k) * 64 + lane;    // 16-byte piece = rows 2 piece, 2 piece + 1
-            const unsigned long long* src = piece * 2 < rows ? base + piece * 2 : zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + (wave + NMS_COL_NWV * k) * 128), 16, 0, 0);
+    // ring position of column `lane` and the consumer progress it has to wait for: one vector load per wave, broadcast by v_readlane
+    // (a scalar load with a dynamic index shares its counter with the LDS reads of the walk and would sit on their s_waitcnt)
+    const int pl_start = g_nms_col_plan.start[min(lane, NMS_COL_NB - 1)], pl_need = g_nms_col_plan.need[min(lane, NMS_COL_NB - 1)];
+    if (tid == 0) DET_TR(16);
+    if (tid < 64) { ready[tid] = 0; kept_w[tid] = 0ull; pre[tid] = 0; }
+    if (tid < 16) ctl[tid] = 0;
+    __syncthreads();
+    if (tid == 0) DET_TR(17);
+    if (wave != 0) {
+        const int pw = wave - 1;
+        // ---- producers.  First their slice of the sorted scores (the consumer's threshold logic reads them from LDS, much later) ...
+        {
+            const int per = (n + NMS_COL_NPROD - 1) / NMS_COL_NPROD;
+            const int r0 = pw * per, r1 = min(r0 + per, n);
+            for (int i = r0 + lane; i < r1; i += 64) sc[i] = s_scores[i];
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&ctl[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    };
-    // scores first (ordinary loads: issued and retired before any DMA is in flight)
-    for (int i = tid; i < n; i += NMS_COL_T) sc[i] = s_scores[i];
-    if (tid < 64) { kept_w[tid] = 0ull; part[tid] = 0ull; }
-    if (tid == 0) { misc[0] = 0ull; misc[1] = 0ull; misc[3] = 0ull; misc[6] = 0ull; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < NMS_COL_RING - 1; ++c) issue(c);
-    int n_keep = 0;
+        // ... then the columns pw, pw + 15, ...
+        for (int c = pw; c < nb; c += NMS_COL_NPROD) {
+            const int need = __builtin_amdgcn_readlane(pl_need, c);
+            bool stopped = false;
+            for (int spin = 0;; ++spin) {                                 // the ring region of column c is free once block need - 1 is done
+                if (lds_ld(&ctl[1])) { stopped = true; break; }
+                if (lds_ld(&ctl[0]) >= need) break;
+                if (spin > NMS_COL_SPIN_MAX) { lds_st(&ctl[6], 1); lds_st(&ctl[1], 1); stopped = true; break; }   // never hang the GPU
+                if (DET_ABL(32)) __builtin_amdgcn_s_sleep(60);
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (stopped) break;
+            if (lane == 0) DET_TR(128 + 2 * c);
+            const unsigned long long* base = maskT + (size_t)c * col_ld;
+            unsigned long long* dst = cl + __builtin_amdgcn_readlane(pl_start, c);
+            const int rows = (c + 1) * 64, pieces = (c + 2) / 2;         // words of this column; 1 KiB pieces
+            for (int k = 0; k < pieces; ++k) {
+                const int word = k * 128 + lane * 2;
+                const unsigned long long* src = word < rows ? base + word : zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + k * 128), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) DET_TR(129 + 2 * c);
+            if (lane == 0) lds_st(&ready[c], 1);                          // (LDS executes a wave's operations in order: the pieces are in)
+        }
+        // ... and the EMISSION of the blocks pw, pw + 15, ... as the consumer decides them: survivors' order / box / score to their
+        // positions (survivors in front of the block + survivors before the row inside it), under the scan instead of behind it
+        for (int b = pw; b < (DET_ABL(16) ? 0 : nb); b += NMS_COL_NPROD) {
+            bool skip = false;
+            for (int spin = 0; lds_ld(&ctl[0]) <= b; ++spin) {
+                if (lds_ld(&ctl[1]) && lds_ld(&ctl[0]) <= b) { skip = true; break; }       // stopped in front of this block: nothing survives here
+                if (spin > NMS_COL_SPIN_MAX) { skip = true; break; }
+                if (DET_ABL(32)) __builtin_amdgcn_s_sleep(60);
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (skip) break;
+            const unsigned long long kw = kept_w[b];
+            const int row = b * 64 + lane;
+            if ((kw >> lane) & 1ull) {
+                const int pos = pre[b] + __popcll(kw & ((1ull << lane) - 1ull));
+                keep_idx[pos] = (long long)s_order[row];
+                *reinterpret_cast<f32x4*>(out_boxes + (size_t)pos * 4) = *reinterpret_cast<const f32x4*>(s_boxes + (size_t)row * 4);
+                out_scores[pos] = sc[row];
+            }
+        }
+        return;
+    }
+    // ---- the consumer: one wave, lane j = row 64 w + j; no global memory operation inside its loop
+    int n_keep = 0, n_out = 0;                                            // survivors / survivors at or above the post_topk-th score
     float thr_score = 0.f;
-    bool have_thr = false;
-    // Two-stage pipeline, ONE barrier per 64-row block.  In step w wave 0 resolves block w while waves 1..15 already reduce column
-    // w+1 over the survivors of blocks 0..w-1 (known since the previous step) into part[w+1]; what block w itself contributes to
-    // column w+1 -- 64 words -- wave 0 adds in step w+1, right after it has decided block w (hoisting those reads in front of
-    // the barrier does not help: the barrier needs lgkmcnt(0) first -- measured 33.8 vs 31.4 us).  The all-thread reduction and its
-    // second barrier are off wave 0's dependent chain (0.86 -> ~0.45 us per block).
+    bool have_thr = false, sc_in = false;
+    if (lane == 0) DET_TR(18);
     for (int w = 0; w < nb; ++w) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NMS_COL_PPW) : "memory");   // this wave's pieces of columns w and w+1 have landed (column w+2 in flight)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // everybody's have; step w-1 is over: kept_w[w-1], part[w] and the verdict are published
-        if (misc[(w + 1) & 1]) break;                          // verdict of step w-1 (parity slots: wave 0 may already be writing step w's)
-        issue(w + NMS_COL_RING - 1);                           // into the slot of column w-1 (last read in step w-1)
-        if (wave != 0) {
-            if (w + 1 < nb) {
-                const unsigned long long* col = cl + ((w + 1) % NMS_COL_RING) * NMS_COL_SLOT;
-                // survivors are few (<= post_topk of thousands): the lanes that hold one OR its word straight into part[w+1]; a 64-bit
-                // shuffle reduction per wave (24 cross-lane LDS ops x 15 waves per block) kept the CU's LDS pipe busy under wave 0's feet
-                for (int r = tid - 64; r < w * 64; r += NMS_COL_T - 64)
-                    if ((kept_w[r >> 6] >> (r & 63)) & 1ull) {
-                        const unsigned long long v = col[r];
-                        if (v) atomicOr(&part[w + 1], v);
-                    }
+        const int start = __builtin_amdgcn_readlane(pl_start, w);
+        bool dead = false;
+        for (int spin = 0; !DET_ABL(4) && lds_ld(&ready[w]) == 0; ++spin) {
+            if (spin > NMS_COL_SPIN_MAX) { dead = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (dead) { if (lane == 0) { lds_st(&ctl[6], 1); lds_st(&ctl[1], 1); } n_out = -1; break; }   // (a protocol error: count -1, never a hang)
+        asm volatile("" ::: "memory");
+        if (lane == 0) DET_TR(20 + 3 * w);
+        const unsigned long long* col = cl + start + lane;
+        const unsigned long long diag = col[w * 64];
+        // eight blocks per batch, all reads in flight together: the lane's own words of the column and the kept masks of those blocks as
+        // BROADCAST reads of kept_w[] (one LDS instruction each; a v_readlane pair per block cost four times as much).  kept_w[b] of
+        // the blocks b >= w a batch touches beyond the column's (w + 1) * 64 words is still 0, so they AND to nothing (NMS_COL_SLACK
+        // words behind the ring keep those addresses inside the allocation).
+        unsigned long long hit = 0ull;
+        for (int b0 = 0; b0 < (DET_ABL(1) ? 0 : w); b0 += 8) {
+            unsigned long long v[8], kb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = col[(b0 + k) * 64]; kb[k] = kept_w[b0 + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hit |= v[k] & kb[k];
+        }
+        unsigned long long rem = __ballot(hit != 0ull);                   // removed by a survivor of an earlier block
+        if (lane == 0) DET_TR(21 + 3 * w);
+        const int nvalid = min(64, n - w * 64);
+        if (nvalid < 64) rem |= ~0ull << nvalid;
+        // Greedy resolution inside the block as a fixpoint: K <- cand & ~{ j : diag[j] & K != 0 } (row j is suppressed by a kept
+        // earlier row of the block).  Iteration i is exact on the first i rows, so the unique fixpoint IS the sequential greedy
+        // answer; it is reached after (longest suppression chain) iterations of one AND + one ballot each (1-4 on dense maps).
+        const unsigned long long cand = ~rem;
+        unsigned long long kept = cand;
+        if (!DET_ABL(2) && __ballot(diag != 0ull) != 0ull) {
+            for (int it = 0; it < 64; ++it) {
+                const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
+                if (kn == kept) break;
+                kept = kn;
             }
-        } else {
-            const unsigned long long* col = cl + (w % NMS_COL_RING) * NMS_COL_SLOT;
-            const int row = w * 64 + lane;
-            const unsigned long long diag = row < n ? col[row] : 0ull;
-            if (w > 0) {                                          // the survivors of block w-1 (decided in the previous step): a handful of
-                if ((kept_w[w - 1] >> lane) & 1ull) {             // lanes OR their word into part[w] (LDS atomics of ONE wave execute in
-                    const unsigned long long v = col[(w - 1) * 64 + lane];   // order, the read below sees them)
-                    if (v) atomicOr(&part[w], v);
-                }
+        }
+        if (lane == 0) { kept_w[w] = kept; pre[w] = n_keep; lds_st(&ctl[0], w + 1); }   // decided: the column's reads are complete, emitters may go
+        const int kc = __popcll(kept);
+        bool stop = false;
+        if (!DET_ABL(8) && post_topk > 0 && (have_thr || n_keep + kc >= post_topk)) {     // at / behind the post_topk-th survivor: the scores decide
+            if (!sc_in) {
+                for (int spin = 0; lds_ld(&ctl[7]) < NMS_COL_NPROD && spin < NMS_COL_SPIN_MAX; ++spin) __builtin_amdgcn_s_sleep(1);
+                sc_in = true;
             }
-            unsigned long long rem = part[w];
-            const int nvalid = min(64, n - w * 64);
-            if (nvalid < 64) rem |= ~0ull << nvalid;
-            const unsigned long long cand = ~rem;
-            unsigned long long kept = cand;
-            if (__ballot(diag != 0ull) != 0ull) {
-                for (int it = 0; it < 64; ++it) {
-                    const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
-                    if (kn == kept) break;
-                    kept = kn;
-                }
-            }
-            const int kc = __popcll(kept);
-            if (post_topk > 0 && !have_thr && n_keep + kc >= post_topk) {      // the post_topk-th survivor sits in this block
+            const float scv = w * 64 + lane < n ? sc[w * 64 + lane] : 0.f;
+            if (!have_thr) {
                 int need = post_topk - n_keep;
                 unsigned long long m = kept;
                 while (need > 1) { m &= m - 1; --need; }
-                thr_score = sc[w * 64 + (__ffsll((long long)m) - 1)];
+                thr_score = __shfl(scv, __ffsll((long long)m) - 1);
                 have_thr = true;
             }
-            n_keep += kc;
-            bool stop = false;
-            if (have_thr) {
-                const int last = min(n, (w + 1) * 64) - 1;
-                if (sc[last] < thr_score) stop = true;                // later rows are all below the threshold score
-            }
-            if (lane == 0) { kept_w[w] = kept; pre[w] = n_keep - kc; misc[w & 1] = stop ? 1ull : 0ull; misc[3] = (unsigned long long)n_keep; }
+            // survivors at or above the post_topk-th score (a prefix of the list: it is in descending score order; ties may keep more)
+            n_out += __popcll(kept & __ballot(scv >= thr_score));
+            if (__shfl(scv, nvalid - 1) < thr_score) stop = true;          // later rows are all below the threshold score
+        } else {
+            n_out += kc;
         }
+        n_keep += kc;
+        if (lane == 0) DET_TR(22 + 3 * w);
+        if (stop) break;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- emit the survivors, all threads: position = survivors of the earlier blocks + those before the row in its own block;
-    // survivors below the post_topk-th score are cut (a prefix: the list is in descending score order)
-    n_keep = (int)misc[3];
-    const float thr = __shfl(thr_score, 0);                   // wave 0 holds it; broadcast through LDS for the other waves
-    float* thr_sh = reinterpret_cast<float*>(&misc[4]);
-    int* have_sh = reinterpret_cast<int*>(&misc[5]);
-    if (tid == 0) { *thr_sh = thr; *have_sh = have_thr ? 1 : 0; }
-    __syncthreads();
-    const bool hthr = *have_sh != 0;
-    const float thr_all = *thr_sh;
-    int cnt = 0;
-    for (int row = tid; row < n; row += NMS_COL_T) {
-        const unsigned long long kw = kept_w[row >> 6];
-        if ((kw >> (row & 63)) & 1ull) {
-            const int pos = pre[row >> 6] + __popcll(kw & ((1ull << (row & 63)) - 1ull));
-            keep_idx[pos] = (long long)s_order[row];
-            *reinterpret_cast<f32x4*>(out_boxes + (size_t)pos * 4) = *reinterpret_cast<const f32x4*>(s_boxes + (size_t)row * 4);
-            const float scv = sc[row];
-            out_scores[pos] = scv;
-            cnt += (!hthr || scv >= thr_all) ? 1 : 0;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
-    if (lane == 0 && cnt) atomicAdd(reinterpret_cast<int*>(&misc[6]), cnt);
-    __syncthreads();
-    if (tid == 0) *n_keep_out = *reinterpret_cast<int*>(&misc[6]);
+    if (lane == 0) { lds_st(&ctl[1], 1); *n_keep_out = n_out; DET_TR(19); }
 }
 
 __device__ __attribute__((aligned(256))) unsigned long long g_zero_nms[32] = {};
 
 // cap = capacity in rows of the workspace the mask lives in; the column-streaming kernel takes cap <= NMS_COL_CAP, even (16-byte columns)
-static bool nms_use_col(int cap) { return cap <= NMS_COL_CAP && (cap & 1) == 0; }
+static bool nms_use_col(int cap) { return cap <= NMS_COL_CAP; }
+static int nms_col_ld(int cap) { return ((cap + 63) / 64) * 64; }        // words between two column blocks of the transposed mask
+
+// the IoU bit matrix in the layout the scan that follows reads: transposed tiles in column blocks (k_nms_scan_t) or row-major words
+static int launch_nms_mask(int words, int cap, hipStream_t st, const float* s_boxes, const int* n_ptr, float thr, unsigned long long* mask) {
+    if (nms_use_col(cap)) {
+        hipLaunchKernelGGL(k_nms_mask_t, dim3(words, words), dim3(256), 0, st, s_boxes, n_ptr, thr, mask, nms_col_ld(cap));
+        return ore_launch_status("k_nms_mask_t");
+    }
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(256), 0, st, s_boxes, n_ptr, thr, mask, words);
+    return ore_launch_status("k_nms_mask");
+}
 
 static int launch_nms_scan(int words, hipStream_t st, const float* s_boxes, const float* s_scores, const int* s_order, const int* n_ptr,
                            const unsigned long long* mask, float thr, int post_topk, long long* keep_idx, float* out_boxes,
@@ -587,12 +712,12 @@ static int launch_nms_scan(int words, hipStream_t st, const float* s_boxes, cons
         ORE_HIP(hipGetDevice(&dev));
         ORE_CHECK_ARG(dev >= 0 && dev < 16, "launch_nms_scan: device %d", dev);
         if (!zp[dev]) { void* q = nullptr; ORE_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_nms))); zp[dev] = (const unsigned long long*)q; }
-        const size_t lds = ((size_t)NMS_COL_RING * NMS_COL_SLOT + 64 + 64 + 8) * sizeof(unsigned long long) + (size_t)NMS_COL_CAP * 4 + 64 * 4;
+        const size_t lds = ((size_t)NMS_COL_RING_WORDS + NMS_COL_SLACK + 64) * sizeof(unsigned long long) + (64 + 64 + 16) * sizeof(int) + (size_t)NMS_COL_CAP * 4;
         static bool attr = false;
-        if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_nms_scan_col, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-        hipLaunchKernelGGL(k_nms_scan_col, dim3(1), dim3(NMS_COL_T), lds, st, s_boxes, s_scores, s_order, n_ptr, mask, col_cap, post_topk,
+        if (!attr) { ORE_HIP(hipFuncSetAttribute((const void*)k_nms_scan_t, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL(k_nms_scan_t, dim3(1), dim3(NMS_COL_T), lds, st, s_boxes, s_scores, s_order, n_ptr, mask, col_cap, post_topk,
                            keep_idx, out_boxes, out_scores, n_keep_out, zp[dev]);
-        return ore_launch_status("k_nms_scan_col");
+        return ore_launch_status("k_nms_scan_t");
     }
     const size_t dl = (size_t)words * 64 * 8;   // diagonal words (<= 128 KB at 16384 boxes)
     if (dl > 48 * 1024) {
@@ -634,12 +759,23 @@ DetLayout det_layout(int L, int P) {
     o.s_scores = a; a = align256(a + cap * 4);
     o.s_order = a; a = align256(a + cap * 4);
     o.words = (int)((cap + 63) / 64);
-    o.mask = a; a = align256(a + cap * (size_t)o.words * 8);
+    o.mask = a; a = align256(a + (size_t)o.words * 64 * (size_t)o.words * 8);   // rows rounded up to whole 64-row blocks (transposed tiles)
     o.total = a;
     return o;
 }
 
 }  // namespace
+
+#ifdef ORE_TRACE
+extern "C" int ore_debug_set_det_ablate(int flags) {
+    ORE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_det_ablate), &flags, sizeof(flags)));
+    return ORE_OK;
+}
+extern "C" int ore_debug_set_trace_det(unsigned long long* buf) {
+    ORE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_det), &buf, sizeof(buf)));
+    return ORE_OK;
+}
+#endif
 
 extern "C" size_t ore_detect_workspace_bytes(int32_t n_levels, int32_t pre_topk) {
     if (n_levels <= 0 || pre_topk <= 0) return 0;
@@ -690,9 +826,7 @@ static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa
         ORE_HIP(hipFuncSetAttribute((const void*)k_rank_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_bytes));
     hipLaunchKernelGGL(k_rank_scatter, dim3(ceil_div(cap, 16)), dim3(256), sc_bytes, st, p);
     if ((rc = ore_launch_status("k_rank_scatter"))) return rc;
-    hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(256), 0, st, p.s_boxes, p.counts, d->nms_thresh, p.mask,
-                       lay.words, nms_use_col(cap) ? cap : 0);
-    if ((rc = ore_launch_status("k_nms_mask"))) return rc;
+    if ((rc = launch_nms_mask(lay.words, cap, st, p.s_boxes, p.counts, d->nms_thresh, p.mask))) return rc;
     sa = ScanArgs{p.s_boxes, p.s_scores, p.s_order, p.counts, p.mask, p.keep_idx, p.out_boxes, p.out_scores, p.counts + 1};
     return ORE_OK;
 }
@@ -707,7 +841,7 @@ extern "C" int ore_detect_fwd(const ore_detect_desc* d, void* stream) {
     const int rc = detect_prepare(d, st, sa, lay, cap);
     if (rc) return rc;
     return launch_nms_scan(lay.words, st, sa.s_boxes, sa.s_scores, sa.s_order, sa.n_ptr, sa.mask, d->nms_thresh, d->post_topk, sa.keep_idx,
-                           sa.out_boxes, sa.out_scores, sa.n_keep_out, nms_use_col(cap) ? cap : 0);
+                           sa.out_boxes, sa.out_scores, sa.n_keep_out, nms_use_col(cap) ? nms_col_ld(cap) : 0);
 }
 
 extern "C" int ore_detect_batch_fwd(const ore_detect_desc* d, int32_t n_images, void* stream) {
@@ -729,7 +863,7 @@ extern "C" int ore_detect_batch_fwd(const ore_detect_desc* d, int32_t n_images, 
             for (int i = 0; i < nb; ++i) {
                 const ScanArgs& a = sb.a[i];
                 const int rc = launch_nms_scan(lay.words, st, a.s_boxes, a.s_scores, a.s_order, a.n_ptr, a.mask, d->nms_thresh, d->post_topk,
-                                               a.keep_idx, a.out_boxes, a.out_scores, a.n_keep_out, nms_use_col(cap) ? cap : 0);
+                                               a.keep_idx, a.out_boxes, a.out_scores, a.n_keep_out, nms_use_col(cap) ? nms_col_ld(cap) : 0);
                 if (rc) return rc;
             }
             continue;
@@ -784,7 +918,7 @@ NmsLayout nms_layout(int n) {
     o.s_order = a; a = align256(a + cap * 4);
     o.n = a; a = align256(a + 16);
     o.words = (int)((cap + 63) / 64);
-    o.mask = a; a = align256(a + cap * (size_t)o.words * 8);
+    o.mask = a; a = align256(a + (size_t)o.words * 64 * (size_t)o.words * 8);   // rows rounded up to whole 64-row blocks (transposed tiles)
     o.out_b = a; a = align256(a + cap * 16);
     o.out_s = a; a = align256(a + cap * 4);
     o.total = a;
@@ -832,10 +966,8 @@ static int nms_pipeline(const float* boxes, const float* scores, int n, const in
                        s_scores, s_order, n_dev);
     if ((rc = ore_launch_status("k_nms_prep"))) return rc;
     if (thr > 0.0f && n > 0) {
-        hipLaunchKernelGGL(k_nms_mask, dim3(lay.words, lay.words), dim3(256), 0, st, s_boxes, n_dev, thr, mask, lay.words,
-                           nms_use_col(n) ? n : 0);
-        if ((rc = ore_launch_status("k_nms_mask"))) return rc;
+        if ((rc = launch_nms_mask(lay.words, n, st, s_boxes, n_dev, thr, mask))) return rc;
     }
     return launch_nms_scan(lay.words, st, s_boxes, s_scores, s_order, n_dev, mask, thr, 0, (long long*)keep_idx,
-                           (float*)(ws + lay.out_b), (float*)(ws + lay.out_s), count, nms_use_col(n) ? n : 0);
+                           (float*)(ws + lay.out_b), (float*)(ws + lay.out_s), count, nms_use_col(n) ? nms_col_ld(n) : 0);
 }
