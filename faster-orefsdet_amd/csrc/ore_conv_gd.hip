@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
     }
 }
 
-int g_gd_mode = 1;                       // tuning aid (ore_conv_set_plan_override(-14, mode)): 0 off, 1 automatic
+int g_gd_mode = 1;                       // tuning aid (ore_conv_set_plan_override(-14, mode)): 0 off, 1 automatic, 3 automatic with the round-4 limit M <= 32768
 int g_gd_force[3] = {0, 0, 0};           // (-15, BM, BN, NS): force the build
 int g_gd_dbg = 0;                        // trace build: ablation flags, ore_conv_set_plan_override(-16, flags)
 
@@ -358,10 +358,12 @@ static GdPlan gd_plan(const ConvP& p) {
     if (g_gd_force[0] > 0) return {g_gd_force[0], g_gd_force[1], g_gd_force[2]};
     // from tools/kw_phase_trace.py gd (profiles/r04_gd_times.txt; eager launches back to back, one MI355X, bs = 1 shapes; ns >= 10: eight waves):
     //   stage-3 concat 352 -> 256 at M = 6400: 17.9 us (k_conv_gs 21.2); stage-2 concat 320 -> 112 at M = 25600: 27.7 (31.1);
-    //   stem_3 3x3 / 2 64 -> 128 at M = 25600: 44.0 (k_conv_igemm 62.7).  Larger batches (training) stay on k_conv_gs / k_conv_igemm: not measured.
+    //   stem_3 3x3 / 2 64 -> 128 at M = 25600: 44.0 (k_conv_igemm 62.7).
     // Every tiling of a layer lands within ~10 % of the others (r04_gd_ablation.txt: the MFMA phase alone runs at ~75 % of the peak,
     // staging adds to it instead of hiding behind it); the choices below are the fastest measured, not a structural preference.
-    if (p.M < 4096 || p.M > 32768) return {0, 0, 0};
+    // (training batch sizes -- the frozen stem_3 / concats over 16 queries + 384 support crops, M up to 1.6 M rows -- run on the same
+    // tiles since round 5: bs-16 step 46.7 -> 43.8 ms, tools/bench_train.py; mode 3 = the round-4 limit M <= 32768 for A/B)
+    if (p.M < 4096 || (p.M > 32768 && g_gd_mode == 3)) return {0, 0, 0};
     if (p.kh == 1 && p.Cout16 == 256 && p.nchunks >= 16) return {64, 64, 4};
     if (p.kh == 1 && p.Cout16 == 112 && p.nchunks >= 16) return {128, 64, 14};
     if (p.kh == 3 && p.stride == 2 && p.Cout16 == 128 && p.Cin == 64) return {112, 128, 14};

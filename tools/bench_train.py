@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="query images per GPU per step (BASELINE configs[2]: 16)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the shape-static dense part (fwd + bwd) into hipGraphs")
+    ap.add_argument("--no-gd-large", action="store_true", help="A/B aid: k_conv_gd only up to M = 32768 as in round 4 (plan override -14 3)")
     ap.add_argument("--no-kd", action="store_true", help="A/B aid: keep the small-M layers on k_conv_kw (plan override -12 0)")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"), help="bf16 = BASELINE configs[4]: frozen stages in bf16 storage, "
                     "bf16 MFMA operands in the trainable convs' forward / data / weight gradients, everything else fp32")
@@ -58,6 +59,8 @@ def main():
     m.train_graph = bool(a.graph)
     import orehip
     orehip.set_conv_precision(a.precision)
+    if a.no_gd_large:
+        orehip.lib().ore_conv_set_plan_override(-14, 3, 0, 0, 0)
     if a.no_kd:
         orehip.lib().ore_conv_set_plan_override(-12, 0, 0, 0, 0)
         orehip.lib().ore_conv_set_plan_override(-10, 0, 0, 0, 0)
