@@ -32,6 +32,36 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
     }
 }
 
+// All the repacks of an optimizer step in ONE launch (round 5: ~86 launches of 4.4 us per step, a third of a millisecond of a 10 ms
+// single-image step).  Element i belongs to the job whose [first, first + n) holds it (binary search over <= 256 jobs in LDS).
+__global__ __launch_bounds__(256) void k_pack_weight_multi(const ore_pack_job* __restrict__ jobs, int n_jobs, long long total) {
+    __shared__ long long first[257];
+    for (int j = threadIdx.x; j <= n_jobs; j += 256) first[j] = j < n_jobs ? jobs[j].first : total;
+    __syncthreads();
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const ore_pack_job jb = jobs[lo];
+    const long long i = g - jb.first;
+    const int Co = jb.Cout, Ci = jb.Cin, taps = jb.kh * jb.kw;
+    if (jb.dgrad == 0) {                               // [Co16][tap][Ci]
+        const int ci = (int)(i % Ci);
+        const int tap = (int)((i / Ci) % taps);
+        const int co = (int)(i / ((long long)Ci * taps));
+        jb.dst[i] = co < Co ? jb.src[((size_t)co * Ci + ci) * taps + tap] : 0.0f;
+    } else {                                           // [Ci16][flipped tap][Co16]
+        const int Co16 = (Co + 15) / 16 * 16;
+        const int co = (int)(i % Co16);
+        const int tap = (int)((i / Co16) % taps);
+        const int ci = (int)(i / ((long long)Co16 * taps));
+        jb.dst[i] = (co < Co && ci < Ci) ? jb.src[((size_t)co * Ci + ci) * taps + (taps - 1 - tap)] : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 struct WgradP {
     const float* x; int x_ld, x_coff;
@@ -741,25 +771,56 @@ __global__ __launch_bounds__(256) void k_gn_bwd_dx(const float* __restrict__ dy,
     *reinterpret_cast<f32x4*>(dx + row * C + c) = o;
 }
 
-// out[b][row][c] = p[b][row][c] * q[b][row][c]  (product fed to the segmented column sum: d gate = sum_hw dy * x)
-__global__ __launch_bounds__(256) void k_prod(const float* __restrict__ p, const float* __restrict__ q, long long n4, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(p)[i] * reinterpret_cast<const f32x4*>(q)[i];
-}
-
-// per-image column sums: x [B][rows][C] -> out [B][C]; one block = 64 channels x 4 row lanes of one image, fixed order
-__global__ __launch_bounds__(256) void k_colsum_seg(const float* __restrict__ x, int rows, int C, float scale, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
-    const float* xb = x + (size_t)b * rows * C;
-    float s = 0.f;
-    if (c < C)
-        for (int r = rl; r < rows; r += 4) s += xb[(size_t)r * C + c];
-    red[rl][cl] = s;
+// per-image column sums of p (* q): [B][rows][C] -> out [B][C].  One block = 64 channels (16 quads) x 16 row lanes of one row slab of one
+// image: 16-byte loads, four rows in flight per thread, the sixteen row lanes and then the S slabs added in a fixed order (round 5: the
+// scalar four-lane form of rounds 2-4 streamed a 25600 x 112 map through TWO blocks -- 33 us per call at one image per step, and the
+// product went through a separate launch and a workspace round trip).  S > 1: slab sums to part [S][B][C], k_colsum_seg_fin adds them.
+template <bool HASQ>
+__global__ __launch_bounds__(256) void k_colsum_seg(const float* __restrict__ p, const float* __restrict__ q, int rows, int C, float scale,
+                                                    float* __restrict__ out, int per, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float red[16][64];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4, b = blockIdx.y, S = gridDim.z, B = gridDim.y;
+    const int r0 = blockIdx.z * per, r1 = min(rows, r0 + per);
+    const float* pb = p + (size_t)b * rows * C + c;
+    const float* qb = HASQ ? q + (size_t)b * rows * C + c : nullptr;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (c < C) {
+        int r = r0 + rl;
+        for (; r + 48 < r1; r += 64) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(pb + (size_t)r * C), v1 = *reinterpret_cast<const f32x4*>(pb + (size_t)(r + 16) * C);
+            f32x4 v2 = *reinterpret_cast<const f32x4*>(pb + (size_t)(r + 32) * C), v3 = *reinterpret_cast<const f32x4*>(pb + (size_t)(r + 48) * C);
+            if (HASQ) {
+                v0 *= *reinterpret_cast<const f32x4*>(qb + (size_t)r * C); v1 *= *reinterpret_cast<const f32x4*>(qb + (size_t)(r + 16) * C);
+                v2 *= *reinterpret_cast<const f32x4*>(qb + (size_t)(r + 32) * C); v3 *= *reinterpret_cast<const f32x4*>(qb + (size_t)(r + 48) * C);
+            }
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; r < r1; r += 16) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(pb + (size_t)r * C);
+            if (HASQ) v0 *= *reinterpret_cast<const f32x4*>(qb + (size_t)r * C);
+            a0 += v0;
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[rl][cq * 4]) = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (rl == 0 && c < C) out[(size_t)b * C + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * scale;
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += red[k][threadIdx.x];
+        if (cc < C) {
+            if (S == 1) out[(size_t)b * C + cc] = sum * scale;
+            else part[((size_t)blockIdx.z * B + b) * C + cc] = sum;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_colsum_seg_fin(const float* __restrict__ part, int S, int n, float scale, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float sum = 0.f;
+    for (int z = 0; z < S; ++z) sum += part[(size_t)z * n + i];
+    out[i] = sum * scale;
 }
 
 // out[b][row][c] = x[b][row][c] * s[b][c] + v[b][c]   (v may be NULL)
@@ -841,6 +902,13 @@ extern "C" int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32
     hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, kh, kw,
                        dgrad ? 1 : 0, dst, total);
     return ore_launch_status("k_pack_weight");
+}
+
+extern "C" int ore_pack_conv_weights_multi_fwd(const ore_pack_job* jobs_dev, int32_t n_jobs, int64_t total, void* stream) {
+    ORE_CHECK_ARG(jobs_dev && n_jobs >= 1 && n_jobs <= 256 && total >= 1 && total < (1ll << 38), "ore_pack_conv_weights_multi_fwd: 1..256 jobs");
+    hipLaunchKernelGGL(k_pack_weight_multi, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs,
+                       (long long)total);
+    return ore_launch_status("k_pack_weight_multi");
 }
 
 // blocks of one split: k_wgrad3 (3x3) owns the three dx taps of a kernel row per block
@@ -1275,17 +1343,26 @@ extern "C" int ore_combine2_bwd(const float* dy, const float* a0_bc, const float
 extern "C" int ore_prod_colsum_fwd(const float* p, const float* q, int32_t B, int32_t rows, int32_t C, float scale, float* out_bc,
                                    float* workspace, size_t workspace_floats, void* stream) {
     ORE_CHECK_ARG(p && out_bc && workspace && B > 0 && rows > 0 && C > 0 && C % 4 == 0, "ore_prod_colsum_fwd: bad args");
-    const float* src = p;
     hipStream_t st = (hipStream_t)stream;
-    if (q) {
-        const size_t n = (size_t)B * rows * C;
-        if (workspace_floats < n) { ore_set_error("ore_prod_colsum_fwd: workspace too small"); return ORE_ENOMEM; }
-        hipLaunchKernelGGL(k_prod, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, p, q, (long long)(n / 4), workspace);
-        int rc = ore_launch_status("k_prod");
-        if (rc) return rc;
-        src = workspace;
+    // row slabs: enough blocks to fill the chip when one image has many rows (a 160 x 160 map of a single query image), whole
+    // multiples of 64 rows, as many as the workspace holds partial sums for
+    const int cb = ceil_div(C, 64);
+    int S = 1;
+    if (rows >= 2048) {
+        S = min(ceil_div(1024, cb * B), rows / 512);
+        const size_t cap = workspace_floats / ((size_t)B * C);
+        if ((size_t)S > cap) S = (int)cap;
+        if (S < 1) S = 1;
     }
-    hipLaunchKernelGGL(k_colsum_seg, dim3(ceil_div(C, 64), B), dim3(256), 0, st, src, rows, C, scale, out_bc);
+    const int per = round_up(ceil_div(rows, S), 64);
+    S = ceil_div(rows, per);
+    if (q) hipLaunchKernelGGL(k_colsum_seg<true>, dim3(cb, B, S), dim3(256), 0, st, p, q, rows, C, scale, out_bc, per, workspace);
+    else hipLaunchKernelGGL(k_colsum_seg<false>, dim3(cb, B, S), dim3(256), 0, st, p, q, rows, C, scale, out_bc, per, workspace);
+    if (S > 1) {
+        int rc = ore_launch_status("k_colsum_seg");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_colsum_seg_fin, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, workspace, S, B * C, scale, out_bc);
+    }
     return ore_launch_status("k_colsum_seg");
 }
 

@@ -127,6 +127,7 @@ class _DensePart(torch.nn.Module):
     def forward(self, xq, xs):
         from orehip import autograd as A
         A.weights_changed()
+        A.prepack(list(self.model.parameters()))               # one captured launch repacks every weight the cache knows from the eager steps
         return dense_part(self.model, xq, xs)
 
 
@@ -423,6 +424,11 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
     for s_ in sups:
         assert s_.shape[0] == N, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
     graph = getattr(model, "train_graph", False)
+    if not graph:
+        # every packed weight the optimizer step has made stale -- both layouts of every trainable conv / linear -- in ONE launch
+        # (orehip.autograd.prepack) instead of ~86 small ones scattered over the step; a captured dense part does the same inside its graph
+        from orehip import autograd as _A
+        _A.prepack(list(model.parameters()))
     same = all(i.shape == imgs[0].shape and i.dtype == imgs[0].dtype for i in imgs) and all(s_.shape == sups[0].shape for s_ in sups)
     if same and not graph and fused_preprocess:
         # one size per batch (the usual case): hand the RAW images to stem_1, which normalises and pads on the fly

@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_pack_conv_weights_multi_fwd", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -757,6 +757,43 @@ def pack_conv_weight_dev(w_oihw: torch.Tensor, dgrad: bool = False, out: Optiona
     _chk(lib().ore_pack_conv_weight_fwd(C.c_void_p(_ptr(w)), co, ci, kh, kw, int(dgrad), C.c_void_p(_ptr(out)), _stream()),
          "ore_pack_conv_weight_fwd")
     return out
+
+
+class PackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("dgrad", C.c_int32), ("reserved", C.c_int32), ("first", C.c_int64)]
+
+
+_PACK_TABLES: Dict[tuple, torch.Tensor] = {}
+
+
+def pack_conv_weights_multi(jobs) -> None:
+    """jobs: [(w_oihw contiguous fp32 device tensor, dgrad, out)] -> every `out` holds pack_conv_weight_dev(w, dgrad): ONE launch
+    (ore_pack_conv_weights_multi_fwd).  The device-side job table is cached by its contents (pointers and shapes): a training loop hands
+    the same list every step, and a captured step replays the launch on the same table."""
+    if not jobs:
+        return
+    assert len(jobs) <= 256
+    dev = jobs[0][0].device
+    rows, first = [], 0
+    for w, dgrad, out in jobs:
+        co, ci, kh, kw = w.shape
+        co16, ci16 = (co + 15) // 16 * 16, (ci + 15) // 16 * 16
+        n = ci16 * kh * kw * co16 if dgrad else co16 * kh * kw * ci
+        assert w.is_contiguous() and w.dtype == torch.float32 and out.numel() == n and (dgrad or ci % 16 == 0)
+        rows.append((_ptr(w), _ptr(out), co, ci, kh, kw, int(bool(dgrad)), first))
+        first += n
+    key = (str(dev), tuple(rows))
+    tab = _PACK_TABLES.get(key)
+    if tab is None:
+        arr = (PackJob * len(rows))()
+        for i, (src, dst, co, ci, kh, kw, dg, f) in enumerate(rows):
+            arr[i] = PackJob(src, dst, co, ci, kh, kw, dg, 0, f)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        if len(_PACK_TABLES) > 64:
+            _PACK_TABLES.clear()
+        tab = _PACK_TABLES[key] = host.to(dev)
+    _chk(lib().ore_pack_conv_weights_multi_fwd(C.c_void_p(_ptr(tab)), len(rows), C.c_int64(first), _stream()), "ore_pack_conv_weights_multi_fwd")
 
 
 _WGWS: Dict[str, torch.Tensor] = {}

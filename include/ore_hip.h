@@ -336,6 +336,15 @@ int ore_sgd_step_fwd(float* params, const float* grads, float* momentum_buf, int
  *   epilogue        = ore_relu_affine_bwd: dZ = dY * (Y > 0) * scale[c]  (scale NULL = 1; in place allowed) */
 int ore_pack_conv_weight_fwd(const float* w_oihw, int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t dgrad,
                              float* dst, void* stream);
+/* The same for up to 256 weights in one launch: jobs_dev is a DEVICE array of n_jobs descriptors, `first` the running sum of the packed
+ * sizes in front of the job (Cout16 * kh * kw * Cin forward, Cin16 * kh * kw * Cout16 data gradient), `total` the sum over all jobs.
+ * The array may be kept and the launch repeated (a captured training step replays it): sources and destinations are read at run time. */
+typedef struct ore_pack_job {
+    const float* src; float* dst;
+    int32_t Cout, Cin, kh, kw, dgrad, reserved;
+    int64_t first;
+} ore_pack_job;
+int ore_pack_conv_weights_multi_fwd(const ore_pack_job* jobs_dev, int32_t n_jobs, int64_t total, void* stream);
 size_t ore_conv_wgrad_workspace_floats(int32_t rows, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw);
 /* dw_oihw[co][ci][ky][kx] = beta * dw_oihw + sum_{b,y,x} dz[b,y,x,co] * x[b,y+ky-pad,x+kx-pad,ci]   (stride 1, k = 2*pad+1).
  * Cin, Cout, ld, coff multiples of 4. */
