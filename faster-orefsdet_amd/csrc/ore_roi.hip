@@ -101,27 +101,6 @@ __global__ __launch_bounds__(256) void k_roi_align(RoiP p) {
 }
 
 // backward of k_roi_align: every sample scatters dOut/count with its 4 bilinear weights (fp32 hardware atomics; dfeat zeroed by the caller)
-__device__ __forceinline__ void bilinear4_scatter(float* f, int ld, int H, int W, float y, float x, int c, f32x4 g) {
-    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return;
-    if (y <= 0.f) y = 0.f;
-    if (x <= 0.f) x = 0.f;
-    int y_low = (int)y, x_low = (int)x, y_high, x_high;
-    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
-    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
-    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
-    float* p1 = f + (size_t)(y_low * W + x_low) * ld + c;
-    float* p2 = f + (size_t)(y_low * W + x_high) * ld + c;
-    float* p3 = f + (size_t)(y_high * W + x_low) * ld + c;
-    float* p4 = f + (size_t)(y_high * W + x_high) * ld + c;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        atomicAdd(p1 + k, hy * hx * g[k]);
-        atomicAdd(p2 + k, hy * lx * g[k]);
-        atomicAdd(p3 + k, ly * hx * g[k]);
-        atomicAdd(p4 + k, ly * lx * g[k]);
-    }
-}
-
 struct RoiBwdP {
     float* dfeat[4]; int ld[4], coff[4], H[4], W[4]; float scale[4];
     int n_levels, min_level, C, pooled;
@@ -129,7 +108,13 @@ struct RoiBwdP {
     const float* boxes; int n;
     const float* dout;
     const int* bidx;
+    long long* acc[4];       // deterministic form: per-level fixed-point accumulators [images][H][W][C] (2^-40 units), else null
 };
+// Fixed-point accumulation (round 5): a contribution v becomes the integer rint(v * 2^40) -- exact for |v| >= 2^-16, 4.5e-13 absolute
+// below -- and is added with a 64-bit INTEGER atomic: integer addition is associative, so the sum does not depend on the order in which
+// overlapping ROIs arrive and a training step becomes bit-reproducible (the fp32 atomics of rounds 1-4 were the one order-dependent sum
+// of the step).  |sum| < 2^23 = 8.4e6 per cell, beyond which the conversion saturates.
+constexpr float ROI_FX = 1099511627776.0f;       // 2^40
 
 constexpr int ROI_BWD_SPLIT = 4;        // blocks per ROI (the 128 sampled ROIs alone leave half of the CUs idle); x2 for small ROI lists
 constexpr int ROI_AX = 8;               // cells one bin's samples can touch along one axis on the separable path (grid <= 7 samples)
@@ -168,7 +153,11 @@ __device__ __forceinline__ int roi_axis_weights(float start, float bin, int g, i
 
 // The bins of one ROI, one (bin, 4 channels) item per thread and pass: (ny)(nx) atomics per item through the separable axis footprints,
 // one scatter per sample where a bin's footprint does not fit ROI_AX cells.  The general path (k_roi_align_bwd_col falls back to it).
-struct RoiGeo { float x0, y0, bw, bh; int gh, gw, H, W, ld; float cnt; float* f; };
+struct RoiGeo { float x0, y0, bw, bh; int gh, gw, H, W, ld; float cnt; float* f; long long* f64; };
+template <bool DET> __device__ __forceinline__ void roi_acc(const RoiGeo& q, size_t cell, int c, float v) {
+    if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(q.f64 + cell * (size_t)q.ld + c), (unsigned long long)__float2ll_rn(v * ROI_FX));
+    else atomicAdd(q.f + cell * (size_t)q.ld + c, v);
+}
 __device__ __forceinline__ RoiGeo roi_geo(const RoiBwdP& p, int r) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
     const float size = sqrtf((b.z - b.x) * (b.w - b.y));
@@ -179,6 +168,8 @@ __device__ __forceinline__ RoiGeo roi_geo(const RoiBwdP& p, int r) {
     RoiGeo g;
     g.H = p.H[l]; g.W = p.W[l]; g.ld = p.ld[l];
     g.f = p.dfeat[l] + p.coff[l] + (p.bidx ? (size_t)p.bidx[r] * g.H * g.W * g.ld : 0);
+    g.f64 = nullptr;
+    if (p.acc[l]) { g.ld = p.C; g.f64 = p.acc[l] + (p.bidx ? (size_t)p.bidx[r] * g.H * g.W * p.C : 0); }   // compact [cell][C] accumulators
     g.x0 = b.x * sc - 0.5f; g.y0 = b.y * sc - 0.5f;
     const float x1 = b.z * sc - 0.5f, y1 = b.w * sc - 0.5f;
     const float rw = x1 - g.x0, rh = y1 - g.y0;
@@ -187,6 +178,27 @@ __device__ __forceinline__ RoiGeo roi_geo(const RoiBwdP& p, int r) {
     g.cnt = (float)max(g.gh * g.gw, 1);
     return g;
 }
+template <bool DET>
+__device__ __forceinline__ void bilinear4_scatter(const RoiGeo& q, float y, float x, int c, f32x4 g) {
+    const int H = q.H, W = q.W;
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+    const size_t c1 = (size_t)(y_low * W + x_low), c2 = (size_t)(y_low * W + x_high), c3 = (size_t)(y_high * W + x_low), c4 = (size_t)(y_high * W + x_high);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        roi_acc<DET>(q, c1, c + k, hy * hx * g[k]);
+        roi_acc<DET>(q, c2, c + k, hy * lx * g[k]);
+        roi_acc<DET>(q, c3, c + k, ly * hx * g[k]);
+        roi_acc<DET>(q, c4, c + k, ly * lx * g[k]);
+    }
+}
+
+template <bool DET>
 __device__ __forceinline__ void roi_bwd_bins(const RoiBwdP& p, const RoiGeo& q, const float* __restrict__ src, int part, int split) {
     const int P = p.pooled, C4 = p.C >> 2;
     for (int i = part * 256 + threadIdx.x; i < P * P * C4; i += 256 * split) {
@@ -207,9 +219,8 @@ __device__ __forceinline__ void roi_bwd_bins(const RoiBwdP& p, const RoiGeo& q, 
                     if (kx >= nx) break;
                     const float wgt = wy[ky] * wx[kx];
                     if (wgt == 0.f) continue;
-                    float* dst = q.f + (size_t)((by + ky) * q.W + bx + kx) * q.ld + c;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) atomicAdd(dst + k, wgt * g[k]);
+                    for (int k = 0; k < 4; ++k) roi_acc<DET>(q, (size_t)((by + ky) * q.W + bx + kx), c + k, wgt * g[k]);
                 }
             }
             continue;
@@ -218,16 +229,17 @@ __device__ __forceinline__ void roi_bwd_bins(const RoiBwdP& p, const RoiGeo& q, 
             const float y = q.y0 + (float)ph * q.bh + ((float)iy + 0.5f) * q.bh / (float)q.gh;
             for (int ix = 0; ix < q.gw; ++ix) {
                 const float x = q.x0 + (float)pw * q.bw + ((float)ix + 0.5f) * q.bw / (float)q.gw;
-                bilinear4_scatter(q.f, q.ld, q.H, q.W, y, x, c, g);
+                bilinear4_scatter<DET>(q, y, x, c, g);
             }
         }
     }
 }
 
+template <bool DET>
 __global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p, int split) {
     const int r = blockIdx.x / split, part = blockIdx.x % split;
     const RoiGeo q = roi_geo(p, r);
-    roi_bwd_bins(p, q, p.dout + (size_t)r * p.pooled * p.pooled * p.C, part, split);
+    roi_bwd_bins<DET>(p, q, p.dout + (size_t)r * p.pooled * p.pooled * p.C, part, split);
 }
 
 // Column form (round 3): the transposed bilinear pooling of a ROI is separable, dF[cy][cx] = sum_by Wy[by][cy] sum_bx Wx[bx][cx] dOut[by][bx]
@@ -237,6 +249,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(RoiBwdP p, int split) {
 // atomics were the whole cost: 1.09 ms per launch at 2048 ROIs x 128 channels).  A bin whose footprint exceeds ROI_AX cells sends the
 // whole ROI to the general path.
 constexpr int ROI_PMAX = 16;
+template <bool DET>
 __global__ __launch_bounds__(256) void k_roi_align_bwd_col(RoiBwdP p, int split) {
     __shared__ float Wy[ROI_PMAX][ROI_AX], Wx[ROI_PMAX][ROI_AX];
     __shared__ int By[ROI_PMAX], Ny[ROI_PMAX], Bx[ROI_PMAX], Nx[ROI_PMAX];
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_col(RoiBwdP p, int split)
         ext[0] = ymin; ext[1] = ymax; ext[2] = xmin; ext[3] = xmax; ext[4] = gen;
     }
     __syncthreads();
-    if (ext[4]) { roi_bwd_bins(p, q, src, part, split); return; }
+    if (ext[4]) { roi_bwd_bins<DET>(p, q, src, part, split); return; }
     const int ymin = ext[0], ymax = ext[1], xmin = ext[2], xmax = ext[3];
     if (ymax < ymin || xmax < xmin) return;                       // no valid sample on an axis: zero gradient
     const int FX = xmax - xmin + 1;
@@ -300,11 +313,23 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_col(RoiBwdP p, int split)
                 }
             }
             if (!any) continue;
-            float* dst = q.f + (size_t)(cy * q.W + cx) * q.ld + c;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(dst + k, acc[k]);
+            for (int k = 0; k < 4; ++k) roi_acc<DET>(q, (size_t)(cy * q.W + cx), c + k, acc[k]);
         }
     }
+}
+
+// dfeat[cell][coff + c] += the fixed-point sum of the cell (exact integer -> double -> float: one rounding)
+__global__ __launch_bounds__(256) void k_roi_bwd_finalize(const long long* __restrict__ acc, long long cells, int C, float* __restrict__ dfeat, int ld, int coff) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells * (C / 4)) return;
+    const long long cell = i / (C / 4);
+    const int c = (int)(i % (C / 4)) * 4;
+    float* d = dfeat + cell * ld + coff + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += (float)((double)acc[cell * C + c + k] * (1.0 / 1099511627776.0));
+    *reinterpret_cast<f32x4*>(d) = v;
 }
 
 struct PredP {
@@ -903,27 +928,56 @@ int oreroi::roi_predict_post(const float* h, int32_t C, int32_t h_parts, const f
     return ore_launch_status("k_roi_finalize");
 }
 
-extern "C" int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
-                                 const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
-                                 const float* boxes, const int32_t* box_image, int32_t n, const float* dout, void* stream) {
+static int roi_align_bwd_impl(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                              const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                              const float* boxes, const int32_t* box_image, int32_t n, const float* dout, long long* const* acc,
+                              int32_t n_images, void* stream) {
     ORE_CHECK_ARG(dfeat && ld && coff && H && W && scales_host && boxes && dout, "ore_roi_align_bwd: null pointer");
     ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && C % 4 == 0 && pooled >= 1 && pooled <= 16 && n >= 1, "ore_roi_align_bwd: bad args");
     RoiBwdP p{};
     for (int l = 0; l < n_levels; ++l) {
         ORE_CHECK_ARG(dfeat[l] && ld[l] % 4 == 0 && coff[l] % 4 == 0 && H[l] > 0 && W[l] > 0, "ore_roi_align_bwd: level %d", l);
+        ORE_CHECK_ARG(!acc || acc[l], "ore_roi_align_bwd_det: accumulator of level %d missing", l);
         p.dfeat[l] = dfeat[l]; p.ld[l] = ld[l]; p.coff[l] = coff[l]; p.H[l] = H[l]; p.W[l] = W[l]; p.scale[l] = scales_host[l];
+        p.acc[l] = acc ? acc[l] : nullptr;
     }
     p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
     p.canonical_size = 224.0f; p.canonical_level = 4;
     p.boxes = boxes; p.n = n; p.dout = dout; p.bidx = box_image;
+    hipStream_t st = (hipStream_t)stream;
     static int col = -1;                                          // ORE_ROI_BWD_BINS=1: the per-bin kernel (A/B and tests)
     if (col < 0) { const char* e = getenv("ORE_ROI_BWD_BINS"); col = (e && e[0] == '1') ? 0 : 1; }
+    int rc;
     if (col && pooled <= ROI_PMAX) {
         const int split = n < 64 ? 4 : 2;
-        hipLaunchKernelGGL(k_roi_align_bwd_col, dim3(n * split), dim3(256), 0, (hipStream_t)stream, p, split);
-        return ore_launch_status("k_roi_align_bwd_col");
+        if (acc) hipLaunchKernelGGL(k_roi_align_bwd_col<true>, dim3(n * split), dim3(256), 0, st, p, split);
+        else hipLaunchKernelGGL(k_roi_align_bwd_col<false>, dim3(n * split), dim3(256), 0, st, p, split);
+        rc = ore_launch_status("k_roi_align_bwd_col");
+    } else {
+        const int split = n < 64 ? 2 * ROI_BWD_SPLIT : ROI_BWD_SPLIT;
+        if (acc) hipLaunchKernelGGL(k_roi_align_bwd<true>, dim3(n * split), dim3(256), 0, st, p, split);
+        else hipLaunchKernelGGL(k_roi_align_bwd<false>, dim3(n * split), dim3(256), 0, st, p, split);
+        rc = ore_launch_status("k_roi_align_bwd");
     }
-    const int split = n < 64 ? 2 * ROI_BWD_SPLIT : ROI_BWD_SPLIT;
-    hipLaunchKernelGGL(k_roi_align_bwd, dim3(n * split), dim3(256), 0, (hipStream_t)stream, p, split);
-    return ore_launch_status("k_roi_align_bwd");
+    if (rc || !acc) return rc;
+    for (int l = 0; l < n_levels; ++l) {
+        const long long cells = (long long)n_images * H[l] * W[l];
+        hipLaunchKernelGGL(k_roi_bwd_finalize, dim3((unsigned)((cells * (C / 4) + 255) / 256)), dim3(256), 0, st, acc[l], cells, C, dfeat[l], ld[l], coff[l]);
+    }
+    return ore_launch_status("k_roi_bwd_finalize");
+}
+
+extern "C" int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                                 const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                                 const float* boxes, const int32_t* box_image, int32_t n, const float* dout, void* stream) {
+    return roi_align_bwd_impl(dfeat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, box_image, n, dout, nullptr, 0, stream);
+}
+
+extern "C" int ore_roi_align_bwd_det(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                                     const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                                     const float* boxes, const int32_t* box_image, int32_t n, const float* dout, int64_t* const* acc,
+                                     int32_t n_images, void* stream) {
+    ORE_CHECK_ARG(acc && n_images >= 1, "ore_roi_align_bwd_det: accumulators / image count");
+    return roi_align_bwd_impl(dfeat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, box_image, n, dout,
+                              reinterpret_cast<long long* const*>(acc), n_images, stream);
 }

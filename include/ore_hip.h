@@ -265,6 +265,14 @@ int ore_roi_align_batched_fwd(const float* const* feat, const int32_t* ld, const
 int ore_roi_align_bwd(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
                       const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
                       const float* boxes, const int32_t* box_image, int32_t n, const float* dout, void* stream);
+/* The same with an ORDER-INDEPENDENT sum (round 5): contributions are accumulated as 64-bit fixed-point integers (2^-40 units, integer
+ * atomics) in acc[l] -- [n_images][H[l]][W[l]][C] int64, ZEROED by the caller -- and a second launch adds their value to dfeat[l]
+ * (one rounding per cell).  Overlapping ROIs then give the same bits whatever order their blocks run in: the training step is
+ * reproducible run to run.  |gradient sum| per cell below 2^23. */
+int ore_roi_align_bwd_det(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                          const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                          const float* boxes, const int32_t* box_image, int32_t n, const float* dout, int64_t* const* acc,
+                          int32_t n_images, void* stream);
 size_t ore_roi_predict_workspace_bytes(int32_t cap);
 int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
                         const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,

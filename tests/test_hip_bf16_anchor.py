@@ -272,7 +272,7 @@ def test_bf16_vs_fp32_training_trajectory_200_steps(ore):
     """Does the bf16 mode TRAIN like fp32?  (ref:fsod_train_net.py:103-105 -> d2z:engine/train_loop.py:133-159 is a 12 000-iteration loop;
     one iteration says nothing about drift.)  200 steps from the same seed in fp32 and in the bf16 mode, plus a second fp32 run that only
     differs in the ROI sampler's seed: the noise floor two correct fp32 runs already have (the sampled ROIs decide the second-stage
-    losses, and the fp32 step itself is not bit-reproducible run to run).  Window = mean total loss over 20 consecutive steps (5 passes
+    losses).  Window = mean total loss over 20 consecutive steps (5 passes
     over the 4 samples).
     Measured on MI355X, two runs: total loss 3.4 -> 1.3-1.6 in every run; the curve has one steep descent (windows 6-8, when the warm-up
     learning rate lets the second stage fit) whose timing moves by a window between runs, so window-for-window the bf16 curve is within

@@ -816,12 +816,14 @@ def test_rccl_one_rank_rehearsal(oh, transport, graph):
     assert p.exitcode == 0
     assert r["backend"] == "nccl" and r["ar"] == [1.0] * 4
     assert r["graph_error"] is None, r["graph_error"]
-    # A one-rank SUM is the identity: after ONE step the gradients the optimizer consumed and the parameters it wrote equal the plain
-    # step's up to the step's own run-to-run noise (the ROIAlign backward accumulates with fp32 atomics, so two plain runs differ in
-    # the last bits too; one step, because later steps amplify such bits through hard decisions -- ReLU masks, the ROI sample).
+    # A one-rank SUM is the identity: after ONE step the gradients the optimizer consumed and the parameters it wrote EQUAL the plain
+    # step's bit for bit -- since round 5 the step is bit-reproducible (the ROIAlign backward accumulates in 64-bit fixed point with
+    # integer atomics, ore_roi_align_bwd_det; rounds 1-4 used fp32 atomics and this test had to compare against run-to-run noise):
+    # two plain runs agree exactly, and so do the plain and the wrapped run.
+    print("rehearsal:", {k: r[k] for k in ("g_scale", "g_noise", "g_diff", "moved1", "p1_noise", "p1_diff")})
     assert r["finite"] and r["moved1"] > 1e-5 and r["moved3"] > r["moved1"] * 0.5, r
-    assert r["g_diff"] <= 8.0 * r["g_noise"] + 1e-5 * r["g_scale"], (r["g_diff"], r["g_noise"], r["g_scale"])
-    assert r["p1_diff"] <= 8.0 * r["p1_noise"] + 1e-3 * r["moved1"], (r["p1_diff"], r["p1_noise"], r["moved1"])
+    assert r["g_noise"] == 0.0 and r["p1_noise"] == 0.0, (r["g_noise"], r["p1_noise"])
+    assert r["g_diff"] == 0.0 and r["p1_diff"] == 0.0, (r["g_diff"], r["p1_diff"])
     assert len(r["logs"]) == 3 and r["n_slices"] >= 2
     for log in r["logs"]:                                          # every slice exactly once per step ...
         assert sorted(s_ for s_, _ in log) == list(range(r["n_slices"])), log
