@@ -101,6 +101,8 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     const int HW = p.H[l] * p.W[l];
     const float* hd = p.head[l];
     const int tid = threadIdx.x;
+    const bool tr = l == 0 && tid == 0;
+    if (tr) DET_TR(0);
 
     // ---- sigmoid once + candidate count
     int cnt = 0;
@@ -109,8 +111,10 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
         sv[i] = s;
         cnt += s > p.score_thresh ? 1 : 0;
     }
+    if (tr) DET_TR(1);
     int nc;
     block_excl_scan(cnt, wsum, &nc);   // (its barriers also publish sv[])
+    if (tr) DET_TR(2);
     const int k = nc < p.pre_topk ? nc : p.pre_topk;
 
     // ---- exact k-th largest sigmoid (bits are order-preserving for positive floats): a sigmoid is in (0, 1], so its key is below 2^30:
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
             prefix |= (unsigned)sh_i[0] << shift;
             pmask |= 1023u << shift;
             remaining = sh_i[1];                   // (sh_i is rewritten only behind the next pass's two barriers: no barrier needed here)
+            if (tr) DET_TR(3 + pass);
         }
         T = prefix; quota = remaining;  // `remaining` of the elements equal to T are taken
     }
@@ -182,8 +187,10 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
         my_gt += (cand && (take_all || key > T)) ? 1 : 0;
         my_tie += (cand && !take_all && key == T) ? 1 : 0;
     }
+    if (tr) DET_TR(6);
     int tot;
     const int pre = block_excl_scan((my_gt << 16) | my_tie, wsum, &tot);
+    if (tr) DET_TR(7);
     int tie_before = pre & 0xffff, gt_before = pre >> 16;
     for (int i = i_lo; i < i_hi; ++i) {
         const float s = sv[i];
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     }
     const int out_base = (tot >> 16) + min(tot & 0xffff, quota);
     if (tid == 0) p.lvl_cnt[l] = out_base;
+    if (tr) DET_TR(8);
 }
 
 // ------------------------------------------------------------------------------------------------
