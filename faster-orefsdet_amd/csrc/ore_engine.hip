@@ -543,6 +543,7 @@ extern "C" int ore_engine_set_roi_head(ore_engine* e, const float* W_host, const
         const size_t MB = (size_t)e->cfg.max_batch;
         // K split of the second-stage GEMM: 32 slices when the shape allows it (k_conv_gd's 80 x 64 tiles, whole 16-channel chunks per slice)
         e->roi_ksplit = (fc_dim % 64 == 0 && K % (16 * 32) == 0 && K >= 2048 && cap <= 512) ? 32 : 1;
+        if (const char* ks = getenv("ORE_ROI_KSPLIT")) { const int v = atoi(ks); if (e->roi_ksplit > 1 && v >= 2 && (K / 16) % v == 0) e->roi_ksplit = v; }   // A/B aid
         if (e->roi_ksplit > 1 && (rc = e->dalloc(&e->roi_hp, (size_t)e->roi_ksplit * cap * fc_dim))) return rc;
         if ((rc = e->dalloc(&e->roi_feat, cap * K)) || (rc = e->dalloc(&e->roi_h, cap * fc_dim)) || (rc = e->dalloc(&e->det_boxes, MB * cap * 4)) ||
             (rc = e->dalloc(&e->det_scores, MB * cap)) || (rc = e->dalloc(&e->det_src, MB * cap)) || (rc = e->dalloc(&e->det_count, MB * 4))) return rc;
