@@ -86,7 +86,7 @@ __device__ __forceinline__ void gd_tile(const GdK& k, int& bx, int& by) {
     else { by = fdiv(t, k.gx, k.inv_gx); bx = t - by * k.gx; }
 }
 
-template <int GA, int GB, int WGM, int WGN, int NS, int KS>
+template <int GA, int GB, int WGM, int WGN, int NS, int KS, bool BF = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
     constexpr int NW = WGM * WGN;                     // 4 waves, or 8 (two per SIMD: the builds whose blocks own a CU alone)
     static_assert((NW == 4 || NW == 8) && GA % WGM == 0 && GB % WGN == 0, "the waves tile the block");
@@ -214,6 +214,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
             // the pieces queued in front of it (every wave of the CU queues its own right after the same barrier), and issued in
             // one go ahead of the MFMAs that wait left the matrix pipe idle for as long as the staging takes.
             constexpr int MF = 4 * TA * TB, SEG = (MF + PPW) / (PPW + 1);  // MFMAs per segment; piece s follows segment s
+            if constexpr (BF) {
+                // bf16-OPERAND mode (ore_conv_set_precision(ORE_CONV_BF16), BASELINE configs[4]'s training form): fp32 tensors in HBM and LDS, both
+                // fragments rounded to bf16 (nearest even) as they leave LDS, ONE v_mfma_f32_16x16x16_bf16 per tile where the fp32 build
+                // issues four 16x16x4 (the fragment layout -- four consecutive k per lane -- is the same), fp32 accumulation
+                constexpr int MFB = TA * TB, SEGB = (MFB + PPW) / (PPW + 1);
+                if (t > 0 && !(dbg & 1)) {
+                    s16x4 ah[TA], bh[TB];
+#pragma unroll
+                    for (int i = 0; i < TA; ++i) ah[i] = to_bf16x4(af[(u & 1) ^ 1][i]);
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) bh[j] = to_bf16x4(bf[(u & 1) ^ 1][j]);
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int j = 0; j < TB; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                            const int idx = i * TB + j;
+                            if (idx % SEGB == SEGB - 1 && idx / SEGB < PPW && !(dbg & 2)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(t + NS - 1, (u + NS - 1) % NS, idx / SEGB);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+#pragma unroll
+                    for (int s2 = (MFB / SEGB < PPW ? MFB / SEGB : PPW); s2 < PPW; ++s2)
+                        if (!(dbg & 2)) issue_piece(t + NS - 1, (u + NS - 1) % NS, s2);
+                } else if (!(dbg & 2)) {
+                    issue(t + NS - 1, (u + NS - 1) % NS);
+                }
+            } else
             if (t > 0 && !(dbg & 1)) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
@@ -308,9 +338,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_gd(GdP q) {
     }
 }
 
-int g_gd_mode = 1;                       // tuning aid (ore_conv_set_plan_override(-14, mode)): 0 off, 1 automatic, 3 automatic with the round-4 limit M <= 32768
+int g_gd_mode = 1;                       // tuning aid (ore_conv_set_plan_override(-14, mode)): 0 off, 1 automatic, 2 automatic + every 1x1 layer at training sizes, 3 automatic with the round-4 limit M <= 32768
 int g_gd_force[3] = {0, 0, 0};           // (-15, BM, BN, NS): force the build
 int g_gd_dbg = 0;                        // trace build: ablation flags, ore_conv_set_plan_override(-16, flags)
+
+template <int GA, int GB, int WGM, int WGN, int NS>
+int launch_gd_bf(const GdP& q, bool k3, dim3 grid, hipStream_t st) {
+    const dim3 block(64 * WGM * WGN);
+    constexpr size_t lds = (size_t)NS * (GA + GB) * 256 * sizeof(float);
+    static_assert(lds <= 64 * 1024, "the bf16-operand builds keep the default LDS limit");
+    if (!k3) hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 1, true>), grid, block, lds, st, q);
+    else hipLaunchKernelGGL((k_conv_gd<GA, GB, WGM, WGN, NS, 3, true>), grid, block, lds, st, q);
+    return ore_launch_status("k_conv_gd<bf16 operands>");
+}
 
 template <int GA, int GB, int WGM, int WGN, int NS>
 int launch_gd(const GdP& q, bool k3, dim3 grid, hipStream_t st) {
@@ -344,7 +384,7 @@ int conv_gd_forced_bm() { return g_gd_force[0]; }
 static bool gd_flat(const ConvP& p) { return p.nlev > 1 && p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0; }
 
 static bool gd_applies(const ConvP& p) {
-    if (p.sb || p.bf16 || p.in_mul || p.in_add || p.in_relu || (p.nlev != 1 && !gd_flat(p)) || p.ep_stride || (p.add && p.nlev != 1)) return false;
+    if (p.sb || p.in_mul || p.in_add || p.in_relu || (p.nlev != 1 && !gd_flat(p)) || p.ep_stride || (p.add && p.nlev != 1)) return false;
     if (p.Cin % 16 != 0 || p.in_ld % 16 != 0 || p.kh != p.kw || (p.kh != 1 && p.kh != 3)) return false;
     if (p.M >= (1 << 22) || p.nchunks > kTab) return false;
     const long long in_rows = gd_flat(p) ? (long long)p.lv[0].irow0 + p.M : (long long)p.lv[0].irow0 + (long long)p.B * p.lv[0].H * p.lv[0].W;
@@ -354,7 +394,7 @@ static bool gd_applies(const ConvP& p) {
 }
 
 struct GdPlan { int bm, bn, ns; };
-static GdPlan gd_plan(const ConvP& p) {
+static GdPlan gd_plan_any(const ConvP& p) {
     if (g_gd_force[0] > 0) return {g_gd_force[0], g_gd_force[1], g_gd_force[2]};
     // from tools/kw_phase_trace.py gd (profiles/r04_gd_times.txt; eager launches back to back, one MI355X, bs = 1 shapes; ns >= 10: eight waves):
     //   stage-3 concat 352 -> 256 at M = 6400: 17.9 us (k_conv_gs 21.2); stage-2 concat 320 -> 112 at M = 25600: 27.7 (31.1);
@@ -371,7 +411,19 @@ static GdPlan gd_plan(const ConvP& p) {
     // 9.4 us against k_conv_kd's 11.7 when 64 x 64 tiles fill the CUs once, 12.6 against 20.1 when they would spill into a second round
     if (p.kh == 1 && p.Cout16 == 128 && p.nchunks == 16 && !p.colsum)
         return ceil_div(p.M, 64) * 2 <= 256 ? GdPlan{64, 64, 14} : GdPlan{32, 64, 4};
+    // every other 1x1 layer at training batch sizes (the trainable concats, laterals, conv3 and their data gradients over 16 queries /
+    // 384 support crops: M >= 16384 rows): 64 x 128 tiles, or 64 x 64 for narrow outputs (round 5; they ran on k_conv_gs / k_conv_igemm)
+    if (g_gd_mode == 2 && p.kh == 1 && p.M >= 16384 && p.nchunks >= 4 && !p.colsum) return p.Cout16 > 64 ? GdPlan{64, 128, 4} : GdPlan{64, 64, 4};
     return {0, 0, 0};
+}
+
+// the bf16-OPERAND mode has builds of the four-wave tiles only (keep in step with GD_BF in conv_gd_launch); a layer planned on another
+// tile is not this kernel's in that mode -- said here, so that the column-sum rows a caller plans are those of the kernel that will run
+static GdPlan gd_plan(const ConvP& p) {
+    const GdPlan pl = gd_plan_any(p);
+    if (p.bf16 && !((pl.bm == 64 && pl.bn == 128 && pl.ns == 4) || (pl.bm == 64 && pl.bn == 64 && pl.ns == 4) || (pl.bm == 32 && pl.bn == 64 && pl.ns == 4)))
+        return {0, 0, 0};
+    return pl;
 }
 
 int conv_gd_tile_rows(const ConvP& p) {
@@ -414,6 +466,12 @@ int conv_gd_launch(ConvP& p, hipStream_t st) {
     }
     const bool k3 = p.kh == 3;
     const dim3 grid(gx, gy, 1);
+    if (p.bf16) {                                            // bf16-operand builds: the four-wave tiles with the default LDS limit
+#define GD_BF(bm_, bn_, wgm_, wgn_, ns_) if (pl.bm == bm_ && pl.bn == bn_ && pl.ns == ns_) return launch_gd_bf<bm_ / 16, bn_ / 16, wgm_, wgn_, ns_>(q, k3, grid, st);
+        GD_BF(64, 128, 2, 2, 4) GD_BF(64, 64, 2, 2, 4) GD_BF(32, 64, 1, 4, 4)
+#undef GD_BF
+        return 1;                                            // no bf16-operand build of this tile: the caller's other kernels take it
+    }
     // ring depth as forced / planned: ns, or 10 + ns for the eight-wave build of the tile
 #define GD_CASE(bm_, bn_, wgm_, wgn_, ns_) if (pl.bm == bm_ && pl.bn == bn_ && pl.ns == ((wgm_) * (wgn_) == 8 ? 10 + ns_ : ns_)) return launch_gd<bm_ / 16, bn_ / 16, wgm_, wgn_, ns_>(q, k3, grid, st);
     GD_CASE(64, 128, 2, 2, 4) GD_CASE(64, 64, 2, 2, 4) GD_CASE(64, 112, 4, 1, 4) GD_CASE(128, 64, 4, 1, 4) GD_CASE(128, 128, 2, 2, 4) GD_CASE(32, 128, 1, 4, 4)

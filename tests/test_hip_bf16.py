@@ -79,6 +79,30 @@ def test_conv_bf16_operands_vs_oracle(ore, bf16, B, H, W, Cin, Cout, k, stride, 
     assert 1e-4 < rel_err(got, full.numpy()) < 2e-2          # it really is the reduced-precision path, and a sane one
 
 
+@pytest.mark.parametrize("bm,bn,H,W,Cin,Cout,k,stride", [(64, 128, 80, 80, 352, 256, 1, 1), (64, 64, 80, 80, 256, 128, 1, 1), (32, 64, 83, 79, 256, 112, 1, 1),
+                                                     (64, 128, 160, 160, 64, 128, 3, 2)])
+def test_conv_gd_bf16_operand_builds_vs_oracle(ore, bf16, bm, bn, H, W, Cin, Cout, k, stride):
+    """The bf16-OPERAND builds of k_conv_gd (round 5: fragments rounded as they leave LDS, one v_mfma_f32_16x16x16_bf16 per tile), each
+    forced on a layer it can serve, against the oracle's restatement of the mode at the fp32 tolerance (a bf16 x bf16 product is
+    exact in fp32), incl. a partial last row tile, a Cout that is not a multiple of the tile and the 3x3 stride-2 chunk table."""
+    g = torch.Generator().manual_seed(bm + bn + H + Cin)
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    with R.operand_precision("bf16"):
+        ref = F.relu(R.dense_conv(x, w, None, stride, k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    L = ore.lib()
+    assert L.ore_conv_set_plan_override(-15, bm, bn, 4, 0) == 0
+    try:
+        y = ore.conv2d(nhwc(x), ore.pack_conv_weight(w).cuda(), Cout, k, stride, scale=sc.cuda(), shift=sh.cuda(), relu_cout=Cout)
+    finally:
+        L.ore_conv_set_plan_override(-15, 0, 0, 0, 0)
+    got = nchw(y).numpy()
+    assert rel_err(got, ref.numpy()) < TOL_LAYER
+    full = F.relu(F.conv2d(x, w, None, stride, k // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert 1e-4 < rel_err(got, full.numpy()) < 2e-2
+
+
 def test_conv_bf16_input_affine_rounds_after_the_affine(ore, bf16):
     """GN / eSE folds: relu(x * mul + add) is computed in fp32 while the tile is staged, THEN rounded as the MFMA operand."""
     g = torch.Generator().manual_seed(11)

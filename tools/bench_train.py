@@ -59,6 +59,8 @@ def main():
     m.train_graph = bool(a.graph)
     import orehip
     orehip.set_conv_precision(a.precision)
+    if os.environ.get("ORE_GD_MODE"):
+        orehip.lib().ore_conv_set_plan_override(-14, int(os.environ["ORE_GD_MODE"]), 0, 0, 0)
     if a.no_gd_large:
         orehip.lib().ore_conv_set_plan_override(-14, 3, 0, 0, 0)
     if a.no_kd:
