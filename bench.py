@@ -638,8 +638,9 @@ def main():
         roof["end_to_end_tflops"] = round(total_images / elapsed * roof["gflop_per_image"] / 1e3, 2)
         cl = _profile_summary("conv_layers_bf16s" if bf16s else "conv_layers") if not (bf16 and not bf16s) else None
         if cl is not None:        # the same launches by rocprofv3 durations (tools/conv_layers_table.py --json on the committed kernel trace)
-            roof.update({"frac_rocprof": cl.get("frac"), "kernel_us_per_image_rocprof": cl.get("conv_us_per_image"),
-                         "mfma_executed_frac_rocprof": cl.get("mfma_executed_frac"), "rocprof_source": cl.get("source")})
+            roof.update({"kernel_us_per_image_rocprof": cl.get("conv_us_per_image"), "rocprof_source": cl.get("source")})
+            if not bf16s:         # (the table prices against the fp32 MFMA peak; the bf16-storage line is HBM-priced below)
+                roof.update({"frac_rocprof": cl.get("frac"), "mfma_executed_frac_rocprof": cl.get("mfma_executed_frac")})
         if bf16s:
             # bf16 storage: at 16x the fp32 MFMA rate the conv stack is bound by the bytes it moves, so the roofline is priced against
             # HBM: algorithmic bytes = every conv layer reads its input and writes its output once in bf16 (half of the 336 MB fp32
