@@ -15,6 +15,17 @@
 #include "ore_common.h"
 #include <stdlib.h>
 
+#ifdef ORE_TRACE
+// make -C csrc trace: s_memtime stamps of thread 0 of k_roi_tail (slots 0..15) and of block 0 of k_roi_predict_mb (16..31): tools/det_phase_trace.py
+__device__ unsigned long long* g_trace_roi = nullptr;
+#define ROI_TR(i) do { if (g_trace_roi && threadIdx.x == 0) g_trace_roi[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int ore_debug_set_trace_roi(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_roi), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#else
+#define ROI_TR(i) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float ore_expf(float x) {
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
     __shared__ unsigned long long supT[ROI_FUSED_CAP * (ROI_FUSED_CAP / 64)];
     __shared__ int wsum[T / 64];
     __shared__ int keep_pos[ROI_FUSED_CAP];
-    __shared__ int sh_keep;
+    __shared__ int sh_keep, sh_stop;
     constexpr int NW = T / 64, WPR = ROI_FUSED_CAP / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the first T rows' filter flag, box and score are requested before the device-side count is read (one dependent round trip
@@ -597,7 +608,9 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
         box_first = *reinterpret_cast<const f32x4*>(p.raw_boxes + (size_t)tid * 4);
         score_first = p.raw_scores[tid];
     }
+    ROI_TR(0);
     const int n = min(p.n_ptr ? *p.n_ptr : p.n_host, p.cap);
+    ROI_TR(1);
     // ---- ordered compaction of the rows that pass the filter
     int base = 0;
     for (int r0 = 0; r0 < n; r0 += T) {
@@ -621,6 +634,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
     }
     const int m = base;
     const int words = (m + 63) >> 6;
+    ROI_TR(2);
     // ---- stable descending rank by counting (score desc, compacted index asc): 4 lanes per element, scatter into sorted order
     for (int e0 = 0; e0 < m; e0 += T / 4) {
         const int e = e0 + (tid >> 2), sub = tid & 3;
@@ -642,83 +656,86 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
         }
     }
     __syncthreads();
-    // ---- suppression bits.  Unit of work = 16 rows of one 64x64 tile (bi <= w); lane = COLUMN of the tile = the candidate that may be
+    ROI_TR(3);
+    // ---- suppression bits and greedy resolution, column block by column block, until `topk` survivors are known (round 5).  Block cb's
+    // rows can only be suppressed by rows of the blocks rb <= cb, so the 64 x 64 tiles (rb, cb), rb = 0 .. cb, are all block cb's verdict
+    // needs; and once topk rows are kept the later rows cannot change the first topk survivors: with topk = 100 and threshold 0.9 (few
+    // suppressions) the walk ends after two blocks -- 3 tiles instead of the 15 of a 320-row list, whose IoU tests were 8.6 us of this
+    // launch's 18 (tools/det_phase_trace.py).  Unit of work = 16 rows of one tile; lane = COLUMN of the tile = the candidate that may be
     // suppressed, the row box is a broadcast LDS read; the lane collects the 16 rows' verdicts in its own word and ORs it into supT (the
     // four units of a tile own disjoint bit ranges).  Same float ops as k_nms_mask (row box = `a`, column box = `q`).
     for (int i = tid; i < m * WPR; i += T) supT[i] = 0ull;
+    if (tid == 0) { sh_keep = 0; sh_stop = 0; }
     __syncthreads();
+    ROI_TR(4);
     {
-        const int ntile = words * (words + 1) / 2;
-        for (int u = wave; u < ntile * 4; u += NW) {
-            int t = u >> 2, bi = 0;
-            while (t >= words - bi) { t -= words - bi; ++bi; }     // tile t of row-block bi: w = bi + t
-            const int w = bi + t, rq = (u & 3) * 16;
-            const int col = w * 64 + lane;
-            const bool cvalid = col < m;
-            const f32x4 q = cvalid ? *reinterpret_cast<const f32x4*>(sb + col * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const float aq = cvalid ? sa[col] : 0.f;
-            const bool dg = w == bi;
-            unsigned long long acc = 0ull;
-#pragma unroll 4
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = bi * 64 + rq + rr;
-                if (row >= m) break;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(sb + row * 4);
-                const float ai = sa[row];
-                const float xx1 = fmaxf(a.x, q.x), yy1 = fmaxf(a.y, q.y);
-                const float xx2 = fminf(a.z, q.z), yy2 = fminf(a.w, q.w);
-                const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
-                const float inter = ww * hh;
-                const float uni = ai + aq - inter;
-                // ovr > thr with ovr = fl(inter / uni), decided without the division wherever the answer is not within 2^-20 of the
-                // threshold (the products below are off by <= 3 * 2^-24 relative): this phase is one CU's VALU throughput -- 41 000 pairs
-                // at ~40 instructions -- and the IEEE division is a quarter of them.  Inside the band (and for uni = 0: NaN, not
-                // suppressed) the exact expression decides, so the bit matrix is the one k_nms_mask / the CPU twin compute.
-                const float tu = p.nms_thresh * uni;
-                bool sup = inter > tu * 1.00000095367431640625f;
-                if (!sup && inter >= tu * 0.99999904632568359375f) sup = inter / uni > p.nms_thresh;
-                if (cvalid && sup && (!dg || rq + rr < lane)) acc |= 1ull << (rq + rr);   // own block: earlier rows only
-            }
-            if (acc) atomicOr(&supT[col * WPR + bi], acc);
-        }
-    }
-    __syncthreads();
-    // ---- greedy resolution, wave 0: lane = row of the current 64-row block; kept masks of the earlier blocks are wave-uniform registers
-    if (wave == 0) {
-        unsigned long long keptw[WPR];
+        unsigned long long keptw[WPR];                                        // wave 0: kept masks of the decided blocks (wave-uniform)
 #pragma unroll
         for (int b2 = 0; b2 < WPR; ++b2) keptw[b2] = 0ull;
         int n_keep = 0;
 #pragma unroll
-        for (int bi = 0; bi < WPR; ++bi) {
-            if (bi < words) {
-                const int row = bi * 64 + lane;
-                const bool rvalid = row < m;
-                unsigned long long hit = 0ull;
-#pragma unroll
-                for (int b2 = 0; b2 < WPR; ++b2)
-                    if (b2 < bi) hit |= (rvalid ? supT[row * WPR + b2] : 0ull) & keptw[b2];
-                const unsigned long long diag = rvalid ? supT[row * WPR + bi] : 0ull;
-                unsigned long long rm = __ballot(hit != 0ull);                   // removed by a survivor of an earlier block
-                const int nvalid = min(64, m - bi * 64);
-                if (nvalid < 64) rm |= ~0ull << nvalid;
-                const unsigned long long cand = ~rm;
-                unsigned long long kept = cand;
-                if (__ballot(diag != 0ull) != 0ull) {
-                    for (int it = 0; it < 64; ++it) {
-                        const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
-                        if (kn == kept) break;
-                        kept = kn;
+        for (int cb = 0; cb < WPR; ++cb) {
+            if (cb < words && !sh_stop) {
+                for (int u = wave; u < 4 * (cb + 1); u += NW) {
+                    const int rb = u >> 2, rq = (u & 3) * 16;
+                    const int col = cb * 64 + lane;
+                    const bool cvalid = col < m;
+                    const f32x4 q = cvalid ? *reinterpret_cast<const f32x4*>(sb + col * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const float aq = cvalid ? sa[col] : 0.f;
+                    const bool dg = rb == cb;
+                    unsigned long long acc = 0ull;
+#pragma unroll 4
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const int row = rb * 64 + rq + rr;
+                        if (row >= m) break;
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(sb + row * 4);
+                        const float ai = sa[row];
+                        const float xx1 = fmaxf(a.x, q.x), yy1 = fmaxf(a.y, q.y);
+                        const float xx2 = fminf(a.z, q.z), yy2 = fminf(a.w, q.w);
+                        const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+                        const float inter = ww * hh;
+                        const float uni = ai + aq - inter;
+                        // ovr > thr with ovr = fl(inter / uni), decided without the division wherever the answer is not within 2^-20 of the
+                        // threshold (the products below are off by <= 3 * 2^-24 relative).  Inside the band (and for uni = 0: NaN, not
+                        // suppressed) the exact expression decides, so the bit matrix is the one k_nms_mask / the CPU twin compute.
+                        const float tu = p.nms_thresh * uni;
+                        bool sup = inter > tu * 1.00000095367431640625f;
+                        if (!sup && inter >= tu * 0.99999904632568359375f) sup = inter / uni > p.nms_thresh;
+                        if (cvalid && sup && (!dg || rq + rr < lane)) acc |= 1ull << (rq + rr);   // own block: earlier rows only
                     }
+                    if (acc) atomicOr(&supT[col * WPR + rb], acc);
                 }
-                if ((kept >> lane) & 1ull) keep_pos[n_keep + __popcll(kept & ((1ull << lane) - 1ull))] = row;
-                n_keep += __popcll(kept);
-                keptw[bi] = kept;
+                __syncthreads();
+                if (wave == 0) {                                              // lane = row of block cb
+                    const int row = cb * 64 + lane;
+                    const bool rvalid = row < m;
+                    unsigned long long hit = 0ull;
+#pragma unroll
+                    for (int b2 = 0; b2 < WPR; ++b2)
+                        if (b2 < cb) hit |= (rvalid ? supT[row * WPR + b2] : 0ull) & keptw[b2];
+                    const unsigned long long diag = rvalid ? supT[row * WPR + cb] : 0ull;
+                    unsigned long long rm = __ballot(hit != 0ull);               // removed by a survivor of an earlier block
+                    const int nvalid = min(64, m - cb * 64);
+                    if (nvalid < 64) rm |= ~0ull << nvalid;
+                    const unsigned long long cand = ~rm;
+                    unsigned long long kept = cand;
+                    if (__ballot(diag != 0ull) != 0ull) {
+                        for (int it = 0; it < 64; ++it) {
+                            const unsigned long long kn = cand & ~__ballot((diag & kept) != 0ull);
+                            if (kn == kept) break;
+                            kept = kn;
+                        }
+                    }
+                    if ((kept >> lane) & 1ull) keep_pos[n_keep + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+                    n_keep += __popcll(kept);
+                    keptw[cb] = kept;
+                    if (lane == 0) { sh_keep = n_keep; sh_stop = (p.topk >= 0 && n_keep >= p.topk) ? 1 : 0; }
+                }
+                __syncthreads();
             }
         }
-        if (lane == 0) sh_keep = n_keep;
     }
-    __syncthreads();
+    ROI_TR(5);
     int nk = sh_keep;
     if (p.topk >= 0 && nk > p.topk) nk = p.topk;
     // ---- detections (score order) + detector_postprocess
@@ -730,6 +747,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
         p.det_src[i] = (long long)csrc[e];
     }
     if (tid == 0) *p.det_count = nk;
+    ROI_TR(6);
     if (p.post != nullptr) {
         const float sx = p.post[0], sy = p.post[1], ow = p.post[2], oh = p.post[3];
         // The caller's result record (boxes [cap][4] f32 | scores [cap] f32 | classes [cap] i64): its device address is handed over in
@@ -779,6 +797,7 @@ __global__ __launch_bounds__(T) void k_roi_tail(TailP p) {
             if (p.host_count) *p.host_count = fbase;      // pinned, device-mapped host word, this kernel's last store: the caller polls it
                                                           // (whatever it does with the record next is stream-ordered behind this kernel)
         }
+        ROI_TR(7);
     }
 }
 

@@ -24,11 +24,17 @@ for _ in range(3):
     e.eval_forward(img, use_graph=False)
 torch.cuda.synchronize()
 buf = torch.zeros(512, dtype=torch.int64, device=dev)
+rbuf = torch.zeros(64, dtype=torch.int64, device=dev)
+L.ore_debug_set_trace_roi(C.c_void_p(rbuf.data_ptr()))
 L.ore_debug_set_trace_det(C.c_void_p(buf.data_ptr()))
 torch.cuda.synchronize()
 e.eval_forward(img, use_graph=False)
 torch.cuda.synchronize()
 L.ore_debug_set_trace_det(C.c_void_p(0))
+L.ore_debug_set_trace_roi(C.c_void_p(0))
+rt = rbuf.cpu().numpy().astype(np.int64)
+print("k_roi_tail, clocks since entry:", {n: int(rt[i] - rt[0]) for i, n in enumerate(
+    ["entry", "count read", "compaction", "rank sort", "IoU bits", "greedy", "detections", "postprocess + record"]) if rt[i]})
 t = buf.cpu().numpy().astype(np.int64)
 c = e.buffer("counts").cpu().numpy().ravel()
 print("counts (n_pre, n_keep):", c[:2])
