@@ -215,3 +215,49 @@ def test_column_scan_vs_oracle_every_ring_position(oh, n):
         got = oh.nms(boxes.cuda(), scores.cuda(), thr).cpu().numpy()
         assert np.array_equal(got, want), (n, thr, len(got), len(want))
         assert 0 < len(want) <= n
+
+
+def test_multi_weight_repack_equals_one_by_one(oh):
+    """ore_pack_conv_weights_multi_fwd (one launch for all the trainable weights of a step) writes, bit for bit, what
+    ore_pack_conv_weight_fwd writes weight by weight -- forward and data-gradient layouts, 1x1 and 3x3, widths that are not multiples
+    of 16 on the data-gradient side -- and the forward layout is the host packer's (ore_pack_conv_weight_host)."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(96, 256, 3, 3), (384, 544, 1, 1), (112, 112, 3, 3), (128, 512, 1, 1), (4, 128, 3, 3), (1, 128, 3, 3), (128, 128, 3, 3)]
+    jobs, want = [], []
+    for (co, ci, kh, kw) in shapes:
+        w = torch.randn(co, ci, kh, kw, generator=g).cuda()
+        for dgrad in (False, True):
+            ref = oh.pack_conv_weight_dev(w, dgrad=dgrad)
+            out = torch.full_like(ref, float("nan"))
+            jobs.append((w, dgrad, out))
+            want.append(ref)
+        assert torch.equal(want[-2].cpu(), oh.pack_conv_weight(w.cpu()))
+    oh.pack_conv_weights_multi(jobs)
+    torch.cuda.synchronize()
+    for (w, dgrad, out), ref in zip(jobs, want):
+        assert torch.equal(out, ref), (tuple(w.shape), dgrad)
+    # the cached job table follows the CONTENTS of the masters: new values through the same pointers are repacked by the same table
+    for w, _, _ in jobs[::2]:                                               # every master appears twice (forward + data-gradient job)
+        w.mul_(-0.5)
+    oh.pack_conv_weights_multi(jobs)
+    for (w, dgrad, out), ref in zip(jobs, want):
+        assert torch.equal(out, ref * -0.5)
+
+
+def test_flop_counter_counts_algorithmic_flops_of_the_entry_points(oh):
+    """ore_flop_counter_read: 2*M*Cout*Cin*kh*kw per forward conv call, whatever kernel the plan picks (Winograd executes fewer
+    multiplies, split-K more launches: neither changes the count) -- the figure bench.py's training roofline is priced with."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 40, 40, 96, generator=g).cuda()
+    w = torch.randn(96, 96, 3, 3, generator=g)
+    wp = oh.pack_conv_weight(w).cuda()
+    oh.flop_counter(reset=True)
+    assert oh.flop_counter() == (0.0, 0)
+    oh.conv2d(x, wp, 96, 3)
+    f1, n1 = oh.flop_counter()
+    assert n1 == 1 and f1 == 2.0 * (2 * 40 * 40) * 96 * 96 * 9
+    oh.conv2d(x, wp, 96, 3, w_wino=oh.winograd_weight(wp, 96, 96) if oh.winograd_covers(96, 96) else None)
+    oh.conv2d(x, wp, 96, 3, stride=2)
+    f3, n3 = oh.flop_counter(reset=True)
+    assert n3 == 3 and f3 == 2 * f1 + 2.0 * (2 * 20 * 20) * 96 * 96 * 9
+    assert oh.flop_counter() == (0.0, 0)
