@@ -123,10 +123,29 @@ static int wg_blocks() {
 }
 #define WG_BLOCKS wg_blocks()
 
+// Which wave of the block owns which 32 x 32 quarter of the 64 x 64 tile rotates with the block index: layers whose widths are not
+// multiples of 64 (96, 112, 16 ...) leave some quarters without real channels, the waves owning them issue no matrix instructions, and
+// the rotation spreads those idle waves over the four SIMDs of a CU (co-resident blocks then fill the freed issue slots) instead of
+// parking them all on the same two.
+__device__ __forceinline__ int wg_wave() { return __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + blockIdx.x + blockIdx.y + blockIdx.z) & 3); }
+// live 16-wide tiles (0, 1 or 2) of the 32 channels starting at c0
+__device__ __forceinline__ int wg_live(int C, int c0) { return C - c0 > 16 ? 2 : C - c0 > 0 ? 1 : 0; }
+struct WgI0 { static constexpr int value = 0; }; struct WgI1 { static constexpr int value = 1; }; struct WgI2 { static constexpr int value = 2; };
+#define WG_DISPATCH(f, nm, nn)                                                                                   \
+    do {                                                                                                         \
+        const int nm_ = (nm), nn_ = (nn);                                                                        \
+        if (nm_ == 0 || nn_ == 0) f(WgI0{}, WgI0{});                                                             \
+        else if (nm_ == 2 && nn_ == 2) f(WgI2{}, WgI2{});                                                        \
+        else if (nm_ == 2) f(WgI2{}, WgI1{});                                                                    \
+        else if (nn_ == 2) f(WgI1{}, WgI2{});                                                                    \
+        else f(WgI1{}, WgI1{});                                                                                  \
+    } while (0)
+
 __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     __shared__ float sA[2][WG_K][WG_LD];   // dZ rows x co
     __shared__ float sB[2][WG_K][WG_LD];   // X  rows x ci
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wg_wave();
     const int wm = wave >> 1, wn = wave & 1;
     const int n_ci_tiles = (p.Cin + WG_T - 1) / WG_T;
     const int co0 = blockIdx.x * WG_T;
@@ -159,29 +178,36 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
     const bool do_b = p.db != nullptr && blockIdx.y == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     int buf = 0;
-    for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
-        if (do_b) bsum += va;                                    // (fp32 dZ: the bias gradient is not an MFMA operand)
-        if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); }
-        *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
-        *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
-        __syncthreads();
-        if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb);          // next step's global loads fly under this step's MFMAs
+    // TM x TN = the 16 x 16 tiles of this wave's 32 x 32 part that hold real channels (wg_live): a wave whose part lies beyond Cout or
+    // Cin still stages and meets the barriers, but issues no matrix instructions
+    auto kloop = [&](auto TMc, auto TNc) {
+        constexpr int TM = decltype(TMc)::value, TN = decltype(TNc)::value;
+        for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+            if (do_b) bsum += va;                                    // (fp32 dZ: the bias gradient is not an MFMA operand)
+            if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); }
+            *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
+            *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
+            __syncthreads();
+            if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb);          // next step's global loads fly under this step's MFMAs
+            if constexpr (TM > 0 && TN > 0) {
 #pragma unroll
-        for (int kk = 0; kk < WG_K / 4; ++kk) {
-            const int k = kk * 4 + (lane >> 4);
-            float a[2], b[2];
+                for (int kk = 0; kk < WG_K / 4; ++kk) {
+                    const int k = kk * 4 + (lane >> 4);
+                    float a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = sA[buf][k][wm * 32 + t * 16 + (lane & 15)];
-                b[t] = sB[buf][k][wn * 32 + t * 16 + (lane & 15)];
+                    for (int t = 0; t < TM; ++t) a[t] = sA[buf][k][wm * 32 + t * 16 + (lane & 15)];
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) b[t] = sB[buf][k][wn * 32 + t * 16 + (lane & 15)];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            buf ^= 1;                                                // the other buffer was last read two barriers ago
         }
-        buf ^= 1;                                                // the other buffer was last read two barriers ago
-    }
+    };
+    WG_DISPATCH(kloop, wg_live(p.Cout, co0 + wm * 32), wg_live(p.Cin, ci0 + wn * 32));
     // D: column = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
     const int taps = p.kh * p.kw;
     float* slab = p.slab + (size_t)blockIdx.z * p.slab_stride;
@@ -214,7 +240,8 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     __shared__ float sA[2][WG_K][WG_LD];       // dZ rows x co
     __shared__ float sB[2][WG_K + 2][WG_LD];   // X rows (m0 + dy*W - 1 ...) x ci
     __shared__ int sM[2][WG_K];                // bit dx: tap (dy, dx) of this output row reads inside the image
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wg_wave();
     const int wm = wave >> 1, wn = wave & 1;
     const int n_ci_tiles = (p.Cin + WG_T - 1) / WG_T;
     const int co0 = blockIdx.x * WG_T;
@@ -254,38 +281,45 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     const bool do_b = p.db != nullptr && blockIdx.y == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     int buf = 0;
-    for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
-        if (do_b) bsum += va;
-        if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); vb2 = bf16_rne4(vb2); }
-        *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
-        *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
-        if (lr < 2) *reinterpret_cast<f32x4*>(&sB[buf][WG_K + lr][lc]) = vb2;
-        if ((tid & 15) == 0) sM[buf][lr] = msk;
-        __syncthreads();
-        if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb, vb2, msk);
+    auto kloop = [&](auto TMc, auto TNc) {                       // (see k_wgrad: only the 16 x 16 tiles with real channels are multiplied)
+        constexpr int TM = decltype(TMc)::value, TN = decltype(TNc)::value;
+        for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
+            if (do_b) bsum += va;
+            if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); vb2 = bf16_rne4(vb2); }
+            *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
+            *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
+            if (lr < 2) *reinterpret_cast<f32x4*>(&sB[buf][WG_K + lr][lc]) = vb2;
+            if ((tid & 15) == 0) sM[buf][lr] = msk;
+            __syncthreads();
+            if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb, vb2, msk);
+            if constexpr (TM > 0 && TN > 0) {
 #pragma unroll
-        for (int kk = 0; kk < WG_K / 4; ++kk) {
-            const int k = kk * 4 + (lane >> 4);
-            const int mk = sM[buf][k];
-            float a[2];
+                for (int kk = 0; kk < WG_K / 4; ++kk) {
+                    const int k = kk * 4 + (lane >> 4);
+                    const int mk = sM[buf][k];
+                    float a[TM];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) a[t] = sA[buf][k][wm * 32 + t * 16 + (lane & 15)];
+                    for (int t = 0; t < TM; ++t) a[t] = sA[buf][k][wm * 32 + t * 16 + (lane & 15)];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float b[2];
+                    for (int d = 0; d < 3; ++d) {
+                        float b[TN];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) b[t] = sB[buf][k + d][wn * 32 + t * 16 + (lane & 15)];
-                const bool on = (mk >> d) & 1;
+                        for (int t = 0; t < TN; ++t) b[t] = sB[buf][k + d][wn * 32 + t * 16 + (lane & 15)];
+                        const bool on = (mk >> d) & 1;
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const float am = on ? a[tm] : 0.f;
+                        for (int tm = 0; tm < TM; ++tm) {
+                            const float am = on ? a[tm] : 0.f;
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, b[tn], acc[d][tm][tn], 0, 0, 0);
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, b[tn], acc[d][tm][tn], 0, 0, 0);
+                        }
+                    }
                 }
             }
+            buf ^= 1;
         }
-        buf ^= 1;
-    }
+    };
+    WG_DISPATCH(kloop, wg_live(p.Cout, co0 + wm * 32), wg_live(p.Cin, ci0 + wn * 32));
     float* slab = p.slab + (size_t)blockIdx.z * p.slab_stride;
     if (do_b) wgrad_bias_out(p, sA[0], bsum, co0, slab);
 #pragma unroll
@@ -350,7 +384,8 @@ __global__ __launch_bounds__(256) void k_wgrad_bf(WgradP p) {
     constexpr int XR = K3 ? WB_K + 2 : WB_K;              // staged X rows
     __shared__ __attribute__((aligned(16))) short sA[2][ND][WB_K][WB_LD];
     __shared__ __attribute__((aligned(16))) short sB[2][XR][WB_LD];          // (tap dx reads rows dx .. dx + 31 of the 34)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wg_wave();
     const int wm = wave >> 1, wn = wave & 1;
     const int n_ci_tiles = (p.Cin + WG_T - 1) / WG_T;
     const int co0 = blockIdx.x * WG_T;
@@ -403,6 +438,8 @@ __global__ __launch_bounds__(256) void k_wgrad_bf(WgradP p) {
     const bool do_b = p.db != nullptr && blockIdx.y == 0;
     f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;
     int buf = 0;
+    auto kloop = [&](auto TMc, auto TNc) {                       // (see k_wgrad: only the 16 x 16 tiles with real channels are multiplied)
+    constexpr int TM = decltype(TMc)::value, TN = decltype(TNc)::value;
     for (int m0 = m_begin; m0 < m_end; m0 += WB_K) {
         if (do_b) { bs0 += za; bs1 += zb; }
         if constexpr (K3) {
@@ -420,21 +457,25 @@ __global__ __launch_bounds__(256) void k_wgrad_bf(WgradP p) {
         }
         __syncthreads();
         if (m0 + WB_K < m_end) load(m0 + WB_K);                  // next step's global loads fly under this step's MFMAs
+        if constexpr (TM > 0 && TN > 0) {
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            bf16x8_t a[2], b[2];
+            for (int d = 0; d < ND; ++d) {
+                bf16x8_t a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = wb_frag(&sA[buf][d][0][wm * 32 + t * 16]);
-                b[t] = wb_frag(&sB[buf][K3 ? d : 0][wn * 32 + t * 16]);     // tap dx: the X rows shifted by d
+                for (int t = 0; t < TM; ++t) a[t] = wb_frag(&sA[buf][d][0][wm * 32 + t * 16]);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) b[t] = wb_frag(&sB[buf][K3 ? d : 0][wn * 32 + t * 16]);     // tap dx: the X rows shifted by d
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[d][tm][tn], 0, 0, 0);
             }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tm], b[tn], acc[d][tm][tn], 0, 0, 0);
         }
         buf ^= 1;                                                // the other buffer was last read two barriers ago
     }
+    };
+    WG_DISPATCH(kloop, wg_live(p.Cout, co0 + wm * 32), wg_live(p.Cin, ci0 + wn * 32));
     const int taps = p.kh * p.kw;
     float* slab = p.slab + (size_t)blockIdx.z * p.slab_stride;
     if (do_b) {                                                  // column sums of the fp32 dZ rows this block staged: 32 rows meet in LDS

@@ -220,7 +220,8 @@ class OSAFn(Function):
             if ctx.needs_input_grad[1 + 3 * i]:
                 grads[3 * i] = orehip.conv2d_wgrad(cat, dzi, 3, x_coff=src, Cin=cin)
             if i > 0 or ctx.needs_input_grad[0]:
-                dcat[..., src:src + cin] += orehip.conv2d(dzi, packed(ws[i], True), cin, 3, 1, 1, w_wino=packed_wino(ws[i], True))
+                # (.add_ on the view: `dcat[...] += x` would follow the in-place add with a copy of the slice onto itself)
+                dcat[..., src:src + cin].add_(orehip.conv2d(dzi, packed(ws[i], True), cin, 3, 1, 1, w_wino=packed_wino(ws[i], True)))
         gx = dcat[..., :in_ch].contiguous() if ctx.needs_input_grad[0] else None
         return (gx, *grads)
 

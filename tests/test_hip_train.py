@@ -237,10 +237,15 @@ def test_sm_block_glue_kernels(oh, B, H, W, G, S):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(1, 6, 9, 32, 16, 3), (2, 40, 44, 96, 96, 3), (1, 64, 64, 128, 128, 1), (4, 30, 30, 256, 112, 1),
-                                              (1, 20, 20, 128, 16, 3)])
+                                              (1, 20, 20, 128, 16, 3),
+                                              # every mix of full / half / quarter / empty 32 x 32 wave parts of the 64 x 64 block tile
+                                              (3, 8, 8, 112, 112, 3), (2, 8, 8, 384, 112, 3), (1, 7, 9, 20, 36, 3), (1, 7, 9, 68, 100, 1),
+                                              (1, 1, 2048, 128, 4, 1), (2, 16, 16, 544, 384, 1), (1, 16, 16, 80, 48, 3), (1, 12, 12, 36, 20, 1)])
 def test_wgrad_with_fused_bias_gradient(oh, B, H, W, Cin, Cout, k):
     """ore_conv2d_wgrad_bias_fwd: weight gradient and bias gradient (column sums of dZ) from ONE launch, with and without a row split
-    (the first shape runs unsplit and writes both outputs directly), against torch.autograd of F.conv2d."""
+    (the first shape runs unsplit and writes both outputs directly), against torch.autograd of F.conv2d.  The widths that are not
+    multiples of 64 leave 16 x 16 tiles of a block without real channels; the waves owning them skip their matrix instructions
+    (wg_live in ore_bwd.hip) and the result must not notice."""
     g = torch.Generator().manual_seed(B * 7 + H + Cin + Cout + k)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).requires_grad_(True)
