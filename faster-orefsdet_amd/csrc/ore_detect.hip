@@ -92,7 +92,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds_w, int* total) {
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
+__device__ __forceinline__ void level_select_body(const DetP& p) {
     extern __shared__ __attribute__((aligned(16))) float sv[];   // sigmoid of every location of this level (computed once)
     __shared__ int hist[1024];
     __shared__ int wsum[SEL_T / 64];
@@ -220,8 +220,36 @@ __global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) {
     if (tr) DET_TR(8);
 }
 
+__global__ __launch_bounds__(SEL_T) void k_level_select(DetP p) { level_select_body(p); }
+
+// ---- the first three launches of up to 16 images in ONE launch each (training: 16 query images per step; round 5) ----------------
+// What differs between the images of a batch is a handful of pointers; everything else (shapes, thresholds, the workspace layout) is
+// common.  blockIdx.y (z for the mask tiles) picks the image, the body is the single-image kernel's.
+constexpr int DET_BATCH = 16;
+struct DetImg { const float* head[4]; char* ws; float* pre_boxes; float* pre_scores; long long* pre_loc; int* pre_level;
+                long long* keep_idx; int* counts; float* out_boxes; float* out_scores; };
+struct DetBatch {
+    DetP common;
+    size_t o_lvl_cnt, o_lvl_boxes, o_lvl_scores, o_lvl_loc, o_s_boxes, o_s_scores, o_s_order, o_mask;
+    DetImg img[DET_BATCH];
+};
+__device__ __forceinline__ DetP det_of(const DetBatch& b, int i) {
+    DetP p = b.common;
+    const DetImg& m = b.img[i];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) p.head[l] = m.head[l];
+    p.lvl_cnt = (int*)(m.ws + b.o_lvl_cnt); p.lvl_boxes = (float*)(m.ws + b.o_lvl_boxes);
+    p.lvl_scores = (float*)(m.ws + b.o_lvl_scores); p.lvl_loc = (long long*)(m.ws + b.o_lvl_loc);
+    p.s_boxes = (float*)(m.ws + b.o_s_boxes); p.s_scores = (float*)(m.ws + b.o_s_scores); p.s_order = (int*)(m.ws + b.o_s_order);
+    p.mask = (unsigned long long*)(m.ws + b.o_mask);
+    p.pre_boxes = m.pre_boxes; p.pre_scores = m.pre_scores; p.pre_loc = m.pre_loc; p.pre_level = m.pre_level;
+    p.keep_idx = m.keep_idx; p.counts = m.counts; p.out_boxes = m.out_boxes; p.out_scores = m.out_scores;
+    return p;
+}
+__global__ __launch_bounds__(SEL_T) void k_level_select_b(DetBatch b) { const DetP p = det_of(b, blockIdx.y); level_select_body(p); }
+
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rank_scatter(DetP p) {
+__device__ __forceinline__ void rank_scatter_body(const DetP& p) {
     extern __shared__ float sc[];  // concatenated scores [n]
     __shared__ int off[9];
     if (threadIdx.x == 0) {
@@ -266,10 +294,13 @@ __global__ __launch_bounds__(256) void k_rank_scatter(DetP p) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_rank_scatter(DetP p) { rank_scatter_body(p); }
+__global__ __launch_bounds__(256) void k_rank_scatter_b(DetBatch b) { const DetP p = det_of(b, blockIdx.y); rank_scatter_body(p); }
+
 // One block = one 64 x 64 tile of the IoU matrix, 4 waves: wave q tests the tile's rows against columns 16q .. 16q+15 (a quarter of
 // the serial IoU chain of the one-wave form: 12 -> ~6 us at n = 3000), the four partial words of a row are OR-ed through LDS.
-__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ n_ptr,
-                                                   float thr, unsigned long long* __restrict__ mask, int words) {
+__device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes, const int* __restrict__ n_ptr,
+                                              float thr, unsigned long long* __restrict__ mask, int words) {
     const int n = *n_ptr;
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj < bi || bi * 64 >= n || bj * 64 >= n) return;
@@ -313,6 +344,15 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
     if (q != 0 || i >= n) return;
     bits = (part[0][t] | part[1][t]) | (part[2][t] | part[3][t]);
     mask[(size_t)i * words + bj] = bits;
+}
+
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ n_ptr,
+                                                   float thr, unsigned long long* __restrict__ mask, int words) {
+    nms_mask_body(boxes, n_ptr, thr, mask, words);
+}
+__global__ __launch_bounds__(256) void k_nms_mask_b(DetBatch b, float thr, int words) {
+    const DetImg& m = b.img[blockIdx.z];
+    nms_mask_body((const float*)(m.ws + b.o_s_boxes), m.counts, thr, (unsigned long long*)(m.ws + b.o_mask), words);
 }
 
 // The same tile for the column scan (k_nms_scan_t), TRANSPOSED: word T[bj][bi][c] = the rows of block bi that suppress column bj*64+c
@@ -792,7 +832,8 @@ extern "C" size_t ore_detect_workspace_bytes(int32_t n_levels, int32_t pre_topk)
 
 namespace {
 // everything of one image up to (not including) the scan; fills the scan's arguments
-static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa, DetLayout& lay, int& cap) {
+// checks + the kernel parameters of one image (no launch)
+static int detect_fill(const ore_detect_desc* d, DetP& p, DetLayout& lay, int& cap, size_t& sv_bytes) {
     ORE_CHECK_ARG(d && d->n_levels > 0 && d->n_levels <= 8 && d->pre_topk > 0, "ore_detect_fwd: bad args");
     ORE_CHECK_ARG(d->head_ld >= 8 && d->head_ld % 4 == 0, "ore_detect_fwd: head_ld=%d (need >= 8, %%4)", d->head_ld);
     ORE_CHECK_ARG(d->pre_boxes && d->pre_scores && d->pre_loc && d->pre_level && d->keep_idx && d->counts && d->out_boxes &&
@@ -806,7 +847,7 @@ static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa
     ORE_CHECK_ARG((size_t)cap * 4 <= 150 * 1024 && lay.words <= NMS_MAX_WORDS, "ore_detect_fwd: cap %d too large", cap);
     ORE_CHECK_ARG(d->nms_thresh > 0.0f, "ore_detect_fwd: nms_thresh <= 0 (NMS disabled) is not supported");
     char* ws = (char*)d->workspace;
-    DetP p{};
+    p = DetP{};
     p.n_levels = d->n_levels; p.head_ld = d->head_ld;
     for (int l = 0; l < d->n_levels; ++l) {
         ORE_CHECK_ARG(d->head[l] && d->H[l] > 0 && d->W[l] > 0 && d->stride[l] > 0, "ore_detect_fwd: level %d", l);
@@ -820,11 +861,18 @@ static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa
     p.mask = (unsigned long long*)(ws + lay.mask); p.mask_words = lay.words;
     p.keep_idx = (long long*)d->keep_idx; p.counts = d->counts; p.out_boxes = d->out_boxes; p.out_scores = d->out_scores;
     p.cap = cap;
-    int rc;
     int hw_max = 0;
     for (int l = 0; l < d->n_levels; ++l) hw_max = max(hw_max, d->H[l] * d->W[l]);
-    const size_t sv_bytes = (size_t)hw_max * 4;
+    sv_bytes = (size_t)hw_max * 4;
     ORE_CHECK_ARG(sv_bytes <= 120 * 1024, "ore_detect_fwd: a level with %d locations exceeds the 30720-location LDS cache", hw_max);
+    return ORE_OK;
+}
+
+static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa, DetLayout& lay, int& cap) {
+    DetP p{};
+    size_t sv_bytes = 0;
+    int rc = detect_fill(d, p, lay, cap, sv_bytes);
+    if (rc) return rc;
     if (sv_bytes > 48 * 1024)
         ORE_HIP(hipFuncSetAttribute((const void*)k_level_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv_bytes));
     hipLaunchKernelGGL(k_level_select, dim3(d->n_levels), dim3(SEL_T), sv_bytes, st, p);
@@ -836,6 +884,50 @@ static int detect_prepare(const ore_detect_desc* d, hipStream_t st, ScanArgs& sa
     if ((rc = ore_launch_status("k_rank_scatter"))) return rc;
     if ((rc = launch_nms_mask(lay.words, cap, st, p.s_boxes, p.counts, d->nms_thresh, p.mask))) return rc;
     sa = ScanArgs{p.s_boxes, p.s_scores, p.s_order, p.counts, p.mask, p.keep_idx, p.out_boxes, p.out_scores, p.counts + 1};
+    return ORE_OK;
+}
+
+// Select / rank / mask of nb images (same shapes and thresholds, <= 4 levels, the row-major mask form) in three launches instead of 3 nb:
+// a training step's 16 query images ran these 48 small launches back to back (level_select is THREE blocks per image).
+static int detect_prepare_batch(const ore_detect_desc* d, int nb, hipStream_t st, ScanBatch& sb, DetLayout& lay, int& cap, bool& done) {
+    done = false;
+    if (nb < 2 || nb > DET_BATCH || d->n_levels > 4) return ORE_OK;
+    DetBatch db{};
+    size_t sv_bytes = 0;
+    for (int i = 0; i < nb; ++i) {
+        DetP p{};
+        DetLayout li{};
+        int ci = 0;
+        size_t svi = 0;
+        const int rc = detect_fill(d + i, p, li, ci, svi);
+        if (rc) return rc;
+        if (i == 0) { db.common = p; lay = li; cap = ci; sv_bytes = svi; if (nms_use_col(cap)) return ORE_OK; }
+        const DetP& c = db.common;
+        bool same = p.n_levels == c.n_levels && p.head_ld == c.head_ld && p.score_thresh == c.score_thresh && p.pre_topk == c.pre_topk;
+        for (int l = 0; l < p.n_levels; ++l) same = same && p.H[l] == c.H[l] && p.W[l] == c.W[l] && p.stride[l] == c.stride[l];
+        if (!same) return ORE_OK;                                  // mixed shapes: image by image
+        DetImg& m = db.img[i];
+        for (int l = 0; l < p.n_levels; ++l) m.head[l] = p.head[l];
+        m.ws = (char*)d[i].workspace;
+        m.pre_boxes = p.pre_boxes; m.pre_scores = p.pre_scores; m.pre_loc = p.pre_loc; m.pre_level = p.pre_level;
+        m.keep_idx = p.keep_idx; m.counts = p.counts; m.out_boxes = p.out_boxes; m.out_scores = p.out_scores;
+        sb.a[i] = ScanArgs{p.s_boxes, p.s_scores, p.s_order, p.counts, p.mask, p.keep_idx, p.out_boxes, p.out_scores, p.counts + 1};
+    }
+    db.o_lvl_cnt = lay.lvl_cnt; db.o_lvl_boxes = lay.lvl_boxes; db.o_lvl_scores = lay.lvl_scores; db.o_lvl_loc = lay.lvl_loc;
+    db.o_s_boxes = lay.s_boxes; db.o_s_scores = lay.s_scores; db.o_s_order = lay.s_order; db.o_mask = lay.mask;
+    int rc;
+    if (sv_bytes > 48 * 1024)
+        ORE_HIP(hipFuncSetAttribute((const void*)k_level_select_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sv_bytes));
+    hipLaunchKernelGGL(k_level_select_b, dim3(db.common.n_levels, nb), dim3(SEL_T), sv_bytes, st, db);
+    if ((rc = ore_launch_status("k_level_select_b"))) return rc;
+    const size_t sc_bytes = (size_t)cap * 4;
+    if (sc_bytes > 64 * 1024)
+        ORE_HIP(hipFuncSetAttribute((const void*)k_rank_scatter_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_bytes));
+    hipLaunchKernelGGL(k_rank_scatter_b, dim3(ceil_div(cap, 16), nb), dim3(256), sc_bytes, st, db);
+    if ((rc = ore_launch_status("k_rank_scatter_b"))) return rc;
+    hipLaunchKernelGGL(k_nms_mask_b, dim3(lay.words, lay.words, nb), dim3(256), 0, st, db, d->nms_thresh, lay.words);
+    if ((rc = ore_launch_status("k_nms_mask_b"))) return rc;
+    done = true;
     return ORE_OK;
 }
 
@@ -864,7 +956,11 @@ extern "C" int ore_detect_batch_fwd(const ore_detect_desc* d, int32_t n_images, 
             const ore_detect_desc* di = d + i0 + i;
             ORE_CHECK_ARG(di->n_levels == d->n_levels && di->pre_topk == d->pre_topk && di->nms_thresh == d->nms_thresh &&
                               di->post_topk == d->post_topk, "ore_detect_batch_fwd: image %d differs in levels / thresholds", i0 + i);
-            const int rc = detect_prepare(di, st, sb.a[i], lay, cap);
+        }
+        bool batched = false;
+        { const int rc = detect_prepare_batch(d + i0, nb, st, sb, lay, cap, batched); if (rc) return rc; }
+        for (int i = 0; i < nb && !batched; ++i) {
+            const int rc = detect_prepare(d + i0 + i, st, sb.a[i], lay, cap);
             if (rc) return rc;
         }
         if (nms_use_col(cap) || nb == 1) {                       // small candidate sets: the column scan is already short

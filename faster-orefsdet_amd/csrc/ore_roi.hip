@@ -330,6 +330,250 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_col(RoiBwdP p, int split)
     }
 }
 
+// Tile-owned form (round 5, second half): the transposed pooling as a GATHER.  One block owns a 16 x 16-cell tile of one level of one
+// image and 32 channels; every thread keeps ITS cells' sums in registers (column cx, 4 channels, 8 rows), the block walks the ROI list
+// in index order and adds each ROI's contribution to the cells it owns -- no atomics, no accumulator planes, no finalize pass, every
+// cell of every map written exactly once (the caller does not zero anything), and the order of the additions is the ROI order, so the
+// result is bit-reproducible like the fixed-point form it replaces in the training step (1.44 ms of 64-bit atomics at 2048 ROIs x 128
+// channels -> see profiles/r05_roi_bwd_tile.txt).  Per ROI the arithmetic is k_roi_align_bwd_col's (separable axis footprints: fold the
+// bins of the thread's column, then one weighted sum per row); a ROI whose sampling grid does not fit ROI_AX cells per bin takes a
+// per-sample walk with the same weights.
+constexpr int RT = 16;        // tile side (cells)
+constexpr int RT_CG = 32;     // channels per block
+struct RoiTileP {
+    RoiBwdP b;
+    int n_images, cgroups, tiles_per_image;
+    int tile_off[5], tiles_x[4];
+    int accumulate;           // 1: dfeat += (the maps hold a gradient already), 0: dfeat = (default)
+};
+
+constexpr int RT_G = 8;       // ROIs whose axis tables are built per barrier round
+
+// ROIs are taken RT_G at a time: 16 threads per ROI build its two axis footprints (one (axis, bin) each, roi_axis_weights) and spread them
+// into DENSE tables over the tile's rows / columns, WyT[roi][tile row][bin] and WxT[roi][tile column][bin] (0 where a bin does not reach the
+// cell) -- one barrier pair per 8 ROIs; the owners then fold and add ROI after ROI with vector LDS reads and no branches on the tables.
+template <int PM>
+__global__ __launch_bounds__(256) void k_roi_align_bwd_tile(RoiTileP tp) {
+    __shared__ __attribute__((aligned(16))) float WyT[RT_G][RT][PM], WxT[RT_G][RT][PM];
+    // the round's dOut slices (P <= 8: 64 bins x 32 channels per ROI), requested together while the axis tables are built: one L2 round
+    // trip per round instead of one per ROI in the owners' fold loops
+    constexpr bool STAGE = PM <= 8;
+    __shared__ __attribute__((aligned(16))) float sD[STAGE ? RT_G : 1][STAGE ? 64 : 1][RT_CG];
+    __shared__ float s_inv[RT_G];
+    __shared__ int s_gen[RT_G], s_roi[RT_G];
+    __shared__ unsigned long long hits[4];
+    __shared__ short list[256];
+    const RoiBwdP& p = tp.b;
+    const int t = threadIdx.x, P = p.pooled;
+    int blk = blockIdx.x;
+    const int cg = blk % tp.cgroups; blk /= tp.cgroups;
+    const int img = blk / tp.tiles_per_image, tt = blk - img * tp.tiles_per_image;
+    int l = 0;
+    while (l + 1 < p.n_levels && tt >= tp.tile_off[l + 1]) ++l;
+    const int tl = tt - tp.tile_off[l], ty = tl / tp.tiles_x[l], tx = tl - ty * tp.tiles_x[l];
+    const int H = p.H[l], W = p.W[l];
+    const int quad = t & 7, cxl = (t >> 3) & 15, half = t >> 7;
+    const int c = cg * RT_CG + quad * 4;
+    const int cx = tx * RT + cxl, row0 = ty * RT + half * 8;
+    const int tile_x0 = tx * RT, tile_x1 = min(tx * RT + RT - 1, W - 1), tile_y0 = ty * RT, tile_y1 = min(ty * RT + RT - 1, H - 1);
+    const bool chan_ok = c < p.C;
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int base = 0; base < p.n; base += 256) {
+        // which of the 256 ROIs of this chunk are pooled from this (image, level) and can reach the tile?  (conservative: samples lie
+        // inside the ROI, a sample touches its cell and the next one)
+        const int r = base + t;
+        bool hit = false;
+        if (r < p.n && (p.bidx ? p.bidx[r] : 0) == img) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.boxes + (size_t)r * 4);
+            const float size = sqrtf((b.z - b.x) * (b.w - b.y));
+            float lv = floorf((float)p.canonical_level + log2f(size / p.canonical_size + 1e-8f));
+            lv = fminf(fmaxf(lv, (float)p.min_level), (float)(p.min_level + p.n_levels - 1));
+            if ((int)lv - p.min_level == l) {
+                const float sc = p.scale[l];
+                const float xa = b.x * sc - 0.5f, xb = b.z * sc - 0.5f, ya = b.y * sc - 0.5f, yb = b.w * sc - 0.5f;
+                const float xlo = fminf(xa, xb), xhi = fmaxf(xa, xb), ylo = fminf(ya, yb), yhi = fmaxf(ya, yb);
+                // non-finite boxes fail every comparison and are left out (the scatter forms drop their samples too)
+                hit = xhi >= (float)tile_x0 - 1.0f && xlo <= (float)tile_x1 + 1.0f && yhi >= (float)tile_y0 - 1.0f && ylo <= (float)tile_y1 + 1.0f;
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        __syncthreads();                                         // the previous chunk's readers of hits[] / list[] are done
+        if ((t & 63) == 0) hits[t >> 6] = bal;
+        __syncthreads();
+        int before = 0, count = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int pc = __popcll(hits[w]);
+            if (w < (t >> 6)) before += pc;
+            count += pc;
+        }
+        if (hit) list[before + __popcll(bal & ((1ull << (t & 63)) - 1ull))] = (short)t;       // index order is kept
+        for (int i0 = 0; i0 < count; i0 += RT_G) {
+            __syncthreads();                                     // list[] is written / the previous round's table readers are done
+            const int ng = min(RT_G, count - i0);
+            f32x4 stage[STAGE ? RT_G : 1][2];
+            if constexpr (STAGE) {
+                const int q4 = t & 7;
+                const bool ok = cg * RT_CG + q4 * 4 < p.C;
+#pragma unroll
+                for (int gi = 0; gi < RT_G; ++gi) {
+                    stage[gi][0] = stage[gi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (gi < ng && ok) {
+                        const float* sp = p.dout + (size_t)(base + list[i0 + gi]) * P * P * p.C + cg * RT_CG + q4 * 4;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int bin = (t >> 3) + 32 * i;
+                            if (bin < P * P) stage[gi][i] = *reinterpret_cast<const f32x4*>(sp + (size_t)bin * p.C);
+                        }
+                    }
+                }
+            }
+            if (t < RT_G * 16) {
+                const int gi = t >> 4, a = t & 15, ax = a >> 3, bin = a & 7;
+                // (PM = 16: two bins per thread; PM = 8: one)
+                if (i0 + gi < count) {
+                    const int rr = base + list[i0 + gi];
+                    const RoiGeo q = roi_geo(p, rr);
+                    int bad = 0;
+                    for (int bb = bin; bb < P; bb += 8) {
+                        float wv[ROI_AX];
+                        int b0 = 0;
+                        const int nn = ax == 0 ? roi_axis_weights(q.y0 + (float)bb * q.bh, q.bh, q.gh, q.H, wv, b0)
+                                               : roi_axis_weights(q.x0 + (float)bb * q.bw, q.bw, q.gw, q.W, wv, b0);
+                        bad |= nn < 0;
+                        float (*tab)[PM] = ax == 0 ? WyT[gi] : WxT[gi];
+                        const int t0 = ax == 0 ? tile_y0 : tile_x0;
+#pragma unroll
+                        for (int k = 0; k < RT; ++k) tab[k][bb] = 0.f;
+                        if (nn > 0) {
+#pragma unroll
+                            for (int k = 0; k < ROI_AX; ++k) {
+                                const int cell = b0 + k - t0;
+                                if (k < nn && cell >= 0 && cell < RT) tab[cell][bb] = wv[k];
+                            }
+                        }
+                    }
+                    // the 16 lanes of a ROI sit in one wave: any lane's "footprint too wide" sends the whole ROI to the per-sample walk
+                    const unsigned long long anyb = __ballot(bad != 0);
+                    const int sh = (t & 63) & ~15;
+                    if (a == 0) {
+                        s_gen[gi] = (int)((anyb >> sh) & 0xffffull) != 0;
+                        s_inv[gi] = 1.0f / q.cnt;
+                        s_roi[gi] = rr;
+                    }
+                    if (PM > 8 && P <= 8) { /* bins 8 .. PM-1 are never read when P <= 8 */ }
+                } else {
+                    (void)__ballot(false);
+                }
+            }
+            if constexpr (STAGE) {
+#pragma unroll
+                for (int gi = 0; gi < RT_G; ++gi)
+                    if (gi < ng) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&sD[gi][(t >> 3) + 32 * i][(t & 7) * 4]) = stage[gi][i];
+                    }
+            }
+            __syncthreads();
+            if (!chan_ok) continue;
+            for (int gi = 0; gi < ng; ++gi) {
+                const int rr = s_roi[gi];
+                const float* src = p.dout + (size_t)rr * P * P * p.C;
+                const float inv = s_inv[gi];
+                if (s_gen[gi]) {
+                    // oversized sampling grid: walk the samples; a sample adds to the (at most four) cells this thread owns
+                    const RoiGeo q = roi_geo(p, rr);
+                    for (int ph = 0; ph < P; ++ph)
+                        for (int pw = 0; pw < P; ++pw) {
+                            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                            bool loaded = false;
+                            for (int iy = 0; iy < q.gh; ++iy) {
+                                float y = q.y0 + (float)ph * q.bh + ((float)iy + 0.5f) * q.bh / (float)q.gh;
+                                if (y < -1.0f || y > (float)H) continue;
+                                if (y <= 0.f) y = 0.f;
+                                int yl = (int)y, yh;
+                                if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                                const float ly = y - (float)yl, hy = 1.f - ly;
+                                if (yh < row0 || yl > row0 + 7) continue;
+                                for (int ix = 0; ix < q.gw; ++ix) {
+                                    float x = q.x0 + (float)pw * q.bw + ((float)ix + 0.5f) * q.bw / (float)q.gw;
+                                    if (x < -1.0f || x > (float)W) continue;
+                                    if (x <= 0.f) x = 0.f;
+                                    int xl = (int)x, xh;
+                                    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                                    const float lx = x - (float)xl, hx = 1.f - lx;
+                                    if (xl != cx && xh != cx) continue;
+                                    if (!loaded) { g = *reinterpret_cast<const f32x4*>(src + (size_t)(ph * P + pw) * p.C + c) * inv; loaded = true; }
+                                    // the four corner adds of bilinear4_scatter, in its order, kept where they land on this thread's cells
+                                    const float wgt[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+                                    const int yy[4] = {yl, yl, yh, yh}, xx[4] = {xl, xh, xl, xh};
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        if (xx[k] != cx) continue;
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j)
+                                            if (yy[k] == row0 + j) acc[j] += wgt[k] * g;
+                                    }
+                                }
+                            }
+                        }
+                    continue;
+                }
+                // my column's bin weights; nothing to do when no bin reaches the column
+                float wx[PM];
+                bool col_hit = false;
+#pragma unroll
+                for (int v = 0; v < PM / 4; ++v) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&WxT[gi][cxl][v * 4]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { wx[v * 4 + k] = w4[k]; col_hit |= w4[k] != 0.f; }
+                }
+                if (!col_hit) continue;
+                f32x4 T[PM];
+#pragma unroll
+                for (int by = 0; by < PM; ++by) T[by] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int bx = 0; bx < PM; ++bx) {
+                    if (bx >= P || wx[bx] == 0.f) continue;
+                    const float w = wx[bx] * inv;
+#pragma unroll
+                    for (int by = 0; by < PM; ++by)
+                        if (by < P) {
+                            if constexpr (STAGE) T[by] += w * *reinterpret_cast<const f32x4*>(&sD[gi][by * P + bx][quad * 4]);
+                            else T[by] += w * *reinterpret_cast<const f32x4*>(src + (size_t)(by * P + bx) * p.C + c);
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int v = 0; v < PM / 4; ++v) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&WyT[gi][half * 8 + j][v * 4]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (v * 4 + k < P && w4[k] != 0.f) a += w4[k] * T[v * 4 + k];
+                    }
+                    acc[j] += a;
+                }
+            }
+        }
+    }
+    if (!chan_ok || cx >= W) return;
+    float* f = p.dfeat[l] + p.coff[l] + (size_t)img * H * W * p.ld[l];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cy = row0 + j;
+        if (cy >= H) continue;
+        float* d = f + (size_t)(cy * W + cx) * p.ld[l] + c;
+        f32x4 v = acc[j];
+        if (tp.accumulate) v += *reinterpret_cast<const f32x4*>(d);
+        *reinterpret_cast<f32x4*>(d) = v;
+    }
+}
+
 // dfeat[cell][coff + c] += the fixed-point sum of the cell (exact integer -> double -> float: one rounding)
 __global__ __launch_bounds__(256) void k_roi_bwd_finalize(const long long* __restrict__ acc, long long cells, int C, float* __restrict__ dfeat, int ld, int coff) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -999,4 +1243,38 @@ extern "C" int ore_roi_align_bwd_det(float* const* dfeat, const int32_t* ld, con
     ORE_CHECK_ARG(acc && n_images >= 1, "ore_roi_align_bwd_det: accumulators / image count");
     return roi_align_bwd_impl(dfeat, ld, coff, H, W, scales_host, n_levels, min_level, C, pooled, boxes, box_image, n, dout,
                               reinterpret_cast<long long* const*>(acc), n_images, stream);
+}
+
+extern "C" int ore_roi_align_bwd_tiled(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                                       const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                                       const float* boxes, const int32_t* box_image, int32_t n, const float* dout, int32_t n_images,
+                                       int32_t accumulate, void* stream) {
+    ORE_CHECK_ARG(dfeat && ld && coff && H && W && scales_host && boxes && dout, "ore_roi_align_bwd_tiled: null pointer");
+    ORE_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && C % 4 == 0 && pooled >= 1 && pooled <= ROI_PMAX && n >= 0 && n_images >= 1,
+                  "ore_roi_align_bwd_tiled: bad args");
+    ORE_CHECK_ARG(box_image || n_images == 1, "ore_roi_align_bwd_tiled: box_image is needed when there is more than one image");
+    RoiTileP tp{};
+    RoiBwdP& p = tp.b;
+    int tiles = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        ORE_CHECK_ARG(dfeat[l] && ld[l] % 4 == 0 && coff[l] % 4 == 0 && H[l] > 0 && W[l] > 0 && coff[l] + C <= ld[l], "ore_roi_align_bwd_tiled: level %d", l);
+        p.dfeat[l] = dfeat[l]; p.ld[l] = ld[l]; p.coff[l] = coff[l]; p.H[l] = H[l]; p.W[l] = W[l]; p.scale[l] = scales_host[l];
+        p.acc[l] = nullptr;
+        tp.tile_off[l] = tiles;
+        tp.tiles_x[l] = ceil_div(W[l], RT);
+        tiles += tp.tiles_x[l] * ceil_div(H[l], RT);
+    }
+    tp.tile_off[n_levels] = tiles;
+    tp.tiles_per_image = tiles;
+    tp.n_images = n_images;
+    tp.cgroups = ceil_div(C, RT_CG);
+    tp.accumulate = accumulate ? 1 : 0;
+    p.n_levels = n_levels; p.min_level = min_level; p.C = C; p.pooled = pooled;
+    p.canonical_size = 224.0f; p.canonical_level = 4;
+    p.boxes = boxes; p.n = n; p.dout = dout; p.bidx = box_image;
+    const long long blocks = (long long)n_images * tiles * tp.cgroups;
+    ORE_CHECK_ARG(blocks < (1ll << 31), "ore_roi_align_bwd_tiled: too many tiles");
+    if (pooled <= 8) hipLaunchKernelGGL(k_roi_align_bwd_tile<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tp);
+    else hipLaunchKernelGGL(k_roi_align_bwd_tile<ROI_PMAX>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tp);
+    return ore_launch_status("k_roi_align_bwd_tile");
 }

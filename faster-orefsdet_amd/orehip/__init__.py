@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_pack_conv_weights_multi_fwd", "ore_roi_align_bwd_det", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_pack_conv_weights_multi_fwd", "ore_roi_align_bwd_det", "ore_roi_align_bwd_tiled", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -614,6 +614,7 @@ def roi_align_batched(feats: Sequence[torch.Tensor], boxes: torch.Tensor, box_im
 
 
 ROI_BWD_DETERMINISTIC = True          # False: the fp32-atomics form of rounds 1-4 (order-dependent in the last bits; A/B aid)
+ROI_BWD_MODE = "tiled"                # the deterministic form: "tiled" (gather, one block per map tile, no atomics) | "fixed" (64-bit fixed-point atomics)
 
 
 def roi_align_bwd(dout: torch.Tensor, feats_like: Sequence[torch.Tensor], boxes: torch.Tensor, strides=(8, 16, 32), min_level: int = 3,
@@ -621,11 +622,17 @@ def roi_align_bwd(dout: torch.Tensor, feats_like: Sequence[torch.Tensor], boxes:
     """dout [n, pooled*pooled*C]; returns/accumulates into per-level gradient buffers shaped like feats_like ([H,W,ld] NHWC)."""
     L = len(feats_like)
     n = boxes.shape[0]
+    tiled = ROI_BWD_DETERMINISTIC and ROI_BWD_MODE == "tiled" and pooled <= 16
+    given = dfeats is not None
     if dfeats is None:
-        dfeats = [torch.zeros_like(f) for f in feats_like]
+        # the tiled form writes every cell of every map itself: nothing to zero
+        dfeats = [torch.empty_like(f, dtype=torch.float32) if tiled else torch.zeros_like(f) for f in feats_like]
     Cc = dfeats[0].shape[-1]
     assert dout.numel() == n * pooled * pooled * Cc
     if n == 0:
+        if tiled and not given:
+            for f in dfeats:
+                f.zero_()
         return list(dfeats)
     ptrs = (C.c_void_p * L)(*[_ptr(_f32(f)) for f in dfeats])
     ld = (C.c_int32 * L)(*[f.shape[-1] for f in dfeats])
@@ -634,6 +641,14 @@ def roi_align_bwd(dout: torch.Tensor, feats_like: Sequence[torch.Tensor], boxes:
     Ws = (C.c_int32 * L)(*[f.shape[-2] for f in dfeats])
     sc = (C.c_float * L)(*[1.0 / s for s in strides])
     n_img = 1 if dfeats[0].dim() == 3 else dfeats[0].shape[0]
+    assert box_image is not None or n_img == 1
+    if tiled:
+        # one block per (image, level, 16 x 16-cell tile, 32 channels) gathers the ROIs that reach its cells in index order: no atomics, no
+        # scratch, bit-reproducible (ore_roi_align_bwd_tiled)
+        _chk(lib().ore_roi_align_bwd_tiled(ptrs, ld, coff, Hs, Ws, sc, L, min_level, Cc, pooled, C.c_void_p(_ptr(_f32(boxes.float().contiguous()))),
+                                           C.c_void_p(_ptr(box_image)), n, C.c_void_p(_ptr(_f32(dout))), n_img, int(given), _stream()),
+             "ore_roi_align_bwd_tiled")
+        return list(dfeats)
     # Two ROIs of one image may touch the same cell: their sum must not depend on the order the blocks run in -> fixed-point accumulation
     # (ore_roi_align_bwd_det, one zeroed int64 scratch for all levels).  With at most one ROI per image (the support crops: one box each)
     # every cell receives ONE add from the column kernel, fp32 atomics are order-free there and the scratch (8 bytes per map element) is

@@ -273,6 +273,16 @@ int ore_roi_align_bwd_det(float* const* dfeat, const int32_t* ld, const int32_t*
                           const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
                           const float* boxes, const int32_t* box_image, int32_t n, const float* dout, int64_t* const* acc,
                           int32_t n_images, void* stream);
+
+/* The same gradient as a GATHER (round 5): one block owns a 16 x 16-cell tile of one level of one image and walks the ROI list in index
+ * order -- no atomics, no accumulator planes; EVERY cell of every map [n_images][H][W][ld] (channels coff .. coff + C) is written once
+ * (accumulate = 0; the maps need not be zeroed) or added to (accumulate = 1).  Bit-reproducible: the additions run in ROI order.
+ * box_image may be NULL only when n_images == 1.  n = 0 writes zeros.  (ref: the autograd of torchvision roi_align behind
+ * d2z:modeling/poolers.py:190-250; replaces ore_roi_align_bwd_det in the training step.) */
+int ore_roi_align_bwd_tiled(float* const* dfeat, const int32_t* ld, const int32_t* coff, const int32_t* H, const int32_t* W,
+                            const float* scales_host, int32_t n_levels, int32_t min_level, int32_t C, int32_t pooled,
+                            const float* boxes, const int32_t* box_image, int32_t n, const float* dout, int32_t n_images,
+                            int32_t accumulate, void* stream);
 size_t ore_roi_predict_workspace_bytes(int32_t cap);
 int ore_roi_predict_fwd(const float* h, int32_t C, const float* cls_w, const float* cls_b, const float* box_w,
                         const float* box_b, const float* boxes, const int32_t* n_dev, int32_t n_host, int32_t cap,

@@ -363,6 +363,55 @@ def test_roi_align_backward(oh):
         _close(a.grad.permute(2, 0, 1)[None], b.grad, tol=1e-5)
 
 
+@pytest.mark.parametrize("Cc,B,hw", [(128, 3, (80, 80)), (48, 2, (50, 38)), (16, 1, (23, 17))])
+def test_roi_align_backward_tiled_vs_scatter_forms(oh, Cc, B, hw):
+    """ore_roi_align_bwd_tiled (gather: one block per 16 x 16-cell tile, ROIs added in index order, no atomics) against the two scatter
+    forms it replaces in the training step -- fixed-point integer atomics (ore_roi_align_bwd_det) and fp32 atomics (ore_roi_align_bwd):
+    clustered ROIs (many per cell), ROIs hanging over every border, degenerate and inverted boxes, a ROI whose sampling grid exceeds the
+    separable path (bins wider than 7 cells), maps whose sides are not multiples of the tile, channel counts that are not multiples of 32."""
+    g = torch.Generator().manual_seed(Cc + B)
+    H0, W0 = hw
+    feats = [torch.empty(B, -(-H0 // (1 << l)), -(-W0 // (1 << l)), Cc, device="cuda") for l in range(3)]
+    n_per = 150
+    ctr = torch.rand(B * n_per, 2, generator=g) * torch.tensor([W0 * 8.0, H0 * 8.0])
+    ctr[: B * n_per // 2] = ctr[:4].repeat(B * n_per // 8 + 1, 1)[: B * n_per // 2] + torch.randn(B * n_per // 2, 2, generator=g) * 6     # clusters
+    wh = torch.exp(torch.rand(B * n_per, 2, generator=g) * 5.3 + 1.5)           # 4.5 .. 900 px: all three levels (224 px <-> level 4)
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    boxes[0] = torch.tensor([-300.0, -200.0, 2600.0, 2300.0])                   # bins wider than 7 cells on the coarsest level
+    boxes[1] = torch.tensor([50.0, 60.0, 50.0, 60.0])                           # empty
+    boxes[2] = torch.tensor([120.0, 90.0, 80.0, 40.0])                          # inverted
+    boxes[3] = torch.tensor([-500.0, -500.0, -400.0, -420.0])                   # entirely outside
+    boxes[4] = torch.tensor([W0 * 8.0 - 3, H0 * 8.0 - 3, W0 * 8.0 + 90, H0 * 8.0 + 70])
+    img = torch.arange(B, dtype=torch.int32).repeat_interleave(n_per)
+    perm = torch.randperm(B * n_per, generator=g)                               # images interleaved in the list
+    boxes, img = boxes[perm].contiguous().cuda(), img[perm].contiguous().cuda()
+    dout = torch.randn(B * n_per, 64 * Cc, generator=g).cuda()
+    outs = {}
+    saved = (oh.ROI_BWD_DETERMINISTIC, oh.ROI_BWD_MODE)
+    try:
+        for mode in ("tiled", "tiled2", "fixed", "atomic"):
+            oh.ROI_BWD_DETERMINISTIC, oh.ROI_BWD_MODE = mode != "atomic", "tiled" if mode.startswith("tiled") else "fixed"
+            outs[mode] = [d.clone() for d in oh.roi_align_bwd(dout, feats, boxes, box_image=img)]
+        oh.ROI_BWD_DETERMINISTIC, oh.ROI_BWD_MODE = True, "tiled"
+        base = [torch.randn(f.shape, generator=g).cuda() for f in feats]
+        acc = oh.roi_align_bwd(dout, feats, boxes, dfeats=[b.clone() for b in base], box_image=img)
+    finally:
+        oh.ROI_BWD_DETERMINISTIC, oh.ROI_BWD_MODE = saved
+    for l in range(3):
+        assert torch.equal(outs["tiled"][l], outs["tiled2"][l])                 # bit-reproducible
+        scale = float(outs["fixed"][l].abs().max())
+        assert scale > 0
+        assert float((outs["tiled"][l] - outs["fixed"][l]).abs().max()) <= 2e-6 * scale, l
+        assert float((outs["tiled"][l] - outs["atomic"][l]).abs().max()) <= 4e-6 * scale, l
+        assert float((acc[l] - (base[l] + outs["tiled"][l])).abs().max()) <= 1e-6 * (scale + float(base[l].abs().max()))    # given maps: added to
+    # a single image without an image list (the per-image autograd node)
+    one = [f[0] for f in feats]
+    sel = img == 0
+    a = oh.roi_align_bwd(dout[sel].contiguous(), one, boxes[sel].contiguous())
+    for l in range(3):
+        assert torch.equal(a[l], outs["tiled"][l][0])
+
+
 def test_centernet_loss_fn_backward(oh):
     from orehip import autograd as A
     g = torch.Generator().manual_seed(5)
@@ -1127,24 +1176,26 @@ def test_detect_batch_equals_per_image_detect(oh):
     image, exactly what ore_detect_fwd returns -- boxes, scores, keep indices and counts bit for bit (4000 / 0.9 / 2000 thresholds)."""
     import orehip
     g = torch.Generator().manual_seed(17)
-    B, shapes = 3, ((40, 48), (20, 24), (10, 12))
+    B, shapes = 5, ((40, 48), (20, 24), (10, 12))
     per_image = []
     for b in range(B):
         hs = []
         for (H, W) in shapes:
             h = torch.zeros(H, W, 16)
             h[..., :4] = torch.rand(H, W, 4, generator=g) * (3.0 + b) + 0.3
-            h[..., 4] = torch.randn(H, W, generator=g) * 2.0 - 1.0
+            h[..., 4] = torch.randn(H, W, generator=g) * 2.0 - (1.0 if b != 3 else 14.0)    # image 3: next to no candidates
             hs.append(h.cuda())
         per_image.append(hs)
     many = orehip.detect_batch(per_image, (8, 16, 32), 1e-5, 4000, 0.9, 2000)
     torch.cuda.synchronize()
     for b in range(B):
         one = orehip.detect(per_image[b], (8, 16, 32), 1e-5, 4000, 0.9, 2000)
-        n = int(one["counts"][1])
-        assert n > 100 and torch.equal(one["counts"], many[b]["counts"])
+        n, n_pre = int(one["counts"][1]), int(one["counts"][0])
+        assert (n > 100 or b == 3) and torch.equal(one["counts"], many[b]["counts"])
         for k in ("out_boxes", "out_scores", "keep_idx"):
             assert torch.equal(one[k][:n], many[b][k][:n]), (b, k)
+        for k in ("pre_boxes", "pre_scores", "pre_loc", "pre_level"):                 # (select / rank / mask of the batch share three launches)
+            assert torch.equal(one[k][:n_pre], many[b][k][:n_pre]), (b, k)
 
 
 def test_sample_rois_device_properties(oh):

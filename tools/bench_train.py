@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--no-kd", action="store_true", help="A/B aid: keep the small-M layers on k_conv_kw (plan override -12 0)")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"), help="bf16 = BASELINE configs[4]: frozen stages in bf16 storage, "
                     "bf16 MFMA operands in the trainable convs' forward / data / weight gradients, everything else fp32")
+    ap.add_argument("--roi-bwd", default=None, choices=("tiled", "fixed", "atomic"), help="A/B aid: the ROIAlign backward form (default: the library's)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -59,6 +60,8 @@ def main():
     m.train_graph = bool(a.graph)
     import orehip
     orehip.set_conv_precision(a.precision)
+    if a.roi_bwd:
+        orehip.ROI_BWD_DETERMINISTIC, orehip.ROI_BWD_MODE = a.roi_bwd != "atomic", "tiled" if a.roi_bwd == "tiled" else "fixed"
     if os.environ.get("ORE_GD_MODE"):
         orehip.lib().ore_conv_set_plan_override(-14, int(os.environ["ORE_GD_MODE"]), 0, 0, 0)
     if a.no_gd_large:
