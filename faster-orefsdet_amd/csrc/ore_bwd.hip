@@ -161,20 +161,36 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto load = [&](int m0, f32x4& va, f32x4& vb) {
-        va = f32x4{0.f, 0.f, 0.f, 0.f};
-        vb = va;
-        const int m = m0 + lr;
-        if (m < m_end) {
-            if (co0 + lc < p.Cout) va = *reinterpret_cast<const f32x4*>(p.dz + (size_t)m * p.dz_ld + p.dz_coff + co0 + lc);
-            const int xq = m % p.W, yq = (m / p.W) % p.H;
+    // operands through buffer descriptors sized to this block's rows (see k_wgrad3): rows / column groups outside read as zeros in
+    // hardware; the tap's validity (row of the image, column of the image) only exists for kernels larger than 1x1 and is carried from
+    // step to step instead of divided out
+    const int x_first = max(0, m_begin + dy * p.W + dx);
+    const int x_last = min(p.M, m_end + dy * p.W + dx + WG_K);                     // exclusive
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz + (size_t)m_begin * p.dz_ld), 0,
+                                                                         (int)((unsigned)(m_end - m_begin) * (unsigned)p.dz_ld * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)x_first * p.x_ld), 0,
+                                                                         (int)((unsigned)max(x_last - x_first, 0) * (unsigned)p.x_ld * 4u), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned vz = co0 + lc < p.Cout ? (unsigned)(lr * p.dz_ld + p.dz_coff + co0 + lc) * 4u : OOB;
+    unsigned vx = ci0 + lc < p.Cin ? (unsigned)((m_begin + lr + dy * p.W + dx - x_first) * p.x_ld + p.x_coff + ci0 + lc) * 4u : OOB;
+    const unsigned step_z = (unsigned)(WG_K * p.dz_ld) * 4u, step_x = (unsigned)(WG_K * p.x_ld) * 4u;
+    const bool multi = p.kh * p.kw > 1;
+    int xq = 0, yq = 0;
+    if (multi) { xq = (m_begin + lr) % p.W; yq = ((m_begin + lr) / p.W) % p.H; }
+    auto load = [&](f32x4& va, f32x4& vb) {
+        va = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)vz, 0, 0));
+        bool ok = true;
+        if (multi) {
             const int ys = yq + dy, xs = xq + dx;
-            if (ci0 + lc < p.Cin && ys >= 0 && ys < p.H && xs >= 0 && xs < p.W)
-                vb = *reinterpret_cast<const f32x4*>(p.x + (size_t)(m + dy * p.W + dx) * p.x_ld + p.x_coff + ci0 + lc);
+            ok = ys >= 0 && ys < p.H && xs >= 0 && xs < p.W;
+            xq += WG_K;
+            while (xq >= p.W) { xq -= p.W; if (++yq == p.H) yq = 0; }
         }
+        vb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (int)vx : (int)OOB, 0, 0));
+        vz += step_z; vx += step_x;
     };
     f32x4 va, vb;
-    load(m_begin, va, vb);
+    load(va, vb);
     const bool do_b = p.db != nullptr && blockIdx.y == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     int buf = 0;
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
             *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
             *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
             __syncthreads();
-            if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb);          // next step's global loads fly under this step's MFMAs
+            if (m0 + WG_K < m_end) load(va, vb);                     // next step's global loads fly under this step's MFMAs
             if constexpr (TM > 0 && TN > 0) {
 #pragma unroll
                 for (int kk = 0; kk < WG_K / 4; ++kk) {
@@ -239,7 +255,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradP p) {
 __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
     __shared__ float sA[2][WG_K][WG_LD];       // dZ rows x co
     __shared__ float sB[2][WG_K + 2][WG_LD];   // X rows (m0 + dy*W - 1 ...) x ci
-    __shared__ int sM[2][WG_K];                // bit dx: tap (dy, dx) of this output row reads inside the image
+    __shared__ float sMf[2][WG_K][2];          // 1 / 0: tap (dy, -1) / (dy, +1) of this output row reads inside the image row (a row whose
+                                               // (dy) neighbour row leaves the image is staged as zeros: no mask for the centre tap)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wg_wave();
     const int wm = wave >> 1, wn = wave & 1;
@@ -258,26 +275,40 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[d][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto xrow = [&](int r, f32x4& v) {                       // X row r of the flattened [M] pixel order, zero outside
-        v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (r >= 0 && r < p.M && ci0 + lc < p.Cin) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)r * p.x_ld + p.x_coff + ci0 + lc);
-    };
-    auto load = [&](int m0, f32x4& va, f32x4& vb, f32x4& vb2, int& msk) {
-        va = f32x4{0.f, 0.f, 0.f, 0.f};
-        msk = 0;
-        const int m = m0 + lr;
-        if (m < m_end) {
-            if (co0 + lc < p.Cout) va = *reinterpret_cast<const f32x4*>(p.dz + (size_t)m * p.dz_ld + p.dz_coff + co0 + lc);
-            const int xq = m % p.W, ys = (m / p.W) % p.H + dy;
-            if (ys >= 0 && ys < p.H) msk = (xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.W ? 4 : 0);
-        }
-        xrow(m0 + lr + dy * p.W - 1, vb);                   // staged rows 0..15
-        vb2 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lr < 2) xrow(m0 + WG_K + lr + dy * p.W - 1, vb2);   // staged rows 16, 17
+    // Both operands come through buffer descriptors sized to what THIS block may read: dZ rows [m_begin, m_end), X rows from the first
+    // row a tap can reach (m_begin + dy W - 1, not below 0) to the last (not beyond M).  A row outside -- before the tensor, behind the
+    // chunk, behind the tensor -- and a column group beyond Cout / Cin (offset forced out of range) read as zeros in hardware: no
+    // branches, no zero-initialised registers, and the per-step address work is one add per load.  (Byte ranges stay below 2^31: checked
+    // on the host.)  The loop's vector instructions share the issue port with the MFMAs -- the round-4 form of this loop spent 3.3 of
+    // them per MFMA and kept the matrix pipe 61 % busy.
+    const int x_first = max(0, m_begin + dy * p.W - 1);
+    const int x_last = min(p.M, m_end + dy * p.W + WG_K + 2);                      // exclusive
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz + (size_t)m_begin * p.dz_ld), 0,
+                                                                         (int)((unsigned)(m_end - m_begin) * (unsigned)p.dz_ld * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)x_first * p.x_ld), 0,
+                                                                         (int)((unsigned)max(x_last - x_first, 0) * (unsigned)p.x_ld * 4u), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned vz = co0 + lc < p.Cout ? (unsigned)(lr * p.dz_ld + p.dz_coff + co0 + lc) * 4u : OOB;
+    const bool ci_ok = ci0 + lc < p.Cin;
+    unsigned vx = ci_ok ? (unsigned)((m_begin + lr + dy * p.W - 1 - x_first) * p.x_ld + p.x_coff + ci0 + lc) * 4u : OOB;
+    unsigned vx2 = ci_ok && lr < 2 ? vx + (unsigned)(WG_K * p.x_ld) * 4u : OOB;
+    const unsigned step_z = (unsigned)(WG_K * p.dz_ld) * 4u, step_x = (unsigned)(WG_K * p.x_ld) * 4u;
+    // (x, y) of this thread's row inside its image, carried from step to step (a step advances the row by WG_K) instead of two integer
+    // divisions per thread and step
+    int xq = (m_begin + lr) % p.W, yq = ((m_begin + lr) / p.W) % p.H;
+    auto load = [&](f32x4& va, f32x4& vb, f32x4& vb2, int& msk) {
+        va = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)vz, 0, 0));
+        vb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vx, 0, 0));       // staged rows 0..15
+        vb2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vx2, 0, 0));     // staged rows 16, 17 (lr < 2)
+        vz += step_z; vx += step_x; vx2 += step_x;
+        const int ys = yq + dy;
+        msk = (ys >= 0 && ys < p.H) ? ((xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.W ? 4 : 0)) : 0;       // (rows behind m_end read dZ = 0: any mask)
+        xq += WG_K;
+        while (xq >= p.W) { xq -= p.W; if (++yq == p.H) yq = 0; }
     };
     f32x4 va, vb, vb2;
     int msk;
-    load(m_begin, va, vb, vb2, msk);
+    load(va, vb, vb2, msk);
     const bool do_b = p.db != nullptr && blockIdx.y == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     int buf = 0;
@@ -286,17 +317,17 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
         for (int m0 = m_begin; m0 < m_end; m0 += WG_K) {
             if (do_b) bsum += va;
             if (p.bf16) { va = bf16_rne4(va); vb = bf16_rne4(vb); vb2 = bf16_rne4(vb2); }
-            *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = va;
+            *reinterpret_cast<f32x4*>(&sA[buf][lr][lc]) = (msk & 2) ? va : f32x4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(&sB[buf][lr][lc]) = vb;
             if (lr < 2) *reinterpret_cast<f32x4*>(&sB[buf][WG_K + lr][lc]) = vb2;
-            if ((tid & 15) == 0) sM[buf][lr] = msk;
+            if ((tid & 15) == 0) { sMf[buf][lr][0] = (msk & 1) ? 1.f : 0.f; sMf[buf][lr][1] = (msk & 4) ? 1.f : 0.f; }
             __syncthreads();
-            if (m0 + WG_K < m_end) load(m0 + WG_K, va, vb, vb2, msk);
+            if (m0 + WG_K < m_end) load(va, vb, vb2, msk);
             if constexpr (TM > 0 && TN > 0) {
 #pragma unroll
                 for (int kk = 0; kk < WG_K / 4; ++kk) {
                     const int k = kk * 4 + (lane >> 4);
-                    const int mk = sM[buf][k];
+                    const float mL = sMf[buf][k][0], mR = sMf[buf][k][1];
                     float a[TM];
 #pragma unroll
                     for (int t = 0; t < TM; ++t) a[t] = sA[buf][k][wm * 32 + t * 16 + (lane & 15)];
@@ -305,10 +336,11 @@ __global__ __launch_bounds__(256) void k_wgrad3(WgradP p) {
                         float b[TN];
 #pragma unroll
                         for (int t = 0; t < TN; ++t) b[t] = sB[buf][k + d][wn * 32 + t * 16 + (lane & 15)];
-                        const bool on = (mk >> d) & 1;
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm) {
-                            const float am = on ? a[tm] : 0.f;
+                            // (a product with 0 / 1 instead of a select: dZ is finite where it matters -- an inf / NaN gradient row is
+                            // poisoned anyway through the centre tap)
+                            const float am = d == 0 ? a[tm] * mL : d == 2 ? a[tm] * mR : a[tm];
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn)
                                 acc[d][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, b[tn], acc[d][tm][tn], 0, 0, 0);
@@ -403,36 +435,49 @@ __global__ __launch_bounds__(256) void k_wgrad_bf(WgradP p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[d][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto ld8 = [&](const float* base, bool ok, int cbase, int cmax, f32x4& a, f32x4& b) {
-        a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a;
-        if (ok && cbase < cmax) a = *reinterpret_cast<const f32x4*>(base);
-        if (ok && cbase + 4 < cmax) b = *reinterpret_cast<const f32x4*>(base + 4);
-    };
+    // operands through buffer descriptors sized to this block's rows (see k_wgrad3): rows / column groups outside read as zeros in
+    // hardware, the row's image coordinates are carried from step to step
+    const int xshift = K3 ? dy * p.W - 1 : dy * p.W + dx1;
+    const int x_first = max(0, m_begin + xshift);
+    const int x_last = min(p.M, m_end + xshift + WB_K + (K3 ? 2 : 0));             // exclusive
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz + (size_t)m_begin * p.dz_ld), 0,
+                                                                         (int)((unsigned)(m_end - m_begin) * (unsigned)p.dz_ld * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)x_first * p.x_ld), 0,
+                                                                         (int)((unsigned)max(x_last - x_first, 0) * (unsigned)p.x_ld * 4u), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned z0 = (unsigned)(lr * p.dz_ld + p.dz_coff + co0 + lc) * 4u;
+    const unsigned x0 = (unsigned)((m_begin + lr + xshift - x_first) * p.x_ld + p.x_coff + ci0 + lc) * 4u;
+    unsigned vz0 = co0 + lc < p.Cout ? z0 : OOB, vz1 = co0 + lc + 4 < p.Cout ? z0 + 16u : OOB;
+    unsigned vx0 = ci0 + lc < p.Cin ? x0 : OOB, vx1 = ci0 + lc + 4 < p.Cin ? x0 + 16u : OOB;
+    const unsigned step_z = (unsigned)(WB_K * p.dz_ld) * 4u, step_x = (unsigned)(WB_K * p.x_ld) * 4u;
+    unsigned vy0 = K3 && lr < 2 && vx0 != OOB ? vx0 + step_x : OOB, vy1 = K3 && lr < 2 && vx1 != OOB ? vx1 + step_x : OOB;
+    const bool coords = K3 || p.kh * p.kw > 1;
+    int xq = 0, yq = 0;
+    if (coords) { xq = (m_begin + lr) % p.W; yq = ((m_begin + lr) / p.W) % p.H; }
+    auto bl = [&](const __amdgpu_buffer_rsrc_t& r, unsigned v) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)v, 0, 0)); };
     f32x4 za, zb, xa, xb, ya, yb;                          // dZ row, X row, (K3) the extra X row of threads lr < 2
     int msk = 0;
-    auto load = [&](int m0) {
-        const int m = m0 + lr;
-        const bool rv = m < m_end;
-        ld8(p.dz + (size_t)(rv ? m : 0) * p.dz_ld + p.dz_coff + co0 + lc, rv, co0 + lc, p.Cout, za, zb);
+    auto load = [&](int) {
+        za = bl(rz, vz0); zb = bl(rz, vz1);
         if constexpr (K3) {
-            msk = 0;
-            if (rv) {
-                const int xq = m % p.W, ys = (m / p.W) % p.H + dy;
-                if (ys >= 0 && ys < p.H) msk = (xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.W ? 4 : 0);
-            }
-            const int r = m0 + lr + dy * p.W - 1;
-            ld8(p.x + (size_t)(r >= 0 && r < p.M ? r : 0) * p.x_ld + p.x_coff + ci0 + lc, r >= 0 && r < p.M, ci0 + lc, p.Cin, xa, xb);
-            const int r2 = m0 + WB_K + lr + dy * p.W - 1;
-            ld8(p.x + (size_t)(r2 >= 0 && r2 < p.M ? r2 : 0) * p.x_ld + p.x_coff + ci0 + lc, lr < 2 && r2 >= 0 && r2 < p.M, ci0 + lc, p.Cin, ya, yb);
+            const int ys = yq + dy;
+            msk = (ys >= 0 && ys < p.H) ? ((xq > 0 ? 1 : 0) | 2 | (xq + 1 < p.W ? 4 : 0)) : 0;     // (rows behind m_end read dZ = 0: any mask)
+            xa = bl(rx, vx0); xb = bl(rx, vx1);
+            ya = bl(rx, vy0); yb = bl(rx, vy1);
+            vy0 += step_x; vy1 += step_x;
         } else {
-            bool xv = false;
-            if (rv) {
-                const int xq = m % p.W, yq = (m / p.W) % p.H;
+            bool xv = true;
+            if (coords) {
                 const int ys = yq + dy, xs = xq + dx1;
                 xv = ys >= 0 && ys < p.H && xs >= 0 && xs < p.W;
             }
-            ld8(p.x + (size_t)(xv ? m + dy * p.W + dx1 : 0) * p.x_ld + p.x_coff + ci0 + lc, xv, ci0 + lc, p.Cin, xa, xb);
+            xa = bl(rx, xv ? vx0 : OOB); xb = bl(rx, xv ? vx1 : OOB);
         }
+        if (coords) {
+            xq += WB_K;
+            while (xq >= p.W) { xq -= p.W; if (++yq == p.H) yq = 0; }
+        }
+        vz0 += step_z; vz1 += step_z; vx0 += step_x; vx1 += step_x;
     };
     load(m_begin);
     const bool do_b = p.db != nullptr && blockIdx.y == 0;
@@ -975,6 +1020,8 @@ extern "C" int ore_conv2d_wgrad_bias_fwd(const float* x, int32_t x_ld, int32_t x
                   x_coff + Cin <= x_ld && dz_coff + Cout <= dz_ld, "ore_conv2d_wgrad_fwd: channel counts/offsets must be multiples of 4 and fit ld");
     const long long M = (long long)B * H * W;
     ORE_CHECK_ARG(M < (1ll << 31), "ore_conv2d_wgrad_fwd: too many rows");
+    // (the kernels address a block's rows through 32-bit buffer offsets: a chunk of rows + its halo must span less than 2^31 bytes --
+    // with the <= 1536-block row split that is a tensor of several hundred GB)
     const long long pw = (long long)Cout * kh * kw * Cin;
     const long long per = pw + Cout;                                   // slab = weight part + bias part
     const int tiles = wgrad_tiles(Cin, Cout, kh, kw);
@@ -987,6 +1034,8 @@ extern "C" int ore_conv2d_wgrad_bias_fwd(const float* x, int32_t x_ld, int32_t x
     const bool bfm = ore_conv_get_precision() == ORE_CONV_BF16;        // bf16 MFMA build: 32-row steps
     p.M = (int)M; p.chunk = round_up(ceil_div((int)M, S), bfm ? WB_K : WG_K);
     S = ceil_div((int)M, p.chunk);
+    ORE_CHECK_ARG(((long long)p.chunk + 2ll * W + 64) * (long long)max(x_ld, dz_ld) * 4 < (1ll << 31),
+                  "ore_conv2d_wgrad_fwd: a row split of %d rows x %d floats exceeds the 2 GiB a block addresses (give more workspace)", p.chunk, max(x_ld, dz_ld));
     p.slab = workspace; p.slab_stride = per;
     p.db = db; p.beta_b = beta_b;
     if (S == 1) { p.dw = dw_oihw; p.beta = beta; }

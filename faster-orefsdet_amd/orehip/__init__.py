@@ -509,23 +509,32 @@ def get_conv_precision() -> str:
     return ("fp32", "bf16", "bf16s")[int(lib().ore_conv_get_precision())]
 
 
-def _detect_desc(heads: Sequence[torch.Tensor], strides, score_thresh, pre_topk, nms_thresh, post_topk, d: "DetectDesc"):
-    """Allocate one image's outputs + workspace and fill its descriptor."""
-    L = len(heads)
-    dev = heads[0].device
+def _detect_spec(L: int, pre_topk: int):
     cap = L * pre_topk
     capa = (cap + 3) // 4 * 4                                   # one zero-filled allocation carved into the 8 outputs (16-byte aligned)
     spec = (("pre_boxes", torch.float32, 4 * capa, (cap, 4)), ("pre_scores", torch.float32, capa, (cap,)),
             ("pre_loc", torch.int64, capa, (cap,)), ("pre_level", torch.int32, capa, (cap,)), ("keep_idx", torch.int64, capa, (cap,)),
             ("counts", torch.int32, 4, (4,)), ("out_boxes", torch.float32, 4 * capa, (cap, 4)), ("out_scores", torch.float32, capa, (cap,)))
-    raw = torch.zeros(sum(n * (8 if dt == torch.int64 else 4) for _, dt, n, _ in spec), dtype=torch.uint8, device=dev)
+    return spec, sum(n * (8 if dt == torch.int64 else 4) for _, dt, n, _ in spec)
+
+
+def _detect_desc(heads: Sequence[torch.Tensor], strides, score_thresh, pre_topk, nms_thresh, post_topk, d: "DetectDesc",
+                 raw: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+    """Allocate one image's outputs + workspace (or carve them out of the caller's `raw` (zeroed) / `ws`) and fill its descriptor."""
+    L = len(heads)
+    dev = heads[0].device
+    cap = L * pre_topk
+    spec, raw_bytes = _detect_spec(L, pre_topk)
+    if raw is None:
+        raw = torch.zeros(raw_bytes, dtype=torch.uint8, device=dev)
     o, off = {}, 0
     for name, dt, n, shape in spec:
         nb = n * (8 if dt == torch.int64 else 4)
         o[name] = raw[off:off + nb].view(dt)[: shape[0] * (4 if len(shape) == 2 else 1)].view(shape)
         off += nb
     wsb = lib().ore_detect_workspace_bytes(L, pre_topk)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    if ws is None:
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     d.n_levels, d.head_ld = L, heads[0].shape[-1]
     for l, h in enumerate(heads):
         _f32(h)
@@ -554,7 +563,15 @@ def detect_batch(heads_per_image: Sequence[Sequence[torch.Tensor]], strides: Seq
     outputs of `detect`, bit for bit.  No host sync inside."""
     B = len(heads_per_image)
     ds = (DetectDesc * B)()
-    outs = [_detect_desc(heads_per_image[b], strides, score_thresh, pre_topk, nms_thresh, post_topk, ds[b]) for b in range(B)]
+    # the outputs and workspaces of all images from two allocations (ONE zero fill instead of B)
+    L = len(heads_per_image[0])
+    _, raw_bytes = _detect_spec(L, pre_topk)
+    raw_bytes = (raw_bytes + 255) // 256 * 256
+    wsb = (int(lib().ore_detect_workspace_bytes(L, pre_topk)) + 255) // 256 * 256
+    dev = heads_per_image[0][0].device
+    raw = torch.zeros(B, raw_bytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(B, wsb, dtype=torch.uint8, device=dev)
+    outs = [_detect_desc(heads_per_image[b], strides, score_thresh, pre_topk, nms_thresh, post_topk, ds[b], raw[b], ws[b]) for b in range(B)]
     _chk(lib().ore_detect_batch_fwd(ds, B, _stream()), "ore_detect_batch_fwd")
     return outs
 
