@@ -36,4 +36,4 @@ extern "C" int ore_flop_counter_read(double* flops, int64_t* calls, int32_t rese
     return ORE_OK;
 }
 extern "C" int32_t ore_det_record_rows(void) { return ORE_DET_RECORD_ROWS; }
-extern "C" int ore_version(void) { return 503; }   // round*100 + revision: bumped whenever a kernel on the eval path changes (bench.py keys the PMC traffic file on it)
+extern "C" int ore_version(void) { return 504; }   // round*100 + revision: bumped whenever a kernel on the eval path changes (bench.py keys the PMC traffic file on it)

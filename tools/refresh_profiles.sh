@@ -30,6 +30,16 @@ for PR in fp32 bf16; do
   cp $OUT/${TAG}_train_step_bs16_${PR}_summary.json profiles/${TAG}_train_step_bs16_${PR}_summary.json
   rm -rf $OUT/train_$PR
 done
+# 3b'. the bs-1 step (graph-captured dense part), the per-call conv tables, the ROIAlign-backward forms, the box's MFMA / HBM ceilings
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_bs1 -o train -- python3 tools/bench_train.py --batch 1 --steps 20 --warmup 5 > $OUT/train_bs1.log 2>&1
+python3 tools/stats_top.py $(ls $OUT/train_bs1/train_kernel_stats.csv $OUT/train_bs1/*/train_kernel_stats.csv 2>/dev/null | head -1) 25 45 > $OUT/${TAG}_train_step_bs1_kernel_stats.txt
+rm -rf $OUT/train_bs1
+timeout -k 10 200 python3 tools/train_conv_table.py > $OUT/${TAG}_train_conv_table_bs16_fp32.txt 2> /dev/null
+timeout -k 10 200 python3 tools/train_conv_table.py --precision bf16 > $OUT/${TAG}_train_conv_table_bs16_bf16.txt 2> /dev/null
+timeout -k 10 200 python3 tools/train_glue_probe.py > $OUT/${TAG}_train_glue_aten.txt 2> /dev/null
+timeout -k 10 200 python3 tools/roi_bwd_bench.py > $OUT/${TAG}_roi_bwd_tile.txt 2> /dev/null
+timeout -k 10 100 python3 tools/hbm_bw_probe.py 2> /dev/null | grep -v amdgpu.ids > $OUT/${TAG}_hbm_bw.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_peak tools/mfma_peak.hip && timeout -k 10 100 /tmp/mfma_peak > $OUT/${TAG}_mfma_peak.txt
 # 3c. the default bench command under the kernel trace (the judged line + its rocprof summary)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 cp $(ls $OUT/bench/bench_kernel_stats.csv $OUT/bench/*/bench_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_bench_kernel_stats.csv
