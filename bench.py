@@ -202,7 +202,11 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
     prev_precision = orehip.set_conv_precision(precision)
     model, cfg = build_model(device)
     model.train()
-    model.train_graph = graph       # the shape-static dense part (fwd + bwd) replays as two hipGraphs; falls back to eager if capture fails
+    # graph = True: the shape-static dense part (fwd + bwd) replays as two hipGraphs; graph = "step": the WHOLE iteration (forward, losses,
+    # backward, clip + SGD) is captured once and replayed (fewx.solver.GraphedTrainStep, single process); either falls back to eager if
+    # the capture fails (reported below)
+    whole = graph == "step" and world == 1
+    model.train_graph = bool(graph) and not whole
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():                                   # second-stage weights: small, so the synthetic losses stay finite
         for n, p in model.named_parameters():
@@ -226,7 +230,16 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
         items.append({"image": synth_image(7 + b + 5000 * rank, size, size).to(device), "instances": inst, "support_images": sup,
                       "support_bboxes": torch.cat([c - side / 2, c + side / 2], 1).numpy()})
 
+    stepper = None
+    if whole:
+        from fewx.solver import GraphedTrainStep
+        stepper = GraphedTrainStep(model, opt)
+
     def step():
+        if stepper is not None and model.__dict__.get("_ore_count_flops") is None:
+            losses = stepper(items)
+            sched.step()
+            return losses
         losses = net(items)
         opt.zero_grad()
         sum(losses.values()).backward()
@@ -253,10 +266,12 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
     # algorithmic FLOPs of one step, counted by the library as the per-op conv calls are made (ore_flop_counter_read): one EAGER step (a
     # replayed hipGraph makes no calls), outside the timed region
     model.train_graph = False
+    model.__dict__["_ore_count_flops"] = True               # (this one step runs eagerly whatever the mode)
     orehip.flop_counter(reset=True)
-    step()
+    last = step()
     step_flops, conv_calls = orehip.flop_counter(reset=True)
-    model.train_graph = graph
+    del last, model.__dict__["_ore_count_flops"]
+    model.train_graph = bool(graph) and not whole
     step()
     el, losses = timed(steps)
     n_steps = steps
@@ -266,10 +281,13 @@ def train_leg(device, steps=8, warmup=4, size=640, shots=24, batch=1, graph=True
     out = {"images_per_s": round(world * batch * n_steps / el, 2), "n_gpus": world, "batch_per_gpu": batch, "global_batch": world * batch,
            "ms_per_step": round(el / n_steps * 1e3, 3), "steps": n_steps, "warmup": warmup, "dtype": "bf16" if precision == "bf16" else "f32",
            "workload": "finetune_vovnet.yaml train step: %d x (1 query %dx%d + %d support 240x240) per GPU, fwd + bwd (HIP backward kernels) + "
-                       "%sflat-bucket clip/SGD, FREEZE_AT=3%s" % (batch, size, size, shots, "RCCL all-reduce of the gradient bucket + " if world > 1 else "",
+                       "%sflat-bucket clip/SGD, FREEZE_AT=3%s%s" % (batch, size, size, shots, "RCCL all-reduce of the gradient bucket + " if world > 1 else "",
+                                                                   "; the whole iteration replayed as one hipGraph" if stepper is not None and stepper.error is None else "",
                                                                    "; bf16: frozen stages in bf16 storage, bf16 MFMA operands in the trainable convs' forward / "
                                                                    "data / weight gradients, fp32 accumulation, fp32 NMS / losses / optimizer" if precision == "bf16" else ""),
-           "dense_part_hipgraph": bool(graph) and model.__dict__.get("_ore_train_graph_error") is None,
+           "dense_part_hipgraph": bool(graph) and not whole and model.__dict__.get("_ore_train_graph_error") is None,
+           "whole_step_hipgraph": bool(stepper is not None and stepper.error is None and stepper.replays > 0),
+           "whole_step_hipgraph_error": None if stepper is None else stepper.error,
            "exchanged_bytes_per_step": 4 * opt.bucket.size if world > 1 else 0, "bucket_bytes": 4 * opt.bucket.size,
            "loss_sum": round(float(sum(v.detach() for v in losses.values())), 4)}
     peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
@@ -708,10 +726,10 @@ def main():
     if not args.no_train_leg:
         try:
             if world == 1:
-                train["train_step"] = train_leg(device, min_time=0.3)
-                train["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, min_time=0.8)   # BASELINE configs[2]
+                train["train_step"] = train_leg(device, min_time=0.3, graph="step")
+                train["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph="step", min_time=0.8)   # BASELINE configs[2]
                 # BASELINE configs[4] ("bf16 MFMA conv path + fp32 NMS") on one GPU: its own dtype, never mixed into `value`
-                train["train_step_bs16_bf16"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, min_time=0.8, precision="bf16")
+                train["train_step_bs16_bf16"] = train_leg(device, steps=6, warmup=3, batch=16, graph="step", min_time=0.8, precision="bf16")
             else:                                           # BASELINE configs[3]: 16 per GPU, gradients over RCCL
                 train["train_step"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, world=world, rank=rank, min_time=0.8)
         except Exception as ex:                             # the headline line must survive a failure of the side measurement

@@ -249,7 +249,8 @@ def roi_stage_losses(rh, qf: List[torch.Tensor], sup8: torch.Tensor, roi_boxes, 
     return {"loss_cls_stage0": loss_cls, "loss_box_reg_stage0": loss_box}, dict(scores=scores, deltas=deltas, h=h)
 
 
-def first_stage_batch(pg, heads: List[torch.Tensor], gts: List[torch.Tensor], norm_avg: Optional[torch.Tensor] = None):
+def first_stage_batch(pg, heads: List[torch.Tensor], gts: Optional[List[torch.Tensor]], norm_avg: Optional[torch.Tensor] = None,
+                      padded=None):
     """CenterNet.forward, training branch, after the head, for the B images of a call (ref:fewx/modeling/fsod/fsod_rpn.py:658-700) with
     NO host sync: ground truth of all images in one launch, the three losses over all rows in one (normalisers the reference's
     max(reduce_sum / num_gpus, 1) over the rank's whole batch -- orehip.autograd.CenterNetLossFn), the *_TRAIN proposals per image.
@@ -260,7 +261,8 @@ def first_stage_batch(pg, heads: List[torch.Tensor], gts: List[torch.Tensor], no
     B = heads[0].shape[0]
     shapes = [tuple(h.shape[1:3]) for h in heads]
     rows = torch.cat([h.reshape(-1, h.shape[-1]) for h in heads], 0)       # level-major, the images of a level in order: the targets' rows
-    tg = orehip.centernet_targets(gts, shapes, pg.strides, pg.sizes_of_interest, pg.hm_min_overlap, pg.min_radius, device=dev)
+    # `padded` = (boxes [B,G,4], counts [B] int32) on the device: the fixed-shape form a captured step uses
+    tg = orehip.centernet_targets(gts, shapes, pg.strides, pg.sizes_of_interest, pg.hm_min_overlap, pg.min_radius, device=dev, padded=padded)
     hp = dict(gamma=pg.loss_gamma, beta=pg.hm_focal_beta, sigmoid_clamp=pg.sigmoid_clamp, ignore_high_fp=pg.ignore_high_fp,
               alpha=pg.hm_focal_alpha, pos_weight=pg.pos_weight, neg_weight=pg.neg_weight, reg_weight=pg.reg_weight, images=B,
               norm_avg=norm_avg)
@@ -315,13 +317,22 @@ def sample_rois_device(rh, prop: torch.Tensor, prop_n: torch.Tensor, gtp: torch.
     boxes = cand.gather(1, pick[:, :, None].expand(B, R, 4))
     lab = labels.gather(1, pick)
     gt = gtp.gather(1, midx.gather(1, pick)[:, :, None].expand(B, R, 4))
-    pad = torch.tensor([0.0, 0.0, 8.0, 8.0], device=dev)
-    boxes = torch.where(valid[:, :, None], boxes, pad)
+    boxes = torch.where(valid[:, :, None], boxes, _pad_box(dev))
     lab = torch.where(valid, lab, 1)
     return boxes.contiguous(), lab, gt, valid
 
 
 _ROI_IMAGE = {}
+_PAD_BOX = {}
+
+
+def _pad_box(dev) -> torch.Tensor:
+    """The box of a padding row, uploaded once per device (a captured step may not copy from pageable host memory)."""
+    k = str(dev)
+    if k not in _PAD_BOX:
+        _PAD_BOX[k] = torch.tensor([0.0, 0.0, 8.0, 8.0]).to(dev)
+    return _PAD_BOX[k]
+
 
 
 def _roi_image(B: int, R: int, dev) -> torch.Tensor:
@@ -401,17 +412,19 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
     labels, gt} replaces the sampled set of every image (parity tests pin the second stage on the reference's sample so a 1-ulp heatmap
     difference cannot change the batch); `cn_norm_avg` = the two averaged CenterNet normalisers of a larger virtual batch;
     `fused_preprocess=False` forces the generic normalise-then-pad input path (otherwise used for mixed sizes and graph capture)."""
+    st = stage_inputs(model, batched_inputs)
+    return train_core(model, st, perm=perm, return_aux=return_aux, roi_override=roi_override, cn_norm_avg=cn_norm_avg,
+                      fused_preprocess=fused_preprocess)
+
+
+def stage_inputs(model, batched_inputs, gt_capacity: Optional[int] = None) -> Dict:
+    """Every host -> device upload of a call (pinned, asynchronous), so nothing in the core waits for the stream to drain:
+    imgs / sups (lists, as given), gts (list of [n_i,4]), gtp [B,G,4] + gt_n [B] int64 (zero padded to the batch maximum, or to
+    `gt_capacity` rows: the fixed-shape form of a captured step), sbx [B*N,4]."""
     import orehip
-    from orehip import autograd as A
     dev = model.device
-    pg, rh = model.proposal_generator, model.roi_heads
-    mean, std = model.pixel_mean.view(-1), model.pixel_std.view(-1)
-    div = model.backbone.size_divisibility
-    aux = {}
-    B = len(batched_inputs)
     N = model.support_way * model.support_shot
     assert model.support_way == 1
-    # every small host -> device upload first (pinned, asynchronous), so nothing below waits for the stream to drain
     gts, sbx = [], []
     for item in batched_inputs:
         inst = item["instances"]
@@ -419,34 +432,63 @@ def train_forward(model, batched_inputs, perm: Optional[Callable[[int], torch.Te
         sbx.append(torch.as_tensor(item["support_bboxes"], dtype=torch.float32))
     sbx = orehip.to_device(torch.cat(sbx, 0), dev)
     gtp, gt_n = _pad_stack(gts, 4, dev)
+    if gt_capacity is not None:
+        assert gtp.shape[1] <= gt_capacity
+        if gtp.shape[1] < gt_capacity:
+            gtp = F.pad(gtp, (0, 0, 0, gt_capacity - gtp.shape[1]))
     imgs = [orehip.to_device(item["image"], dev) for item in batched_inputs]
     sups = [orehip.to_device(item["support_images"], dev) for item in batched_inputs]
     for s_ in sups:
         assert s_.shape[0] == N, "support_images must hold SUPPORT_WAY * SUPPORT_SHOT crops"
-    graph = getattr(model, "train_graph", False)
-    if not graph:
-        # every packed weight the optimizer step has made stale -- both layouts of every trainable conv / linear -- in ONE launch
-        # (orehip.autograd.prepack) instead of ~86 small ones scattered over the step; a captured dense part does the same inside its graph
-        from orehip import autograd as _A
-        _A.prepack(list(model.parameters()))
-    same = all(i.shape == imgs[0].shape and i.dtype == imgs[0].dtype for i in imgs) and all(s_.shape == sups[0].shape for s_ in sups)
-    if same and not graph and fused_preprocess:
-        # one size per batch (the usual case): hand the RAW images to stem_1, which normalises and pads on the fly
-        xq = torch.stack(imgs) if B > 1 else imgs[0][None]
-        xs = torch.cat(sups, 0) if B > 1 else sups[0]
-        outs = dense_part(model, xq.contiguous(), xs.contiguous(), raw=True)
+    return dict(imgs=imgs, sups=sups, gts=gts, gtp=gtp.contiguous(), gt_n=gt_n, sbx=sbx)
+
+
+def train_core(model, st: Dict, perm=None, return_aux: bool = False, roi_override=None, cn_norm_avg=None, fused_preprocess: bool = True,
+               static: bool = False):
+    """train_forward behind its uploads.  `static`: the inputs are the fixed buffers of a captured step (st["xq"] / st["xs"] stacked raw
+    images, gtp / gt_n / sbx; no per-image lists) -- nothing in here may then touch host memory or depend on a host-known count."""
+    import orehip
+    from orehip import autograd as A
+    dev = model.device
+    pg, rh = model.proposal_generator, model.roi_heads
+    mean, std = model.pixel_mean.view(-1), model.pixel_std.view(-1)
+    div = model.backbone.size_divisibility
+    aux = {}
+    N = model.support_way * model.support_shot
+    gtp, gt_n, sbx = st["gtp"], st["gt_n"], st["sbx"]
+    gts = st.get("gts")
+    graph = getattr(model, "train_graph", False) and not static
+    if static:
+        B = int(st["xq"].shape[0])
+        # inside a captured step: the packed copies are rebuilt by launches that belong to the graph (as in _DensePart)
+        A.weights_changed()
+        A.prepack(list(model.parameters()))
+        outs = dense_part(model, st["xq"], st["xs"], raw=True)
     else:
-        imgs = [i.float() for i in imgs]
-        Hm, Wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
-        # ImageList.from_tensors semantics (d2z:structures/image_list.py:69-121): normalise each image, zero-pad bottom/right to the
-        # batch maximum rounded up to the size divisibility; the whole batch goes through the backbone at once (fsod_cen.py:156,165)
-        xq = torch.cat([F.pad(_normalise_pad(i[None], mean, std, 1), (0, Wm - i.shape[-1], 0, Hm - i.shape[-2])) for i in imgs], 0)
-        xq = F.pad(xq, (0, (Wm + div - 1) // div * div - Wm, 0, (Hm + div - 1) // div * div - Hm)).contiguous()
-        xs = _normalise_pad(torch.cat(sups, 0) if B > 1 else sups[0], mean, std, div)
-        outs = graphed_dense_part(model, xq, xs) if graph else dense_part(model, xq, xs)
+        imgs, sups = st["imgs"], st["sups"]
+        B = len(imgs)
+        if not graph:
+            # every packed weight the optimizer step has made stale -- both layouts of every trainable conv / linear -- in ONE launch
+            # (orehip.autograd.prepack) instead of ~86 small ones scattered over the step; a captured dense part does the same inside its graph
+            A.prepack(list(model.parameters()))
+        same = all(i.shape == imgs[0].shape and i.dtype == imgs[0].dtype for i in imgs) and all(s_.shape == sups[0].shape for s_ in sups)
+        if same and not graph and fused_preprocess:
+            # one size per batch (the usual case): hand the RAW images to stem_1, which normalises and pads on the fly
+            xq = torch.stack(imgs) if B > 1 else imgs[0][None]
+            xs = torch.cat(sups, 0) if B > 1 else sups[0]
+            outs = dense_part(model, xq.contiguous(), xs.contiguous(), raw=True)
+        else:
+            imgs = [i.float() for i in imgs]
+            Hm, Wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+            # ImageList.from_tensors semantics (d2z:structures/image_list.py:69-121): normalise each image, zero-pad bottom/right to the
+            # batch maximum rounded up to the size divisibility; the whole batch goes through the backbone at once (fsod_cen.py:156,165)
+            xq = torch.cat([F.pad(_normalise_pad(i[None], mean, std, 1), (0, Wm - i.shape[-1], 0, Hm - i.shape[-2])) for i in imgs], 0)
+            xq = F.pad(xq, (0, (Wm + div - 1) // div * div - Wm, 0, (Hm + div - 1) // div * div - Hm)).contiguous()
+            xs = _normalise_pad(torch.cat(sups, 0) if B > 1 else sups[0], mean, std, div)
+            outs = graphed_dense_part(model, xq, xs) if graph else dense_part(model, xq, xs)
     qf, sf_levels, heads = list(outs[0:3]), list(outs[3:6]), list(outs[6:9])
     # ---- first stage: ground truth, losses, proposals (no gradient through the proposals)
-    dets, l_rpn, tg, cn_counts = first_stage_batch(pg, heads, gts, cn_norm_avg)
+    dets, l_rpn, tg, cn_counts = first_stage_batch(pg, heads, gts, cn_norm_avg, padded=(gtp, gt_n.to(torch.int32)) if static else None)
     # ---- fg/bg sample per image
     counts_host = None
     if roi_override is not None:

@@ -290,6 +290,7 @@ class FlatSGD:
         self.momentum = float(momentum)
         self.clip_value = float(clip_value)
         self.lr_factor = 1.0                       # schedule factor; param_groups[i]["lr"] = group base x factor
+        self.lr_dev: Optional[torch.Tensor] = None # the same factor on the device (a captured step reads it there: GraphedTrainStep)
         self._apply = apply_fn
         self.param_groups = []
         for p, g, wd in zip(bucket.tensors, bucket.base_lrs, bucket.weight_decays):
@@ -301,6 +302,8 @@ class FlatSGD:
 
     def set_lr_factor(self, f: float):
         self.lr_factor = float(f)
+        if self.lr_dev is not None:
+            self.lr_dev.fill_(self.lr_factor)
         for g in self.param_groups:
             g["lr"] = g["initial_lr"] * self.lr_factor
 
@@ -316,10 +319,15 @@ class FlatSGD:
         import orehip
         from orehip import autograd as A
         orehip.sgd_step(b.params, b.grads, b.momentum, b.chunk_lr, b.chunk_wd, lr_scale=self.lr_factor, momentum=self.momentum,
-                        clip_value=self.clip_value, grad_scale=scale)
+                        clip_value=self.clip_value, grad_scale=scale, lr_scale_dev=self.lr_dev)
         # The kernel rewrote the parameters through raw pointers: tell torch (every cache in the package -- engines, hipGraphs,
         # packed / composed weights -- keys on the parameters' version counters) and drop the packed copies.
-        torch.autograd.graph.increment_version(b.tensors)
+        self.after_step()
+
+    def after_step(self):
+        """Host-side bookkeeping of a parameter update (also called after every replay of a captured step)."""
+        from orehip import autograd as A
+        torch.autograd.graph.increment_version(self.bucket.tensors)
         A.weights_changed()
 
     def state_dict(self) -> Dict:

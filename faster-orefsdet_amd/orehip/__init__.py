@@ -717,24 +717,31 @@ def to_device(t: torch.Tensor, dev) -> torch.Tensor:
 
 def centernet_targets(gt_boxes: Sequence[torch.Tensor], shapes: Sequence[Tuple[int, int]], strides=(8, 16, 32),
                       soi=((0, 64), (48, 192), (128, 1000000)), hm_min_overlap: float = 0.8, min_radius: float = 4.0,
-                      device=None) -> Dict[str, torch.Tensor]:
-    """CenterNet._get_ground_truth (ref:fewx/modeling/fsod/fsod_rpn.py:803-901) on device.  gt_boxes: per image [N_i,4]."""
+                      device=None, padded: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """CenterNet._get_ground_truth (ref:fewx/modeling/fsod/fsod_rpn.py:803-901) on device.  gt_boxes: per image [N_i,4]; or
+    `padded` = (boxes [B,G,4] fp32, counts [B] int32) already on the device (fixed shapes: a captured training step)."""
     dev = torch.device(device or "cuda")
-    B, L = len(gt_boxes), len(strides)
-    ns = [int(b.shape[0]) for b in gt_boxes]
-    max_n = max(1, max(ns))
-    # no blocking copy in either direction: device boxes are padded on the device, host boxes go up through pinned memory
-    if any(b.is_cuda for b in gt_boxes):
-        gt = torch.zeros(B, max_n, 4, dtype=torch.float32, device=dev)
-        for i, b in enumerate(gt_boxes):
-            if ns[i]:
-                gt[i, :ns[i]] = to_device(b.detach().float(), dev)
+    L = len(strides)
+    if padded is not None:
+        gt, cnt = padded
+        assert gt.is_cuda and gt.dtype == torch.float32 and gt.is_contiguous() and cnt.dtype == torch.int32 and cnt.numel() == gt.shape[0]
+        B, max_n = int(gt.shape[0]), int(gt.shape[1])
     else:
-        gt = torch.zeros(B, max_n, 4, dtype=torch.float32)
-        for i, b in enumerate(gt_boxes):
-            gt[i, :ns[i]] = b.detach().float()
-        gt = to_device(gt, dev)
-    cnt = to_device(torch.tensor(ns, dtype=torch.int32), dev)
+        B = len(gt_boxes)
+        ns = [int(b.shape[0]) for b in gt_boxes]
+        max_n = max(1, max(ns))
+        # no blocking copy in either direction: device boxes are padded on the device, host boxes go up through pinned memory
+        if any(b.is_cuda for b in gt_boxes):
+            gt = torch.zeros(B, max_n, 4, dtype=torch.float32, device=dev)
+            for i, b in enumerate(gt_boxes):
+                if ns[i]:
+                    gt[i, :ns[i]] = to_device(b.detach().float(), dev)
+        else:
+            gt = torch.zeros(B, max_n, 4, dtype=torch.float32)
+            for i, b in enumerate(gt_boxes):
+                gt[i, :ns[i]] = b.detach().float()
+            gt = to_device(gt, dev)
+        cnt = to_device(torch.tensor(ns, dtype=torch.int32), dev)
     rows = sum(B * h * w for h, w in shapes)
     o = {"reg_targets": torch.empty(rows, 4, device=dev), "hm_targets": torch.empty(rows, device=dev),
          "pos_inds": torch.zeros(B * max_n * L, dtype=torch.int64, device=dev), "pos_count": torch.zeros(1, dtype=torch.int32, device=dev)}

@@ -1000,6 +1000,61 @@ def test_graph_captured_dense_part_matches_eager(oh):
     assert float((res["eager"][1] - res["graph"][1]).abs().max()) <= 1e-5        # ROIAlign backward uses fp32 atomics: order differs run to run
 
 
+def test_whole_step_graph_matches_eager(oh, monkeypatch):
+    """fewx.solver.GraphedTrainStep: forward + losses + backward + clip / SGD of one iteration captured once and replayed.  With the same
+    inputs, the same sampling keys and the schedule factor changing every step, the parameters after three eager + three replayed
+    iterations must be those of six eager iterations: the replay runs the same kernels in the same order, the ROIAlign backward adds in
+    ROI order, the LR factor is read from the device -- equality to the last bit is the expectation, 1e-6 of the largest weight the bar."""
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.solver import GraphedTrainStep, build_optimizer
+    shots, B = 4, 2
+    items = []
+    for b in range(B):
+        img, gt, sup, sbox = T.synth_train_inputs(2 + b, (256, 320), n_gt=5 + b, shots=shots, support_hw=96)
+        inst = Instances((256, 320))
+        inst.gt_boxes, inst.gt_classes = Boxes(gt.cuda()), torch.zeros(len(gt), dtype=torch.int64).cuda()
+        items.append({"image": img.cuda(), "instances": inst, "support_images": sup.cuda(), "support_bboxes": sbox.cuda()})
+    keys = torch.rand(B, 16384, generator=torch.Generator().manual_seed(3)).cuda()
+    real_rand = torch.rand
+
+    def fixed_rand(*shape, **kw):                           # the fg / bg subsample draws its keys here: the same for both runs
+        if len(shape) == 2 and kw.get("device") is not None and torch.device(kw["device"]).type == "cuda":
+            return keys[:shape[0], :shape[1]].clone()
+        return real_rand(*shape, **kw)
+
+    monkeypatch.setattr(torch, "rand", fixed_rand)
+    res = {}
+    for mode in ("eager", "graph"):
+        m, sd, cfg = _train_model(shots)
+        opt = build_optimizer(cfg, m)
+        stepper = GraphedTrainStep(m, opt, warmup=3) if mode == "graph" else None
+        losses_log = []
+        for it in range(6):
+            opt.set_lr_factor(0.02 * (1.0 + 0.25 * it))     # a schedule that moves every iteration
+            if stepper is not None:
+                losses = stepper(items)
+            else:
+                losses = m(items)
+                opt.zero_grad()
+                sum(losses.values()).backward()
+                opt.step()
+            losses_log.append({k: float(v.detach()) for k, v in losses.items()})
+        torch.cuda.synchronize()
+        if stepper is not None:
+            assert stepper.error is None, stepper.error
+            assert stepper.eager_steps == 3 and stepper.replays == 3
+        res[mode] = (losses_log, opt.bucket.params.detach().clone(), opt.bucket.momentum.detach().clone())
+    for it in range(6):
+        for k, v in res["eager"][0][it].items():
+            assert abs(v - res["graph"][0][it][k]) <= 1e-5 * max(abs(v), 1e-3), (it, k, v, res["graph"][0][it][k])
+    pe, pg = res["eager"][1], res["graph"][1]
+    assert float((pe - pg).abs().max()) <= 1e-6 * float(pe.abs().max()), float((pe - pg).abs().max())
+    assert float((res["eager"][2] - res["graph"][2]).abs().max()) <= 1e-5 * float(res["eager"][2].abs().max())
+    # a later eval on the replay-trained model sees the new weights (the replay bumps the version counters host-side)
+    assert all(p._version > 0 for p in [next(iter(m.parameters()))])
+
+
 def test_centernet_normaliser_is_the_references(oh):
     """ref:fewx/modeling/fsod/fsod_rpn.py:712-716,748-751: the CenterNet sums of a rank's WHOLE batch are divided by
     max(reduce_sum(n) / num_gpus, 1).  In the clamped regime -- here two images without any ground truth, n = 0 -- the batch loss is

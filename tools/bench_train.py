@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--no-kd", action="store_true", help="A/B aid: keep the small-M layers on k_conv_kw (plan override -12 0)")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"), help="bf16 = BASELINE configs[4]: frozen stages in bf16 storage, "
                     "bf16 MFMA operands in the trainable convs' forward / data / weight gradients, everything else fp32")
+    ap.add_argument("--graph-step", action="store_true", help="the WHOLE iteration (forward, losses, backward, clip + SGD) as one replayed hipGraph "
+                    "(fewx.solver.GraphedTrainStep; single process)")
     ap.add_argument("--roi-bwd", default=None, choices=("tiled", "fixed", "atomic"), help="A/B aid: the ROIAlign backward form (default: the library's)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,7 +81,17 @@ def main():
         inst.gt_boxes, inst.gt_classes = Boxes(gt.cuda()), torch.zeros(len(gt), dtype=torch.int64).cuda()
         items.append({"image": img.cuda(), "instances": inst, "support_images": sup.cuda(), "support_bboxes": sbox.numpy()})
 
+    stepper = None
+    if a.graph_step:
+        assert world == 1, "--graph-step is single-process"
+        from fewx.solver import GraphedTrainStep
+        stepper = GraphedTrainStep(m, opt)
+
     def step():
+        if stepper is not None:
+            losses = stepper(items)
+            sched.step()
+            return losses
         losses = model(items)
         opt.zero_grad()
         sum(losses.values()).backward()
@@ -111,6 +123,7 @@ def main():
                                      "batch_per_gpu": a.batch,
                                      "bucket_bytes": 4 * opt.bucket.size},
                           "train_graph": bool(a.graph), "train_graph_error": m.__dict__.get("_ore_train_graph_error"),
+                          "whole_step_graph": None if stepper is None else {"replays": stepper.replays, "eager_steps": stepper.eager_steps, "error": stepper.error},
                           "losses": {k: float(v.detach()) for k, v in losses.items()}}))
     if world > 1:
         dist.destroy_process_group()
