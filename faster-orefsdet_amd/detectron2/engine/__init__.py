@@ -52,6 +52,18 @@ class SimpleTrainer:
         start = time.perf_counter()
         data = next(self._data_loader_iter)
         data_time = time.perf_counter() - start
+        if getattr(self, "graph_step", False):
+            # opt-in (trainer.graph_step = True; single process, the HIP detector): the whole iteration -- forward, losses, backward, clip
+            # + SGD -- captured once and replayed as one hipGraph (fewx.solver.GraphedTrainStep; eager while it warms up or cannot capture)
+            if self.__dict__.get("_graphed") is None:
+                from fewx.solver import GraphedTrainStep
+                self._graphed = GraphedTrainStep(self.model, self.optimizer)
+            loss_dict = self._graphed(data)
+            self.flush_metrics(keep=self.metrics_lag - 1)
+            self.last_losses = {k: v.detach().clone() for k, v in loss_dict.items()}   # (the graph's loss buffers are rewritten by the next replay)
+            self.last_data_time = data_time
+            self._write_metrics(self.last_losses, data_time)
+            return
         loss_dict = self.model(data)
         self.flush_metrics(keep=self.metrics_lag - 1)            # step i-1's losses, behind step i's forward launches
         if isinstance(loss_dict, torch.Tensor):

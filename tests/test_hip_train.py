@@ -1304,6 +1304,63 @@ def test_sample_rois_device_properties(oh):
     assert got == sorted(map(tuple, rb.cpu().tolist())) and int((labels[2].cpu()[v] == 0).sum()) == int((rl == 0).sum())
 
 
+def test_default_trainer_with_captured_step(oh, tmp_path):
+    """trainer.graph_step = True: DefaultTrainer.run_step hands the iteration to fewx.solver.GraphedTrainStep -- three eager iterations,
+    one capture, then replays on changing data (different images, different numbers of ground-truth boxes inside the capacity) under the
+    warm-up LR schedule; the losses stay finite and are reported per iteration, the weights move, the checkpoint holds what the replays
+    wrote."""
+    import os
+    from conftest import PKG
+    from oracle import ref_train as T
+    from detectron2.engine import DefaultTrainer
+    from detectron2.structures import Boxes, Instances
+    from fewx.config import get_cfg
+    shots = 4
+
+    def batches():
+        i = 0
+        while True:
+            img, gt, sup, sbox = T.synth_train_inputs(40 + i % 5, (256, 320), n_gt=3 + i % 4, shots=shots, support_hw=96)
+            inst = Instances((256, 320))
+            inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+            yield [{"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}]
+            i += 1
+
+    class Trainer(DefaultTrainer):
+        @classmethod
+        def build_train_loader(cls, cfg):
+            return batches()
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(PKG, "configs", "fsod", "finetune_vovnet.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "INPUT.FS.SUPPORT_SHOT", shots, "SOLVER.MAX_ITER", 9, "SOLVER.CHECKPOINT_PERIOD", 100,
+                         "OUTPUT_DIR", str(tmp_path), "MODEL.WEIGHTS", ""])
+    cfg.freeze()
+    torch.manual_seed(0)
+    tr = Trainer(cfg)
+    tr.resume_or_load(resume=False)
+    tr.graph_step = True
+    seen = []
+    orig = tr._write_metrics
+
+    def spy(loss_dict, data_time, prefix=""):
+        seen.append({k: float(v) for k, v in loss_dict.items()})
+        return orig(loss_dict, data_time, prefix)
+
+    tr._write_metrics = spy
+    w0 = tr.model.conv3.weight.detach().clone()
+    tr.train()
+    g = tr._graphed
+    assert g.error is None, g.error
+    assert g.eager_steps == 3 and g.replays == 6 and tr.iter == 8
+    assert len(seen) == 9 and all(all(v == v and abs(v) < 1e6 for v in d.values()) for d in seen)
+    assert len({round(d["loss_centernet_loc"], 6) for d in seen}) >= 5                 # the replays report their own losses, not a stale buffer
+    assert not torch.equal(tr.model.conv3.weight.detach(), w0)
+    from detectron2.checkpoint import DetectionCheckpointer
+    sd = torch.load(os.path.join(str(tmp_path), "model_final.pth"), map_location="cpu", weights_only=False)["model"]
+    assert torch.equal(torch.as_tensor(sd["conv3.weight"]), tr.model.conv3.weight.detach().cpu())
+
+
 def test_default_trainer_loop_with_synthetic_loader(oh, tmp_path):
     """The reference's training protocol end to end (ref:fsod_train_net.py:36-73,96-118): a DefaultTrainer subclass with a synthetic
     loader runs run_step + scheduler + periodic checkpoint, then resumes from the checkpoint (model, momentum, iteration)."""
