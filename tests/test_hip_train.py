@@ -412,6 +412,32 @@ def test_roi_align_backward_tiled_vs_scatter_forms(oh, Cc, B, hw):
         assert torch.equal(a[l], outs["tiled"][l][0])
 
 
+@pytest.mark.parametrize("pooled", [4, 7, 14])
+def test_roi_align_backward_tiled_other_pool_sizes(oh, pooled):
+    """The tiled gather at pooled sizes other than the detector's 8: fewer bins than table columns (4, 7: the reference's dead 4 x 4
+    branch has this shape) and the 16-bin build without the LDS stage (14) -- against the fixed-point scatter form."""
+    g = torch.Generator().manual_seed(pooled)
+    B, Cc, n_per = 2, 32, 60
+    feats = [torch.empty(B, 44 >> l, 36 >> l, Cc, device="cuda") for l in range(3)]
+    ctr = torch.rand(B * n_per, 2, generator=g) * torch.tensor([288.0, 352.0])
+    wh = torch.exp(torch.rand(B * n_per, 2, generator=g) * 4.5 + 2.0)
+    wh[::9] = torch.rand(len(wh[::9]), 2, generator=g) * 300 + 460       # some on the coarsest level (sqrt(area) >= 448)
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).cuda().contiguous()
+    img = torch.arange(B, dtype=torch.int32).repeat_interleave(n_per).cuda()
+    dout = torch.randn(B * n_per, pooled * pooled * Cc, generator=g).cuda()
+    saved = (oh.ROI_BWD_DETERMINISTIC, oh.ROI_BWD_MODE)
+    try:
+        oh.ROI_BWD_DETERMINISTIC, oh.ROI_BWD_MODE = True, "tiled"
+        a = [d.clone() for d in oh.roi_align_bwd(dout, feats, boxes, pooled=pooled, box_image=img)]
+        oh.ROI_BWD_MODE = "fixed"
+        b = oh.roi_align_bwd(dout, feats, boxes, pooled=pooled, box_image=img)
+    finally:
+        oh.ROI_BWD_DETERMINISTIC, oh.ROI_BWD_MODE = saved
+    for l in range(3):
+        scale = float(b[l].abs().max())
+        assert scale > 0 and float((a[l] - b[l]).abs().max()) <= 2e-6 * scale, (l, float((a[l] - b[l]).abs().max()), scale)
+
+
 def test_centernet_loss_fn_backward(oh):
     from orehip import autograd as A
     g = torch.Generator().manual_seed(5)
@@ -1302,6 +1328,39 @@ def test_sample_rois_device_properties(oh):
     assert int(v.sum()) == rb.shape[0] == 41
     got = sorted(map(tuple, boxes[2].cpu()[v].tolist()))
     assert got == sorted(map(tuple, rb.cpu().tolist())) and int((labels[2].cpu()[v] == 0).sum()) == int((rl == 0).sum())
+
+
+def test_captured_step_recaptures_and_falls_back(oh):
+    """GraphedTrainStep outside its comfort zone: more ground-truth boxes than the capacity -> a new capture with a doubled capacity;
+    images of two sizes in one batch -> that iteration runs eagerly (no error recorded, the graph is kept); back to the captured shapes ->
+    replay again."""
+    from oracle import ref_train as T
+    from detectron2.structures import Boxes, Instances
+    from fewx.solver import GraphedTrainStep, build_optimizer
+    shots = 4
+
+    def item(seed, hw, n_gt):
+        img, gt, sup, sbox = T.synth_train_inputs(seed, hw, n_gt=n_gt, shots=shots, support_hw=96)
+        inst = Instances(hw)
+        inst.gt_boxes, inst.gt_classes = Boxes(gt), torch.zeros(len(gt), dtype=torch.int64)
+        return {"image": img, "instances": inst, "support_images": sup, "support_bboxes": sbox.numpy()}
+
+    m, sd, cfg = _train_model(shots)
+    opt = build_optimizer(cfg, m)
+    opt.set_lr_factor(0.02)
+    st = GraphedTrainStep(m, opt, warmup=2, gt_capacity=8)
+    for i in range(4):                                      # 2 eager, capture at capacity 8, 2 replays
+        losses = st([item(50 + i, (256, 320), 5)])
+    assert st.error is None and st.eager_steps == 2 and st.replays == 2 and st.gt_capacity == 8
+    g0 = st.graph
+    losses = st([item(60, (256, 320), 11)])                 # 11 boxes > 8: capacity 16, a new graph
+    assert st.error is None and st.gt_capacity == 16 and st.graph is not g0 and st.replays == 3
+    assert all(bool(torch.isfinite(v)) for v in losses.values())
+    g1 = st.graph
+    losses = st([item(61, (256, 320), 4), item(62, (224, 320), 4)])      # two sizes: eager for this call
+    assert st.error is None and st.eager_steps == 3 and st.graph is g1
+    losses = st([item(63, (256, 320), 6)])
+    assert st.replays == 4 and all(bool(torch.isfinite(v)) for v in losses.values())
 
 
 def test_default_trainer_with_captured_step(oh, tmp_path):
