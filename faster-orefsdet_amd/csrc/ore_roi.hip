@@ -464,10 +464,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_tile(RoiTileP tp) {
                         s_inv[gi] = 1.0f / q.cnt;
                         s_roi[gi] = rr;
                     }
-                    if (PM > 8 && P <= 8) { /* bins 8 .. PM-1 are never read when P <= 8 */ }
-                } else {
-                    (void)__ballot(false);
-                }
+                }                                            // (table columns of bins >= P are never read)
             }
             if constexpr (STAGE) {
 #pragma unroll
