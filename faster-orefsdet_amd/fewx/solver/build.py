@@ -96,6 +96,7 @@ class FlatBucket:
                 self.params[o:o + n].copy_(p.detach().reshape(-1))
             p.data = self.params[o:o + n].view(p.shape)
             p.grad = self.grads[o:o + n].view(p.shape)
+            p._ore_direct_grad = True                   # zero_grad() zeroes this buffer every step: the weight-gradient kernels may add into it
             self.tensors.append(p)
         # exchange slices: contiguous, chunk aligned, about equal bytes, never splitting a parameter
         target = max(self.size // max(n_slices, 1), min_slice_bytes // 4)
@@ -182,6 +183,7 @@ class FlatDataParallel(torch.nn.Module):
             if transport == "rccl":
                 self._init_rccl()
             for i, p in enumerate(self.bucket.tensors):
+                p._ore_direct_grad = False              # the exchange is issued from these hooks: the engine's AccumulateGrad has to run
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
         self._reset()
 

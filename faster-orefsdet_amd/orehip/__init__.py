@@ -862,9 +862,11 @@ def _wgrad_ws(device, n: int) -> torch.Tensor:
 
 
 def conv2d_wgrad(x: torch.Tensor, dz: torch.Tensor, k: int, *, x_coff: int = 0, Cin: Optional[int] = None, dz_coff: int = 0,
-                 Cout: Optional[int] = None, out: Optional[torch.Tensor] = None, beta: float = 0.0, want_bias: bool = False):
+                 Cout: Optional[int] = None, out: Optional[torch.Tensor] = None, beta: float = 0.0, want_bias: bool = False,
+                 db_out: Optional[torch.Tensor] = None, beta_b: float = 0.0):
     """x [B,H,W,x_ld], dz [B,H,W,dz_ld] NHWC -> dW [Cout,Cin,k,k] (OIHW); stride 1, pad k//2.  want_bias: also the bias gradient
-    (column sums of dz) from the same launch -> (dW, db)."""
+    (column sums of dz) from the same launch -> (dW, db).  out / beta, db_out / beta_b: dW = beta * out + ..., db = beta_b * db_out + ...
+    written in place (a parameter's gradient accumulated by the launch itself)."""
     _f32(x); _f32(dz)
     B, H, W, xld = x.shape
     dld = dz.shape[-1]
@@ -877,9 +879,13 @@ def conv2d_wgrad(x: torch.Tensor, dz: torch.Tensor, k: int, *, x_coff: int = 0, 
     assert out.shape == (Cout, Cin, k, k) and out.is_contiguous()
     n = lib().ore_conv_wgrad_workspace_floats(B * H * W, Cin, Cout, k, k)
     ws = _wgrad_ws(x.device, n)
-    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None
+    if want_bias and db_out is not None:
+        assert db_out.shape == (Cout,) and db_out.is_contiguous() and db_out.dtype == torch.float32
+        db = db_out
+    else:
+        db, beta_b = (torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None), 0.0
     _chk(lib().ore_conv2d_wgrad_bias_fwd(C.c_void_p(_ptr(x)), xld, x_coff, C.c_void_p(_ptr(dz)), dld, dz_coff, B, H, W, Cin, Cout, k, k,
-                                         k // 2, C.c_void_p(_ptr(out)), C.c_float(beta), C.c_void_p(_ptr(db)), C.c_float(0.0),
+                                         k // 2, C.c_void_p(_ptr(out)), C.c_float(beta), C.c_void_p(_ptr(db)), C.c_float(beta_b),
                                          C.c_void_p(_ptr(ws)), C.c_size_t(ws.numel()), _stream()), "ore_conv2d_wgrad_bias_fwd")
     return (out, db) if want_bias else out
 

@@ -110,12 +110,34 @@ def packed_wino(w: torch.Tensor, dgrad: bool):
     return e[1]
 
 
-def _conv_backward(x, x_coff, Cin, weight, dz, k, need_x: bool, need_w: bool, need_b: bool):
-    """dz [B,H,W,Cout16] contiguous -> (dX [B,H,W,Cin] | None, dW | None, db | None)."""
+def direct_grad(p) -> Optional[torch.Tensor]:
+    """The buffer a parameter's gradient may be accumulated into BY THE KERNEL (dW = 1 * grad + ...; the backward then hands autograd no
+    gradient for it): its `.grad`, when the owner of that buffer allows it (`p._ore_direct_grad`, set by fewx.solver.FlatBucket whose
+    zero_grad() zeroes the buffer every step) -- else None.  The backbone runs twice per step (query and support branch): without this
+    every trainable conv weight costs an add of the two branch gradients plus an in-place add into `.grad`, ~100 launches of a few
+    microseconds per step.  Not under a data-parallel wrapper (its exchange is issued from post-accumulate hooks, which need the
+    engine's AccumulateGrad to run) and not with tensor hooks on the parameter."""
+    if p is None or not getattr(p, "_ore_direct_grad", False):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
+def _conv_backward(x, x_coff, Cin, weight, dz, k, need_x: bool, need_w: bool, need_b: bool, bias=None):
+    """dz [B,H,W,Cout16] contiguous -> (dX [B,H,W,Cin] | None, dW | None, db | None).  A gradient accumulated in place (direct_grad)
+    comes back as None."""
     Cout = weight.shape[0]
     gx = gw = gb = None
     if need_x:
         gx = orehip.conv2d(dz, packed(weight, True), Cin, k, 1, k // 2, w_wino=packed_wino(weight, True) if k == 3 else None)
+    full = dz.shape[-1] == Cout                              # (a Cout padded to 16 has no in-place form: the kernel writes Cout16 rows)
+    dgw = direct_grad(weight) if need_w and full else None
+    dgb = direct_grad(bias) if need_b and full else None
+    if dgw is not None and (not need_b or dgb is not None):
+        orehip.conv2d_wgrad(x, dz, k, x_coff=x_coff, Cin=Cin, out=dgw.view(Cout, Cin, k, k), beta=1.0, want_bias=need_b, db_out=dgb, beta_b=1.0)
+        return gx, None, None
     if need_w and need_b:                                    # the weight-gradient launch sums the dZ rows it stages anyway
         gw, gb = orehip.conv2d_wgrad(x, dz, k, x_coff=x_coff, Cin=Cin, want_bias=True)
         gw, gb = gw[:Cout], gb[:Cout]
@@ -143,6 +165,7 @@ class ConvFn(Function):
         y = orehip.conv2d(x, packed(weight, False), Cout, k, 1, k // 2, scale=scale, shift=sh, relu_cout=Cout if relu else 0, out=out,
                           add=add.contiguous() if add is not None else None, w_wino=packed_wino(weight, False) if k == 3 and add is None else None)
         ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.bias_ref = bias                                     # (only looked at for direct_grad; its values are not needed)
         ctx.meta = (k, relu, bias is not None, Cout, Cin, co16)
         ctx.has_add = add is not None
         return y if co16 == Cout else y[..., :Cout]
@@ -161,7 +184,7 @@ class ConvFn(Function):
         elif scale is not None:
             dz = dz * scale
         gx, gw, gb = _conv_backward(x, 0, Cin, weight, dz, k, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                    has_bias and ctx.needs_input_grad[2])
+                                    has_bias and ctx.needs_input_grad[2], bias=ctx.bias_ref)
         gadd = orehip.sumpool2x2(dz) if (ctx.has_add and ctx.needs_input_grad[6]) else None
         return gx, gw, gb, None, None, None, gadd
 
@@ -210,15 +233,22 @@ class OSAFn(Function):
         ws, scs = saved[2:2 + n + 1], saved[3 + n:3 + n + n + 1]
         grads: List[Optional[torch.Tensor]] = [None] * (3 * (n + 1))
         dz = orehip.relu_affine_bwd(dy.contiguous(), y, scs[n])
+        def wgrad(i, xbuf, dzi, k, **kw):                       # into the parameter's gradient where allowed, else returned to autograd
+            dg = direct_grad(ws[i])
+            if dg is not None and dzi.shape[-1] == ws[i].shape[0]:
+                orehip.conv2d_wgrad(xbuf, dzi, k, out=dg, beta=1.0, **kw)
+                return None
+            return orehip.conv2d_wgrad(xbuf, dzi, k, **kw)
+
         if ctx.needs_input_grad[1 + 3 * n]:
-            grads[3 * n] = orehip.conv2d_wgrad(cat, dz, 1)
+            grads[3 * n] = wgrad(n, cat, dz, 1)
         dcat = orehip.conv2d(dz, packed(ws[n], True), cat.shape[-1], 1, 1, 0)          # gradient of every concat slice
         for i in range(n - 1, -1, -1):
             dst = in_ch + i * stage_ch
             src, cin = (0, in_ch) if i == 0 else (dst - stage_ch, stage_ch)
             dzi = orehip.relu_affine_bwd(dcat, cat, scs[i], dy_coff=dst, y_coff=dst, Cc=stage_ch)
             if ctx.needs_input_grad[1 + 3 * i]:
-                grads[3 * i] = orehip.conv2d_wgrad(cat, dzi, 3, x_coff=src, Cin=cin)
+                grads[3 * i] = wgrad(i, cat, dzi, 3, x_coff=src, Cin=cin)
             if i > 0 or ctx.needs_input_grad[0]:
                 # (.add_ on the view: `dcat[...] += x` would follow the in-place add with a copy of the slice onto itself)
                 dcat[..., src:src + cin].add_(orehip.conv2d(dzi, packed(ws[i], True), cin, 3, 1, 1, w_wino=packed_wino(ws[i], True)))

@@ -26,6 +26,7 @@ class Count(TorchDispatchMode):
         super().__init__()
         self.rows = collections.Counter()
         self.numel = collections.Counter()
+        self.shapes = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
@@ -43,6 +44,8 @@ class Count(TorchDispatchMode):
         n = out.numel() if isinstance(out, torch.Tensor) else -1
         self.rows[(site, name)] += 1
         self.numel[(site, name)] = max(self.numel[(site, name)], n)
+        if site.startswith("<backward") and "aten.add" in name and isinstance(out, torch.Tensor):
+            self.shapes[(name, tuple(out.shape))] += 1
         return out
 
 
@@ -94,6 +97,9 @@ def main():
     print("## by call site")
     for site, n in by_site.most_common():
         print("%5d  %s" % (n, site))
+    print("## the autograd engine's adds by shape (sums of gradients of tensors with several consumers; in-place adds into .grad)")
+    for (name, shape), n in sorted(c.shapes.items(), key=lambda kv: -kv[1]):
+        print("%5d  %-22s %s" % (n, name, shape))
     print("## by (call site, operator)   count  max numel")
     for (site, name), n in sorted(c.rows.items(), key=lambda kv: -kv[1]):
         print("%5d %10d  %-70s %s" % (n, c.numel[(site, name)], site, name))
