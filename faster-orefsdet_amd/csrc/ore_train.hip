@@ -281,6 +281,70 @@ int fill_tgt(TgtP& p, int n_levels, const int32_t* H, const int32_t* W, const in
     return rows;
 }
 
+
+// ---- the two second-stage losses and their gradients in ONE launch (round 5) ----------------------------------------------------
+// CustomFastRCNNOutputLayers.losses for the single cascade stage (ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:52-81,
+// d2z:modeling/box_regression.py:41-75): per image b with n_b valid sampled rows, w_i = valid_i / (n_b * B);
+//   loss_cls = sum_i w_i * CE(scores_i, label_i)                      (2 classes: 0 = foreground, 1 = background)
+//   loss_box = sum_i w_i * [label_i == 0] * sum_k |deltas_ik - get_deltas(box_i, gt_i)_k|      (smooth-L1 with beta = 0)
+// and d loss_cls / d scores, d loss_box / d deltas -- what ~50 element-wise torch launches and ~40 more in their backward computed.  One
+// block, fixed reduction order (deterministic); RT = B * R rows (a few thousand).
+struct RoiLossP {
+    const float* scores; const float* deltas; const float* boxes; const float* gt;
+    const long long* labels; const unsigned char* valid;
+    int B, R;
+    float wx, wy, ww, wh;
+    float* out2; float* dscores; float* ddeltas;
+};
+__global__ __launch_bounds__(256) void k_roi_losses(RoiLossP p) {
+    __shared__ float inv_nb[256];
+    __shared__ float red[2][256];
+    const int t = threadIdx.x, RT = p.B * p.R;
+    for (int b = t; b < p.B; b += 256) {
+        int n = 0;
+        for (int j = 0; j < p.R; ++j) n += p.valid[(size_t)b * p.R + j] ? 1 : 0;
+        inv_nb[b] = 1.0f / ((float)max(n, 1) * (float)p.B);
+    }
+    __syncthreads();
+    float lc = 0.f, lb = 0.f;
+    for (int i = t; i < RT; i += 256) {
+        const bool v = p.valid[i] != 0;
+        const float w = v ? inv_nb[i / p.R] : 0.f;
+        const long long lab = p.labels[i];
+        const float s0 = p.scores[2 * i], s1 = p.scores[2 * i + 1];
+        const float m = fmaxf(s0, s1);
+        const float e0 = expf(s0 - m), e1 = expf(s1 - m), se = e0 + e1;
+        const float lse = m + logf(se);
+        lc += w * (lse - (lab == 0 ? s0 : s1));
+        p.dscores[2 * i] = w * (e0 / se - (lab == 0 ? 1.f : 0.f));
+        p.dscores[2 * i + 1] = w * (e1 / se - (lab == 0 ? 0.f : 1.f));
+        const bool fg = v && lab == 0;
+        f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+        if (fg) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(p.boxes + 4 * (size_t)i), g = *reinterpret_cast<const f32x4*>(p.gt + 4 * (size_t)i);
+            const float sw = s.z - s.x, sh = s.w - s.y, sx = s.x + 0.5f * sw, sy = s.y + 0.5f * sh;
+            const float tw = g.z - g.x, th = g.w - g.y, tx = g.x + 0.5f * tw, ty = g.y + 0.5f * th;
+            const float tgt[4] = {p.wx * (tx - sx) / sw, p.wy * (ty - sy) / sh, p.ww * logf(tw / sw), p.wh * logf(th / sh)};
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p.deltas + 4 * (size_t)i);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float df = d[k] - tgt[k];
+                acc += fabsf(df);
+                dd[k] = w * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+            }
+            lb += w * acc;
+        }
+        *reinterpret_cast<f32x4*>(p.ddeltas + 4 * (size_t)i) = dd;
+    }
+    red[0][t] = lc; red[1][t] = lb;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (t < d) { red[0][t] += red[0][t + d]; red[1][t] += red[1][t + d]; }
+        __syncthreads();
+    }
+    if (t == 0) { p.out2[0] = red[0][0]; p.out2[1] = red[1][0]; }
+}
 }  // namespace
 
 extern "C" int ore_centernet_targets_fwd(int32_t n_levels, const int32_t* H, const int32_t* W, const int32_t* stride, int32_t B,
@@ -324,6 +388,17 @@ extern "C" int ore_centernet_losses_fwd(const float* head, int32_t head_ld, cons
     if (rc) return rc;
     hipLaunchKernelGGL(k_cn_loss_final, dim3(1), dim3(64), 0, st, p, nb);
     return ore_launch_status("k_cn_loss_final");
+}
+
+extern "C" int ore_roi_losses_fwd(const float* scores, const float* deltas, const float* boxes, const float* gt, const int64_t* labels,
+                                  const uint8_t* valid, int32_t B, int32_t R, const float* reg_weights4, float* losses2, float* dscores,
+                                  float* ddeltas, void* stream) {
+    ORE_CHECK_ARG(scores && deltas && boxes && gt && labels && valid && reg_weights4 && losses2 && dscores && ddeltas, "ore_roi_losses_fwd: null pointer");
+    ORE_CHECK_ARG(B >= 1 && B <= 256 && R >= 1 && (long long)B * R < (1 << 24), "ore_roi_losses_fwd: B=%d R=%d", B, R);
+    RoiLossP p{scores, deltas, boxes, gt, (const long long*)labels, valid, B, R, reg_weights4[0], reg_weights4[1], reg_weights4[2],
+               reg_weights4[3], losses2, dscores, ddeltas};
+    hipLaunchKernelGGL(k_roi_losses, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+    return ore_launch_status("k_roi_losses");
 }
 
 extern "C" int ore_sgd_step_fwd(float* params, const float* grads, float* momentum_buf, int64_t n_chunks, const float* chunk_lr,

@@ -372,13 +372,10 @@ def roi_stage_losses_padded(rh, qf: List[torch.Tensor], sup8: torch.Tensor, boxe
     pr = rh.box_predictor[0]
     scores = A.linear(h, pr.cls_score.weight, pr.cls_score.bias)
     deltas = A.linear(h, pr.bbox_pred.weight, pr.bbox_pred.bias)
-    n_b = valid.sum(1).clamp(min=1).to(torch.float32)
-    w = vf.to(torch.float32) / (n_b * B)[img]
-    loss_cls = (F.cross_entropy(scores, lb, reduction="none") * w).sum()
-    fg = (lb == 0) & vf
-    zero = torch.zeros((), device=dev)
-    tgt = torch.where(fg[:, None], get_deltas(bx, gtf, rh.bbox_reg_weights), zero)       # background / padding rows: no target
-    loss_box = (torch.where(fg[:, None], (deltas - tgt).abs(), zero).sum(1) * w).sum()    # smooth_l1, beta = 0
+    # both losses and their gradients from ONE launch (ore_roi_losses_fwd): w_i = valid_i / (n_b * B), n_b = an image's valid rows;
+    # cross-entropy over the two classes; |deltas - get_deltas(box, gt)| on the foreground rows (smooth_l1 with beta = 0; background and
+    # padding rows have no target) -- what ~50 element-wise launches and ~40 more in their backward computed
+    loss_cls, loss_box = A.roi_losses(scores, deltas, bx, gtf, lb, vf, B, R, rh.bbox_reg_weights)
     return {"loss_cls_stage0": loss_cls, "loss_box_reg_stage0": loss_box}, dict(scores=scores, deltas=deltas, h=h)
 
 

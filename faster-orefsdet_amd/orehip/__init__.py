@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_pack_conv_weights_multi_fwd", "ore_roi_align_bwd_det", "ore_roi_align_bwd_tiled", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_pack_conv_weights_multi_fwd", "ore_roi_align_bwd_det", "ore_roi_align_bwd_tiled", "ore_roi_losses_fwd", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -783,6 +783,24 @@ def centernet_loss_grad(head: torch.Tensor, reg_targets: torch.Tensor, hm_target
                                         C.c_float(ignore_high_fp), C.c_void_p(_ptr(_f32(coef3))), C.c_void_p(_ptr(dhead)), ld, _stream()),
          "ore_centernet_losses_bwd")
     return dhead
+
+
+def roi_losses(scores: torch.Tensor, deltas: torch.Tensor, boxes: torch.Tensor, gt: torch.Tensor, labels: torch.Tensor, valid: torch.Tensor,
+               B: int, R: int, reg_weights) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The second stage's two losses and their gradients in one launch (ore_roi_losses_fwd): scores [B*R,2], deltas / boxes / gt [B*R,4],
+    labels [B*R] int64 (0 fg / 1 bg), valid [B*R] bool -> (losses [2] = (cls, box), dscores [B*R,2], ddeltas [B*R,4])."""
+    RT = B * R
+    dev = scores.device
+    assert scores.shape == (RT, 2) and deltas.shape == (RT, 4) and boxes.shape == (RT, 4) and gt.shape == (RT, 4)
+    assert labels.dtype == torch.int64 and labels.numel() == RT and valid.dtype == torch.bool and valid.numel() == RT
+    out = torch.empty(2, device=dev, dtype=torch.float32)
+    ds = torch.empty(RT, 2, device=dev, dtype=torch.float32)
+    dd = torch.empty(RT, 4, device=dev, dtype=torch.float32)
+    rw = (C.c_float * 4)(*[float(v) for v in reg_weights])
+    _chk(lib().ore_roi_losses_fwd(C.c_void_p(_ptr(_f32(scores))), C.c_void_p(_ptr(_f32(deltas))), C.c_void_p(_ptr(_f32(boxes))),
+                                  C.c_void_p(_ptr(_f32(gt))), C.c_void_p(_ptr(labels.contiguous())), C.c_void_p(_ptr(valid.contiguous())), B, R, rw,
+                                  C.c_void_p(_ptr(out)), C.c_void_p(_ptr(ds)), C.c_void_p(_ptr(dd)), _stream()), "ore_roi_losses_fwd")
+    return out, ds, dd
 
 
 def sgd_step(params: torch.Tensor, grads: torch.Tensor, momentum_buf: torch.Tensor, chunk_lr: torch.Tensor, chunk_wd: torch.Tensor,

@@ -588,6 +588,27 @@ def roi_align_batched(feats, boxes, box_image, strides=(8, 16, 32), pooled: int 
     return RoiAlignBatchedFn.apply(boxes.detach().float().contiguous(), box_image, tuple(strides), pooled, *feats)
 
 
+class RoiLossFn(Function):
+    """loss_cls_stage0 / loss_box_reg_stage0 of the sampled ROIs of B images (custom_fast_rcnn.py:52-81) with their gradients from the
+    same launch (ore_roi_losses_fwd); backward scales the stored gradients by the upstream ones."""
+
+    @staticmethod
+    def forward(ctx, scores, deltas, boxes, gt, labels, valid, B: int, R: int, reg_weights):
+        out, ds, dd = orehip.roi_losses(scores.contiguous(), deltas.contiguous(), boxes.contiguous(), gt.contiguous(), labels, valid, B, R,
+                                        reg_weights)
+        ctx.save_for_backward(ds, dd)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box):
+        ds, dd = ctx.saved_tensors
+        return ds * g_cls, dd * g_box, None, None, None, None, None, None, None
+
+
+def roi_losses(scores, deltas, boxes, gt, labels, valid, B, R, reg_weights):
+    return RoiLossFn.apply(scores, deltas, boxes, gt, labels, valid, B, R, tuple(float(v) for v in reg_weights))
+
+
 class CenterNetLossFn(Function):
     """head [rows, ld>=5] (cols 0..3 ltrb after Scale+ReLU, col 4 heatmap logit) -> [loss_loc, loss_agn_pos, loss_agn_neg, reg rows,
     positives] (ref:fewx/modeling/fsod/fsod_rpn.py:702-779; the last two are this rank's un-normalised counts, no gradient).

@@ -333,6 +333,14 @@ int ore_centernet_losses_bwd(const float* head, int32_t head_ld, const float* re
                              int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, int32_t max_pos, float gamma,
                              float beta, float sigmoid_clamp, float ignore_high_fp, const float* coef3, float* dhead,
                              int32_t dhead_ld, void* stream);
+/* The second stage's two losses AND their gradients in one launch (ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:52-81,
+ * d2z:modeling/box_regression.py:41-75): rows i = b * R + j of B images x R sampled ROIs; w_i = valid_i / (n_b * B), n_b = max(#valid of
+ * image b, 1); losses2[0] = sum_i w_i CE(scores_i [2], labels_i), losses2[1] = sum_i w_i [labels_i == 0] sum_k |deltas_ik -
+ * get_deltas(boxes_i, gt_i; reg_weights4)_k|; dscores [B*R][2], ddeltas [B*R][4] = their gradients (scale by the upstream gradient).
+ * labels int64 (0 foreground, 1 background), valid bytes, reg_weights4 host-readable.  One block, fixed summation order. */
+int ore_roi_losses_fwd(const float* scores, const float* deltas, const float* boxes, const float* gt, const int64_t* labels,
+                       const uint8_t* valid, int32_t B, int32_t R, const float* reg_weights4, float* losses2, float* dscores,
+                       float* ddeltas, void* stream);
 /* One launch of value-clip + SGD over the flat parameter bucket (row a13):
  *   g = clamp(grad_scale*grad, -clip, clip) (clip <= 0: off); g += wd*p; buf = momentum*buf + g; p -= lr*buf
  * = torch.nn.utils.clip_grad_value_ + torch.optim.SGD.step as wired by ref:fewx/solver/build.py:18-60,110-139 and

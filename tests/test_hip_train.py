@@ -438,6 +438,55 @@ def test_roi_align_backward_tiled_other_pool_sizes(oh, pooled):
         assert scale > 0 and float((a[l] - b[l]).abs().max()) <= 2e-6 * scale, (l, float((a[l] - b[l]).abs().max()), scale)
 
 
+def test_roi_losses_one_launch_vs_torch(oh):
+    """ore_roi_losses_fwd (both second-stage losses and their gradients from one launch) against the element-wise torch expression it
+    replaced (custom_fast_rcnn.py:52-81 with per-image 1/n_b weights): values and gradients, on a batch with an image without valid rows,
+    an image without foreground and padding rows with degenerate boxes (no loss, no gradient)."""
+    import torch.nn.functional as F
+    from orehip import autograd as A
+    from fewx.modeling.fsod.train_forward import get_deltas
+    g = torch.Generator().manual_seed(9)
+    B, R = 5, 96
+    RT = B * R
+    ctr = torch.rand(RT, 2, generator=g) * 500 + 50
+    wh = torch.rand(RT, 2, generator=g) * 150 + 10
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    gt = boxes + torch.randn(RT, 4, generator=g) * 1.5         # (sides stay positive: min side 10)
+    labels = (torch.rand(RT, generator=g) > 0.3).long()
+    valid = torch.rand(RT, generator=g) > 0.15
+    valid[2 * R:3 * R] = False                                 # an image without a single valid row
+    labels[3 * R:4 * R] = 1                                    # an image without foreground
+    boxes[~valid] = torch.tensor([0.0, 0.0, 8.0, 8.0])
+    gt[~valid] = 0.0                                           # log(0 / 8) on rows that must not count
+    weights = (10.0, 10.0, 5.0, 5.0)
+    scores0 = torch.randn(RT, 2, generator=g) * 2
+    deltas0 = torch.randn(RT, 4, generator=g)
+    up = torch.tensor([1.7, 0.6])
+    res = []
+    for hip in (False, True):
+        sc = scores0.clone().cuda().requires_grad_(True)
+        de = deltas0.clone().cuda().requires_grad_(True)
+        bx, gtf, lb, vf = boxes.cuda(), gt.cuda(), labels.cuda(), valid.cuda()
+        if hip:
+            lc, lbx = A.roi_losses(sc, de, bx, gtf, lb, vf, B, R, weights)
+        else:
+            img = torch.arange(B).repeat_interleave(R).cuda()
+            n_b = vf.reshape(B, R).sum(1).clamp(min=1).float()
+            w = vf.float() / (n_b * B)[img]
+            lc = (F.cross_entropy(sc, lb, reduction="none") * w).sum()
+            fg = (lb == 0) & vf
+            zero = torch.zeros((), device="cuda")
+            tgt = torch.where(fg[:, None], get_deltas(bx, gtf, weights), zero)
+            lbx = (torch.where(fg[:, None], (de - tgt).abs(), zero).sum(1) * w).sum()
+        (lc * up[0] + lbx * up[1]).backward()
+        res.append((float(lc), float(lbx), sc.grad.clone(), de.grad.clone()))
+    (c0, b0, gs0, gd0), (c1, b1, gs1, gd1) = res
+    assert abs(c0 - c1) <= 2e-6 * abs(c0) and abs(b0 - b1) <= 2e-6 * abs(b0), (c0, c1, b0, b1)
+    assert float((gs0 - gs1).abs().max()) <= 1e-6 * float(gs0.abs().max())
+    assert torch.equal(gd0, gd1)                               # +-w or 0: no arithmetic to differ in
+    assert float(gd1[~valid.cuda()].abs().max()) == 0.0 and float(gs1[~valid.cuda()].abs().max()) == 0.0
+
+
 def test_centernet_loss_fn_backward(oh):
     from orehip import autograd as A
     g = torch.Generator().manual_seed(5)
