@@ -345,6 +345,124 @@ __global__ __launch_bounds__(256) void k_roi_losses(RoiLossP p) {
     }
     if (t == 0) { p.out2[0] = red[0][0]; p.out2[1] = red[1][0]; }
 }
+
+// ---- label_and_sample_proposals of a batch in ONE launch (round 5) ---------------------------------------------------------------
+// d2z:modeling/roi_heads/roi_heads.py:181-295, sampling.py:10-53, matcher.py:8-128 as train_forward.sample_rois_device states them:
+// candidates = the image's proposals (+ its ground-truth boxes), IoU matcher against the ground truth (>= thr -> foreground (label 0),
+// else background (1)), R samples with at most P foreground, drawn as the P (R - n_pos) smallest of the caller's iid uniform keys among
+// the foreground (background) candidates, foreground first, each group in ascending key order (ties: the lower candidate index).  One
+// block per image: labels and keys in LDS, a candidate's slot is its rank by counting.  Rows beyond an image's sample count are padding
+// (box (0, 0, 8, 8), label 1, valid 0).  Replaces ~65 element-wise / top-k / gather launches; same picks for the same keys.
+constexpr int SMP_T = 1024;
+constexpr int SMP_MAXN = 12800;               // candidates per image (the detector hands its 3 x 4000-row proposal buffer + the ground truth)
+constexpr int SMP_MAXG = 256;
+struct SampleP {
+    const float* prop; const long long* prop_n; const float* gtp; const long long* gt_n; const float* u;
+    int cap, G, N, R, P, append_gt;
+    float thr;
+    float* boxes; long long* labels; float* gt; unsigned char* valid;
+};
+__global__ __launch_bounds__(SMP_T) void k_sample_rois(SampleP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smp_lds[];      // 11 bytes per candidate, carved below
+    const int Na = (p.N + 7) & ~7;
+    float* key = reinterpret_cast<float*>(smp_lds);
+    unsigned short* mi = reinterpret_cast<unsigned short*>(smp_lds + (size_t)Na * 4);
+    unsigned short* elig0 = mi + Na;
+    unsigned short* elig1 = elig0 + Na;
+    unsigned char* lab = reinterpret_cast<unsigned char*>(elig1 + Na);
+    __shared__ float gb[SMP_MAXG][4];
+    __shared__ float ga[SMP_MAXG];
+    __shared__ int cnt[2], ne[2], cut[2];
+    __shared__ int hist[2][256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int pn = (int)min(p.prop_n[b], (long long)p.cap), gn = (int)min(p.gt_n[b], (long long)p.G);
+    const float* prop = p.prop + (size_t)b * p.cap * 4;
+    const float* gtp = p.gtp + (size_t)b * p.G * 4;
+    if (t < 2) cnt[t] = 0;
+    for (int g = t; g < p.G; g += SMP_T) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gtp + 4 * (size_t)g);
+        gb[g][0] = v.x; gb[g][1] = v.y; gb[g][2] = v.z; gb[g][3] = v.w;
+        ga[g] = (v.z - v.x) * (v.w - v.y);
+    }
+    __syncthreads();
+    for (int c = t; c < p.N; c += SMP_T) {
+        const bool isp = c < p.cap;
+        const bool cv = isp ? c < pn : (c - p.cap) < gn;
+        const f32x4 bx = *reinterpret_cast<const f32x4*>(isp ? prop + 4 * (size_t)c : gtp + 4 * (size_t)(c - p.cap));
+        const float ac = (bx.z - bx.x) * (bx.w - bx.y);
+        float best = -1.0f;                                   // no valid ground truth at all: -1 -> background, match index 0
+        int bi = 0;
+        for (int g = 0; g < gn; ++g) {
+            const float w = fmaxf(fminf(gb[g][2], bx.z) - fmaxf(gb[g][0], bx.x), 0.f);
+            const float h = fmaxf(fminf(gb[g][3], bx.w) - fmaxf(gb[g][1], bx.y), 0.f);
+            const float inter = w * h;
+            const float iou = inter > 0.f ? inter / (ga[g] + ac - inter) : 0.f;
+            if (iou > best) { best = iou; bi = g; }
+        }
+        const int L = cv ? (best >= p.thr ? 0 : 1) : 2;
+        lab[c] = (unsigned char)L;
+        mi[c] = (unsigned short)bi;
+        key[c] = p.u[(size_t)b * p.N + c];
+        if (L < 2) atomicAdd(&cnt[L], 1);
+    }
+    __syncthreads();
+    const int n_pos = min(cnt[0], p.P), n_neg = min(cnt[1], p.R - n_pos);
+    float* ob = p.boxes + (size_t)b * p.R * 4;
+    float* og = p.gt + (size_t)b * p.R * 4;
+    long long* ol = p.labels + (size_t)b * p.R;
+    unsigned char* ov = p.valid + (size_t)b * p.R;
+    for (int j = n_pos + n_neg + t; j < p.R; j += SMP_T) {    // padding rows
+        *reinterpret_cast<f32x4*>(ob + 4 * (size_t)j) = f32x4{0.f, 0.f, 8.f, 8.f};
+        *reinterpret_cast<f32x4*>(og + 4 * (size_t)j) = f32x4{0.f, 0.f, 0.f, 0.f};
+        ol[j] = 1;
+        ov[j] = 0;
+    }
+    // the k smallest keys of a label without ranking everybody: a 256-bin histogram of the keys finds the bin the k-th smallest falls in,
+    // only the candidates up to that bin (k plus a bin's worth) are ranked against each other -- exact, since every smaller key is among them
+    for (int i = t; i < 512; i += SMP_T) hist[i >> 8][i & 255] = 0;
+    if (t < 2) ne[t] = 0;
+    __syncthreads();
+    for (int c = t; c < p.N; c += SMP_T) {
+        const int L = lab[c];
+        if (L < 2) atomicAdd(&hist[L][min(255, max(0, (int)(key[c] * 256.0f)))], 1);
+    }
+    __syncthreads();
+    if (t < 2) {
+        const int lim = t == 0 ? n_pos : n_neg;
+        int cb = -1, acc = 0;
+        if (lim > 0)
+            for (int q = 0; q < 256; ++q) { acc += hist[t][q]; if (acc >= lim) { cb = q; break; } }
+        cut[t] = lim > 0 ? (cb < 0 ? 255 : cb) : -1;
+    }
+    __syncthreads();
+    for (int c = t; c < p.N; c += SMP_T) {
+        const int L = lab[c];
+        if (L < 2 && min(255, max(0, (int)(key[c] * 256.0f))) <= cut[L]) (L == 0 ? elig0 : elig1)[atomicAdd(&ne[L], 1)] = (unsigned short)c;
+    }
+    __syncthreads();
+    for (int L = 0; L < 2; ++L) {
+        const int lim = L == 0 ? n_pos : n_neg, m = ne[L];
+        const unsigned short* el = L == 0 ? elig0 : elig1;
+        for (int e = t; e < m; e += SMP_T) {
+            const int c = el[e];
+            const float k = key[c];
+            int rank = 0;
+            for (int d = 0; d < m; ++d) {
+                const int cd = el[d];
+                const float kd = key[cd];
+                rank += (kd < k || (kd == k && cd < c)) ? 1 : 0;
+            }
+            if (rank >= lim) continue;
+            const int j = L == 0 ? rank : n_pos + rank;
+            const f32x4 bx = *reinterpret_cast<const f32x4*>(c < p.cap ? prop + 4 * (size_t)c : gtp + 4 * (size_t)(c - p.cap));
+            *reinterpret_cast<f32x4*>(ob + 4 * (size_t)j) = bx;
+            const int g = mi[c];
+            *reinterpret_cast<f32x4*>(og + 4 * (size_t)j) = f32x4{gb[g][0], gb[g][1], gb[g][2], gb[g][3]};
+            ol[j] = L;
+            ov[j] = 1;
+        }
+    }
+}
 }  // namespace
 
 extern "C" int ore_centernet_targets_fwd(int32_t n_levels, const int32_t* H, const int32_t* W, const int32_t* stride, int32_t B,
@@ -399,6 +517,25 @@ extern "C" int ore_roi_losses_fwd(const float* scores, const float* deltas, cons
                reg_weights4[3], losses2, dscores, ddeltas};
     hipLaunchKernelGGL(k_roi_losses, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
     return ore_launch_status("k_roi_losses");
+}
+
+extern "C" int ore_sample_rois_fwd(const float* prop, const int64_t* prop_n, const float* gtp, const int64_t* gt_n, const float* keys,
+                                   int32_t B, int32_t cap, int32_t G, int32_t append_gt, int32_t R, int32_t P, float iou_thr, float* boxes,
+                                   int64_t* labels, float* gt, uint8_t* valid, void* stream) {
+    ORE_CHECK_ARG(prop && prop_n && gtp && gt_n && keys && boxes && labels && gt && valid, "ore_sample_rois_fwd: null pointer");
+    const int N = cap + (append_gt ? G : 0);
+    ORE_CHECK_ARG(B >= 1 && cap >= 1 && G >= 1 && G <= SMP_MAXG && N <= SMP_MAXN && R >= 1 && P >= 0 && P <= R,
+                  "ore_sample_rois_fwd: B=%d cap=%d G=%d (<= %d) N=%d (<= %d) R=%d P=%d", B, cap, G, SMP_MAXG, N, SMP_MAXN, R, P);
+    SampleP p{prop, (const long long*)prop_n, gtp, (const long long*)gt_n, keys, cap, G, N, R, P, append_gt ? 1 : 0, iou_thr,
+              boxes, (long long*)labels, gt, valid};
+    const size_t lds = (size_t)((N + 7) & ~7) * 11;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        ORE_HIP(hipFuncSetAttribute((const void*)k_sample_rois, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_sample_rois, dim3(B), dim3(SMP_T), lds, (hipStream_t)stream, p);
+    return ore_launch_status("k_sample_rois");
 }
 
 extern "C" int ore_sgd_step_fwd(float* params, const float* grads, float* momentum_buf, int64_t n_chunks, const float* chunk_lr,

@@ -276,6 +276,23 @@ def first_stage_batch(pg, heads: List[torch.Tensor], gts: Optional[List[torch.Te
 
 @torch.no_grad()
 def sample_rois_device(rh, prop: torch.Tensor, prop_n: torch.Tensor, gtp: torch.Tensor, gt_n: torch.Tensor):
+    """label_and_sample_proposals for B images at once, on the device, without a host sync: ONE launch (ore_sample_rois_fwd) behind the
+    draw of the iid uniform keys.  Same contract and, for the same keys, the same sample as `sample_rois_torch` below (the element-wise
+    form of rounds 3-5, kept as the statement of the semantics and for the test that pins the kernel to it)."""
+    import orehip
+    B, cap, _ = prop.shape
+    G = gtp.shape[1]
+    N = cap + (G if rh.proposal_append_gt else 0)
+    R = int(rh.batch_size_per_image)
+    if N > 12800 or G > 256:
+        return sample_rois_torch(rh, prop, prop_n, gtp, gt_n)
+    u = torch.rand(B, N, device=prop.device)
+    return orehip.sample_rois(prop.contiguous(), prop_n, gtp.contiguous(), gt_n, u, R, int(R * rh.positive_fraction), float(rh.iou_threshold),
+                              bool(rh.proposal_append_gt))
+
+
+@torch.no_grad()
+def sample_rois_torch(rh, prop: torch.Tensor, prop_n: torch.Tensor, gtp: torch.Tensor, gt_n: torch.Tensor):
     """label_and_sample_proposals (d2z:modeling/roi_heads/roi_heads.py:181-295, sampling.py:10-53) for B images at once, entirely on
     the device and without a host sync.  prop [B,cap,4] with prop_n [B] valid rows, gtp [B,G,4] with gt_n [B] valid rows.
     Candidates = proposals then ground truth (proposal_append_gt); IoU matcher (>= IOUS[0] -> foreground = class 0, else background

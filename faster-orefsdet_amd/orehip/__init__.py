@@ -64,7 +64,7 @@ class ModelCfg(C.Structure):
 
 
 # every symbol include/ore_hip.h declares (checked by tests/test_capi_symbols.py without a GPU)
-SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_pack_conv_weights_multi_fwd", "ore_roi_align_bwd_det", "ore_roi_align_bwd_tiled", "ore_roi_losses_fwd", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
+SYMBOLS = ["ore_last_error", "ore_version", "ore_flop_counter_read", "ore_engine_profile_executed_flops", "ore_pack_conv_weights_multi_fwd", "ore_roi_align_bwd_det", "ore_roi_align_bwd_tiled", "ore_roi_losses_fwd", "ore_sample_rois_fwd", "ore_det_record_rows", "ore_winograd_covers", "ore_winograd_weight_floats", "ore_winograd_weight_fwd", "ore_packed_weight_bf16_elems", "ore_pack_conv_weight_bf16_host", "ore_engine_buffer_is_bf16", "ore_stem1_bf16_fwd", "ore_ese_gate_bf16_fwd", "ore_maxpool3x3s2_bf16_fwd", "ore_correlation_levels_bf16_fwd", "ore_groupnorm_affine_levels_bf16_fwd", "ore_groupnorm_apply_bf16_fwd", "ore_head_pred_fwd", "ore_head_pred_bf16_fwd", "ore_head_pred_gn_fwd", "ore_head_pred_gn_bf16_fwd", "ore_groupnorm_apply_levels_bf16_fwd", "ore_ese_gate_scaled_weight_bf16_fwd", "ore_ese_gate_pool_fwd", "ore_ese_gate_pool_bf16_fwd", "ore_roi_align_bf16_fwd", "ore_conv2d_fwd", "ore_conv2d_levels_fwd", "ore_conv_workspace_floats", "ore_conv_colsum_rows", "ore_conv_set_plan_override", "ore_packed_weight_floats", "ore_pack_conv_weight_host",
            "ore_stem1_fwd", "ore_maxpool3x3s2_fwd", "ore_ese_gate_fwd", "ore_ese_gate_from_colsum_fwd", "ore_ese_gate_scaled_weight_fwd", "ore_correlation_levels_fwd",
            "ore_groupnorm_affine_levels_fwd", "ore_scale_channels_fwd", "ore_correlation_fwd",
            "ore_support_kernels_fwd", "ore_groupnorm_affine_fwd", "ore_detect_workspace_bytes", "ore_detect_fwd", "ore_detect_batch_fwd",
@@ -783,6 +783,26 @@ def centernet_loss_grad(head: torch.Tensor, reg_targets: torch.Tensor, hm_target
                                         C.c_float(ignore_high_fp), C.c_void_p(_ptr(_f32(coef3))), C.c_void_p(_ptr(dhead)), ld, _stream()),
          "ore_centernet_losses_bwd")
     return dhead
+
+
+def sample_rois(prop: torch.Tensor, prop_n: torch.Tensor, gtp: torch.Tensor, gt_n: torch.Tensor, keys: torch.Tensor, R: int, P: int,
+                iou_thr: float, append_gt: bool = True):
+    """label_and_sample_proposals of B images in one launch (ore_sample_rois_fwd).  prop [B,cap,4], prop_n [B] int64, gtp [B,G,4],
+    gt_n [B] int64, keys [B, cap (+G)] fp32 -> boxes [B,R,4], labels [B,R] int64, matched gt [B,R,4], valid [B,R] bool."""
+    B, cap, _ = prop.shape
+    G = gtp.shape[1]
+    N = cap + (G if append_gt else 0)
+    dev = prop.device
+    assert keys.shape == (B, N) and keys.dtype == torch.float32 and keys.is_contiguous()
+    assert prop_n.dtype == torch.int64 and gt_n.dtype == torch.int64 and prop.is_contiguous() and gtp.is_contiguous()
+    boxes = torch.empty(B, R, 4, device=dev, dtype=torch.float32)
+    gt = torch.empty(B, R, 4, device=dev, dtype=torch.float32)
+    labels = torch.empty(B, R, device=dev, dtype=torch.int64)
+    valid = torch.empty(B, R, device=dev, dtype=torch.bool)
+    _chk(lib().ore_sample_rois_fwd(C.c_void_p(_ptr(_f32(prop))), C.c_void_p(_ptr(prop_n)), C.c_void_p(_ptr(_f32(gtp))), C.c_void_p(_ptr(gt_n)),
+                                   C.c_void_p(_ptr(keys)), B, cap, G, int(bool(append_gt)), R, P, C.c_float(iou_thr), C.c_void_p(_ptr(boxes)),
+                                   C.c_void_p(_ptr(labels)), C.c_void_p(_ptr(gt)), C.c_void_p(_ptr(valid)), _stream()), "ore_sample_rois_fwd")
+    return boxes, labels, gt, valid
 
 
 def roi_losses(scores: torch.Tensor, deltas: torch.Tensor, boxes: torch.Tensor, gt: torch.Tensor, labels: torch.Tensor, valid: torch.Tensor,

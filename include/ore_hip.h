@@ -333,6 +333,15 @@ int ore_centernet_losses_bwd(const float* head, int32_t head_ld, const float* re
                              int32_t rows, const int64_t* pos_inds, const int32_t* pos_count, int32_t max_pos, float gamma,
                              float beta, float sigmoid_clamp, float ignore_high_fp, const float* coef3, float* dhead,
                              int32_t dhead_ld, void* stream);
+/* label_and_sample_proposals for B images in one launch (d2z:modeling/roi_heads/roi_heads.py:181-295, sampling.py:10-53, matcher.py):
+ * prop [B][cap][4] with prop_n [B] valid rows, gtp [B][G][4] with gt_n [B] valid rows (int64 counts on the device); candidates = proposals
+ * (+ ground truth when append_gt); IoU >= iou_thr against any valid ground truth -> foreground (label 0) else background (1); R samples
+ * with at most P foreground: the smallest of `keys` [B][cap (+G)] (iid uniform, the caller's) among the foreground, then among the
+ * background, each in ascending key order.  boxes / gt [B][R][4], labels [B][R] int64, valid [B][R] bytes; rows beyond an image's sample
+ * count are padding (box (0,0,8,8), label 1, valid 0).  cap + G <= 12800, G <= 256. */
+int ore_sample_rois_fwd(const float* prop, const int64_t* prop_n, const float* gtp, const int64_t* gt_n, const float* keys, int32_t B,
+                        int32_t cap, int32_t G, int32_t append_gt, int32_t R, int32_t P, float iou_thr, float* boxes, int64_t* labels,
+                        float* gt, uint8_t* valid, void* stream);
 /* The second stage's two losses AND their gradients in one launch (ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:52-81,
  * d2z:modeling/box_regression.py:41-75): rows i = b * R + j of B images x R sampled ROIs; w_i = valid_i / (n_b * B), n_b = max(#valid of
  * image b, 1); losses2[0] = sum_i w_i CE(scores_i [2], labels_i), losses2[1] = sum_i w_i [labels_i == 0] sum_k |deltas_ik -

@@ -1371,6 +1371,12 @@ def test_sample_rois_device_properties(oh):
         else:
             assert torch.all(lb == 1)
         assert torch.all(labels[b].cpu()[~v] == 1)
+    # the one-launch kernel against the element-wise torch form it replaced, same keys (same seed, same single draw): the same sample,
+    # row for row -- boxes, labels, matched gt, padding
+    torch.manual_seed(3)
+    tb, tl, tg, tv = TF.sample_rois_torch(rh, prop.cuda(), torch.tensor(n).cuda(), gtp, gt_n)
+    assert torch.equal(valid, tv) and torch.equal(boxes, tb) and torch.equal(labels, tl)
+    assert torch.equal(rgt[valid], tg[tv])
     # image 2 has 41 candidates: nothing is dropped, so the sample is the whole candidate set, as the reference logic returns it
     _, rb, rl, _ = TF.label_and_sample(rh, prop[2, :40].cuda(), gts[2].cuda(), lambda k: torch.randperm(k))
     v = valid[2].cpu()
