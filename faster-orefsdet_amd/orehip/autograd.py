@@ -15,6 +15,7 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+import torch.nn.functional as F
 from torch.autograd import Function
 
 import orehip
@@ -315,7 +316,7 @@ class EseFn(Function):
         B, H, W, C = x.shape
         m = orehip.prod_colsum(x, None, 1.0 / (H * W))                                 # [B,C] average pool
         z = torch.addmm(fc_b, m, fc_w.reshape(C, C).t())
-        g = torch.clamp(z + 3.0, 0.0, 6.0) / 6.0
+        g = F.hardsigmoid(z)                                                           # relu6(z + 3) / 6 in one launch
         y = orehip.scale_add_channels(x, g.contiguous(), None)
         ctx.save_for_backward(x, fc_w, m, z, g)
         return y
@@ -326,7 +327,7 @@ class EseFn(Function):
         B, H, W, C = x.shape
         dy = dy.contiguous()
         dg = orehip.prod_colsum(dy, x, 1.0)                                            # [B,C] = sum_hw dy * x
-        dz = dg * ((z > -3.0) & (z < 3.0)).to(dg.dtype) / 6.0
+        dz = torch.ops.aten.hardsigmoid_backward(dg, z)                                # dg / 6 where -3 < z < 3, else 0 (one launch)
         Wm = fc_w.reshape(C, C)
         dm = dz @ Wm                                                                   # [B,C]
         dx = orehip.scale_add_channels(dy, g.contiguous(), (dm / (H * W)).contiguous())
