@@ -10,8 +10,9 @@ head run batched as the reference's do, the per-image stages loop, and the losse
     ref:CenterNet2/centernet/modeling/roi_heads/custom_fast_rcnn.py:52-81,131-157   losses
 What runs where: convs / linears (forward, data gradient, weight gradient), ROIAlign fwd/bwd, CenterNet targets + losses + their
 gradient, the depthwise correlation fwd/bwd, GroupNorm fwd/bwd, the eSE scale and its gradient, max-pool fwd/bwd, the FPN top-down
-add and its gradient, top-k / decode / NMS are HIP kernels.  Still torch tensor ops on the device this round (small, listed in
-DESIGN.md): the [B,C]-sized gate algebra of eSE, SM_Block pointwise math, proposal matching/sampling, the two ROI losses.
+add and its gradient, top-k / decode / NMS, the fg / bg subsample of the proposals (one launch) and the two ROI losses with their
+gradients (one launch) are HIP kernels.  Still torch tensor ops on the device (small, listed in DESIGN.md): the [B,C]-sized gate
+algebra of eSE, SM_Block pointwise math, the head's scale / ReLU / concat.
 """
 from __future__ import annotations
 
