@@ -150,7 +150,14 @@ def graphed_dense_part(model, xq, xs):
             _w = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if _w is not None:
                 _w(False)
-            cache[key] = torch.cuda.make_graphed_callables(mod, (xq.clone(), xs.clone()), num_warmup_iters=3, allow_unused_input=True)
+            # (the captured backward hands its gradients to autograd: its warm-up passes run torch.autograd.grad, whose side effects --
+            # weight gradients accumulated in place -- would otherwise land in the bucket)
+            from orehip import autograd as _A
+            _A.DIRECT_GRAD_OFF = True
+            try:
+                cache[key] = torch.cuda.make_graphed_callables(mod, (xq.clone(), xs.clone()), num_warmup_iters=3, allow_unused_input=True)
+            finally:
+                _A.DIRECT_GRAD_OFF = False
         except Exception as ex:                                   # noqa: BLE001 -- capture is an optimisation, never a requirement
             cache[key] = None
             model.__dict__["_ore_train_graph_error"] = repr(ex)[:500]

@@ -111,6 +111,10 @@ def packed_wino(w: torch.Tensor, dgrad: bool):
     return e[1]
 
 
+DIRECT_GRAD_OFF = False      # set while a backward is run for its RESULT only (torch.autograd.grad inside make_graphed_callables: its warm-up
+                             # passes must not leave gradients in the bucket)
+
+
 def direct_grad(p) -> Optional[torch.Tensor]:
     """The buffer a parameter's gradient may be accumulated into BY THE KERNEL (dW = 1 * grad + ...; the backward then hands autograd no
     gradient for it): its `.grad`, when the owner of that buffer allows it (`p._ore_direct_grad`, set by fewx.solver.FlatBucket whose
@@ -118,7 +122,7 @@ def direct_grad(p) -> Optional[torch.Tensor]:
     every trainable conv weight costs an add of the two branch gradients plus an in-place add into `.grad`, ~100 launches of a few
     microseconds per step.  Not under a data-parallel wrapper (its exchange is issued from post-accumulate hooks, which need the
     engine's AccumulateGrad to run) and not with tensor hooks on the parameter."""
-    if p is None or not getattr(p, "_ore_direct_grad", False):
+    if p is None or DIRECT_GRAD_OFF or not getattr(p, "_ore_direct_grad", False):
         return None
     g = p.grad
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
