@@ -437,6 +437,8 @@ def main():
                     help="also time the same requests folded F at a time into one engine pass (\"folded_serving\" in the output); 0/1 = skip")
     ap.add_argument("--inflight", type=int, default=4,
                     help="\"in_flight\" leg: images kept in flight per GPU, each a bs=1 forward on its own engine + HIP stream")
+    ap.add_argument("--probe-step-graph", action="store_true",
+                    help="(internal) child mode: capture and replay one whole training iteration (bs 1) and exit 0 if that worked")
     ap.add_argument("--dry", action="store_true",
                     help="rehearse the launch / rendezvous / max-over-ranks / JSON plumbing only (no GPU legs; CPU test of --gpus N)")
     args = ap.parse_args()
@@ -452,6 +454,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dry:
         return dry_run(args, world, rank)
+    if args.probe_step_graph:
+        torch.cuda.set_device(0)
+        out = train_leg(torch.device("cuda", 0), steps=2, warmup=4, batch=1, graph="step")
+        sys.exit(0 if out.get("whole_step_hipgraph") else 3)
+    # The train legs replay the whole iteration as one hipGraph.  A capture that goes wrong inside the runtime takes its process down
+    # (seen once during development: a graph that depended on an uncaptured stream segfaulted in hipGraphInstantiate), and the headline
+    # line must not depend on that: the capture is rehearsed in a CHILD first -- started before this process has touched the GPU -- and
+    # the legs fall back to the dense-part graph / eager step if the child did not come back clean.
+    step_probe = None
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if under_profiler:
+        step_probe = "skipped: a profiler's preloaded library has initialised the GPU in this process already (no child may be started)"
+    elif world == 1 and not args.no_train_leg:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-step-graph"], stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, timeout=300)
+            step_probe = "ok" if r.returncode == 0 else "child exit %d" % r.returncode
+        except Exception as ex:                              # noqa: BLE001
+            step_probe = repr(ex)[:120]
+    step_graph = step_probe == "ok"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     # ORE_BENCH_BACKEND=gloo: rehearsal of the N-rank code path on a box with fewer GPUs than ranks (ranks share the cards; the
     # exchange then runs over gloo, so its timings say nothing about RCCL).  The driver's runs use the default, nccl = RCCL.
@@ -726,10 +749,12 @@ def main():
     if not args.no_train_leg:
         try:
             if world == 1:
-                train["train_step"] = train_leg(device, min_time=0.3, graph="step")
-                train["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph="step", min_time=0.8)   # BASELINE configs[2]
+                train["train_step"] = train_leg(device, min_time=0.3, graph="step" if step_graph else True)
+                train["train_step"]["whole_step_probe"] = step_probe
+                train["train_step_bs16"] = train_leg(device, steps=6, warmup=3, batch=16, graph="step" if step_graph else False, min_time=0.8)   # BASELINE configs[2]
                 # BASELINE configs[4] ("bf16 MFMA conv path + fp32 NMS") on one GPU: its own dtype, never mixed into `value`
-                train["train_step_bs16_bf16"] = train_leg(device, steps=6, warmup=3, batch=16, graph="step", min_time=0.8, precision="bf16")
+                train["train_step_bs16_bf16"] = train_leg(device, steps=6, warmup=3, batch=16, graph="step" if step_graph else False, min_time=0.8,
+                                                          precision="bf16")
             else:                                           # BASELINE configs[3]: 16 per GPU, gradients over RCCL
                 train["train_step"] = train_leg(device, steps=6, warmup=3, batch=16, graph=False, world=world, rank=rank, min_time=0.8)
         except Exception as ex:                             # the headline line must survive a failure of the side measurement
